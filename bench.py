@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Llama-3-8B (bf16, random-init) served by the native MI355X
+engine, 500 requests at concurrency 20, 64 max tokens, streaming — the request
+mix of the reference's headline example (README.md:66-76): p95 latency, TTFT,
+RPS and $/1k tokens.
+
+One *step* = one complete pass of that mix (``--requests`` requests through the
+OpenAI endpoint, closed at ``--concurrency`` in flight) against one model replica
+per GPU.  With N GPUs every rank (one process per GPU, launched by torchrun) runs
+its own replica + load generator (data parallel, weak scaling: per-GPU work is
+fixed), per-request samples and lock-step amd-smi telemetry are all-gathered over
+RCCL, and rank 0 reduces them (p50/p95/p99 by the HIP histogram/quantile kernel)
+and prints ONE JSON line.  ``value`` is the aggregate request throughput (RPS)
+over all GPUs; p95 / TTFT / $ per 1k tokens / Wh per 1k tokens ride along in the
+same line with their own ratios against the baseline numbers.
+
+Arrival pacing: the reference's "steady" pattern offers 2 x concurrency = 40 RPS,
+which caps measured throughput below its own published 47.2 RPS; the default here
+is ``--target-rps 0`` = saturating arrivals (all requests due immediately, 20 in
+flight at all times), i.e. the same mix at the highest load concurrency 20 allows.
+``--target-rps 40`` reproduces the reference pacing.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from typing import Any, Dict, List, Optional
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BASELINE = {"rps": 47.2, "p95_ms": 342.1, "ttft_ms": 23.4, "cost_per_1k_tokens": 0.0023, "wh_per_1k_tokens": 15.7}
+
+
+class LoadChild:
+    """Persistent load-generator process (see kvmini/loadgen/worker.py)."""
+
+    def __init__(self) -> None:
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        env["OMP_NUM_THREADS"] = "1"
+        # the child never touches the GPU
+        env["HIP_VISIBLE_DEVICES"] = ""
+        env["CUDA_VISIBLE_DEVICES"] = ""
+        self.p = subprocess.Popen([sys.executable, "-u", "-m", "kvmini.loadgen.worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+
+    def call(self, cmd: Dict[str, Any]) -> Dict[str, Any]:
+        assert self.p.stdin and self.p.stdout
+        self.p.stdin.write(json.dumps(cmd) + "\n")
+        self.p.stdin.flush()
+        line = self.p.stdout.readline()
+        if not line:
+            raise RuntimeError("load generator child died")
+        out = json.loads(line)
+        if not out.get("ok"):
+            raise RuntimeError(f"load generator failed: {out.get('error')}")
+        return out
+
+    def close(self) -> None:
+        try:
+            if self.p.stdin:
+                self.p.stdin.write(json.dumps({"cmd": "quit"}) + "\n")
+                self.p.stdin.flush()
+            self.p.wait(10)
+        except Exception:
+            self.p.kill()
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--requests", type=int, default=500)
+    ap.add_argument("--concurrency", type=int, default=20)
+    ap.add_argument("--max-tokens", type=int, default=64)
+    ap.add_argument("--pattern", default="steady")
+    ap.add_argument("--target-rps", type=float, default=0.0, help="0 = saturate (closed loop at --concurrency)")
+    ap.add_argument("--kernels", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--max-num-seqs", type=int, default=32)
+    ap.add_argument("--max-batched-tokens", type=int, default=256)
+    ap.add_argument("--max-model-len", type=int, default=2048)
+    ap.add_argument("--out-dir", default=None, help="write run artifacts (requests.csv, power.json, results.json) here")
+    ap.add_argument("--gpu-hourly", type=float, default=None, help="$/GPU-hour (default: cost.yaml MI355X entry)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a ROCm GPU", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.server.native import start_native_in_thread
+    from kvmini.telemetry.amdsmi_sampler import TelemetrySampler
+
+    proc_start = time.time()
+    engine = LLMEngine(
+        EngineConfig(
+            model=args.model,
+            device=str(device),
+            dtype="bf16",
+            seed=rank,
+            max_num_seqs=args.max_num_seqs,
+            max_batched_tokens=args.max_batched_tokens,
+            max_model_len=args.max_model_len,
+            use_graphs=not args.no_graphs,
+            kernels=args.kernels,
+            kv_memory_fraction=0.3,
+        )
+    )
+    engine.warmup()
+    _srv, url, stop_server = start_native_in_thread(engine, model_name=args.model)
+    child = LoadChild()
+    sampler = TelemetrySampler(0.1, gpu_indices=[local_rank]).start()
+
+    target = args.target_rps if args.target_rps > 0 else 1e6
+    cmd = {
+        "cmd": "run",
+        "url": url,
+        "model": args.model,
+        "requests": args.requests,
+        "concurrency": args.concurrency,
+        "max_tokens": args.max_tokens,
+        "pattern": args.pattern,
+        "target_rps": target,
+        "stream": True,
+        "seed": rank,
+    }
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        child.call(cmd)
+
+    passes: List[Dict[str, Any]] = []
+    steps_before = engine.stats.steps
+    barrier()
+    t0_wall = time.time()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        c = dict(cmd)
+        if args.out_dir and k == args.steps - 1:
+            c["run_dir"] = os.path.join(args.out_dir, f"rank{rank}")
+            c["trace"] = True
+            c["token_events"] = True
+        passes.append(child.call(c))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t1_wall = time.time()
+    engine_steps = engine.stats.steps - steps_before
+    samples = sampler.stop()
+
+    # ---- reduce across ranks -------------------------------------------------
+    def cat(key: str) -> "np.ndarray":
+        return np.array([np.nan if v is None else v for p in passes for v in p[key]], dtype=np.float64)
+
+    local = {k: cat(k) for k in ("latency_ms", "ttfb_ms", "ttft_ms", "status", "completion_tokens", "total_tokens")}
+    itl = cat("itl_ms")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed_max = float(el.item())
+
+    n_local = local["latency_ms"].size
+    mat = torch.from_numpy(np.stack([local[k] for k in ("latency_ms", "ttfb_ms", "ttft_ms", "status", "completion_tokens", "total_tokens")])).to(device)
+    itl_fixed = np.full(args.steps * args.requests * max(1, args.max_tokens), np.nan)
+    itl_fixed[: min(itl.size, itl_fixed.size)] = itl[: itl_fixed.size]
+    itl_t = torch.from_numpy(itl_fixed).to(device)
+    if world > 1:
+        g = torch.empty((world,) + tuple(mat.shape), dtype=mat.dtype, device=device)
+        dist.all_gather_into_tensor(g.view(-1), mat.reshape(-1))
+        mat_all = g.permute(1, 0, 2).reshape(mat.shape[0], world * n_local)
+        gi = torch.empty((world, itl_t.numel()), dtype=itl_t.dtype, device=device)
+        dist.all_gather_into_tensor(gi.view(-1), itl_t)
+        itl_all = gi.reshape(1, -1)
+    else:
+        mat_all, itl_all = mat, itl_t.reshape(1, -1)
+
+    # lock-step telemetry table over RCCL
+    from kvmini.parallel.telemetry_gather import TelemetryGather, table_to_power_json
+
+    tw = torch.tensor([t0_wall, t1_wall], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.broadcast(tw, 0)
+    tg = TelemetryGather(device=device)
+    table = tg.gather_table(samples, float(tw[0]), float(tw[1]), 0.1)
+
+    rc = 0
+    if rank == 0:
+        from kvmini.ops import hist_quantile as hq
+
+        status = mat_all[3]
+        ok = status == 200
+        lat = torch.where(ok, mat_all[0], torch.full_like(mat_all[0], float("nan")))
+        ttfb = torch.where(ok, mat_all[1], torch.full_like(mat_all[1], float("nan")))
+        ttft = torch.where(ok, mat_all[2], torch.full_like(mat_all[2], float("nan")))
+        q, stats = hq.batched_quantiles(torch.stack([lat, ttfb, ttft]), (0.5, 0.95, 0.99), return_stats=True)
+        qi, istats = hq.batched_quantiles(itl_all, (0.5, 0.95, 0.99), return_stats=True)
+        n_ok = int(ok.sum().item())
+        n_total = int(status.numel())
+        completion = float(mat_all[4][ok].sum().item())
+        total_tokens = float(mat_all[5][ok].sum().item())
+        rps = n_ok / elapsed_max
+
+        # cost: resource-seconds model of cost_estimator (GPU + CPU + memory share, +overhead)
+        from kvmini.cost.pricing import load_pricing
+
+        pricing = load_pricing(os.path.join(ROOT, "cost.yaml"))
+        gpu_hourly = args.gpu_hourly if args.gpu_hourly is not None else pricing.gpu_hourly("AMD_Instinct_MI355X")
+        cpu_cores, mem_gib = 8.0, 64.0
+        dollars = world * elapsed_max / 3600.0 * (gpu_hourly + cpu_cores * pricing.cpu_hourly_per_core + mem_gib * pricing.mem_hourly_per_gib) * (1.0 + pricing.overhead_fraction)
+        cost_1k = dollars / total_tokens * 1000.0 if total_tokens else None
+
+        pj = table_to_power_json(table, 0.1)
+        watts = [s["watts"] for s in pj["samples"] if s["watts"] is not None]
+        wh = None
+        if len(watts) >= 2:
+            from kvmini.telemetry.energy import PowerSample, trapezoidal_wh
+
+            wh = trapezoidal_wh([PowerSample(s["ts_s"], s["watts"]) for s in pj["samples"]], float(tw[0]), float(tw[1]))
+        wh_1k = wh / total_tokens * 1000.0 if wh and total_tokens else None
+
+        p95 = float(q[0][1])
+        ttft_mean = stats[1].get("mean")
+        out = {
+            "metric": "aggregate RPS (with p95 latency ms, TTFT ms, $/1k-tok), Llama-3-8B @ 500req/c20",
+            "value": round(rps, 3),
+            "unit": "requests/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / args.steps * 1000.0, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": round(rps / BASELINE["rps"], 4),
+            "dtype": "bf16",
+            "data": "synthetic prompts ('Hello, world!' chat, 14 prompt tokens), random-init weights, synthetic tokenizer",
+            "config": {
+                "model": args.model,
+                "requests_per_step_per_gpu": args.requests,
+                "concurrency_per_gpu": args.concurrency,
+                "max_tokens": args.max_tokens,
+                "global_batch": args.concurrency * world,
+                "seq_len": 14 + args.max_tokens,
+                "pattern": args.pattern,
+                "target_rps": "saturate" if args.target_rps <= 0 else args.target_rps,
+                "stream": True,
+                "parallelism": f"dp{world}",
+                "kernels": args.kernels,
+                "hip_graphs": not args.no_graphs,
+            },
+            "p50_ms": float(q[0][0]),
+            "p95_ms": p95,
+            "p99_ms": float(q[0][2]),
+            "ttft_mean_ms": ttft_mean,
+            "ttft_p50_ms": float(q[1][0]),
+            "ttft_p95_ms": float(q[1][1]),
+            "first_content_token_mean_ms": stats[2].get("mean"),
+            "itl_p50_ms": float(qi[0][0]),
+            "itl_p95_ms": float(qi[0][1]),
+            "itl_p99_ms": float(qi[0][2]),
+            "tokens_per_sec": completion / elapsed_max,
+            "error_rate": (n_total - n_ok) / n_total if n_total else None,
+            "cost_per_1k_tokens": cost_1k,
+            "gpu_hourly_usd": gpu_hourly,
+            "gpu_power_watts_avg": sum(watts) / len(watts) if watts else None,
+            "energy_wh_per_1k_tokens": wh_1k,
+            "engine_step_ms": round(engine.stats.busy_s / max(1, engine.stats.steps) * 1000.0, 4),
+            "engine_steps_timed": engine_steps,
+            "model_load_s": round(engine.load_s, 2),
+            "graph_warmup_s": round(engine.warm_s, 2),
+            "vs_baseline_detail": {
+                "rps": round(rps / BASELINE["rps"], 3),
+                "p95_ms": round(p95 / BASELINE["p95_ms"], 3),
+                "ttft_ms": round(ttft_mean / BASELINE["ttft_ms"], 3) if ttft_mean else None,
+                "cost_per_1k_tokens": round(cost_1k / BASELINE["cost_per_1k_tokens"], 4) if cost_1k else None,
+                "wh_per_1k_tokens": round(wh_1k / BASELINE["wh_per_1k_tokens"], 5) if wh_1k else None,
+            },
+            "quantile_engine": "hip:kv_radix_select",
+            "telemetry": pj["source"] if watts else "unavailable",
+        }
+        if n_ok == 0:
+            out["error"] = passes[-1].get("errors")
+            rc = 1
+        if args.out_dir:
+            from kvmini.utils import write_json
+
+            write_json(os.path.join(args.out_dir, "power.json"), pj)
+            write_json(os.path.join(args.out_dir, "bench.json"), out)
+        print(json.dumps(out), flush=True)
+
+    child.close()
+    stop_server()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,199 @@
+// Python bindings (torch extension `kvmini._C`) of the gfx950 kernels.  Every function
+// validates shapes/dtypes/devices on the host — an out-of-bounds access in a kernel can
+// take the whole node down — and launches on PyTorch's current HIP stream, so calls are
+// capturable into a HIP graph.
+
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime.h>
+
+extern "C" {
+size_t kv_stream_state_bytes();
+size_t kv_radix_state_bytes();
+int kv_stream_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, unsigned int* hist, void* state, float lo_log2, float hi_log2,
+                   hipStream_t stream);
+int kv_radix_init(const void* stream_state, void* st, const double* ps, int n_ps, int n_metrics, hipStream_t stream);
+int kv_radix_select(const void* x, long long n, long long row_stride, int n_metrics, int dtype, void* st, unsigned int* hist, hipStream_t stream);
+int kv_equal_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, const void* state, unsigned long long* out, int n_bins,
+                  hipStream_t stream);
+int kv_energy_trapz(const double* ts, const double* watts, const int* n, int n_series, int max_samples, double t0, double t1, double* out, hipStream_t stream);
+int kv_add_rmsnorm(const void* x, void* residual, const void* w, void* y, int T, int H, float eps, hipStream_t stream);
+int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache, const int* slot_mapping, int T,
+                     int nh, int nkv, int hd, int block_size, hipStream_t stream);
+int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                       const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale, hipStream_t stream);
+int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
+int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
+int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
+                   hipStream_t stream);
+int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
+}
+
+namespace {
+
+hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+
+void check(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed: ", rc < 0 ? "unsupported shape/arguments" : hipGetErrorString((hipError_t)rc));
+}
+
+#define CHECK_DEV(t) TORCH_CHECK((t).is_cuda(), #t " must be a GPU tensor")
+#define CHECK_CONTIG(t) TORCH_CHECK((t).is_contiguous(), #t " must be contiguous")
+#define CHECK_BF16(t) TORCH_CHECK((t).scalar_type() == at::kBFloat16, #t " must be bfloat16")
+#define CHECK_I32(t) TORCH_CHECK((t).scalar_type() == at::kInt, #t " must be int32")
+
+int sample_dtype(const at::Tensor& x) {
+  if (x.scalar_type() == at::kFloat) return 0;
+  if (x.scalar_type() == at::kDouble) return 1;
+  TORCH_CHECK(false, "samples must be float32 or float64");
+}
+
+// ---- latency statistics ------------------------------------------------------------
+int64_t stream_state_bytes() { return (int64_t)kv_stream_state_bytes(); }
+int64_t radix_state_bytes() { return (int64_t)kv_radix_state_bytes(); }
+
+void stream_hist(at::Tensor x, int64_t n, at::Tensor hist, at::Tensor state, double lo_log2, double hi_log2) {
+  CHECK_DEV(x); CHECK_DEV(hist); CHECK_DEV(state); CHECK_CONTIG(x); CHECK_CONTIG(hist); CHECK_CONTIG(state);
+  TORCH_CHECK(x.dim() == 2, "x must be [n_metrics, row_stride]");
+  const int64_t m = x.size(0);
+  TORCH_CHECK(n >= 0 && n <= x.size(1), "n exceeds the row length");
+  TORCH_CHECK(hist.scalar_type() == at::kInt && hist.numel() == m * 2048, "hist must be int32 [n_metrics, 2048]");
+  TORCH_CHECK(state.scalar_type() == at::kByte && state.numel() == m * stream_state_bytes(), "state must be uint8 [n_metrics * state_bytes]");
+  TORCH_CHECK(hi_log2 > lo_log2, "empty bin range");
+  check(kv_stream_hist(x.data_ptr(), n, x.size(1), (int)m, sample_dtype(x), (unsigned int*)hist.data_ptr(), state.data_ptr(), (float)lo_log2, (float)hi_log2,
+                       cur_stream()),
+        "kv_stream_hist");
+}
+
+void radix_select(at::Tensor x, int64_t n, at::Tensor stream_state, at::Tensor ps, at::Tensor rstate, at::Tensor hist) {
+  CHECK_DEV(x); CHECK_DEV(stream_state); CHECK_DEV(ps); CHECK_DEV(rstate); CHECK_DEV(hist);
+  CHECK_CONTIG(x); CHECK_CONTIG(stream_state); CHECK_CONTIG(ps); CHECK_CONTIG(rstate); CHECK_CONTIG(hist);
+  TORCH_CHECK(x.dim() == 2, "x must be [n_metrics, row_stride]");
+  const int64_t m = x.size(0);
+  TORCH_CHECK(n >= 0 && n <= x.size(1), "n exceeds the row length");
+  TORCH_CHECK(ps.scalar_type() == at::kDouble && ps.numel() >= 1 && ps.numel() <= 4, "ps must be float64 with 1..4 quantile levels");
+  TORCH_CHECK(stream_state.scalar_type() == at::kByte && stream_state.numel() == m * stream_state_bytes(), "bad stream state size");
+  TORCH_CHECK(rstate.scalar_type() == at::kByte && rstate.numel() == m * radix_state_bytes(), "bad radix state size");
+  TORCH_CHECK(hist.scalar_type() == at::kInt && hist.numel() == m * 8 * 2048, "hist must be int32 [n_metrics, 8, 2048] (zeroed)");
+  auto s = cur_stream();
+  check(kv_radix_init(stream_state.data_ptr(), rstate.data_ptr(), (const double*)ps.data_ptr(), (int)ps.numel(), (int)m, s), "kv_radix_init");
+  check(kv_radix_select(x.data_ptr(), n, x.size(1), (int)m, sample_dtype(x), rstate.data_ptr(), (unsigned int*)hist.data_ptr(), s), "kv_radix_select");
+}
+
+void equal_hist(at::Tensor x, int64_t n, at::Tensor stream_state, at::Tensor out, int64_t n_bins) {
+  CHECK_DEV(x); CHECK_DEV(stream_state); CHECK_DEV(out); CHECK_CONTIG(x); CHECK_CONTIG(stream_state); CHECK_CONTIG(out);
+  TORCH_CHECK(x.dim() == 2, "x must be [n_metrics, row_stride]");
+  const int64_t m = x.size(0);
+  TORCH_CHECK(n >= 0 && n <= x.size(1), "n exceeds the row length");
+  TORCH_CHECK(n_bins >= 1 && n_bins <= 64, "n_bins must be in 1..64");
+  TORCH_CHECK(out.scalar_type() == at::kLong && out.numel() == m * 64, "out must be int64 [n_metrics, 64] (zeroed)");
+  TORCH_CHECK(stream_state.scalar_type() == at::kByte && stream_state.numel() == m * stream_state_bytes(), "bad stream state size");
+  check(kv_equal_hist(x.data_ptr(), n, x.size(1), (int)m, sample_dtype(x), stream_state.data_ptr(), (unsigned long long*)out.data_ptr(), (int)n_bins, cur_stream()),
+        "kv_equal_hist");
+}
+
+at::Tensor energy_trapz(at::Tensor ts, at::Tensor watts, at::Tensor n, double t0, double t1) {
+  CHECK_DEV(ts); CHECK_DEV(watts); CHECK_DEV(n); CHECK_CONTIG(ts); CHECK_CONTIG(watts); CHECK_CONTIG(n); CHECK_I32(n);
+  TORCH_CHECK(ts.scalar_type() == at::kDouble && watts.scalar_type() == at::kDouble, "ts/watts must be float64");
+  TORCH_CHECK(ts.dim() == 2 && watts.sizes() == ts.sizes() && n.numel() == ts.size(0), "shapes: ts/watts [series, samples], n [series]");
+  TORCH_CHECK(n.max().item<int>() <= ts.size(1) && n.min().item<int>() >= 0, "n out of range");
+  auto out = at::zeros({ts.size(0), 3}, ts.options());
+  check(kv_energy_trapz((const double*)ts.data_ptr(), (const double*)watts.data_ptr(), (const int*)n.data_ptr(), (int)ts.size(0), (int)ts.size(1), t0, t1,
+                        (double*)out.data_ptr(), cur_stream()),
+        "kv_energy_trapz");
+  return out;
+}
+
+// ---- engine ops ----------------------------------------------------------------------
+void add_rmsnorm(at::Tensor x, at::Tensor residual, at::Tensor w, at::Tensor y, double eps) {
+  CHECK_DEV(x); CHECK_BF16(x); CHECK_BF16(residual); CHECK_BF16(w); CHECK_BF16(y);
+  CHECK_CONTIG(x); CHECK_CONTIG(residual); CHECK_CONTIG(w); CHECK_CONTIG(y);
+  TORCH_CHECK(x.dim() == 2 && residual.sizes() == x.sizes() && y.sizes() == x.sizes() && w.numel() == x.size(1), "add_rmsnorm shape mismatch");
+  TORCH_CHECK(x.size(1) % 8 == 0 && x.size(1) <= 32768, "hidden size must be a multiple of 8 and <= 32768");
+  check(kv_add_rmsnorm(x.data_ptr(), residual.data_ptr(), w.data_ptr(), y.data_ptr(), (int)x.size(0), (int)x.size(1), (float)eps, cur_stream()), "kv_add_rmsnorm");
+}
+
+void rope_kv_write(at::Tensor qkv, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache, at::Tensor slot_mapping,
+                   int64_t nh, int64_t nkv, int64_t hd) {
+  CHECK_DEV(qkv); CHECK_BF16(qkv); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_I32(positions); CHECK_I32(slot_mapping);
+  CHECK_CONTIG(qkv); CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t); CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping);
+  const int64_t T = qkv.size(0);
+  TORCH_CHECK(qkv.dim() == 2 && qkv.size(1) == (nh + 2 * nkv) * hd, "qkv must be [T, (nh + 2 nkv) * hd]");
+  TORCH_CHECK(positions.numel() >= T && slot_mapping.numel() >= T, "positions/slot_mapping shorter than T");
+  TORCH_CHECK(cos_t.scalar_type() == at::kFloat && sin_t.scalar_type() == at::kFloat && cos_t.dim() == 2 && cos_t.size(1) == hd / 2 && sin_t.sizes() == cos_t.sizes(),
+              "cos/sin must be float32 [max_pos, hd/2]");
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(1) == nkv && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  // positions and slots are device data: bounds are guaranteed by the scheduler (positions < max_model_len = rows of cos/sin; slots < blocks * block_size)
+  check(kv_rope_kv_write(qkv.data_ptr(), (const int*)positions.data_ptr(), (const float*)cos_t.data_ptr(), (const float*)sin_t.data_ptr(), k_cache.data_ptr(),
+                         v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), cur_stream()),
+        "kv_rope_kv_write");
+}
+
+void paged_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor out,
+                     double scale) {
+  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
+  CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tok_seq); CHECK_CONTIG(ctx_lens);
+  TORCH_CHECK(q.dim() == 3 && q.stride(2) == 1 && q.stride(1) == q.size(2), "q must be [T, nh, hd] with contiguous heads (row stride free)");
+  const int64_t T = q.size(0), nh = q.size(1), hd = q.size(2);
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  const int64_t nkv = k_cache.size(1);
+  TORCH_CHECK(block_tables.dim() == 2 && out.dim() == 2 && out.size(0) == T && out.size(1) == nh * hd, "bad block_tables/out shape");
+  TORCH_CHECK(tok_seq.numel() >= T && ctx_lens.numel() >= T, "tok_seq/ctx_lens shorter than T");
+  check(kv_paged_attention(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1),
+                           (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(), out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd,
+                           (int)k_cache.size(2), (float)scale, cur_stream()),
+        "kv_paged_attention");
+}
+
+void argmax(at::Tensor logits, at::Tensor out) {
+  CHECK_DEV(logits); CHECK_BF16(logits); CHECK_DEV(out); CHECK_CONTIG(out);
+  TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1, "logits must be [S, V] with unit inner stride");
+  TORCH_CHECK(out.scalar_type() == at::kLong && out.numel() >= logits.size(0), "out must be int64 with >= S elements");
+  check(kv_argmax(logits.data_ptr(), logits.stride(0), (int)logits.size(0), (int)logits.size(1), (long long*)out.data_ptr(), cur_stream()), "kv_argmax");
+}
+
+void swiglu_interleaved(at::Tensor gu, at::Tensor act) {
+  CHECK_DEV(gu); CHECK_BF16(gu); CHECK_BF16(act); CHECK_CONTIG(gu); CHECK_CONTIG(act);
+  TORCH_CHECK(gu.dim() == 2 && act.dim() == 2 && gu.size(0) == act.size(0) && gu.size(1) == 2 * act.size(1), "gu [T, 2I], act [T, I]");
+  check(kv_swiglu_interleaved(gu.data_ptr(), act.data_ptr(), (int)gu.size(0), (int)act.size(1), cur_stream()), "kv_swiglu_interleaved");
+}
+
+// y[M, N(or N/2 with swiglu)] = x[M, K] @ W[N, K]^T.  x rows may be strided; M in {16,32,48,64}.
+void skinny_gemm(at::Tensor W, at::Tensor x, at::Tensor y, bool swiglu, bool packed, int64_t waves) {
+  CHECK_DEV(W); CHECK_BF16(W); CHECK_BF16(x); CHECK_BF16(y); CHECK_CONTIG(W);
+  TORCH_CHECK(W.dim() == 2 && x.dim() == 2 && y.dim() == 2 && x.stride(1) == 1 && y.stride(1) == 1, "W [N, K], x [M, K], y [M, N]");
+  const int64_t N = W.size(0), K = W.size(1), M = x.size(0);
+  TORCH_CHECK(x.size(1) == K && y.size(0) == M && y.size(1) == (swiglu ? N / 2 : N), "skinny_gemm shape mismatch");
+  TORCH_CHECK(x.stride(0) % 8 == 0 && y.stride(0) % 4 == 0, "row strides must keep 16-byte (x) / 8-byte (y) alignment");
+  TORCH_CHECK(waves == 0 || waves == 4 || waves == 8, "waves must be 0, 4 or 8");
+  check(kv_skinny_gemm(W.data_ptr(), x.data_ptr(), y.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), y.stride(0), swiglu ? 1 : 0, packed ? 1 : 0, (int)waves,
+                       cur_stream()),
+        "kv_skinny_gemm");
+}
+
+at::Tensor pack_weight(at::Tensor W) {
+  CHECK_DEV(W); CHECK_BF16(W); CHECK_CONTIG(W);
+  TORCH_CHECK(W.dim() == 2, "W must be [N, K]");
+  auto Wp = at::empty_like(W);
+  check(kv_pack_weight(W.data_ptr(), Wp.data_ptr(), (int)W.size(0), (int)W.size(1), cur_stream()), "kv_pack_weight");
+  return Wp;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "kvmini gfx950 kernels";
+  m.def("stream_state_bytes", &stream_state_bytes);
+  m.def("radix_state_bytes", &radix_state_bytes);
+  m.def("stream_hist", &stream_hist);
+  m.def("radix_select", &radix_select);
+  m.def("equal_hist", &equal_hist);
+  m.def("energy_trapz", &energy_trapz);
+  m.def("add_rmsnorm", &add_rmsnorm);
+  m.def("rope_kv_write", &rope_kv_write);
+  m.def("paged_attention", &paged_attention);
+  m.def("argmax", &argmax);
+  m.def("swiglu_interleaved", &swiglu_interleaved);
+  m.def("skinny_gemm", &skinny_gemm);
+  m.def("pack_weight", &pack_weight);
+}

@@ -1,0 +1,389 @@
+// Memory-bound decoder kernels of the native engine for gfx950 (MI355X):
+// fused residual-add + RMSNorm, RoPE + paged-KV write, ragged paged attention, argmax.
+//
+// All activations are token-major bf16 ([T, hidden]); T mixes decode tokens and
+// prefill-chunk tokens of many sequences.  Loads/stores are 16 bytes per lane
+// (8 bf16), math is fp32, wavefronts are 64 lanes, workgroups are 256 threads.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) unsigned short bf16x8;  // 16 bytes
+
+__device__ inline float bf2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+__device__ inline unsigned short f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ inline float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------
+// residual' = bf16(residual + x);  y = bf16(rmsnorm(residual') * w).  One workgroup per
+// token row; H must be a multiple of 8.  x/residual/y may not alias each other except
+// that residual is updated in place.
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ residual,
+                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ y, int H, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);               // 4 floats
+  unsigned short* row = reinterpret_cast<unsigned short*>(smem + 16);  // H bf16: the summed row
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const bf16x8* xv = reinterpret_cast<const bf16x8*>(x + (long long)t * H);
+  bf16x8* rv = reinterpret_cast<bf16x8*>(residual + (long long)t * H);
+  bf16x8* rowv = reinterpret_cast<bf16x8*>(row);
+  const int nv = H >> 3;
+  float ss = 0.f;
+  for (int i = tid; i < nv; i += 256) {
+    bf16x8 a = xv[i], b = rv[i], c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned short s = f2bf(bf2f(a[j]) + bf2f(b[j]));
+      c[j] = s;
+      float f = bf2f(s);
+      ss += f * f;
+    }
+    rv[i] = c;
+    rowv[i] = c;
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+  const bf16x8* wv = reinterpret_cast<const bf16x8*>(w);
+  bf16x8* yv = reinterpret_cast<bf16x8*>(y + (long long)t * H);
+  for (int i = tid; i < nv; i += 256) {
+    bf16x8 c = rowv[i], g = wv[i], o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(c[j]) * inv * bf2f(g[j]));
+    yv[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// RoPE (rotate-half pairing) on the q and k parts of the fused qkv row, in place for q;
+// rotated k and v are scattered into the paged cache
+//   cache[block][kv_head][slot_in_block][head_dim],  slot = slot_mapping[t] (-1: skip).
+// One workgroup per token; a thread task = 8 consecutive dims of the first half of one
+// head together with the matching 8 dims of the second half.
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __restrict__ qkv, const int* __restrict__ positions,
+                                                            const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                            unsigned short* __restrict__ k_cache, unsigned short* __restrict__ v_cache,
+                                                            const int* __restrict__ slot_mapping, int nh, int nkv, int hd, int block_size) {
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int half = hd >> 1;
+  const int tasks_per_head = half >> 3;
+  const int width = (nh + 2 * nkv) * hd;
+  unsigned short* row = qkv + (long long)t * width;
+  const int pos = positions[t];
+  const int slot = slot_mapping[t];
+  const float* cs = cos_t + (long long)pos * half;
+  const float* sn = sin_t + (long long)pos * half;
+  const int blk = slot >= 0 ? slot / block_size : 0, off = slot >= 0 ? slot % block_size : 0;
+
+  const int rot_tasks = (nh + nkv) * tasks_per_head;
+  for (int task = tid; task < rot_tasks; task += 256) {
+    const int head = task / tasks_per_head, d0 = (task % tasks_per_head) << 3;
+    unsigned short* hp = row + head * hd;
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(hp + d0);
+    bf16x8 b = *reinterpret_cast<const bf16x8*>(hp + half + d0);
+    bf16x8 oa, ob;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float c = cs[d0 + j], s = sn[d0 + j];
+      float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
+      oa[j] = f2bf(x1 * c - x2 * s);
+      ob[j] = f2bf(x2 * c + x1 * s);
+    }
+    if (head < nh) {
+      *reinterpret_cast<bf16x8*>(hp + d0) = oa;
+      *reinterpret_cast<bf16x8*>(hp + half + d0) = ob;
+    } else if (slot >= 0) {
+      const int g = head - nh;
+      unsigned short* kp = k_cache + (((long long)blk * nkv + g) * block_size + off) * hd;
+      *reinterpret_cast<bf16x8*>(kp + d0) = oa;
+      *reinterpret_cast<bf16x8*>(kp + half + d0) = ob;
+    }
+  }
+  if (slot >= 0) {
+    const int v_tasks = nkv * (hd >> 3);
+    const unsigned short* vsrc = row + (nh + nkv) * hd;
+    for (int task = tid; task < v_tasks; task += 256) {
+      const int g = task / (hd >> 3), d0 = (task % (hd >> 3)) << 3;
+      unsigned short* vp = v_cache + (((long long)blk * nkv + g) * block_size + off) * hd;
+      *reinterpret_cast<bf16x8*>(vp + d0) = *reinterpret_cast<const bf16x8*>(vsrc + g * hd + d0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Ragged paged attention.  One workgroup per (token, kv head); the REP = nh/nkv query
+// heads of the group share every K/V load.  Each of the 4 waves walks KV blocks
+// w, w+4, ... of the token's sequence with an online softmax, then the waves merge
+// through LDS.  Specialised for head_dim 128, block_size 16, REP <= 8 (host checks).
+//
+// Lane roles inside a wave, per 16-token KV block:
+//   QK: lane = 4*token + c; the lane dots dims [32c, 32c+32) of the 16-B-vector K row
+//       against the REP query heads; two xor-shuffles finish the 128-dim dot.
+//   PV: lane = 16*tg + dv; it owns output dims [8dv, 8dv+8) and tokens {tg, tg+4, tg+8,
+//       tg+12} of the block; the 4 token groups are summed once at the end.
+template <int REP>
+__global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
+                                                              const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
+                                                              const int* __restrict__ block_tables, int max_blocks_per_seq,
+                                                              const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
+                                                              unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
+  constexpr int HD = 128, BS = 16;
+  __shared__ float p_lds[4][REP][BS];        // per-wave probabilities of the current block
+  __shared__ float m_lds[4][REP], l_lds[4][REP];
+  __shared__ float o_lds[4][REP][HD];
+  const int t = blockIdx.x, g = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ctx = ctx_lens[t];
+  unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
+  if (ctx <= 0) {  // padding token
+    for (int i = tid; i < REP * HD; i += 256) orow[i] = 0;
+    return;
+  }
+  const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
+  const int n_blocks = (ctx + BS - 1) / BS;
+
+  // this lane's 32-dim slice of the REP query heads, pre-scaled by scale*log2(e)
+  const int qk_tok = lane >> 2, qk_c = lane & 3;
+  float qf[REP][32];
+  {
+    const unsigned short* qrow = q + (long long)t * q_row_stride + (long long)g * REP * HD + qk_c * 32;
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(qrow + h * HD + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[h][v * 8 + j] = bf2f(a[j]) * scale_log2e;
+      }
+  }
+  const int pv_tg = lane >> 4, pv_dv = lane & 15;
+  float acc[REP][8];
+  float m_run[REP], l_run[REP];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) {
+    m_run[h] = -1e30f; l_run[h] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+  }
+
+  for (int b = wave; b < n_blocks; b += 4) {
+    const long long base = ((long long)bt[b] * nkv + g) * BS * HD;
+    // ---- QK^T
+    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
+    bf16x8 kv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+    // V loads issued early: they do not depend on the softmax
+    bf16x8 vv[4];
+    const unsigned short* vp = v_cache + base + pv_dv * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+    float s[REP];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += qf[h][v * 8 + j] * bf2f(kv[v][j]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      s[h] = (b * BS + qk_tok < ctx) ? d : -1e30f;
+    }
+    // ---- online softmax over the block's 16 tokens (token index lives in lane bits 2..5)
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float mx = s[h];
+      for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float m_new = fmaxf(m_run[h], mx);
+      const float p = exp2f(s[h] - m_new);
+      float ps = p;
+      for (int o = 4; o < 64; o <<= 1) ps += __shfl_xor(ps, o, 64);
+      const float corr = exp2f(m_run[h] - m_new);
+      l_run[h] = l_run[h] * corr + ps;
+      m_run[h] = m_new;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[h][j] *= corr;
+      if (qk_c == 0) p_lds[wave][h][qk_tok] = p;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): p_lds visible to the wave (single wave: no barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    // ---- PV
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tok = pv_tg + 4 * i;
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float p = p_lds[wave][h][tok];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[h][j] += p * bf2f(vv[i][j]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- sum the 4 token groups inside the wave (lanes l, l^16, l^32, ...)
+#pragma unroll
+  for (int h = 0; h < REP; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[h][j];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[h][j] = v;
+    }
+  if (pv_tg == 0) {
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o_lds[wave][h][pv_dv * 8 + j] = acc[h][j];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int h = 0; h < REP; ++h) { m_lds[wave][h] = m_run[h]; l_lds[wave][h] = l_run[h]; }
+  }
+  __syncthreads();
+  // ---- merge the 4 waves; thread i handles output element i (REP*128 elements)
+  for (int i = tid; i < REP * HD; i += 256) {
+    const int h = i / HD, d = i % HD;
+    float m = fmaxf(fmaxf(m_lds[0][h], m_lds[1][h]), fmaxf(m_lds[2][h], m_lds[3][h]));
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float c = exp2f(m_lds[w][h] - m);
+      num += o_lds[w][h][d] * c;
+      den += l_lds[w][h] * c;
+    }
+    orow[i] = f2bf(den > 0.f ? num / den : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Row-wise argmax of bf16 logits [S, V] -> int64 ids.  One 1024-thread workgroup per row.
+__global__ __launch_bounds__(1024) void argmax_kernel(const unsigned short* __restrict__ logits, long long row_stride, int V, long long* __restrict__ out) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const unsigned short* row = logits + (long long)r * row_stride;
+  float best = -INFINITY;
+  int besti = 0;
+  const int nv = V >> 3;
+  const bool aligned = ((((uintptr_t)row) & 15) == 0);
+  if (aligned) {
+    const bf16x8* rv = reinterpret_cast<const bf16x8*>(row);
+    for (int i = tid; i < nv; i += 1024) {
+      bf16x8 a = rv[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = bf2f(a[j]);
+        if (f > best) { best = f; besti = i * 8 + j; }
+      }
+    }
+  }
+  for (int i = (aligned ? nv * 8 : 0) + tid; i < V; i += 1024) {
+    float f = bf2f(row[i]);
+    if (f > best) { best = f; besti = i; }
+  }
+  // first-index tie-break, like torch.argmax
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+    out[r] = besti;
+  }
+}
+
+// silu(gate) * up for the group-of-16 interleaved layout: gu [T, 2I] -> act [T, I]
+__global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ act, int I) {
+  const int t = blockIdx.y;
+  const int grp = blockIdx.x * 256 + threadIdx.x;  // one thread = 8 outputs (half a 16-group)
+  const int n_tasks = I >> 3;
+  if (grp >= n_tasks) return;
+  const int g16 = grp >> 1, hsel = grp & 1;
+  const unsigned short* src = gu + (long long)t * 2 * I + g16 * 32 + hsel * 8;
+  bf16x8 a = *reinterpret_cast<const bf16x8*>(src);
+  bf16x8 b = *reinterpret_cast<const bf16x8*>(src + 16);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float gte = bf2f(a[j]), up = bf2f(b[j]);
+    o[j] = f2bf(gte / (1.f + __expf(-gte)) * up);
+  }
+  *reinterpret_cast<bf16x8*>(act + (long long)t * I + g16 * 16 + hsel * 8) = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kv_add_rmsnorm(const void* x, void* residual, const void* w, void* y, int T, int H, float eps, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (H % 8) return -1;
+  size_t smem = 16 + (size_t)H * 2;
+  hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(T), dim3(256), smem, stream, (const unsigned short*)x, (unsigned short*)residual, (const unsigned short*)w,
+                     (unsigned short*)y, H, eps);
+  return (int)hipGetLastError();
+}
+
+int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache, const int* slot_mapping, int T,
+                     int nh, int nkv, int hd, int block_size, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (hd % 16) return -1;
+  hipLaunchKernelGGL(rope_kv_write_kernel, dim3(T), dim3(256), 0, stream, (unsigned short*)qkv, positions, cos_t, sin_t, (unsigned short*)k_cache,
+                     (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size);
+  return (int)hipGetLastError();
+}
+
+int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                       const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale,
+                       hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (hd != 128 || block_size != 16 || nh % nkv) return -1;
+  const int rep = nh / nkv;
+  const float sl = scale * 1.4426950408889634f;
+  dim3 grid(T, nkv), block(256);
+#define KV_LAUNCH(R)                                                                                                                          \
+  hipLaunchKernelGGL(paged_attention_kernel<R>, grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
+                     (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, sl)
+  switch (rep) {
+    case 1: KV_LAUNCH(1); break;
+    case 2: KV_LAUNCH(2); break;
+    case 4: KV_LAUNCH(4); break;
+    case 8: KV_LAUNCH(8); break;
+    default: return -1;
+  }
+#undef KV_LAUNCH
+  return (int)hipGetLastError();
+}
+
+int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream) {
+  if (S <= 0) return 0;
+  hipLaunchKernelGGL(argmax_kernel, dim3(S), dim3(1024), 0, stream, (const unsigned short*)logits, row_stride, V, out);
+  return (int)hipGetLastError();
+}
+
+int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (I % 16) return -1;
+  dim3 grid(((I >> 3) + 255) / 256, T);
+  hipLaunchKernelGGL(swiglu_interleaved_kernel, grid, dim3(256), 0, stream, (const unsigned short*)gu, (unsigned short*)act, I);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

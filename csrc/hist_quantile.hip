@@ -1,0 +1,462 @@
+// Latency statistics kernels for gfx950 (MI355X): LDS-binned histograms and exact quantiles.
+//
+// What this replaces: the reference reduces request/token latencies on the CPU by
+// sorting a Python list once per percentile (analyze.py:59-81, ~25 sorts per run) and
+// by a Python loop for its 20-bin histograms (analyze.py:84-122).  At per-token
+// granularity (10^6..10^8 inter-token gaps per run) that is the harness's only
+// compute-bound path, so it lives on the GPU:
+//
+//   kv_stream_hist      streaming histogram with 2048 log-spaced bins per metric, plus
+//                        count / sum / min / max, accumulated into persistent device
+//                        state (launch it on every new slice of token events; the state
+//                        is never re-read from the samples).  Per-wavefront private
+//                        sub-histograms live in LDS (4 waves x 2048 bins x 4 B = 32 KiB of
+//                        the CU's 160 KiB) and are updated with LDS atomics; one global
+//                        atomic per non-empty bin per workgroup flushes them.
+//   kv_radix_hist/scan  exact order statistics by MSD radix select on order-preserving
+//                        integer keys: 11-bit digits, i.e. the same 2048-bin LDS histogram,
+//                        restricted to samples whose higher digits match the prefix of a
+//                        target rank; a single-workgroup scan kernel turns the bin counts
+//                        into the next prefix.  Up to 8 ranks are tracked at once (floor and
+//                        ceil rank of p50/p95/p99), so three quantiles of 10^8 doubles cost 6
+//                        streaming passes and no sort.  The result is bit-exact: the CPU
+//                        interpolates between the two selected samples exactly like
+//                        analyze.py does.
+//   kv_equal_hist       the 20-bin equal-width histogram over [min, max] (last bin closed),
+//                        LDS-binned the same way, with min/max read from device memory.
+//
+// Batching: samples are a row-major [n_metrics, row_stride] matrix; NaN entries are
+// skipped (analyze.py drops NaNs), so ragged metrics are NaN-padded and one launch with
+// grid.y = metric handles latency / TTFT / TLLT / generation / per-token x all / cold /
+// warm together.
+//
+// Wavefront width is 64 on CDNA; workgroups are 256 threads = 4 waves, one per SIMD.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KV_BINS 2048
+#define KV_WAVES 4
+#define KV_THREADS 256
+#define KV_MAX_RANKS 8
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// order-preserving keys
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> {
+  using type = uint32_t;
+  static constexpr int bits = 32;
+  __device__ static inline uint32_t key(float v) {
+    uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  }
+};
+template <> struct KeyOf<double> {
+  using type = uint64_t;
+  static constexpr int bits = 64;
+  __device__ static inline uint64_t key(double v) {
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+  }
+};
+
+// log-spaced bin of a positive value: 2048 bins over [2^lo_log2, 2^hi_log2)
+__device__ inline int log_bin(float v, float lo_log2, float inv_step) {
+  if (!(v > 0.f)) return 0;
+  float f = (__log2f(v) - lo_log2) * inv_step;
+  int b = (int)f;
+  return b < 0 ? 0 : (b >= KV_BINS ? KV_BINS - 1 : b);
+}
+
+// Histogram increment with wave-level aggregation of the common bin.  Latency samples
+// are heavily clustered (most of a wave's 64 lanes hit the same bin), which would
+// serialise 64 LDS atomics on one address; instead the lanes that share the first
+// active lane's bin elect one lane to add their population count.  Must be called by
+// exactly the lanes that hold a valid sample (the active set is the participant set).
+__device__ inline void hist_add(unsigned int* h, unsigned int d) {
+  unsigned int d0 = __builtin_amdgcn_readfirstlane(d);
+  bool same = d == d0;
+  unsigned long long mask = __ballot(same);
+  if (same) {
+    if ((int)__lane_id() == __ffsll((long long)mask) - 1) atomicAdd(&h[d0], (unsigned int)__popcll(mask));
+  } else {
+    atomicAdd(&h[d], 1u);
+  }
+}
+
+__device__ inline double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename K> __device__ inline K wave_min(K v) {
+  for (int o = 32; o > 0; o >>= 1) { K w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+  return v;
+}
+template <typename K> __device__ inline K wave_max(K v) {
+  for (int o = 32; o > 0; o >>= 1) { K w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+
+// Per-metric persistent state of the streaming histogram.
+struct StreamState {
+  unsigned long long count;
+  double sum;
+  unsigned long long min_key;  // order-preserving key of the minimum (init: ~0)
+  unsigned long long max_key;  // order-preserving key of the maximum (init: 0)
+};
+
+// ---------------------------------------------------------------------------------
+// kv_stream_hist: x[n_metrics][row_stride] (first n valid columns), hist[n_metrics][2048]
+template <typename T>
+__global__ __launch_bounds__(KV_THREADS) void stream_hist_kernel(const T* __restrict__ x, long long n, long long row_stride,
+                                                                 unsigned int* __restrict__ hist, StreamState* __restrict__ state,
+                                                                 float lo_log2, float inv_step) {
+  __shared__ unsigned int lds[KV_WAVES * KV_BINS];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int m = blockIdx.y;
+  for (int i = tid; i < KV_WAVES * KV_BINS; i += KV_THREADS) lds[i] = 0;
+  __syncthreads();
+
+  const T* row = x + (long long)m * row_stride;
+  unsigned int* my = lds + wave * KV_BINS;
+  using KT = typename KeyOf<T>::type;
+  unsigned long long cnt = 0;
+  double sum = 0.0;
+  KT kmin = ~(KT)0, kmax = 0;
+
+  constexpr int VEC = 16 / sizeof(T);  // 16-byte loads: 4 floats or 2 doubles per lane
+  const long long nvec = n / VEC;
+  const long long stride = (long long)gridDim.x * KV_THREADS;
+  struct alignas(16) Pack { T v[VEC]; };
+  const bool aligned = (((uintptr_t)row) & 15) == 0;
+  if (aligned) {
+    const Pack* pv = reinterpret_cast<const Pack*>(row);
+    for (long long i = (long long)blockIdx.x * KV_THREADS + tid; i < nvec; i += stride) {
+      Pack p = pv[i];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        T v = p.v[j];
+        if (v == v) {
+          hist_add(my, (unsigned int)log_bin((float)v, lo_log2, inv_step));
+          ++cnt; sum += (double)v;
+          KT k = KeyOf<T>::key(v);
+          kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+        }
+      }
+    }
+  }
+  // tail (or everything, when the row is not 16-byte aligned)
+  for (long long i = (aligned ? nvec * VEC : 0) + (long long)blockIdx.x * KV_THREADS + tid; i < n; i += stride) {
+    T v = row[i];
+    if (v == v) {
+      hist_add(my, (unsigned int)log_bin((float)v, lo_log2, inv_step));
+      ++cnt; sum += (double)v;
+      KT k = KeyOf<T>::key(v);
+      kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+    }
+  }
+  __syncthreads();
+  unsigned int* gh = hist + (long long)m * KV_BINS;
+  for (int b = tid; b < KV_BINS; b += KV_THREADS) {
+    unsigned int c = lds[b] + lds[KV_BINS + b] + lds[2 * KV_BINS + b] + lds[3 * KV_BINS + b];
+    if (c) atomicAdd(&gh[b], c);
+  }
+  // scalars: wave reduction, then one atomic per wave
+  cnt = wave_sum_u64(cnt);
+  sum = wave_sum(sum);
+  kmin = wave_min<KT>(kmin);
+  kmax = wave_max<KT>(kmax);
+  if ((tid & 63) == 0 && cnt) {
+    StreamState* s = state + m;
+    atomicAdd(&s->count, cnt);
+    atomicAdd(&s->sum, sum);
+    // widen 32-bit keys so one state layout serves both dtypes
+    unsigned long long k0 = (unsigned long long)kmin << (64 - KeyOf<T>::bits);
+    unsigned long long k1 = (unsigned long long)kmax << (64 - KeyOf<T>::bits);
+    atomicMin(&s->min_key, k0);
+    atomicMax(&s->max_key, k1);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Radix select.  Per metric: U distinct prefixes (U <= 8).  hist[m][u][2048].
+struct RadixState {
+  unsigned long long prefix[KV_MAX_RANKS];  // key bits decided so far (high bits), per rank
+  unsigned long long k[KV_MAX_RANKS];       // rank remaining inside the prefix
+  unsigned long long uniq[KV_MAX_RANKS];    // distinct prefixes for the next histogram pass
+  int slot[KV_MAX_RANKS];                   // rank -> index into uniq
+  int n_uniq;
+  int n_ranks;
+};
+
+template <typename T>
+__global__ __launch_bounds__(KV_THREADS) void radix_hist_kernel(const T* __restrict__ x, long long n, long long row_stride,
+                                                                const RadixState* __restrict__ st, unsigned int* __restrict__ hist,
+                                                                int shift, int digit_bits, int first_pass) {
+  // first pass: one prefix (empty) -> per-wave private sub-histograms; later passes: one
+  // workgroup-shared histogram per distinct prefix.
+  __shared__ unsigned int lds[KV_MAX_RANKS * KV_BINS];  // 64 KiB
+  using KT = typename KeyOf<T>::type;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int m = blockIdx.y;
+  const RadixState* s = st + m;
+  const int U = first_pass ? 1 : s->n_uniq;
+  const int nclear = first_pass ? KV_WAVES * KV_BINS : U * KV_BINS;
+  for (int i = tid; i < nclear; i += KV_THREADS) lds[i] = 0;
+  KT pre[KV_MAX_RANKS];
+#pragma unroll
+  for (int u = 0; u < KV_MAX_RANKS; ++u) pre[u] = (KT)(u < U && !first_pass ? (s->uniq[u] >> (64 - KeyOf<T>::bits)) : 0);
+  __syncthreads();
+
+  const T* row = x + (long long)m * row_stride;
+  const KT dmask = (KT)((1u << digit_bits) - 1u);
+  // bits above the current digit
+  const int hi_shift = shift + digit_bits;
+  constexpr int VEC = 16 / sizeof(T);
+  struct alignas(16) Pack { T v[VEC]; };
+  const long long nvec = n / VEC;
+  const long long stride = (long long)gridDim.x * KV_THREADS;
+  const bool aligned = (((uintptr_t)row) & 15) == 0;
+
+  auto visit = [&](T v) {
+    if (v == v) {
+      KT key = KeyOf<T>::key(v);
+      unsigned int d = (unsigned int)((key >> shift) & dmask);
+      if (first_pass) {
+        hist_add(lds + wave * KV_BINS, d);
+      } else {
+        KT hi = hi_shift >= KeyOf<T>::bits ? (KT)0 : (KT)(key >> hi_shift);
+#pragma unroll
+        for (int u = 0; u < KV_MAX_RANKS; ++u)
+          if (u < U && hi == (hi_shift >= KeyOf<T>::bits ? (KT)0 : (KT)(pre[u] >> hi_shift))) hist_add(lds + u * KV_BINS, d);
+      }
+    }
+  };
+  if (aligned) {
+    const Pack* pv = reinterpret_cast<const Pack*>(row);
+    for (long long i = (long long)blockIdx.x * KV_THREADS + tid; i < nvec; i += stride) {
+      Pack p = pv[i];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) visit(p.v[j]);
+    }
+  }
+  for (long long i = (aligned ? nvec * VEC : 0) + (long long)blockIdx.x * KV_THREADS + tid; i < n; i += stride) visit(row[i]);
+  __syncthreads();
+
+  unsigned int* gh = hist + (long long)m * KV_MAX_RANKS * KV_BINS;
+  if (first_pass) {
+    for (int b = tid; b < KV_BINS; b += KV_THREADS) {
+      unsigned int c = lds[b] + lds[KV_BINS + b] + lds[2 * KV_BINS + b] + lds[3 * KV_BINS + b];
+      if (c) atomicAdd(&gh[b], c);
+    }
+  } else {
+    for (int i = tid; i < U * KV_BINS; i += KV_THREADS) {
+      unsigned int c = lds[i];
+      if (c) atomicAdd(&gh[i], c);
+    }
+  }
+}
+
+// Ranks from quantile levels, on the device (no host round trip between the streaming
+// pass that counts the non-NaN samples and the selection): pos = p*(n-1), ranks floor(pos)
+// and ceil(pos) — the definition of analyze.py:75-81.
+__global__ void radix_init_kernel(const StreamState* __restrict__ stream, RadixState* __restrict__ st, const double* __restrict__ ps, int n_ps) {
+  const int m = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  RadixState* s = st + m;
+  unsigned long long n = stream[m].count;
+  int r = 0;
+  if (n > 0) {
+    for (int i = 0; i < n_ps && r + 1 < KV_MAX_RANKS; ++i) {
+      double p = ps[i];
+      p = p < 0.0 ? 0.0 : (p > 1.0 ? 1.0 : p);
+      double pos = p * (double)(n - 1);
+      s->prefix[r] = 0; s->k[r] = (unsigned long long)floor(pos); ++r;
+      s->prefix[r] = 0; s->k[r] = (unsigned long long)ceil(pos); ++r;
+    }
+  }
+  for (int i = r; i < KV_MAX_RANKS; ++i) { s->prefix[i] = 0; s->k[i] = 0; }
+  for (int i = 0; i < KV_MAX_RANKS; ++i) { s->uniq[i] = 0; s->slot[i] = 0; }
+  s->n_uniq = r ? 1 : 0;
+  s->n_ranks = r;
+}
+
+// One workgroup per metric: prefix-scan each rank's histogram, pick the bin that holds
+// rank k, append the digit to the prefix, subtract the counts below it, rebuild the
+// distinct-prefix list, and clear the histograms for the next pass.
+__global__ __launch_bounds__(KV_THREADS) void radix_scan_kernel(RadixState* __restrict__ st, unsigned int* __restrict__ hist, int shift, int first_pass) {
+  __shared__ unsigned long long part[KV_THREADS];
+  __shared__ int sel_bin;
+  __shared__ unsigned long long sel_below;
+  const int tid = threadIdx.x;
+  const int m = blockIdx.x;
+  RadixState* s = st + m;
+  unsigned int* gh = hist + (long long)m * KV_MAX_RANKS * KV_BINS;
+  const int R = s->n_ranks;
+  constexpr int PER = KV_BINS / KV_THREADS;  // 8 bins per thread
+
+  for (int r = 0; r < R; ++r) {
+    const unsigned int* h = gh + (first_pass ? 0 : s->slot[r]) * KV_BINS;
+    unsigned long long k = s->k[r];
+    unsigned int c[PER];
+    unsigned long long local = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { c[j] = h[tid * PER + j]; local += c[j]; }
+    part[tid] = local;
+    __syncthreads();
+    // inclusive scan over the 256 partial sums (Hillis-Steele in LDS)
+    for (int o = 1; o < KV_THREADS; o <<= 1) {
+      unsigned long long v = tid >= o ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    unsigned long long before = part[tid] - local;  // samples in bins below this thread's
+    if (k >= before && k < before + local) {
+      unsigned long long run = before;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (k >= run && k < run + c[j]) { sel_bin = tid * PER + j; sel_below = run; }
+        run += c[j];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s->prefix[r] |= ((unsigned long long)sel_bin) << shift;
+      s->k[r] = k - sel_below;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int nu = 0;
+    for (int r = 0; r < R; ++r) {
+      int f = -1;
+      for (int u = 0; u < nu; ++u) if (s->uniq[u] == s->prefix[r]) f = u;
+      if (f < 0) { s->uniq[nu] = s->prefix[r]; f = nu++; }
+      s->slot[r] = f;
+    }
+    s->n_uniq = nu;
+  }
+  __syncthreads();
+  for (int i = tid; i < KV_MAX_RANKS * KV_BINS; i += KV_THREADS) gh[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------
+// 20-bin (n_bins <= 64) equal-width histogram over [min, max] taken from StreamState.
+template <typename T>
+__global__ __launch_bounds__(KV_THREADS) void equal_hist_kernel(const T* __restrict__ x, long long n, long long row_stride,
+                                                                const StreamState* __restrict__ state, unsigned long long* __restrict__ out, int n_bins) {
+  __shared__ unsigned int lds[KV_WAVES * 64];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int m = blockIdx.y;
+  for (int i = tid; i < KV_WAVES * 64; i += KV_THREADS) lds[i] = 0;
+  __syncthreads();
+  const StreamState* s = state + m;
+  // decode min/max keys back to values
+  auto unkey = [](unsigned long long k) -> double {
+    if (sizeof(T) == 4) {
+      uint32_t b = (uint32_t)(k >> 32);
+      b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
+      return (double)__uint_as_float(b);
+    }
+    unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+  };
+  const double lo = unkey(s->min_key), hi = unkey(s->max_key);
+  const double width = (hi - lo) / (double)n_bins;
+  const T* row = x + (long long)m * row_stride;
+  const long long stride = (long long)gridDim.x * KV_THREADS;
+  if (s->count && hi > lo) {
+    for (long long i = (long long)blockIdx.x * KV_THREADS + tid; i < n; i += stride) {
+      T v = row[i];
+      if (v == v) {
+        int b = (int)(((double)v - lo) / width);
+        b = b >= n_bins ? n_bins - 1 : (b < 0 ? 0 : b);
+        hist_add(lds + wave * 64, (unsigned int)b);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < n_bins) {
+    unsigned int c = lds[tid] + lds[64 + tid] + lds[128 + tid] + lds[192 + tid];
+    if (c) atomicAdd(&out[(long long)m * 64 + tid], (unsigned long long)c);
+  }
+}
+
+inline int grid_x(long long n, int per_thread) {
+  long long blocks = (n + (long long)KV_THREADS * per_thread - 1) / ((long long)KV_THREADS * per_thread);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks; grid-stride covers the rest
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t kv_stream_state_bytes() { return sizeof(StreamState); }
+size_t kv_radix_state_bytes() { return sizeof(RadixState); }
+
+// dtype: 0 = float32, 1 = float64
+int kv_stream_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, unsigned int* hist, void* state,
+                   float lo_log2, float hi_log2, hipStream_t stream) {
+  if (n <= 0 || n_metrics <= 0) return 0;
+  float inv_step = (float)KV_BINS / (hi_log2 - lo_log2);
+  dim3 grid(grid_x(n, 16), n_metrics);
+  if (dtype == 0)
+    hipLaunchKernelGGL(stream_hist_kernel<float>, grid, dim3(KV_THREADS), 0, stream, (const float*)x, n, row_stride, hist, (StreamState*)state, lo_log2, inv_step);
+  else
+    hipLaunchKernelGGL(stream_hist_kernel<double>, grid, dim3(KV_THREADS), 0, stream, (const double*)x, n, row_stride, hist, (StreamState*)state, lo_log2, inv_step);
+  return (int)hipGetLastError();
+}
+
+// Initialise the selection state from quantile levels ``ps`` (device array, n_ps <= 4)
+// and the sample counts that kv_stream_hist accumulated.
+int kv_radix_init(const void* stream_state, void* st, const double* ps, int n_ps, int n_metrics, hipStream_t stream) {
+  hipLaunchKernelGGL(radix_init_kernel, dim3(n_metrics), dim3(64), 0, stream, (const StreamState*)stream_state, (RadixState*)st, ps, n_ps);
+  return (int)hipGetLastError();
+}
+
+// Runs every radix pass.  ``st`` must be initialised by the caller (prefix = 0, k = target
+// rank, n_ranks), ``hist`` is [n_metrics][8][2048] zeros.  On return st->prefix[r]
+// holds the order-preserving key of rank r (left-aligned in 64 bits).
+int kv_radix_select(const void* x, long long n, long long row_stride, int n_metrics, int dtype, void* st, unsigned int* hist, hipStream_t stream) {
+  if (n <= 0 || n_metrics <= 0) return 0;
+  const int key_bits = dtype == 0 ? 32 : 64;
+  dim3 grid(grid_x(n, 16), n_metrics);
+  int top = key_bits;
+  int first = 1;
+  while (top > 0) {
+    int digit_bits = top >= 11 ? 11 : top;
+    int shift = top - digit_bits;
+    if (dtype == 0)
+      hipLaunchKernelGGL(radix_hist_kernel<float>, grid, dim3(KV_THREADS), 0, stream, (const float*)x, n, row_stride, (const RadixState*)st, hist, shift, digit_bits, first);
+    else
+      hipLaunchKernelGGL(radix_hist_kernel<double>, grid, dim3(KV_THREADS), 0, stream, (const double*)x, n, row_stride, (const RadixState*)st, hist, shift, digit_bits, first);
+    // prefixes are kept left-aligned in 64 bits for both dtypes
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(n_metrics), dim3(KV_THREADS), 0, stream, (RadixState*)st, hist, shift + (64 - key_bits), first);
+    first = 0;
+    top = shift;
+  }
+  return (int)hipGetLastError();
+}
+
+int kv_equal_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, const void* state, unsigned long long* out, int n_bins,
+                  hipStream_t stream) {
+  if (n <= 0 || n_metrics <= 0) return 0;
+  if (n_bins > 64) return -1;
+  dim3 grid(grid_x(n, 8), n_metrics);
+  if (dtype == 0)
+    hipLaunchKernelGGL(equal_hist_kernel<float>, grid, dim3(KV_THREADS), 0, stream, (const float*)x, n, row_stride, (const StreamState*)state, out, n_bins);
+  else
+    hipLaunchKernelGGL(equal_hist_kernel<double>, grid, dim3(KV_THREADS), 0, stream, (const double*)x, n, row_stride, (const StreamState*)state, out, n_bins);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

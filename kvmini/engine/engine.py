@@ -1,0 +1,296 @@
+"""LLM engine: request intake, scheduling loop, token delivery.
+
+The engine owns one model replica (one GPU, or one TP group) and runs its step
+loop on a dedicated thread: drain newly submitted requests, ask the scheduler
+for a ragged batch, execute it (one HIP-graph replay), commit the sampled
+tokens, and hand every request its new tokens through a callback.  The HTTP
+front-end (``kvmini.server.native``) bridges that callback into per-request
+asyncio queues with ONE ``call_soon_threadsafe`` per step.
+"""
+
+from __future__ import annotations
+
+import itertools
+import queue
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from kvmini.models.llama import LlamaWeights, get_config, random_weights
+
+from .kv_cache import BlockManager
+from .runner import ModelRunner, RunnerConfig
+from .scheduler import Batch, SamplingParams, Scheduler, Sequence, SeqStatus
+
+
+@dataclass
+class EngineConfig:
+    model: str = "tiny"
+    device: str = "auto"
+    dtype: str = "bf16"
+    seed: int = 0
+    max_num_seqs: int = 64
+    max_batched_tokens: int = 256
+    max_model_len: int = 8192
+    block_size: int = 16
+    num_blocks: int = 0
+    kv_memory_fraction: float = 0.5
+    use_graphs: bool = True
+    kernels: str = "auto"
+    enable_prefix_caching: bool = True
+    weights_path: Optional[str] = None
+    quantization: Optional[str] = None  # None | fp8
+    # speculative decoding
+    draft_model: Optional[str] = None
+    num_speculative_tokens: int = 0
+    tp_size: int = 1
+    tp_rank: int = 0
+
+
+# (request id, new token ids, finished?, finish reason, sequence)
+TokenEvent = Tuple[int, List[int], bool, Optional[str], Sequence]
+
+
+@dataclass
+class EngineStats:
+    steps: int = 0
+    prompt_tokens: int = 0
+    generation_tokens: int = 0
+    requests_finished: int = 0
+    busy_s: float = 0.0
+    spec_proposed: int = 0
+    spec_accepted: int = 0
+    step_ms_ewma: float = 0.0
+
+
+def _resolve_device(name: str) -> torch.device:
+    if name == "auto":
+        return torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+    return torch.device(name)
+
+
+def _sample_row(logits: torch.Tensor, p: SamplingParams, gen: Optional[torch.Generator]) -> int:
+    """Temperature / top-k / top-p sampling of one logits row (fp32)."""
+    x = logits.float() / max(p.temperature, 1e-5)
+    if p.top_k and p.top_k > 0:
+        kth = torch.topk(x, min(p.top_k, x.numel())).values[-1]
+        x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
+    probs = torch.softmax(x, dim=-1)
+    if p.top_p < 1.0:
+        sp, si = torch.sort(probs, descending=True)
+        keep = (torch.cumsum(sp, 0) - sp) < p.top_p
+        sp = sp * keep
+        probs = torch.zeros_like(probs).scatter_(0, si, sp)
+        probs = probs / probs.sum()
+    return int(torch.multinomial(probs, 1, generator=gen).item())
+
+
+class LLMEngine:
+    def __init__(self, ecfg: EngineConfig, weights: Optional[LlamaWeights] = None, tp_group: Any = None):
+        self.ecfg = ecfg
+        self.device = _resolve_device(ecfg.device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        self.mcfg = get_config(ecfg.model) if weights is None else weights.cfg
+        dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[ecfg.dtype]
+        t0 = time.perf_counter()
+        if weights is None:
+            if ecfg.weights_path:
+                from kvmini.models.llama import load_hf_safetensors
+
+                weights = load_hf_safetensors(ecfg.weights_path, self.mcfg, self.device, dtype, ecfg.tp_rank, ecfg.tp_size)
+            else:
+                weights = random_weights(self.mcfg, self.device, dtype, ecfg.seed, ecfg.tp_rank, ecfg.tp_size)
+        self.weights = weights
+        rcfg = RunnerConfig(
+            max_num_seqs=ecfg.max_num_seqs,
+            max_batched_tokens=ecfg.max_batched_tokens,
+            max_model_len=ecfg.max_model_len,
+            block_size=ecfg.block_size,
+            num_blocks=ecfg.num_blocks,
+            kv_memory_fraction=ecfg.kv_memory_fraction,
+            use_graphs=ecfg.use_graphs,
+            kernels=ecfg.kernels,
+        )
+        self.runner = ModelRunner(weights, rcfg, tp_group)
+        if ecfg.quantization == "fp8":
+            self.runner.enable_fp8()
+        self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)
+        self.scheduler = Scheduler(self.bm, ecfg.max_num_seqs, ecfg.max_batched_tokens, ecfg.max_model_len, self.mcfg.eos_token_id)
+        self.spec = None
+        if ecfg.draft_model and ecfg.num_speculative_tokens > 0:
+            from .speculative import SpeculativeDecoder
+
+            self.spec = SpeculativeDecoder(self, ecfg.draft_model, ecfg.num_speculative_tokens)
+        self.load_s = time.perf_counter() - t0
+        self.stats = EngineStats()
+        self._ids = itertools.count(1)
+        self._inbox: "queue.SimpleQueue[Any]" = queue.SimpleQueue()
+        self._wake = threading.Event()
+        self._stop = False
+        self._thread: Optional[threading.Thread] = None
+        self.on_tokens: Optional[Callable[[List[TokenEvent]], None]] = None
+        self._gens: Dict[int, torch.Generator] = {}
+        self.warm_s = 0.0
+
+    # ------------------------------------------------------------------
+    def warmup(self) -> float:
+        """Capture the HIP graphs (and JIT/allocator warm-up).  Returns seconds."""
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            self.runner.capture_graphs()
+            if self.spec is not None:
+                self.spec.warmup()
+        self.warm_s = time.perf_counter() - t0
+        return self.warm_s
+
+    # --- synchronous API (tests, offline generation) ---------------------
+    def make_sequence(self, prompt_ids: List[int], params: Optional[SamplingParams] = None, user: Any = None) -> Sequence:
+        return Sequence(next(self._ids), list(prompt_ids), params or SamplingParams(), user=user)
+
+    def step(self) -> List[TokenEvent]:
+        """One engine iteration.  Empty list when nothing is schedulable."""
+        if self.spec is not None:
+            return self.spec.step()
+        batch = self.scheduler.schedule()
+        if not batch.chunks:
+            return []
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ids, logits = self.runner.execute(batch)
+        events = self._commit(batch, ids, logits)
+        dt = time.perf_counter() - t0
+        st = self.stats
+        st.steps += 1
+        st.busy_s += dt
+        st.step_ms_ewma = dt * 1e3 if st.step_ms_ewma == 0 else 0.9 * st.step_ms_ewma + 0.1 * dt * 1e3
+        return events
+
+    def _commit(self, batch: Batch, ids: List[int], logits: Optional[torch.Tensor]) -> List[TokenEvent]:
+        events: List[TokenEvent] = []
+        row = 0
+        for ch in batch.chunks:
+            seq = ch.seq
+            if ch.start < len(seq.prompt_ids):
+                self.stats.prompt_tokens += min(ch.n_tokens, len(seq.prompt_ids) - ch.start)
+            if not ch.sample:
+                self.scheduler.commit(ch, [])
+                continue
+            tok = ids[row]
+            p = seq.params
+            if p.temperature > 0 and logits is not None:
+                gen = None
+                if p.seed is not None:
+                    gen = self._gens.get(seq.req_id)
+                    if gen is None:
+                        gen = torch.Generator(device=logits.device)
+                        gen.manual_seed(p.seed)
+                        self._gens[seq.req_id] = gen
+                tok = _sample_row(logits[row], p, gen)
+            row += 1
+            new = self.scheduler.commit(ch, [tok])
+            self.stats.generation_tokens += len(new)
+            done = seq.status == SeqStatus.FINISHED
+            if done:
+                self.stats.requests_finished += 1
+                self._gens.pop(seq.req_id, None)
+            events.append((seq.req_id, new, done, seq.finish_reason, seq))
+        return events
+
+    def generate(self, prompts: List[List[int]], params: Optional[SamplingParams] = None) -> List[List[int]]:
+        """Offline batch generation (blocking)."""
+        seqs = [self.make_sequence(p, params and SamplingParams(**vars(params))) for p in prompts]
+        for s in seqs:
+            self.scheduler.add(s)
+        while self.scheduler.has_work():
+            if not self.step() and not self.scheduler.running and self.scheduler.waiting:
+                raise RuntimeError("scheduler cannot make progress (KV cache too small for the prompt?)")
+        return [s.output_ids for s in seqs]
+
+    # --- asynchronous API (server) ----------------------------------------
+    def start(self) -> None:
+        if self._thread is not None:
+            return
+        self._stop = False
+        self._thread = threading.Thread(target=self._loop, name="kvmini-engine", daemon=True)
+        self._thread.start()
+
+    def stop(self) -> None:
+        self._stop = True
+        self._wake.set()
+        if self._thread is not None:
+            self._thread.join(10)
+            self._thread = None
+
+    def submit(self, prompt_ids: List[int], params: SamplingParams, user: Any = None) -> int:
+        seq = self.make_sequence(prompt_ids, params, user)
+        self._inbox.put(("add", seq))
+        self._wake.set()
+        return seq.req_id
+
+    def abort(self, req_id: int) -> None:
+        self._inbox.put(("abort", req_id))
+        self._wake.set()
+
+    def _drain_inbox(self) -> None:
+        while True:
+            try:
+                kind, item = self._inbox.get_nowait()
+            except queue.Empty:
+                return
+            if kind == "add":
+                self.scheduler.add(item)
+            elif kind == "abort":
+                self.scheduler.abort(item)
+
+    def _loop(self) -> None:
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        while not self._stop:
+            self._drain_inbox()
+            if not self.scheduler.has_work():
+                self._wake.wait(0.05)
+                self._wake.clear()
+                continue
+            try:
+                events = self.step()
+            except Exception as e:  # fail the in-flight requests, keep serving
+                import traceback
+
+                traceback.print_exc()
+                events = []
+                for s in list(self.scheduler.running):
+                    self.scheduler._finish(s, "error")
+                    events.append((s.req_id, [], True, f"error: {e}", s))
+            if events and self.on_tokens is not None:
+                self.on_tokens(events)
+            elif not events:
+                # nothing schedulable right now (e.g. waiting for KV blocks)
+                time.sleep(0.0005)
+
+    # ------------------------------------------------------------------
+    def metrics(self) -> Dict[str, Any]:
+        st = self.stats
+        return {
+            "steps": st.steps,
+            "prompt_tokens": st.prompt_tokens,
+            "generation_tokens": st.generation_tokens,
+            "requests_finished": st.requests_finished,
+            "running": len(self.scheduler.running),
+            "waiting": len(self.scheduler.waiting),
+            "busy_s": st.busy_s,
+            "step_ms_ewma": st.step_ms_ewma,
+            "kv_blocks_total": self.bm.num_blocks,
+            "kv_blocks_free": self.bm.num_free,
+            "prefix_cache_queries": self.bm.prefix_queries,
+            "prefix_cache_hits": self.bm.prefix_hits,
+            "preemptions": self.scheduler.num_preemptions,
+            "spec_proposed": st.spec_proposed,
+            "spec_accepted": st.spec_accepted,
+            "graphs": sorted(self.runner.graphs),
+            "load_s": self.load_s,
+            "warm_s": self.warm_s,
+        }

@@ -1,0 +1,283 @@
+"""Model runner: static device buffers, the ragged forward pass, HIP-graph replay.
+
+One forward pass serves a flat batch of ``T`` tokens (decode tokens and
+prefill-chunk tokens mixed).  ``T`` is padded to a bucket; for every bucket the
+whole pass — embedding gather, 32 x (norm, QKV GEMM, RoPE + KV write, paged
+attention, O GEMM, norm, gate/up GEMM + SwiGLU, down GEMM), final norm, LM head
+and greedy argmax — is captured once into a HIP graph (``torch.cuda.CUDAGraph``
+records hipGraph nodes on ROCm) and replayed per step, so a decode step costs one
+graph launch instead of ~300 kernel launches.  Per-step inputs are packed into
+one pinned int32 staging buffer and moved with a single async H2D copy.
+
+With tensor parallelism each rank holds a shard of the heads / MLP columns and
+the partial O-proj / down-proj outputs are summed with an all-reduce
+(``torch.distributed`` -> RCCL over xGMI; captured inside the graph).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from kvmini.models.llama import LlamaConfig, LlamaWeights, rope_tables
+
+from .scheduler import Batch
+
+DEFAULT_BUCKETS = (8, 16, 32, 64, 128, 256, 512, 1024, 2048)
+
+
+@dataclass
+class RunnerConfig:
+    max_num_seqs: int = 64
+    max_batched_tokens: int = 256
+    max_model_len: int = 8192
+    block_size: int = 16
+    num_blocks: int = 0  # 0 = size from memory
+    kv_memory_fraction: float = 0.5
+    use_graphs: bool = True
+    kernels: str = "auto"  # auto | hip | torch
+    return_logits: bool = False
+
+
+def select_ops(kernels: str, device: torch.device) -> Any:
+    """``hip`` = hand-written gfx950 kernels (required on a GPU unless ``torch``
+    is requested explicitly: a missing extension is an error, not a silent
+    fallback); ``torch`` = reference ops."""
+    if kernels == "torch" or (kernels == "auto" and device.type != "cuda"):
+        from kvmini.ops import torch_ops
+
+        return torch_ops
+    from kvmini.ops import hip_ops
+
+    hip_ops.require()
+    return hip_ops
+
+
+class ModelRunner:
+    def __init__(self, weights: LlamaWeights, rcfg: RunnerConfig, tp_group: Any = None):
+        self.w = weights
+        self.cfg: LlamaConfig = weights.cfg
+        self.rcfg = rcfg
+        self.device = weights.device
+        self.tp_group = tp_group
+        self.tp_size = weights.tp_size
+        self.ops = select_ops(rcfg.kernels, self.device)
+        cfg = self.cfg
+        self.nh = cfg.num_heads // self.tp_size
+        self.nkv = cfg.num_kv_heads // self.tp_size
+        self.hd = cfg.head_dim
+        self.scale = 1.0 / math.sqrt(cfg.head_dim)
+        self.block_size = rcfg.block_size
+        self.max_blocks_per_seq = (rcfg.max_model_len + rcfg.block_size - 1) // rcfg.block_size
+        self.cos, self.sin = rope_tables(cfg, rcfg.max_model_len, self.device)
+
+        self.num_blocks = rcfg.num_blocks or self._auto_num_blocks()
+        dt = weights.embed.dtype
+        # [layer, k/v, block, kv_head, slot_in_block, head_dim]
+        self.kv_cache = torch.zeros((cfg.num_layers, 2, self.num_blocks, self.nkv, self.block_size, self.hd), dtype=dt, device=self.device)
+
+        self.buckets = tuple(b for b in DEFAULT_BUCKETS if b < rcfg.max_batched_tokens) + (rcfg.max_batched_tokens,)
+        tmax = self.buckets[-1]
+        self.tmax = tmax
+        smax = rcfg.max_num_seqs
+        # packed int32 staging layout: tokens | positions | slot_mapping | tok_seq | ctx_lens | sample_idx | block_tables
+        self._off = {}
+        off = 0
+        for name, n in (("tokens", tmax), ("positions", tmax), ("slots", tmax), ("tok_seq", tmax), ("ctx", tmax), ("sample_idx", tmax)):
+            self._off[name] = (off, n)
+            off += n
+        self._off["block_tables"] = (off, smax * self.max_blocks_per_seq)
+        off += smax * self.max_blocks_per_seq
+        pin = self.device.type == "cuda"
+        self.stage_cpu = torch.zeros(off, dtype=torch.int32, pin_memory=pin)
+        self.stage_np = self.stage_cpu.numpy()
+        self.stage_dev = torch.zeros(off, dtype=torch.int32, device=self.device)
+        self.bt_np = self.stage_np[self._off["block_tables"][0] :].reshape(smax, self.max_blocks_per_seq)
+        self.out_ids = torch.zeros(tmax, dtype=torch.int64, device=self.device)
+        self.out_ids_cpu = torch.zeros(tmax, dtype=torch.int64, pin_memory=pin)
+        self.logits_buf: Optional[torch.Tensor] = None
+        self.spec_width = 1  # positions sampled per sequence per step (k+1 with speculation)
+        self.s_cap = tmax
+        self.set_spec_width(1)
+        self.graphs: Dict[int, Any] = {}
+        self._graph_pool = None
+        self.steps = 0
+
+    def set_spec_width(self, width: int) -> None:
+        self.spec_width = width
+        need = self.rcfg.max_num_seqs * width
+        self.s_cap = next((b for b in self.buckets if b >= need), self.buckets[-1])
+
+    # ------------------------------------------------------------------
+    def _auto_num_blocks(self) -> int:
+        cfg, r = self.cfg, self.rcfg
+        per_block = cfg.num_layers * 2 * self.nkv * r.block_size * self.hd * self.w.embed.element_size()
+        want = r.max_num_seqs * self.max_blocks_per_seq + 64
+        if self.device.type == "cuda":
+            free, _total = torch.cuda.mem_get_info(self.device)
+            by_mem = int(free * r.kv_memory_fraction) // per_block
+            return max(64, min(want, by_mem))
+        return max(64, min(want, 4096))
+
+    def _dev(self, name: str, n: Optional[int] = None) -> torch.Tensor:
+        off, full = self._off[name]
+        return self.stage_dev[off : off + (full if n is None else n)]
+
+    def sample_rows(self, t_pad: int) -> int:
+        """Rows of the LM-head GEMM for a token bucket: at most one per sequence
+        (times the speculative width), never more than the bucket."""
+        return min(t_pad, self.s_cap)
+
+    def bucket_for(self, t: int) -> int:
+        for b in self.buckets:
+            if t <= b:
+                return b
+        raise ValueError(f"{t} tokens exceed max_batched_tokens={self.buckets[-1]}")
+
+    # ------------------------------------------------------------------
+    def forward(self, t_pad: int, max_blocks: Optional[int] = None) -> torch.Tensor:
+        """The ragged forward pass over the first ``t_pad`` staged tokens; writes
+        sampled ids into ``out_ids[:t_pad]`` and returns the logits ``[t_pad, V]``."""
+        ops, cfg, w = self.ops, self.cfg, self.w
+        tokens = self._dev("tokens", t_pad)
+        positions = self._dev("positions", t_pad)
+        slots = self._dev("slots", t_pad)
+        tok_seq = self._dev("tok_seq", t_pad)
+        ctx = self._dev("ctx", t_pad)
+        sample_idx = self._dev("sample_idx", t_pad)
+        bt = self._dev("block_tables").view(self.rcfg.max_num_seqs, self.max_blocks_per_seq)
+
+        x = w.embed[tokens.long()] if w.embed.device.type == "cpu" else torch.index_select(w.embed, 0, tokens)
+        residual = torch.zeros_like(x)
+        for li, lw in enumerate(w.layers):
+            h, residual = ops.add_rmsnorm(x, residual, lw.attn_norm, cfg.rms_eps)
+            qkv = ops.linear(h, lw.wqkv)
+            kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
+            q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
+            a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
+            x = ops.linear(a, lw.wo)
+            if self.tp_size > 1:
+                torch.distributed.all_reduce(x, group=self.tp_group)
+            h, residual = ops.add_rmsnorm(x, residual, lw.mlp_norm, cfg.rms_eps)
+            act = ops.linear_swiglu(h, lw.wgu)
+            x = ops.linear(act, lw.wdown)
+            if self.tp_size > 1:
+                torch.distributed.all_reduce(x, group=self.tp_group)
+        h, residual = ops.add_rmsnorm(x, residual, w.final_norm, cfg.rms_eps)
+        hs = torch.index_select(h, 0, sample_idx[: self.sample_rows(t_pad)])
+        logits = ops.linear(hs, w.lm_head)
+        self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
+        return logits
+
+    # ------------------------------------------------------------------
+    def capture_graphs(self, buckets: Optional[Sequence[int]] = None) -> None:
+        """Capture one HIP graph per token bucket (largest first so the smaller
+        ones share its memory pool)."""
+        if self.device.type != "cuda" or not self.rcfg.use_graphs:
+            return
+        self._stage_dummy()
+        for b in sorted(buckets or self.buckets, reverse=True):
+            if b in self.graphs:
+                continue
+            # warm-up on a side stream (allocator + lazy init), then capture
+            s = torch.cuda.Stream(self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self.forward(b)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                logits = self.forward(b)
+            if self._graph_pool is None:
+                self._graph_pool = g.pool()
+            self.graphs[b] = (g, logits)
+        torch.cuda.synchronize(self.device)
+
+    def _stage_dummy(self) -> None:
+        """Inputs that are safe for warm-up/capture: every token is padding."""
+        self.stage_np[:] = 0
+        o, n = self._off["slots"]
+        self.stage_np[o : o + n] = -1
+        self.stage_dev.copy_(self.stage_cpu)
+
+    # ------------------------------------------------------------------
+    def execute(self, batch: Batch) -> Tuple[List[int], Optional[torch.Tensor]]:
+        """Run one step.  Returns (sampled ids, logits) with one row per position
+        flagged for sampling, in chunk order: a chunk flagged ``sample`` contributes
+        its last position — or, when it carries draft tokens to verify, every
+        position from the last accepted token on."""
+        t = batch.num_tokens
+        t_pad = self.bucket_for(t)
+        st = self.stage_np
+        o_tok, o_pos, o_slot, o_seq, o_ctx, o_smp = (self._off[k][0] for k in ("tokens", "positions", "slots", "tok_seq", "ctx", "sample_idx"))
+        bs = self.block_size
+        i = 0
+        n_samples = 0
+        max_ctx = 1
+        for ch in batch.chunks:
+            seq = ch.seq
+            n = ch.n_tokens
+            blocks = seq.blocks
+            self.bt_np[seq.slot, : len(blocks)] = blocks
+            p0 = ch.start
+            if n == 1 and not seq.draft_ids:
+                npmt = len(seq.prompt_ids)
+                st[o_tok + i] = seq.prompt_ids[p0] if p0 < npmt else seq.output_ids[p0 - npmt]
+                st[o_pos + i] = p0
+                st[o_slot + i] = blocks[p0 // bs] * bs + p0 % bs
+                st[o_seq + i] = seq.slot
+                st[o_ctx + i] = p0 + 1
+                if ch.sample:
+                    st[o_smp + n_samples] = i
+                    n_samples += 1
+                i += 1
+            else:
+                ids = seq.all_ids
+                first_sampled = n - 1
+                if seq.draft_ids and not seq.is_prefilling:
+                    ids = ids + seq.draft_ids
+                    first_sampled = max(0, seq.num_tokens - 1 - p0)
+                pos = np.arange(p0, p0 + n, dtype=np.int32)
+                st[o_tok + i : o_tok + i + n] = ids[p0 : p0 + n]
+                st[o_pos + i : o_pos + i + n] = pos
+                blk = np.asarray(blocks, dtype=np.int32)[pos // bs]
+                st[o_slot + i : o_slot + i + n] = blk * bs + pos % bs
+                st[o_seq + i : o_seq + i + n] = seq.slot
+                st[o_ctx + i : o_ctx + i + n] = pos + 1
+                if ch.sample:
+                    k = n - first_sampled
+                    st[o_smp + n_samples : o_smp + n_samples + k] = np.arange(i + first_sampled, i + n, dtype=np.int32)
+                    n_samples += k
+                i += n
+            max_ctx = max(max_ctx, p0 + n)
+        # padding tokens: token 0, position 0, no KV write, empty context
+        if t_pad > t:
+            st[o_tok + t : o_tok + t_pad] = 0
+            st[o_pos + t : o_pos + t_pad] = 0
+            st[o_slot + t : o_slot + t_pad] = -1
+            st[o_seq + t : o_seq + t_pad] = 0
+            st[o_ctx + t : o_ctx + t_pad] = 0
+        st[o_smp + n_samples : o_smp + t_pad] = 0
+
+        self.stage_dev.copy_(self.stage_cpu, non_blocking=True)
+        entry = self.graphs.get(t_pad)
+        if entry is not None:
+            g, logits = entry
+            g.replay()
+        else:
+            with torch.no_grad():
+                logits = self.forward(t_pad, max_blocks=(max_ctx + bs - 1) // bs)
+        self.steps += 1
+        if self.device.type == "cuda":
+            self.out_ids_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            ids_out = self.out_ids_cpu[:n_samples].tolist()
+        else:
+            ids_out = self.out_ids[:n_samples].tolist()
+        return ids_out, (logits[:n_samples] if logits is not None else None)

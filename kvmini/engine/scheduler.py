@@ -1,0 +1,253 @@
+"""Continuous-batching scheduler with chunked prefill over a ragged token batch.
+
+Every engine step runs ONE forward pass over a flat list of tokens: one token
+for each decoding sequence plus chunks of prompt tokens for sequences that are
+still prefilling, up to ``max_batched_tokens``.  Decodes are scheduled first (no
+running request is ever stalled by an arriving prompt), then prefill chunks of
+running sequences, then newly admitted sequences — so a new request normally
+joins the very next step, which is what keeps time-to-first-token at "one step +
+one chunk" under concurrency.  When KV blocks run out the most recently admitted
+sequence is preempted (its blocks are freed and it is recomputed later).
+"""
+
+from __future__ import annotations
+
+import time
+from collections import deque
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Any, Deque, Dict, List, Optional
+
+from .kv_cache import BlockManager
+
+
+class SeqStatus(Enum):
+    WAITING = 0
+    RUNNING = 1
+    FINISHED = 2
+
+
+@dataclass
+class SamplingParams:
+    max_tokens: int = 64
+    temperature: float = 0.0
+    top_p: float = 1.0
+    top_k: int = 0
+    seed: Optional[int] = None
+    ignore_eos: bool = False
+    logprobs: int = 0
+    stop_token_ids: List[int] = field(default_factory=list)
+
+
+@dataclass
+class Sequence:
+    req_id: int
+    prompt_ids: List[int]
+    params: SamplingParams
+    arrival: float = field(default_factory=time.perf_counter)
+    output_ids: List[int] = field(default_factory=list)
+    status: SeqStatus = SeqStatus.WAITING
+    num_computed: int = 0  # tokens whose K/V are in the cache
+    blocks: List[int] = field(default_factory=list)
+    published_blocks: int = 0
+    slot: int = -1  # row in the block-table tensor
+    cached_prefix_tokens: int = 0
+    first_token_time: Optional[float] = None
+    finish_reason: Optional[str] = None
+    user: Any = None  # opaque handle for the front-end (stream queue, ...)
+    # speculative decoding state: draft tokens proposed for the next verify step
+    draft_ids: List[int] = field(default_factory=list)
+    preemptions: int = 0
+
+    @property
+    def all_ids(self) -> List[int]:
+        return self.prompt_ids + self.output_ids
+
+    @property
+    def num_tokens(self) -> int:
+        return len(self.prompt_ids) + len(self.output_ids)
+
+    @property
+    def is_prefilling(self) -> bool:
+        return self.num_computed < len(self.prompt_ids)
+
+
+@dataclass
+class ScheduledChunk:
+    seq: Sequence
+    start: int  # first position computed in this step
+    n_tokens: int  # number of positions computed in this step
+    sample: bool  # the chunk ends at the sequence's last known token -> sample next
+
+
+@dataclass
+class Batch:
+    chunks: List[ScheduledChunk]
+    num_tokens: int
+
+    @property
+    def num_samples(self) -> int:
+        return sum(1 for c in self.chunks if c.sample)
+
+
+class Scheduler:
+    def __init__(
+        self,
+        block_manager: BlockManager,
+        max_num_seqs: int = 64,
+        max_batched_tokens: int = 256,
+        max_model_len: int = 8192,
+        eos_token_id: int = 2,
+    ):
+        self.bm = block_manager
+        self.max_num_seqs = max_num_seqs
+        self.max_batched_tokens = max_batched_tokens
+        self.max_model_len = max_model_len
+        self.eos_token_id = eos_token_id
+        self.waiting: Deque[Sequence] = deque()
+        self.running: List[Sequence] = []
+        self._free_slots: List[int] = list(range(max_num_seqs - 1, -1, -1))
+        self.num_preemptions = 0
+
+    # ------------------------------------------------------------------
+    def add(self, seq: Sequence) -> None:
+        if len(seq.prompt_ids) + seq.params.max_tokens > self.max_model_len:
+            seq.params.max_tokens = max(1, self.max_model_len - len(seq.prompt_ids))
+        self.waiting.append(seq)
+
+    def has_work(self) -> bool:
+        return bool(self.waiting or self.running)
+
+    def abort(self, req_id: int) -> Optional[Sequence]:
+        for s in list(self.running):
+            if s.req_id == req_id:
+                self._finish(s, "abort")
+                return s
+        for s in list(self.waiting):
+            if s.req_id == req_id:
+                self.waiting.remove(s)
+                s.status = SeqStatus.FINISHED
+                s.finish_reason = "abort"
+                return s
+        return None
+
+    def _blocks_needed(self, seq: Sequence, upto_tokens: int) -> int:
+        bs = self.bm.block_size
+        return max(0, (upto_tokens + bs - 1) // bs - len(seq.blocks))
+
+    def _preempt_one(self, keep: Sequence, protected: "set[int]") -> bool:
+        """Evict the most recently admitted sequence that is neither ``keep`` nor
+        already part of the batch being built."""
+        for victim in reversed(self.running):
+            if victim is keep or victim.req_id in protected:
+                continue
+            self.bm.free(victim.blocks)
+            victim.blocks = []
+            victim.published_blocks = 0
+            victim.num_computed = 0
+            victim.draft_ids = []
+            victim.status = SeqStatus.WAITING
+            victim.preemptions += 1
+            self._free_slots.append(victim.slot)
+            victim.slot = -1
+            self.running.remove(victim)
+            self.waiting.appendleft(victim)
+            self.num_preemptions += 1
+            return True
+        return False
+
+    def schedule(self, spec_tokens: int = 0) -> Batch:
+        """Pick the chunks for the next step.  ``spec_tokens`` > 0 lets a decoding
+        sequence carry that many draft tokens to verify in the same pass."""
+        budget = self.max_batched_tokens
+        chunks: List[ScheduledChunk] = []
+        scheduled = set()
+
+        # 1) running sequences: decodes first, then in-flight prefills
+        order = sorted(self.running, key=lambda s: s.is_prefilling)
+        for seq in order:
+            if budget <= 0:
+                break
+            if seq not in self.running:  # preempted while serving an earlier sequence
+                continue
+            known = seq.num_tokens + (len(seq.draft_ids) if not seq.is_prefilling else 0)
+            n_new = known - seq.num_computed
+            if n_new <= 0:
+                continue
+            n = min(n_new, budget)
+            need = self._blocks_needed(seq, seq.num_computed + n)
+            while need and not self.bm.can_allocate(need):
+                if not self._preempt_one(seq, scheduled):
+                    break
+            if need:
+                got = self.bm.allocate(need)
+                if got is None:
+                    continue  # cannot run this step
+                seq.blocks += got
+            chunks.append(ScheduledChunk(seq, seq.num_computed, n, seq.num_computed + n == known))
+            scheduled.add(seq.req_id)
+            budget -= n
+
+        # 2) admit waiting sequences
+        while self.waiting and budget > 0 and len(self.running) < self.max_num_seqs and self._free_slots:
+            seq = self.waiting[0]
+            if not seq.blocks:
+                cached_blocks, cached_tokens = self.bm.match_prefix(seq.all_ids)
+                seq.blocks = list(cached_blocks)
+                seq.num_computed = cached_tokens
+                seq.cached_prefix_tokens = cached_tokens
+                seq.published_blocks = len(cached_blocks)
+            n_new = seq.num_tokens - seq.num_computed
+            n = min(n_new, budget)
+            need = self._blocks_needed(seq, seq.num_computed + n)
+            if need and not self.bm.can_allocate(need):
+                # give the cached prefix back; retry when blocks free up
+                self.bm.free(seq.blocks)
+                seq.blocks, seq.num_computed, seq.published_blocks = [], 0, 0
+                break
+            if need:
+                seq.blocks += self.bm.allocate(need) or []
+            self.waiting.popleft()
+            seq.slot = self._free_slots.pop()
+            seq.status = SeqStatus.RUNNING
+            self.running.append(seq)
+            chunks.append(ScheduledChunk(seq, seq.num_computed, n, seq.num_computed + n == seq.num_tokens))
+            budget -= n
+
+        return Batch(chunks, sum(c.n_tokens for c in chunks))
+
+    # ------------------------------------------------------------------
+    def _finish(self, seq: Sequence, reason: str) -> None:
+        seq.status = SeqStatus.FINISHED
+        seq.finish_reason = reason
+        self.bm.free(seq.blocks)
+        seq.blocks = []
+        if seq.slot >= 0:
+            self._free_slots.append(seq.slot)
+            seq.slot = -1
+        if seq in self.running:
+            self.running.remove(seq)
+
+    def commit(self, chunk: ScheduledChunk, new_tokens: List[int], num_accepted_positions: Optional[int] = None) -> List[int]:
+        """Account for a finished step.  ``new_tokens`` are the tokens to append
+        (1 for plain decoding, up to k+1 with speculative verification); returns
+        the tokens actually appended (after max_tokens / EOS truncation)."""
+        seq = chunk.seq
+        seq.num_computed = chunk.start + (chunk.n_tokens if num_accepted_positions is None else num_accepted_positions)
+        seq.published_blocks = self.bm.register_full_blocks(seq.all_ids, seq.blocks, min(seq.num_computed, seq.num_tokens), seq.published_blocks)
+        appended: List[int] = []
+        if not chunk.sample:
+            return appended
+        for tok in new_tokens:
+            seq.output_ids.append(tok)
+            appended.append(tok)
+            if seq.first_token_time is None:
+                seq.first_token_time = time.perf_counter()
+            stop = (not seq.params.ignore_eos and tok == self.eos_token_id) or tok in seq.params.stop_token_ids
+            if stop:
+                self._finish(seq, "stop")
+                break
+            if len(seq.output_ids) >= seq.params.max_tokens or seq.num_tokens >= self.max_model_len:
+                self._finish(seq, "length")
+                break
+        return appended

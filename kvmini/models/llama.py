@@ -1,0 +1,281 @@
+"""Llama-family decoder (Llama-2/3, Mistral, CodeLlama shapes) for the native engine.
+
+The reference never touches model code: it benchmarks whatever a KServe runtime
+serves and names models only in configs (``reference-matrix.yaml:24-34``,
+``profiles/tensorrt-llm/*.yaml``, ``README.md:66-72``).  Producing the headline
+numbers on an MI355X box with no vLLM and no network needs a model of the same
+architecture with random-init weights, so this module holds the architecture
+presets and a weight container laid out for the engine's kernels:
+
+* ``wqkv``   [(n_heads + 2 n_kv) * head_dim, hidden]  — fused Q/K/V projection
+* ``wo``     [hidden, n_heads * head_dim]
+* ``wgu``    [2 * intermediate, hidden] — gate and up rows interleaved in groups
+  of 16 (rows 32j..32j+15 = gate[16j..], rows 32j+16..32j+31 = up[16j..]) so a
+  GEMM wave that owns a 32-row tile holds matching gate/up values and can apply
+  SwiGLU in its epilogue
+* ``wdown``  [hidden, intermediate]
+
+All matrices are ``[out, in]`` row-major (``y = x @ W.T``) in bf16; with tensor
+parallelism ``wqkv``/``wgu`` are split by output rows (heads / intermediate
+columns) and ``wo``/``wdown`` by input columns, followed by an all-reduce.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, replace
+from typing import Any, Dict, List, Optional
+
+import torch
+
+GU_GROUP = 16  # gate/up interleave granularity (rows)
+
+
+@dataclass(frozen=True)
+class LlamaConfig:
+    name: str = "tiny"
+    vocab_size: int = 512
+    hidden_size: int = 128
+    intermediate_size: int = 256
+    num_layers: int = 2
+    num_heads: int = 4
+    num_kv_heads: int = 2
+    head_dim: int = 32
+    rope_theta: float = 500000.0
+    rms_eps: float = 1e-5
+    max_position: int = 8192
+    bos_token_id: int = 1
+    eos_token_id: int = 2
+
+    @property
+    def q_size(self) -> int:
+        return self.num_heads * self.head_dim
+
+    @property
+    def kv_size(self) -> int:
+        return self.num_kv_heads * self.head_dim
+
+    def param_count(self) -> int:
+        per_layer = (self.q_size + 2 * self.kv_size) * self.hidden_size + self.hidden_size * self.q_size + 3 * self.intermediate_size * self.hidden_size + 2 * self.hidden_size
+        return self.num_layers * per_layer + 2 * self.vocab_size * self.hidden_size + self.hidden_size
+
+    def weight_bytes(self, bytes_per_param: float = 2.0) -> float:
+        return self.param_count() * bytes_per_param
+
+
+PRESETS: Dict[str, LlamaConfig] = {
+    # test-sized
+    "tiny": LlamaConfig(),
+    "tiny-draft": LlamaConfig(name="tiny-draft", num_layers=1),
+    # smallest shape that exercises every HIP kernel specialisation (head_dim 128)
+    "small-hd128": LlamaConfig("small-hd128", 1024, 256, 512, 2, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
+    "small-hd128-draft": LlamaConfig("small-hd128-draft", 1024, 256, 512, 1, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
+    # Llama 3
+    "llama-3-8b": LlamaConfig("llama-3-8b", 128256, 4096, 14336, 32, 32, 8, 128, 500000.0, 1e-5, 8192, 128000, 128001),
+    "llama-3-70b": LlamaConfig("llama-3-70b", 128256, 8192, 28672, 80, 64, 8, 128, 500000.0, 1e-5, 8192, 128000, 128001),
+    "llama-3.2-1b": LlamaConfig("llama-3.2-1b", 128256, 2048, 8192, 16, 32, 8, 64, 500000.0, 1e-5, 131072, 128000, 128001),
+    "llama-3.2-3b": LlamaConfig("llama-3.2-3b", 128256, 3072, 8192, 28, 24, 8, 128, 500000.0, 1e-5, 131072, 128000, 128001),
+    # Llama 2 / CodeLlama / Mistral (names used by the reference's matrices and engine profiles)
+    "llama-2-7b": LlamaConfig("llama-2-7b", 32000, 4096, 11008, 32, 32, 32, 128, 10000.0, 1e-5, 4096, 1, 2),
+    "llama-2-13b": LlamaConfig("llama-2-13b", 32000, 5120, 13824, 40, 40, 40, 128, 10000.0, 1e-5, 4096, 1, 2),
+    "codellama-7b": LlamaConfig("codellama-7b", 32016, 4096, 11008, 32, 32, 32, 128, 1000000.0, 1e-5, 16384, 1, 2),
+    "mistral-7b": LlamaConfig("mistral-7b", 32000, 4096, 14336, 32, 32, 8, 128, 10000.0, 1e-5, 32768, 1, 2),
+    # a 2.7B dense decoder in Llama form (stand-in shape for the phi-2 engine profile)
+    "phi-2.7b": LlamaConfig("phi-2.7b", 51200, 2560, 10240, 32, 32, 32, 80, 10000.0, 1e-5, 2048, 1, 2),
+}
+
+_ALIASES = {
+    "llama-3.1-8b": "llama-3-8b",
+    "meta-llama/llama-3.1-8b-instruct": "llama-3-8b",
+    "meta-llama/meta-llama-3-8b-instruct": "llama-3-8b",
+    "llama3-8b": "llama-3-8b",
+    "llama-3.1-70b": "llama-3-70b",
+    "llama3-70b": "llama-3-70b",
+    "llama2-7b": "llama-2-7b",
+    "llama-7b": "llama-2-7b",
+    "llama2-13b": "llama-2-13b",
+    "phi-2": "phi-2.7b",
+}
+
+
+def get_config(name: str) -> LlamaConfig:
+    key = name.lower()
+    key = _ALIASES.get(key, key)
+    if key not in PRESETS:
+        raise KeyError(f"unknown model preset {name!r}; known: {sorted(PRESETS)}")
+    return PRESETS[key]
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor, group: int = GU_GROUP) -> torch.Tensor:
+    """[I, H], [I, H] -> [2I, H] with rows interleaved in groups of ``group``."""
+    i, h = gate.shape
+    assert i % group == 0, "intermediate size must be a multiple of the interleave group"
+    g = gate.view(i // group, group, h)
+    u = up.view(i // group, group, h)
+    return torch.stack((g, u), dim=1).reshape(2 * i, h)
+
+
+def deinterleave_gate_up(gu: torch.Tensor, group: int = GU_GROUP) -> "tuple[torch.Tensor, torch.Tensor]":
+    """Inverse of :func:`interleave_gate_up` on the last dimension of an activation
+    ``[..., 2I]`` (or on the rows of a weight, via ``.T``)."""
+    *lead, n = gu.shape
+    x = gu.reshape(*lead, n // (2 * group), 2, group)
+    return x[..., 0, :].reshape(*lead, n // 2), x[..., 1, :].reshape(*lead, n // 2)
+
+
+@dataclass
+class LayerWeights:
+    attn_norm: torch.Tensor
+    wqkv: torch.Tensor
+    wo: torch.Tensor
+    mlp_norm: torch.Tensor
+    wgu: torch.Tensor
+    wdown: torch.Tensor
+    # optional fp8 (e4m3) copies + per-output-row scales for the quantised GEMM path
+    fp8: Dict[str, Any] = field(default_factory=dict)
+
+
+@dataclass
+class LlamaWeights:
+    cfg: LlamaConfig
+    embed: torch.Tensor
+    layers: List[LayerWeights]
+    final_norm: torch.Tensor
+    lm_head: torch.Tensor
+    tp_rank: int = 0
+    tp_size: int = 1
+
+    @property
+    def device(self) -> torch.device:
+        return self.embed.device
+
+    def nbytes(self) -> int:
+        n = self.embed.numel() * self.embed.element_size() + self.lm_head.numel() * self.lm_head.element_size()
+        for lw in self.layers:
+            for t in (lw.wqkv, lw.wo, lw.wgu, lw.wdown):
+                n += t.numel() * t.element_size()
+        return n
+
+
+def random_weights(
+    cfg: LlamaConfig,
+    device: torch.device | str = "cpu",
+    dtype: torch.dtype = torch.bfloat16,
+    seed: int = 0,
+    tp_rank: int = 0,
+    tp_size: int = 1,
+) -> LlamaWeights:
+    """Random-init weights (N(0, 0.02) like HF initialisation, norms = 1).  Every
+    TP rank draws the *full* matrix from the same seed and keeps its shard, so a
+    TP=k model equals the TP=1 model of the same seed (what the multi-process
+    tests check).  Generation happens on ``device`` layer by layer, so the 16 GB of
+    an 8B model never exist on the host."""
+    assert cfg.num_heads % tp_size == 0 and cfg.num_kv_heads % tp_size == 0 and cfg.intermediate_size % (tp_size * GU_GROUP) == 0
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+
+    def rnd(rows: int, cols: int) -> torch.Tensor:
+        return (torch.randn(rows, cols, generator=gen, device=dev, dtype=torch.float32) * 0.02).to(dtype)
+
+    h, hd = cfg.hidden_size, cfg.head_dim
+    nh_l, nkv_l, i_l = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size, cfg.intermediate_size // tp_size
+
+    def shard_rows(w: torch.Tensor, n_local: int) -> torch.Tensor:
+        return w[tp_rank * n_local : (tp_rank + 1) * n_local].contiguous()
+
+    def shard_cols(w: torch.Tensor, n_local: int) -> torch.Tensor:
+        return w[:, tp_rank * n_local : (tp_rank + 1) * n_local].contiguous()
+
+    embed = rnd(cfg.vocab_size, h)
+    layers: List[LayerWeights] = []
+    for _ in range(cfg.num_layers):
+        wq = shard_rows(rnd(cfg.q_size, h), nh_l * hd)
+        wk = shard_rows(rnd(cfg.kv_size, h), nkv_l * hd)
+        wv = shard_rows(rnd(cfg.kv_size, h), nkv_l * hd)
+        wo = shard_cols(rnd(h, cfg.q_size), nh_l * hd)
+        wg = shard_rows(rnd(cfg.intermediate_size, h), i_l)
+        wu = shard_rows(rnd(cfg.intermediate_size, h), i_l)
+        wd = shard_cols(rnd(h, cfg.intermediate_size), i_l)
+        layers.append(
+            LayerWeights(
+                attn_norm=torch.ones(h, device=dev, dtype=dtype),
+                wqkv=torch.cat((wq, wk, wv), dim=0).contiguous(),
+                wo=wo,
+                mlp_norm=torch.ones(h, device=dev, dtype=dtype),
+                wgu=interleave_gate_up(wg, wu).contiguous(),
+                wdown=wd,
+            )
+        )
+        del wq, wk, wv, wg, wu
+    final_norm = torch.ones(h, device=dev, dtype=dtype)
+    lm_head = rnd(cfg.vocab_size, h)
+    return LlamaWeights(cfg, embed, layers, final_norm, lm_head, tp_rank, tp_size)
+
+
+def load_hf_safetensors(path: str, cfg: LlamaConfig, device: torch.device | str = "cpu", dtype: torch.dtype = torch.bfloat16, tp_rank: int = 0, tp_size: int = 1) -> LlamaWeights:
+    """Load a Hugging Face Llama checkpoint directory (``*.safetensors``) into the
+    fused layout.  Only safetensors is read — nothing is unpickled."""
+    import glob
+    import os
+
+    from safetensors import safe_open
+
+    tensors: Dict[str, torch.Tensor] = {}
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no .safetensors files under {path}")
+    for fpath in files:
+        with safe_open(fpath, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                tensors[k] = f.get_tensor(k)
+    dev = torch.device(device)
+    hd = cfg.head_dim
+    nh_l, nkv_l, i_l = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size, cfg.intermediate_size // tp_size
+
+    def rows(w: torch.Tensor, n: int) -> torch.Tensor:
+        return w[tp_rank * n : (tp_rank + 1) * n]
+
+    def cols(w: torch.Tensor, n: int) -> torch.Tensor:
+        return w[:, tp_rank * n : (tp_rank + 1) * n]
+
+    def get(name: str) -> torch.Tensor:
+        return tensors[name].to(dtype)
+
+    layers = []
+    for li in range(cfg.num_layers):
+        p = f"model.layers.{li}."
+        wqkv = torch.cat((rows(get(p + "self_attn.q_proj.weight"), nh_l * hd), rows(get(p + "self_attn.k_proj.weight"), nkv_l * hd), rows(get(p + "self_attn.v_proj.weight"), nkv_l * hd)), 0)
+        wgu = interleave_gate_up(rows(get(p + "mlp.gate_proj.weight"), i_l).contiguous(), rows(get(p + "mlp.up_proj.weight"), i_l).contiguous())
+        layers.append(
+            LayerWeights(
+                attn_norm=get(p + "input_layernorm.weight").to(dev),
+                wqkv=wqkv.contiguous().to(dev),
+                wo=cols(get(p + "self_attn.o_proj.weight"), nh_l * hd).contiguous().to(dev),
+                mlp_norm=get(p + "post_attention_layernorm.weight").to(dev),
+                wgu=wgu.contiguous().to(dev),
+                wdown=cols(get(p + "mlp.down_proj.weight"), i_l).contiguous().to(dev),
+            )
+        )
+    embed = get("model.embed_tokens.weight").to(dev)
+    lm_head = tensors.get("lm_head.weight")
+    lm_head = embed if lm_head is None else lm_head.to(dtype).to(dev)
+    return LlamaWeights(cfg, embed, layers, get("model.norm.weight").to(dev), lm_head, tp_rank, tp_size)
+
+
+def rope_tables(cfg: LlamaConfig, max_pos: int, device: torch.device | str) -> "tuple[torch.Tensor, torch.Tensor]":
+    """cos/sin tables [max_pos, head_dim/2] in fp32 (rotate-half / NeoX pairing:
+    element i pairs with i + head_dim/2, as in HF Llama)."""
+    half = cfg.head_dim // 2
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, half, dtype=torch.float64) / half))
+    ang = torch.arange(max_pos, dtype=torch.float64)[:, None] * inv[None, :]
+    return ang.cos().float().to(device), ang.sin().float().to(device)
+
+
+def quantize_fp8_rows(w: torch.Tensor) -> "tuple[torch.Tensor, torch.Tensor]":
+    """Per-output-row symmetric quantisation to OCP e4m3 (gfx950's native FP8 —
+    not the FNUZ encoding of the previous generation).  Returns (w_fp8, scale[rows])."""
+    amax = w.float().abs().amax(dim=1).clamp_min(1e-12)
+    scale = amax / 448.0
+    q = (w.float() / scale[:, None]).to(torch.float8_e4m3fn)
+    return q, scale.float()

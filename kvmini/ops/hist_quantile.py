@@ -1,0 +1,214 @@
+"""Python side of ``csrc/hist_quantile.hip``: exact batched quantiles, 20-bin
+histograms and a persistent streaming histogram on the GPU.
+
+Exactness: the kernel selects the order statistics ``floor(p*(n-1))`` and
+``ceil(p*(n-1))`` exactly (radix select on order-preserving keys); the linear
+interpolation between them happens here in float64 with the reference's formula
+(``analyze.py:75-81``), so results equal the CPU oracle bit for bit on float64
+input.
+"""
+
+from __future__ import annotations
+
+import math
+import struct
+from typing import Any, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import gpu_available, native, native_built
+
+BINS = 2048
+# streaming histogram range: 2^-10 ms (~1 us) .. 2^20 ms (~17 min), ~68 bins per octave (~1 % wide)
+LO_LOG2 = -10.0
+HI_LOG2 = 20.0
+
+
+def available() -> bool:
+    return native_built() and gpu_available()
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _key_to_value(key: int, is_double: bool) -> float:
+    if is_double:
+        bits = (key & 0x7FFFFFFFFFFFFFFF) if (key >> 63) else (~key & 0xFFFFFFFFFFFFFFFF)
+        return struct.unpack("<d", struct.pack("<Q", bits))[0]
+    k32 = key >> 32
+    bits = (k32 & 0x7FFFFFFF) if (k32 >> 31) else (~k32 & 0xFFFFFFFF)
+    return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+
+def _new_stream_state(m: int, device: Any):
+    torch = _torch()
+    C = native()
+    sb = C.stream_state_bytes()
+    one = np.zeros(sb, dtype=np.uint8)
+    one[16:24] = 0xFF  # min_key = ~0
+    state = torch.from_numpy(np.tile(one, m)).to(device)
+    hist = torch.zeros((m, BINS), dtype=torch.int32, device=device)
+    return state, hist
+
+
+def _decode_stream_state(state_cpu: np.ndarray, m: int, is_double: bool) -> List[Dict[str, Any]]:
+    sb = state_cpu.size // m
+    out = []
+    for i in range(m):
+        count, total, kmin, kmax = struct.unpack("<QdQQ", state_cpu[i * sb : i * sb + 32].tobytes())
+        d: Dict[str, Any] = {"count": count, "sum": total}
+        if count:
+            d["min"] = _key_to_value(kmin, is_double)
+            d["max"] = _key_to_value(kmax, is_double)
+            d["mean"] = total / count
+        out.append(d)
+    return out
+
+
+def batched_quantiles(samples: Any, ps: Sequence[float] = (0.5, 0.95, 0.99), return_stats: bool = False):
+    """Quantiles of every row of a ``[n_metrics, n]`` matrix (NaN = missing).
+
+    ``samples``: numpy array or torch tensor, float32/float64.  Returns an array
+    ``[n_metrics, len(ps)]`` (NaN for empty rows) and, optionally, per-row
+    count/sum/min/max/mean."""
+    torch = _torch()
+    C = native()
+    if not gpu_available():
+        raise RuntimeError("HIP quantiles need a GPU")
+    if not 1 <= len(ps) <= 4:
+        raise ValueError("1..4 quantile levels per call")
+    if isinstance(samples, np.ndarray):
+        if samples.dtype not in (np.float32, np.float64):
+            samples = samples.astype(np.float64)
+        x = torch.from_numpy(np.ascontiguousarray(samples)).cuda()
+    else:
+        x = samples if samples.is_cuda else samples.cuda()
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.double()
+        x = x.contiguous()
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    m, n = x.shape
+    is_double = x.dtype == torch.float64
+    dev = x.device
+    state, hist = _new_stream_state(m, dev)
+    C.stream_hist(x, n, hist, state, LO_LOG2, HI_LOG2)
+    rstate = torch.zeros(m * C.radix_state_bytes(), dtype=torch.uint8, device=dev)
+    rhist = torch.zeros((m, 8, BINS), dtype=torch.int32, device=dev)
+    ps_dev = torch.tensor(list(ps), dtype=torch.float64, device=dev)
+    C.radix_select(x, n, state, ps_dev, rstate, rhist)
+    rs = rstate.cpu().numpy()
+    stats = _decode_stream_state(state.cpu().numpy(), m, is_double)
+    rb = C.radix_state_bytes()
+    out = np.full((m, len(ps)), np.nan, dtype=np.float64)
+    for i in range(m):
+        cnt = stats[i]["count"]
+        if cnt == 0:
+            continue
+        prefixes = struct.unpack("<8Q", rs[i * rb : i * rb + 64].tobytes())
+        for j, p in enumerate(ps):
+            p = max(0.0, min(float(p), 1.0))
+            pos = p * (cnt - 1)
+            lo = math.floor(pos)
+            v_lo = _key_to_value(prefixes[2 * j], is_double)
+            v_hi = _key_to_value(prefixes[2 * j + 1], is_double)
+            out[i, j] = v_lo if cnt == 1 or lo == math.ceil(pos) else v_lo + (pos - lo) * (v_hi - v_lo)
+    return (out, stats) if return_stats else out
+
+
+def quantiles(a: Iterable[float], ps: Sequence[float] = (0.5, 0.95, 0.99)) -> List[float]:
+    arr = np.asarray(a, dtype=np.float64).reshape(1, -1)
+    out: List[float] = []
+    ps = list(ps)
+    for i in range(0, len(ps), 4):
+        out += batched_quantiles(arr, ps[i : i + 4])[0].tolist()
+    return out
+
+
+def equal_width_histogram(data: Iterable[float], num_bins: int = 20) -> Dict[str, Any]:
+    """Same dict as ``analysis.histograms.compute_histogram`` (reference
+    ``analyze.py:84-122``), computed on the GPU."""
+    torch = _torch()
+    C = native()
+    arr = np.asarray(data, dtype=np.float64).reshape(1, -1)
+    x = torch.from_numpy(arr).cuda()
+    n = x.shape[1]
+    state, hist = _new_stream_state(1, x.device)
+    C.stream_hist(x, n, hist, state, LO_LOG2, HI_LOG2)
+    out = torch.zeros((1, 64), dtype=torch.int64, device=x.device)
+    C.equal_hist(x, n, state, out, num_bins)
+    st = _decode_stream_state(state.cpu().numpy(), 1, True)[0]
+    if st["count"] == 0:
+        return {"bins": [], "counts": [], "bin_edges": []}
+    lo, hi = st["min"], st["max"]
+    if lo == hi:
+        return {"bins": [lo], "counts": [int(st["count"])], "bin_edges": [lo, hi]}
+    width = (hi - lo) / num_bins
+    edges = [lo + i * width for i in range(num_bins + 1)]
+    counts = out[0, :num_bins].cpu().tolist()
+    return {
+        "bins": [(edges[i] + edges[i + 1]) / 2 for i in range(num_bins)],
+        "counts": [int(c) for c in counts],
+        "bin_edges": edges,
+        "min": lo,
+        "max": hi,
+        "total_samples": int(st["count"]),
+    }
+
+
+class StreamingHistogram:
+    """Persistent device histogram for live inter-token-latency statistics.
+
+    ``update()`` bins a new slice of samples (ms) into 2048 log-spaced bins per
+    metric and keeps count/sum/min/max; nothing is ever re-read.  ``snapshot()``
+    returns approximate quantiles (log-interpolated inside the bin, ~1 % bin
+    width) — the live view; the exact offline numbers come from
+    :func:`batched_quantiles` over the stored events."""
+
+    def __init__(self, n_metrics: int = 1, device: Any = "cuda"):
+        torch = _torch()
+        self.m = n_metrics
+        self.device = torch.device(device)
+        self.state, self.hist = _new_stream_state(n_metrics, self.device)
+        self.is_double = False
+
+    def update(self, samples: Any) -> None:
+        torch = _torch()
+        x = torch.as_tensor(samples)
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.float()
+        self.is_double = x.dtype == torch.float64
+        x = x.to(self.device).contiguous()
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        assert x.shape[0] == self.m
+        native().stream_hist(x, x.shape[1], self.hist, self.state, LO_LOG2, HI_LOG2)
+
+    def merge_counts(self, other_hist: Any) -> None:
+        """Add another rank's bin counts (after an all-reduce/all-gather)."""
+        self.hist += other_hist.to(self.hist.device)
+
+    def snapshot(self, ps: Sequence[float] = (0.5, 0.95, 0.99)) -> List[Dict[str, Any]]:
+        hist = self.hist.cpu().numpy().astype(np.int64)
+        stats = _decode_stream_state(self.state.cpu().numpy(), self.m, self.is_double)
+        step = (HI_LOG2 - LO_LOG2) / BINS
+        for i, st in enumerate(stats):
+            n = int(hist[i].sum())
+            st["quantiles"] = {}
+            if n == 0:
+                continue
+            cum = np.cumsum(hist[i])
+            for p in ps:
+                k = p * (n - 1)
+                b = int(np.searchsorted(cum, k, side="right"))
+                b = min(b, BINS - 1)
+                below = cum[b - 1] if b else 0
+                frac = (k - below + 0.5) / max(1, hist[i][b])
+                v = 2.0 ** (LO_LOG2 + (b + min(max(frac, 0.0), 1.0)) * step)
+                if "min" in st:
+                    v = min(max(v, st["min"]), st["max"])
+                st["quantiles"][p] = v
+        return stats

@@ -1,0 +1,412 @@
+"""OpenAI-compatible HTTP front-end of the native MI355X engine (``kvmini serve``).
+
+Endpoints: ``POST /v1/chat/completions``, ``POST /v1/completions`` (stream and
+non-stream, ``stream_options.include_usage``, ``n`` = 1), ``GET /v1/models``,
+``GET /health``, ``GET /metrics`` (Prometheus text with the ``vllm:*`` names the
+dashboards and the analyzer's cache-hit query use), TGI ``/generate`` and
+``/generate_stream`` for the A/B harness.
+
+This is the stand-in for "KServe vLLM-ROCm runtime" on a box with no vLLM and no
+Kubernetes: the benchmark harness talks to it exactly as it would talk to a
+KServe predictor URL.  Tokens flow engine thread -> per-request ``asyncio.Queue``
+with one ``call_soon_threadsafe`` per engine step; the first content chunk is
+written as soon as the first sampled token arrives (TCP_NODELAY).
+"""
+
+from __future__ import annotations
+
+import argparse
+import asyncio
+import json
+import os
+import sys
+import time
+import uuid
+from typing import Any, AsyncIterator, Dict, List, Optional, Tuple
+
+from kvmini.engine.engine import EngineConfig, LLMEngine, TokenEvent
+from kvmini.engine.scheduler import SamplingParams
+from kvmini.engine.tokenizer import get_tokenizer
+
+from .httpd import HttpServer, Request, Response, StreamingResponse, sse_event
+
+
+class NativeServer:
+    def __init__(self, engine: LLMEngine, model_name: Optional[str] = None, tokenizer_path: Optional[str] = None, ignore_eos: bool = True, api_key: Optional[str] = None):
+        self.engine = engine
+        self.model_name = model_name or engine.mcfg.name
+        cfg = engine.mcfg
+        self.tok = get_tokenizer(cfg.vocab_size, cfg.bos_token_id, cfg.eos_token_id, tokenizer_path)
+        # random-init weights have no meaningful EOS: generate exactly max_tokens
+        self.ignore_eos = ignore_eos
+        self.api_key = api_key
+        self.started_at = time.time()
+        self.ready_at: Optional[float] = None
+        self.loop: Optional[asyncio.AbstractEventLoop] = None
+        self._queues: Dict[int, asyncio.Queue] = {}
+        self.requests_total = 0
+        self.errors_total = 0
+        engine.on_tokens = self._on_tokens
+
+    # engine thread -> event loop ---------------------------------------
+    def _on_tokens(self, events: List[TokenEvent]) -> None:
+        loop = self.loop
+        if loop is not None:
+            loop.call_soon_threadsafe(self._deliver, events)
+
+    def _deliver(self, events: List[TokenEvent]) -> None:
+        for req_id, toks, done, reason, seq in events:
+            q = self._queues.get(req_id)
+            if q is not None:
+                q.put_nowait((toks, done, reason, seq))
+
+    # helpers --------------------------------------------------------------
+    def _params(self, body: Dict[str, Any]) -> SamplingParams:
+        max_tokens = body.get("max_tokens") or body.get("max_completion_tokens") or 16
+        ignore = body.get("ignore_eos")
+        return SamplingParams(
+            max_tokens=int(max_tokens),
+            temperature=float(body.get("temperature") or 0.0),
+            top_p=float(body.get("top_p") or 1.0),
+            top_k=int(body.get("top_k") or 0),
+            seed=body.get("seed"),
+            ignore_eos=self.ignore_eos if ignore is None else bool(ignore),
+            logprobs=int(body.get("top_logprobs") or (1 if body.get("logprobs") else 0)),
+        )
+
+    def _auth(self, req: Request) -> Optional[Response]:
+        if self.api_key and req.headers.get("authorization", "") != f"Bearer {self.api_key}":
+            return Response.json({"error": {"message": "invalid api key", "type": "authentication_error"}}, 401)
+        return None
+
+    async def _run(self, prompt_ids: List[int], params: SamplingParams) -> Tuple[int, asyncio.Queue]:
+        q: asyncio.Queue = asyncio.Queue()
+        rid = self.engine.submit(prompt_ids, params)
+        self._queues[rid] = q
+        return rid, q
+
+    # OpenAI ---------------------------------------------------------------
+    async def chat(self, req: Request) -> Any:
+        return await self._openai(req, chat=True)
+
+    async def completions(self, req: Request) -> Any:
+        return await self._openai(req, chat=False)
+
+    async def _openai(self, req: Request, chat: bool) -> Any:
+        bad = self._auth(req)
+        if bad:
+            return bad
+        body = req.json() or {}
+        self.requests_total += 1
+        if chat:
+            msgs = body.get("messages")
+            if not isinstance(msgs, list) or not msgs:
+                self.errors_total += 1
+                return Response.json({"error": {"message": "messages must be a non-empty list", "type": "invalid_request_error"}}, 400)
+            prompt_ids = self.tok.apply_chat_template(msgs)
+        else:
+            prompt = body.get("prompt", "")
+            if isinstance(prompt, list):
+                prompt = prompt[0] if prompt else ""
+            prompt_ids = self.tok.encode(str(prompt), add_bos=True)
+        if len(prompt_ids) >= self.engine.ecfg.max_model_len:
+            self.errors_total += 1
+            return Response.json({"error": {"message": f"prompt has {len(prompt_ids)} tokens; max_model_len is {self.engine.ecfg.max_model_len}", "type": "invalid_request_error"}}, 400)
+        params = self._params(body)
+        stream = bool(body.get("stream"))
+        include_usage = bool((body.get("stream_options") or {}).get("include_usage"))
+        model = body.get("model") or self.model_name
+        oid = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex[:24]
+        created = int(time.time())
+        rid, q = await self._run(prompt_ids, params)
+        n_prompt = len(prompt_ids)
+        obj = "chat.completion" if chat else "text_completion"
+
+        if not stream:
+            out: List[int] = []
+            reason = None
+            try:
+                while True:
+                    toks, done, reason, _seq = await q.get()
+                    out += toks
+                    if done:
+                        break
+            finally:
+                self._queues.pop(rid, None)
+            if reason and reason.startswith("error"):
+                self.errors_total += 1
+                return Response.json({"error": {"message": reason, "type": "internal_error"}}, 500)
+            text = self.tok.decode(out)
+            usage = {"prompt_tokens": n_prompt, "completion_tokens": len(out), "total_tokens": n_prompt + len(out)}
+            if chat:
+                choice: Dict[str, Any] = {"index": 0, "message": {"role": "assistant", "content": text}, "finish_reason": reason}
+            else:
+                choice = {"index": 0, "text": text, "finish_reason": reason}
+            return Response.json({"id": oid, "object": obj, "created": created, "model": model, "choices": [choice], "usage": usage})
+
+        async def gen() -> AsyncIterator[bytes]:
+            base = {"id": oid, "object": (obj + ".chunk") if chat else obj, "created": created, "model": model}
+            n_out = 0
+            finished = False
+            try:
+                if chat:
+                    yield sse_event({**base, "choices": [{"index": 0, "delta": {"role": "assistant", "content": ""}, "finish_reason": None}]})
+                while True:
+                    toks, done, reason, _seq = await q.get()
+                    for t in toks:
+                        n_out += 1
+                        piece = self.tok.decode_token(t) or " "
+                        ch = {"index": 0, "delta": {"content": piece}, "finish_reason": None} if chat else {"index": 0, "text": piece, "finish_reason": None}
+                        yield sse_event({**base, "choices": [ch]})
+                    if done:
+                        finished = True
+                        fin = {"index": 0, "delta": {}, "finish_reason": reason} if chat else {"index": 0, "text": "", "finish_reason": reason}
+                        yield sse_event({**base, "choices": [fin]})
+                        break
+                if include_usage:
+                    yield sse_event({**base, "choices": [], "usage": {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}})
+                yield sse_event("[DONE]")
+            finally:
+                self._queues.pop(rid, None)
+                if not finished:
+                    self.engine.abort(rid)  # client went away
+
+        return StreamingResponse(gen())
+
+    # TGI ------------------------------------------------------------------
+    async def tgi(self, req: Request) -> Any:
+        body = req.json() or {}
+        self.requests_total += 1
+        prm = body.get("parameters") or {}
+        params = SamplingParams(
+            max_tokens=int(prm.get("max_new_tokens") or 20),
+            temperature=float(prm.get("temperature") or 0.0) if prm.get("do_sample") else 0.0,
+            top_p=float(prm.get("top_p") or 1.0),
+            top_k=int(prm.get("top_k") or 0),
+            seed=prm.get("seed"),
+            ignore_eos=self.ignore_eos,
+        )
+        prompt_ids = self.tok.encode(str(body.get("inputs", "")), add_bos=True)
+        rid, q = await self._run(prompt_ids, params)
+        if not req.path.endswith("_stream"):
+            out: List[int] = []
+            try:
+                while True:
+                    toks, done, reason, _ = await q.get()
+                    out += toks
+                    if done:
+                        break
+            finally:
+                self._queues.pop(rid, None)
+            return Response.json({"generated_text": self.tok.decode(out), "details": {"finish_reason": reason, "generated_tokens": len(out), "prefill": [{"id": t} for t in prompt_ids]}})
+
+        async def gen() -> AsyncIterator[bytes]:
+            out: List[int] = []
+            finished = False
+            try:
+                while True:
+                    toks, done, reason, _ = await q.get()
+                    for i, t in enumerate(toks):
+                        out.append(t)
+                        ev: Dict[str, Any] = {"index": len(out) - 1, "token": {"id": t, "text": self.tok.decode_token(t) or " ", "logprob": 0.0, "special": False}, "generated_text": None, "details": None}
+                        if done and i == len(toks) - 1:
+                            ev["generated_text"] = self.tok.decode(out)
+                            ev["details"] = {"finish_reason": reason, "generated_tokens": len(out)}
+                        yield sse_event(ev)
+                    if done:
+                        finished = True
+                        break
+            finally:
+                self._queues.pop(rid, None)
+                if not finished:
+                    self.engine.abort(rid)
+
+        return StreamingResponse(gen())
+
+    # misc -----------------------------------------------------------------
+    async def models(self, req: Request) -> Response:
+        return Response.json({"object": "list", "data": [{"id": self.model_name, "object": "model", "created": int(self.started_at), "owned_by": "kvmini", "max_model_len": self.engine.ecfg.max_model_len}]})
+
+    async def health(self, req: Request) -> Response:
+        return Response.json({"status": "ok", "model": self.model_name, "uptime_s": time.time() - self.started_at, "ready_after_s": (self.ready_at or time.time()) - self.started_at})
+
+    async def info(self, req: Request) -> Response:
+        e = self.engine
+        return Response.json({"model_id": self.model_name, "max_total_tokens": e.ecfg.max_model_len, "version": "kvmini-native", "model_device_type": e.device.type, "engine": e.metrics()})
+
+    async def metrics(self, req: Request) -> Response:
+        m = self.engine.metrics()
+        name = self.model_name
+        lb = f'{{model_name="{name}"}}'
+        lines = [
+            "# TYPE vllm:num_requests_running gauge",
+            f"vllm:num_requests_running{lb} {m['running']}",
+            "# TYPE vllm:num_requests_waiting gauge",
+            f"vllm:num_requests_waiting{lb} {m['waiting']}",
+            "# TYPE vllm:prompt_tokens_total counter",
+            f"vllm:prompt_tokens_total{lb} {m['prompt_tokens']}",
+            "# TYPE vllm:generation_tokens_total counter",
+            f"vllm:generation_tokens_total{lb} {m['generation_tokens']}",
+            "# TYPE vllm:gpu_prefix_cache_hits_total counter",
+            f"vllm:gpu_prefix_cache_hits_total{lb} {m['prefix_cache_hits']}",
+            "# TYPE vllm:gpu_prefix_cache_queries_total counter",
+            f"vllm:gpu_prefix_cache_queries_total{lb} {m['prefix_cache_queries']}",
+            "# TYPE vllm:gpu_cache_usage_perc gauge",
+            f"vllm:gpu_cache_usage_perc{lb} {1.0 - m['kv_blocks_free'] / max(1, m['kv_blocks_total']):.6f}",
+            "# TYPE vllm:num_preemptions_total counter",
+            f"vllm:num_preemptions_total{lb} {m['preemptions']}",
+            "# TYPE kvmini_engine_steps_total counter",
+            f"kvmini_engine_steps_total {m['steps']}",
+            "# TYPE kvmini_engine_step_ms gauge",
+            f"kvmini_engine_step_ms {m['step_ms_ewma']:.4f}",
+            "# TYPE kvmini_spec_tokens_proposed_total counter",
+            f"kvmini_spec_tokens_proposed_total {m['spec_proposed']}",
+            "# TYPE kvmini_spec_tokens_accepted_total counter",
+            f"kvmini_spec_tokens_accepted_total {m['spec_accepted']}",
+            "# TYPE kvmini_requests_total counter",
+            f"kvmini_requests_total {self.requests_total}",
+            f"kvmini_request_errors_total {self.errors_total}",
+        ]
+        return Response.text("\n".join(lines) + "\n", content_type="text/plain; version=0.0.4")
+
+    def build_server(self) -> HttpServer:
+        s = HttpServer()
+        s.route("POST", "/v1/chat/completions", self.chat)
+        s.route("POST", "/v1/completions", self.completions)
+        s.route("GET", "/v1/models", self.models)
+        s.route("GET", "/health", self.health)
+        s.route("GET", "/", self.health)
+        s.route("GET", "/info", self.info)
+        s.route("GET", "/metrics", self.metrics)
+        s.route("POST", "/generate", self.tgi)
+        s.route("POST", "/generate_stream", self.tgi)
+        return s
+
+    async def serve(self, host: str, port: int, announce: bool = True) -> None:
+        self.loop = asyncio.get_running_loop()
+        srv = self.build_server()
+        p = await srv.start(host, port)
+        self.engine.start()
+        self.ready_at = time.time()
+        if announce:
+            print(f"kvmini serve: {self.model_name} on http://{host}:{p} (load {self.engine.load_s:.1f}s, warmup {self.engine.warm_s:.1f}s)", flush=True)
+        await srv.serve_forever()
+
+
+def start_native_in_thread(engine: LLMEngine, port: int = 0, **kw: Any):
+    """(server, base_url, stop) — engine + HTTP front-end on a background thread."""
+    import threading
+
+    ns = NativeServer(engine, **kw)
+    ready = threading.Event()
+    box: Dict[str, Any] = {}
+
+    def _run() -> None:
+        loop = asyncio.new_event_loop()
+        asyncio.set_event_loop(loop)
+        ns.loop = loop
+        srv = ns.build_server()
+        box["port"] = loop.run_until_complete(srv.start("127.0.0.1", port))
+        box["loop"], box["srv"] = loop, srv
+        engine.start()
+        ns.ready_at = time.time()
+        ready.set()
+        try:
+            loop.run_forever()
+        finally:
+            loop.run_until_complete(srv.stop())
+            loop.close()
+
+    th = threading.Thread(target=_run, daemon=True, name="kvmini-native-http")
+    th.start()
+    if not ready.wait(60):
+        raise RuntimeError("native server did not start")
+
+    def stop() -> None:
+        engine.stop()
+        box["loop"].call_soon_threadsafe(box["loop"].stop)
+        th.join(5)
+
+    return ns, f"http://127.0.0.1:{box['port']}", stop
+
+
+def add_engine_args(ap: argparse.ArgumentParser) -> None:
+    ap.add_argument("--model", default="llama-3-8b", help="architecture preset (see kvmini.models.llama.PRESETS)")
+    ap.add_argument("--device", default="auto")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--random-init", action="store_true", help="random-init weights (default when no --weights)")
+    ap.add_argument("--weights", default=None, help="directory with HF *.safetensors")
+    ap.add_argument("--tokenizer", default=None, help="tokenizer.json (default: synthetic tokenizer)")
+    ap.add_argument("--max-num-seqs", type=int, default=64)
+    ap.add_argument("--max-batched-tokens", type=int, default=256)
+    ap.add_argument("--max-model-len", type=int, default=8192)
+    ap.add_argument("--block-size", type=int, default=16)
+    ap.add_argument("--num-blocks", type=int, default=0)
+    ap.add_argument("--kv-memory-fraction", type=float, default=0.5)
+    ap.add_argument("--no-graphs", action="store_true", help="disable HIP-graph capture (eager launches)")
+    ap.add_argument("--kernels", default="auto", choices=["auto", "hip", "torch"])
+    ap.add_argument("--no-prefix-caching", action="store_true")
+    ap.add_argument("--quantization", default=None, choices=[None, "fp8"])
+    ap.add_argument("--speculative-model", default=None, help="draft model preset for speculative decoding")
+    ap.add_argument("--num-speculative-tokens", type=int, default=0)
+    ap.add_argument("--honor-eos", action="store_true", help="stop at EOS (default: ignore EOS with random-init weights)")
+
+
+def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
+    return EngineConfig(
+        model=a.model,
+        device=a.device,
+        dtype=a.dtype,
+        seed=a.seed,
+        max_num_seqs=a.max_num_seqs,
+        max_batched_tokens=a.max_batched_tokens,
+        max_model_len=a.max_model_len,
+        block_size=a.block_size,
+        num_blocks=a.num_blocks,
+        kv_memory_fraction=a.kv_memory_fraction,
+        use_graphs=not a.no_graphs,
+        kernels=a.kernels,
+        enable_prefix_caching=not a.no_prefix_caching,
+        weights_path=a.weights,
+        quantization=a.quantization,
+        draft_model=a.speculative_model,
+        num_speculative_tokens=a.num_speculative_tokens,
+    )
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    ap = argparse.ArgumentParser(prog="kvmini serve", description="Native MI355X OpenAI-compatible LLM server")
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--served-model-name", default=None)
+    ap.add_argument("--api-key", default=None)
+    ap.add_argument("--service", default="demo-llm", help="name in the local cluster registry")
+    ap.add_argument("--namespace", default="local")
+    ap.add_argument("--no-register", action="store_true")
+    add_engine_args(ap)
+    a = ap.parse_args(argv)
+    proc_start = time.time()
+    engine = LLMEngine(engine_config_from_args(a))
+    engine.warmup()
+    ns = NativeServer(engine, a.served_model_name or a.model, a.tokenizer, ignore_eos=not a.honor_eos, api_key=a.api_key)
+    ns.started_at = proc_start
+    if not a.no_register:
+        from kvmini.cluster import LocalBackend
+
+        LocalBackend().register_server(a.service, f"http://{a.host}:{a.port}", os.getpid(), proc_start, namespace=a.namespace, gpus=1 if engine.device.type == "cuda" else 0)
+    try:
+        asyncio.run(ns.serve(a.host, a.port))
+    except KeyboardInterrupt:
+        pass
+    finally:
+        engine.stop()
+        if not a.no_register:
+            from kvmini.cluster import LocalBackend
+
+            LocalBackend().mark_finished(os.getpid())
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

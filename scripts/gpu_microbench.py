@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Kernel- and step-level timings on one MI355X (writes JSON under gpurun_out/).
+
+* skinny GEMM variants vs the library GEMM for the Llama-3-8B decode shapes;
+  reports achieved weight-streaming bandwidth (HBM roofline is ~6.3 TB/s achievable);
+* one full decode step of the engine (HIP graph) at a given batch.
+All variants are timed interleaved in one process (median of rounds).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+
+def time_fns(fns, rounds=20, inner=10):
+    """fns: dict name -> callable. Interleaved rounds; returns median us per call."""
+    res = {k: [] for k in fns}
+    for k, f in fns.items():
+        f()
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for k, f in fns.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(inner):
+                f()
+            e1.record()
+            e1.synchronize()
+            res[k].append(e0.elapsed_time(e1) * 1000.0 / inner)
+    return {k: statistics.median(v) for k, v in res.items()}
+
+
+def gemm_bench(out):
+    from kvmini.ops import native
+
+    C = native()
+    dev = torch.device("cuda:0")
+    shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (28672, 4096), "down": (4096, 14336), "lm_head": (128256, 4096)}
+    # rotate through several weight copies so the 256 MiB Infinity Cache cannot serve re-reads
+    for name, (N, K) in shapes.items():
+        copies = max(2, int(600e6 // (N * K * 2)) + 1)
+        Ws = [(torch.randn(N, K, device=dev) * 0.02).bfloat16() for _ in range(copies)]
+        Wps = [C.pack_weight(w) for w in Ws]
+        for M in (16, 32, 64):
+            x = torch.randn(M, K, device=dev).bfloat16()
+            y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            st = {"i": 0}
+
+            def nxt(lst):
+                st["i"] = (st["i"] + 1) % copies
+                return lst[st["i"]]
+
+            fns = {
+                "hipblaslt": lambda: torch.nn.functional.linear(x, nxt(Ws)),
+                "skinny_w4": lambda: C.skinny_gemm(nxt(Ws), x, y, False, False, 4),
+                "skinny_w8": lambda: C.skinny_gemm(nxt(Ws), x, y, False, False, 8),
+                "packed_w4": lambda: C.skinny_gemm(nxt(Wps), x, y, False, True, 4),
+                "packed_w8": lambda: C.skinny_gemm(nxt(Wps), x, y, False, True, 8),
+            }
+            t = time_fns(fns)
+            row = {"shape": name, "N": N, "K": K, "M": M, "us": t, "TBps": {k: N * K * 2 / (v * 1e-6) / 1e12 for k, v in t.items()}}
+            print(json.dumps(row), flush=True)
+            out.append(row)
+        del Ws, Wps
+        torch.cuda.empty_cache()
+
+
+def step_bench(out, model, batch, kernels_list):
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    for kernels in kernels_list:
+        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=256, max_model_len=512 if kernels == "torch" else 2048, kernels=kernels, kv_memory_fraction=0.2))
+        eng.warmup()
+        prompts = [[1] + list(range(100 + i, 113 + i)) for i in range(batch)]
+        for rep in range(2):
+            seqs = [eng.make_sequence(p, SamplingParams(max_tokens=64, ignore_eos=True)) for p in prompts]
+            for s in seqs:
+                eng.scheduler.add(s)
+            eng.step()  # prefill step
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            while eng.scheduler.has_work():
+                eng.step()
+                n += 1
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / max(1, n)
+        row = {"bench": "decode_step", "model": model, "batch": batch, "kernels": kernels, "ms_per_step": dt * 1e3, "steps": n, "weight_GB": eng.weights.nbytes() / 1e9, "eff_TBps": eng.weights.nbytes() / dt / 1e12, "load_s": eng.load_s, "warm_s": eng.warm_s}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+        del eng
+        torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="gemm,step")
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--batch", type=int, default=20)
+    ap.add_argument("--kernels", default="hip,torch")
+    ap.add_argument("--out", default="gpurun_out/microbench.json")
+    a = ap.parse_args()
+    out = []
+    if "gemm" in a.what:
+        gemm_bench(out)
+    if "step" in a.what:
+        step_bench(out, a.model, a.batch, a.kernels.split(","))
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
