@@ -27,7 +27,7 @@ ARCH = os.environ.get("KVMINI_GPU_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-KERNEL_SOURCES = ["hist_quantile.hip", "energy_trapz.hip", "engine_kernels.hip", "skinny_gemm.hip"]
+KERNEL_SOURCES = ["hist_quantile.hip", "energy_trapz.hip", "engine_kernels.hip", "skinny_gemm.hip", "stream_gemm.hip"]
 RT_SOURCES = ["amdsmi_sampler.cpp", "telemetry_gather.cpp"]
 
 

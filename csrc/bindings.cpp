@@ -27,6 +27,13 @@ int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t s
 int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
                    hipStream_t stream);
 int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
+int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
+int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
+                   int chunks_per_split, long long slab_stride, hipStream_t stream);
+int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride, void* residual, const void* w, void* y, int T, int H, float eps,
+                         hipStream_t stream);
+int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_stride, void* q_out, const int* positions, const float* cos_t, const float* sin_t,
+                           void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, hipStream_t stream);
 }
 
 namespace {
@@ -179,6 +186,63 @@ at::Tensor pack_weight(at::Tensor W) {
   return Wp;
 }
 
+// ---- weight-streaming GEMM v2 (packed weights, LDS-shared x, split-K slabs) -------------
+std::pair<int64_t, int64_t> stream_gemm_plan(int64_t N, int64_t K, int64_t ks_per_chunk, int64_t max_splits) {
+  int cps = 0;
+  int splits = kv_stream_gemm_plan((int)N, (int)K, (int)ks_per_chunk, (int)max_splits, &cps);
+  return {splits, cps};
+}
+
+// epi 0: out bf16 [M, N]; epi 1: out fp32 [splits, M, N]; epi 2: out bf16 [M, N/2] (SwiGLU).
+void stream_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t ks_per_chunk, int64_t splits, int64_t chunks_per_split) {
+  CHECK_DEV(Wp); CHECK_BF16(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
+  TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
+  const int64_t M = x.size(0);
+  long long ldy = 0, slab_stride = 0;
+  if (epi == 1) {
+    TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && out.dim() == 3 && out.size(0) == splits && out.size(1) == M && out.size(2) == N,
+                "slab output must be contiguous fp32 [splits, M, N]");
+    ldy = N; slab_stride = M * N;
+  } else {
+    CHECK_BF16(out);
+    TORCH_CHECK(out.dim() == 2 && out.size(0) == M && out.size(1) == (epi == 2 ? N / 2 : N) && out.stride(1) == 1 && out.stride(0) % 4 == 0, "bad output shape");
+    TORCH_CHECK(splits == 1, "bf16 / SwiGLU epilogues need a single split");
+    ldy = out.stride(0);
+  }
+  check(kv_stream_gemm(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)ks_per_chunk, (int)splits,
+                       (int)chunks_per_split, slab_stride, cur_stream()),
+        "kv_stream_gemm");
+}
+
+void add_rmsnorm_slabs(at::Tensor slabs, at::Tensor residual, at::Tensor w, at::Tensor y, double eps) {
+  CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_BF16(residual); CHECK_BF16(w); CHECK_BF16(y); CHECK_CONTIG(residual); CHECK_CONTIG(w); CHECK_CONTIG(y);
+  TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3, "slabs must be fp32 [S, T, H]");
+  const int64_t T = slabs.size(1), H = slabs.size(2);
+  TORCH_CHECK(residual.dim() == 2 && residual.size(0) == T && residual.size(1) == H && y.sizes() == residual.sizes() && w.numel() == H, "shape mismatch");
+  TORCH_CHECK(H % 8 == 0 && H <= 32768, "hidden size must be a multiple of 8 and <= 32768");
+  check(kv_add_rmsnorm_slabs((const float*)slabs.data_ptr(), (int)slabs.size(0), T * H, residual.data_ptr(), w.data_ptr(), y.data_ptr(), (int)T, (int)H, (float)eps,
+                             cur_stream()),
+        "kv_add_rmsnorm_slabs");
+}
+
+void rope_kv_write_slabs(at::Tensor slabs, at::Tensor q_out, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
+                         at::Tensor slot_mapping, int64_t nh, int64_t nkv, int64_t hd) {
+  CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_BF16(q_out); CHECK_CONTIG(q_out); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_I32(positions); CHECK_I32(slot_mapping);
+  CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t); CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping);
+  TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3 && slabs.size(2) == (nh + 2 * nkv) * hd, "slabs must be fp32 [S, T, (nh + 2 nkv) * hd]");
+  const int64_t T = slabs.size(1);
+  TORCH_CHECK(q_out.numel() == T * nh * hd, "q_out must hold T*nh*hd elements");
+  TORCH_CHECK(positions.numel() >= T && slot_mapping.numel() >= T, "positions/slot_mapping shorter than T");
+  TORCH_CHECK(cos_t.scalar_type() == at::kFloat && sin_t.scalar_type() == at::kFloat && cos_t.dim() == 2 && cos_t.size(1) == hd / 2 && sin_t.sizes() == cos_t.sizes(),
+              "cos/sin must be float32 [max_pos, hd/2]");
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(1) == nkv && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  check(kv_rope_kv_write_slabs((const float*)slabs.data_ptr(), (int)slabs.size(0), T * slabs.size(2), q_out.data_ptr(), (const int*)positions.data_ptr(),
+                               (const float*)cos_t.data_ptr(), (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                               (const int*)slot_mapping.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), cur_stream()),
+        "kv_rope_kv_write_slabs");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -196,4 +260,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("swiglu_interleaved", &swiglu_interleaved);
   m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);
+  m.def("stream_gemm_plan", &stream_gemm_plan);
+  m.def("stream_gemm", &stream_gemm);
+  m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
+  m.def("rope_kv_write_slabs", &rope_kv_write_slabs);
 }

@@ -65,13 +65,67 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const unsigned short* 
   }
 }
 
+// Same, with x given as n_slabs fp32 partial sums [n_slabs][T][H] written by the split-K
+// weight-streaming GEMM: the slabs are summed here, in the consumer's prologue.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__global__ __launch_bounds__(256) void add_rmsnorm_slab_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+                                                               unsigned short* __restrict__ residual, const unsigned short* __restrict__ w,
+                                                               unsigned short* __restrict__ y, int H, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);
+  unsigned short* row = reinterpret_cast<unsigned short*>(smem + 16);
+  const int t = blockIdx.x, tid = threadIdx.x;
+  bf16x8* rv = reinterpret_cast<bf16x8*>(residual + (long long)t * H);
+  bf16x8* rowv = reinterpret_cast<bf16x8*>(row);
+  const int nv = H >> 3;
+  float ss = 0.f;
+  for (int i = tid; i < nv; i += 256) {
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    for (int sidx = 0; sidx < n_slabs; ++sidx) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + (long long)t * H + i * 8);
+      f32x4 lo = p[0], hi = p[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] += lo[j]; a[4 + j] += hi[j]; }
+    }
+    bf16x8 b = rv[i], c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // the GEMM output is rounded to bf16 first, like the unsplit kernel's store
+      unsigned short s = f2bf(bf2f(f2bf(a[j])) + bf2f(b[j]));
+      c[j] = s;
+      float f = bf2f(s);
+      ss += f * f;
+    }
+    rv[i] = c;
+    rowv[i] = c;
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+  const bf16x8* wv = reinterpret_cast<const bf16x8*>(w);
+  bf16x8* yv = reinterpret_cast<bf16x8*>(y + (long long)t * H);
+  for (int i = tid; i < nv; i += 256) {
+    bf16x8 c = rowv[i], g = wv[i], o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(c[j]) * inv * bf2f(g[j]));
+    yv[i] = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // RoPE (rotate-half pairing) on the q and k parts of the fused qkv row, in place for q;
 // rotated k and v are scattered into the paged cache
 //   cache[block][kv_head][slot_in_block][head_dim],  slot = slot_mapping[t] (-1: skip).
 // One workgroup per token; a thread task = 8 consecutive dims of the first half of one
 // head together with the matching 8 dims of the second half.
-__global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __restrict__ qkv, const int* __restrict__ positions,
+// SLAB = true: qkv arrives as n_slabs fp32 partial sums [n_slabs][T][width] (split-K GEMM
+// output) that are summed on load, and rotated q is written to q_out [T, nh*hd] (bf16).
+template <bool SLAB>
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __restrict__ qkv, const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+                                                            unsigned short* __restrict__ q_out, const int* __restrict__ positions,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                             unsigned short* __restrict__ k_cache, unsigned short* __restrict__ v_cache,
                                                             const int* __restrict__ slot_mapping, int nh, int nkv, int hd, int block_size) {
@@ -79,7 +133,23 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __re
   const int half = hd >> 1;
   const int tasks_per_head = half >> 3;
   const int width = (nh + 2 * nkv) * hd;
-  unsigned short* row = qkv + (long long)t * width;
+  unsigned short* row = SLAB ? nullptr : qkv + (long long)t * width;
+  auto load8 = [&](int col) -> bf16x8 {
+    if (!SLAB) return *reinterpret_cast<const bf16x8*>(row + col);
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    for (int sidx = 0; sidx < n_slabs; ++sidx) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + (long long)t * width + col);
+      f32x4 lo = p[0], hi = p[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] += lo[j]; a[4 + j] += hi[j]; }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(a[j]);
+    return o;
+  };
   const int pos = positions[t];
   const int slot = slot_mapping[t];
   const float* cs = cos_t + (long long)pos * half;
@@ -89,9 +159,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __re
   const int rot_tasks = (nh + nkv) * tasks_per_head;
   for (int task = tid; task < rot_tasks; task += 256) {
     const int head = task / tasks_per_head, d0 = (task % tasks_per_head) << 3;
-    unsigned short* hp = row + head * hd;
-    bf16x8 a = *reinterpret_cast<const bf16x8*>(hp + d0);
-    bf16x8 b = *reinterpret_cast<const bf16x8*>(hp + half + d0);
+    bf16x8 a = load8(head * hd + d0);
+    bf16x8 b = load8(head * hd + half + d0);
     bf16x8 oa, ob;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -101,6 +170,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __re
       ob[j] = f2bf(x2 * c + x1 * s);
     }
     if (head < nh) {
+      unsigned short* hp = SLAB ? q_out + (long long)t * nh * hd + head * hd : row + head * hd;
       *reinterpret_cast<bf16x8*>(hp + d0) = oa;
       *reinterpret_cast<bf16x8*>(hp + half + d0) = ob;
     } else if (slot >= 0) {
@@ -112,11 +182,10 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __re
   }
   if (slot >= 0) {
     const int v_tasks = nkv * (hd >> 3);
-    const unsigned short* vsrc = row + (nh + nkv) * hd;
     for (int task = tid; task < v_tasks; task += 256) {
       const int g = task / (hd >> 3), d0 = (task % (hd >> 3)) << 3;
       unsigned short* vp = v_cache + (((long long)blk * nkv + g) * block_size + off) * hd;
-      *reinterpret_cast<bf16x8*>(vp + d0) = *reinterpret_cast<const bf16x8*>(vsrc + g * hd + d0);
+      *reinterpret_cast<bf16x8*>(vp + d0) = load8((nh + nkv) * hd + g * hd + d0);
     }
   }
 }
@@ -341,12 +410,31 @@ int kv_add_rmsnorm(const void* x, void* residual, const void* w, void* y, int T,
   return (int)hipGetLastError();
 }
 
+int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride, void* residual, const void* w, void* y, int T, int H, float eps,
+                         hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (H % 8 || n_slabs < 1) return -1;
+  size_t smem = 16 + (size_t)H * 2;
+  hipLaunchKernelGGL(add_rmsnorm_slab_kernel, dim3(T), dim3(256), smem, stream, slabs, n_slabs, slab_stride, (unsigned short*)residual,
+                     (const unsigned short*)w, (unsigned short*)y, H, eps);
+  return (int)hipGetLastError();
+}
+
+int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_stride, void* q_out, const int* positions, const float* cos_t, const float* sin_t,
+                           void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (hd % 16 || n_slabs < 1) return -1;
+  hipLaunchKernelGGL(rope_kv_write_kernel<true>, dim3(T), dim3(256), 0, stream, (unsigned short*)nullptr, slabs, n_slabs, slab_stride, (unsigned short*)q_out,
+                     positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size);
+  return (int)hipGetLastError();
+}
+
 int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache, const int* slot_mapping, int T,
                      int nh, int nkv, int hd, int block_size, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd % 16) return -1;
-  hipLaunchKernelGGL(rope_kv_write_kernel, dim3(T), dim3(256), 0, stream, (unsigned short*)qkv, positions, cos_t, sin_t, (unsigned short*)k_cache,
-                     (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size);
+  hipLaunchKernelGGL(rope_kv_write_kernel<false>, dim3(T), dim3(256), 0, stream, (unsigned short*)qkv, (const float*)nullptr, 0, 0LL, (unsigned short*)nullptr,
+                     positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size);
   return (int)hipGetLastError();
 }
 

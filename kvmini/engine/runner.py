@@ -27,7 +27,7 @@ from kvmini.models.llama import LlamaConfig, LlamaWeights, rope_tables
 
 from .scheduler import Batch
 
-DEFAULT_BUCKETS = (8, 16, 32, 64, 128, 256, 512, 1024, 2048)
+DEFAULT_BUCKETS = (16, 32, 48, 64, 128, 256, 512, 1024, 2048)
 
 
 @dataclass
@@ -66,6 +66,9 @@ class ModelRunner:
         self.tp_group = tp_group
         self.tp_size = weights.tp_size
         self.ops = select_ops(rcfg.kernels, self.device)
+        if hasattr(self.ops, "prepare_weights"):
+            # one-time re-order of every linear weight into MFMA fragment order
+            self.ops.prepare_weights(weights)
         cfg = self.cfg
         self.nh = cfg.num_heads // self.tp_size
         self.nkv = cfg.num_kv_heads // self.tp_size
@@ -155,16 +158,16 @@ class ModelRunner:
         residual = torch.zeros_like(x)
         for li, lw in enumerate(w.layers):
             h, residual = ops.add_rmsnorm(x, residual, lw.attn_norm, cfg.rms_eps)
-            qkv = ops.linear(h, lw.wqkv)
+            qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
             a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
-            x = ops.linear(a, lw.wo)
+            x = ops.linear(a, lw.wo, allow_slabs=self.tp_size == 1)
             if self.tp_size > 1:
                 torch.distributed.all_reduce(x, group=self.tp_group)
             h, residual = ops.add_rmsnorm(x, residual, lw.mlp_norm, cfg.rms_eps)
             act = ops.linear_swiglu(h, lw.wgu)
-            x = ops.linear(act, lw.wdown)
+            x = ops.linear(act, lw.wdown, allow_slabs=self.tp_size == 1)
             if self.tp_size > 1:
                 torch.distributed.all_reduce(x, group=self.tp_group)
         h, residual = ops.add_rmsnorm(x, residual, w.final_norm, cfg.rms_eps)

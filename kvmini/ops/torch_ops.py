@@ -35,7 +35,8 @@ def add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, w: torch.Tensor, eps: f
     return rmsnorm(r, w, eps), r
 
 
-def linear(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+def linear(x: torch.Tensor, w: torch.Tensor, allow_slabs: bool = False) -> torch.Tensor:
+    """``allow_slabs`` is a hint for the HIP path (split-K partial sums); ignored here."""
     return F.linear(x, w)
 
 

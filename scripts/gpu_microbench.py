@@ -59,12 +59,25 @@ def gemm_bench(out):
                 st["i"] = (st["i"] + 1) % copies
                 return lst[st["i"]]
 
+            def sg(ks, slabs):
+                def f():
+                    wp = nxt(Wps)
+                    if slabs:
+                        splits, cps = C.stream_gemm_plan(N, K, ks, 16)
+                        out = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
+                        C.stream_gemm(wp, N, K, x, out, 1, ks, splits, cps)
+                    else:
+                        C.stream_gemm(wp, N, K, x, y, 0, ks, 1, (K // 32) // ks)
+                return f
+
             fns = {
+                "v2_ks4": sg(4, False),
+                "v2_ks8": sg(8, False),
+                "v2_ks4_slab": sg(4, True),
+                "v2_ks8_slab": sg(8, True),
                 "hipblaslt": lambda: torch.nn.functional.linear(x, nxt(Ws)),
                 "skinny_w4": lambda: C.skinny_gemm(nxt(Ws), x, y, False, False, 4),
-                "skinny_w8": lambda: C.skinny_gemm(nxt(Ws), x, y, False, False, 8),
                 "packed_w4": lambda: C.skinny_gemm(nxt(Wps), x, y, False, True, 4),
-                "packed_w8": lambda: C.skinny_gemm(nxt(Wps), x, y, False, True, 8),
             }
             t = time_fns(fns)
             row = {"shape": name, "N": N, "K": K, "M": M, "us": t, "TBps": {k: N * K * 2 / (v * 1e-6) / 1e12 for k, v in t.items()}}
@@ -75,6 +88,7 @@ def gemm_bench(out):
 
 
 def step_bench(out, model, batch, kernels_list):
+    kernels_list = [k for k in kernels_list if k == "hip"]  # the torch ops are not graph-capturable
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
 

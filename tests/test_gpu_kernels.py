@@ -252,3 +252,71 @@ def test_engine_hip_matches_dense_reference(graphs):
             top = lg.max().item()
             assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05, (p, o)
             ids.append(tok)
+
+
+# ---- weight-streaming GEMM v2 ---------------------------------------------------------
+@pytest.mark.parametrize("M", [16, 32, 48, 64, 20, 100])
+@pytest.mark.parametrize("N,K", [(256, 128), (4096, 4096), (6144, 4096), (4096, 14336), (1000, 512)])
+def test_stream_gemm_bf16_and_slabs(M, N, K):
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(0)
+    W = (torch.randn(N, K, device=_dev()) * 0.05).bfloat16()
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    x[:, 0] += torch.arange(M, device=_dev()).bfloat16()
+    ref = x.float() @ W.float().T
+    tol = 2e-2 * ref.abs().max().item() + 1e-2
+    pw = hip_ops.PackedLinear(W)
+    y = hip_ops.linear(x, pw)
+    assert y.shape == (M, N)
+    assert (y.float() - ref).abs().max().item() <= tol
+    s = hip_ops.linear(x, pw, allow_slabs=True)
+    if s.dim() == 3:
+        assert (s.sum(0) - ref).abs().max().item() <= tol
+    else:
+        assert (s.float() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("M", [16, 64, 33])
+def test_stream_gemm_swiglu(M):
+    from kvmini.models.llama import interleave_gate_up
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(1)
+    I, K = 1024, 512
+    wg = (torch.randn(I, K, device=_dev()) * 0.05).bfloat16()
+    wu = (torch.randn(I, K, device=_dev()) * 0.05).bfloat16()
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    act = hip_ops.linear_swiglu(x, hip_ops.PackedLinear(interleave_gate_up(wg, wu).contiguous()))
+    ref = torch.nn.functional.silu(x.float() @ wg.float().T) * (x.float() @ wu.float().T)
+    assert act.shape == (M, I)
+    assert (act.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-2
+
+
+def test_slab_consumers_match_unsplit():
+    from kvmini.models.llama import get_config, rope_tables
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(2)
+    T, H = 32, 4096
+    slabs = torch.randn(4, T, H, device=_dev())
+    r = torch.randn(T, H, device=_dev()).bfloat16()
+    w = (1 + 0.1 * torch.randn(H, device=_dev())).bfloat16()
+    y_ref, r_ref = torch_ops.add_rmsnorm(slabs.sum(0).bfloat16(), r.clone(), w, 1e-5)
+    r2 = r.clone()
+    y, _ = hip_ops.add_rmsnorm(slabs, r2, w, 1e-5)
+    assert (r2.float() - r_ref.float()).abs().max().item() <= 6e-2  # one bf16 ulp of the fp32 slab sum
+    assert (y.float() - y_ref.float()).abs().max().item() <= 6e-2
+
+    nh, nkv, hd, bs, nb = 8, 2, 128, 16, 32
+    cos, sin = rope_tables(get_config("llama-3-8b"), 512, _dev())
+    qs = torch.randn(3, T, (nh + 2 * nkv) * hd, device=_dev())
+    pos = torch.randint(0, 512, (T,), device=_dev(), dtype=torch.int32)
+    slots = torch.randperm(nb * bs, device=_dev())[:T].int()
+    kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    q_ref = torch_ops.rope_kv_write(qs.sum(0).bfloat16(), pos.long(), cos, sin, kc_ref, vc_ref, slots.long(), nh, nkv, hd)
+    q = hip_ops.rope_kv_write(qs, pos, cos, sin, kc, vc, slots, nh, nkv, hd)
+    assert (q.float() - q_ref.float()).abs().max().item() <= 6e-2
+    assert (kc.float() - kc_ref.float()).abs().max().item() <= 6e-2
+    assert (vc.float() - vc_ref.float()).abs().max().item() <= 6e-2
