@@ -29,11 +29,14 @@ int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, l
 int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
-                   int chunks_per_split, long long slab_stride, hipStream_t stream);
+                   int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, hipStream_t stream);
+int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
+                       hipStream_t stream);
 int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride, void* residual, const void* w, void* y, int T, int H, float eps,
                          hipStream_t stream);
 int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_stride, void* q_out, const int* positions, const float* cos_t, const float* sin_t,
-                           void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, hipStream_t stream);
+                           void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, const float* row_ss,
+                           int ss_parts, int h_in, float eps, hipStream_t stream);
 }
 
 namespace {
@@ -194,11 +197,23 @@ std::pair<int64_t, int64_t> stream_gemm_plan(int64_t N, int64_t K, int64_t ks_pe
 }
 
 // epi 0: out bf16 [M, N]; epi 1: out fp32 [splits, M, N]; epi 2: out bf16 [M, N/2] (SwiGLU).
-void stream_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t ks_per_chunk, int64_t splits, int64_t chunks_per_split) {
+const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* parts) {
+  *parts = 0;
+  if (!row_ss.has_value()) return nullptr;
+  const at::Tensor& t = *row_ss;
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.dim() == 2 && t.size(0) >= rows, "row_ss must be contiguous fp32 [>=rows, parts]");
+  *parts = (int)t.size(1);
+  return (const float*)t.data_ptr();
+}
+
+void stream_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t ks_per_chunk, int64_t splits, int64_t chunks_per_split,
+                 c10::optional<at::Tensor> row_ss, double eps) {
   CHECK_DEV(Wp); CHECK_BF16(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
   TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
   const int64_t M = x.size(0);
+  int parts = 0;
+  const float* ssp = ss_ptr(row_ss, M, &parts);
   long long ldy = 0, slab_stride = 0;
   if (epi == 1) {
     TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && out.dim() == 3 && out.size(0) == splits && out.size(1) == M && out.size(2) == N,
@@ -211,7 +226,7 @@ void stream_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor o
     ldy = out.stride(0);
   }
   check(kv_stream_gemm(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)ks_per_chunk, (int)splits,
-                       (int)chunks_per_split, slab_stride, cur_stream()),
+                       (int)chunks_per_split, slab_stride, ssp, parts, (float)eps, cur_stream()),
         "kv_stream_gemm");
 }
 
@@ -227,20 +242,46 @@ void add_rmsnorm_slabs(at::Tensor slabs, at::Tensor residual, at::Tensor w, at::
 }
 
 void rope_kv_write_slabs(at::Tensor slabs, at::Tensor q_out, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
-                         at::Tensor slot_mapping, int64_t nh, int64_t nkv, int64_t hd) {
+                         at::Tensor slot_mapping, int64_t nh, int64_t nkv, int64_t hd, c10::optional<at::Tensor> row_ss, int64_t h_in, double eps) {
   CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_BF16(q_out); CHECK_CONTIG(q_out); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_I32(positions); CHECK_I32(slot_mapping);
   CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t); CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping);
   TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3 && slabs.size(2) == (nh + 2 * nkv) * hd, "slabs must be fp32 [S, T, (nh + 2 nkv) * hd]");
   const int64_t T = slabs.size(1);
   TORCH_CHECK(q_out.numel() == T * nh * hd, "q_out must hold T*nh*hd elements");
+  int parts = 0;
+  const float* ssp = ss_ptr(row_ss, T, &parts);
+  TORCH_CHECK(ssp == nullptr || h_in > 0, "h_in (input width of the projection) is required with row_ss");
   TORCH_CHECK(positions.numel() >= T && slot_mapping.numel() >= T, "positions/slot_mapping shorter than T");
   TORCH_CHECK(cos_t.scalar_type() == at::kFloat && sin_t.scalar_type() == at::kFloat && cos_t.dim() == 2 && cos_t.size(1) == hd / 2 && sin_t.sizes() == cos_t.sizes(),
               "cos/sin must be float32 [max_pos, hd/2]");
   TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(1) == nkv && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
   check(kv_rope_kv_write_slabs((const float*)slabs.data_ptr(), (int)slabs.size(0), T * slabs.size(2), q_out.data_ptr(), (const int*)positions.data_ptr(),
                                (const float*)cos_t.data_ptr(), (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-                               (const int*)slot_mapping.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), cur_stream()),
+                               (const int*)slot_mapping.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps,
+                               cur_stream()),
         "kv_rope_kv_write_slabs");
+}
+
+// residual' = residual + x (x: bf16 [T, H] or fp32 slabs [S, T, H]); returns the per-row
+// partial sums of squares [T, ceil(H/512)] of residual'.
+at::Tensor residual_reduce(at::Tensor x, at::Tensor residual, bool has_residual) {
+  CHECK_DEV(x); CHECK_CONTIG(x); CHECK_BF16(residual); CHECK_CONTIG(residual);
+  TORCH_CHECK(residual.dim() == 2, "residual must be [T, H]");
+  const int64_t T = residual.size(0), H = residual.size(1);
+  TORCH_CHECK(H % 8 == 0, "hidden size must be a multiple of 8");
+  auto ss = at::empty({T, (H + 511) / 512}, residual.options().dtype(at::kFloat));
+  if (x.dim() == 3) {
+    TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(1) == T && x.size(2) == H && x.size(0) >= 1, "slabs must be fp32 [S, T, H]");
+    check(kv_residual_reduce((const float*)x.data_ptr(), (int)x.size(0), T * H, nullptr, residual.data_ptr(), has_residual ? 1 : 0, (float*)ss.data_ptr(), (int)T, (int)H,
+                             cur_stream()),
+          "kv_residual_reduce");
+  } else {
+    CHECK_BF16(x);
+    TORCH_CHECK(x.dim() == 2 && x.size(0) == T && x.size(1) == H, "x must be bf16 [T, H]");
+    check(kv_residual_reduce(nullptr, 0, 0, x.data_ptr(), residual.data_ptr(), has_residual ? 1 : 0, (float*)ss.data_ptr(), (int)T, (int)H, cur_stream()),
+          "kv_residual_reduce");
+  }
+  return ss;
 }
 
 }  // namespace
@@ -264,4 +305,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_gemm", &stream_gemm);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs);
+  m.def("residual_reduce", &residual_reduce);
 }

@@ -116,6 +116,58 @@ __global__ __launch_bounds__(256) void add_rmsnorm_slab_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------
+// Parallel residual update for the norm-folded pipeline.  RMSNorm's gain is folded into
+// the next projection's weights and its per-row scale 1/rms is applied in that
+// projection's epilogue, so what is left of "residual add + RMSNorm" is
+//     residual' = bf16(residual + bf16(sum of slabs))      (or + x for a bf16 input)
+//     ss_part[t][p] = sum of residual'^2 over the p-th 512-column segment of row t.
+// grid = (ceil(H/512), T), one wavefront per workgroup, 8 columns per lane: a [32, 4096]
+// activation is 256 independent waves instead of 32 serial row loops.
+template <bool SLAB>
+__global__ __launch_bounds__(64) void residual_reduce_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+                                                             const unsigned short* __restrict__ x, unsigned short* __restrict__ residual, int has_residual,
+                                                             float* __restrict__ ss_part, int H) {
+  const int t = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
+  const int col = (p * 64 + lane) * 8;
+  float ss = 0.f;
+  if (col < H) {
+    float a[8];
+    const long long off = (long long)t * H + col;
+    if (SLAB) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll 4
+      for (int sidx = 0; sidx < n_slabs; ++sidx) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + off);
+        f32x4 lo = q[0], hi = q[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += lo[j]; a[4 + j] += hi[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = bf2f(f2bf(a[j]));
+    } else {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(x + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = bf2f(v[j]);
+    }
+    bf16x8 c;
+    if (has_residual) {
+      bf16x8 b = *reinterpret_cast<const bf16x8*>(residual + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] = f2bf(a[j] + bf2f(b[j]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] = f2bf(a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { float f = bf2f(c[j]); ss += f * f; }
+    *reinterpret_cast<bf16x8*>(residual + off) = c;
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) ss_part[(long long)t * gridDim.x + p] = ss;
+}
+
+// ---------------------------------------------------------------------------------
 // RoPE (rotate-half pairing) on the q and k parts of the fused qkv row, in place for q;
 // rotated k and v are scattered into the paged cache
 //   cache[block][kv_head][slot_in_block][head_dim],  slot = slot_mapping[t] (-1: skip).
@@ -124,12 +176,21 @@ __global__ __launch_bounds__(256) void add_rmsnorm_slab_kernel(const float* __re
 // SLAB = true: qkv arrives as n_slabs fp32 partial sums [n_slabs][T][width] (split-K GEMM
 // output) that are summed on load, and rotated q is written to q_out [T, nh*hd] (bf16).
 template <bool SLAB>
-__global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __restrict__ qkv, const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+__global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __restrict__ qkv, const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                             unsigned short* __restrict__ q_out, const int* __restrict__ positions,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                             unsigned short* __restrict__ k_cache, unsigned short* __restrict__ v_cache,
-                                                            const int* __restrict__ slot_mapping, int nh, int nkv, int hd, int block_size) {
-  const int t = blockIdx.x, tid = threadIdx.x;
+                                                            const int* __restrict__ slot_mapping, int nh, int nkv, int hd, int block_size,
+                                                            const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps) {
+  // grid = (T, ceil(tasks / 64)), one wavefront per workgroup: tasks of a token run on
+  // several CUs instead of one 256-thread loop.
+  const int t = blockIdx.x, tid = blockIdx.y * 64 + threadIdx.x;
+  float rs = 1.f;  // 1/rms of the row when the preceding RMSNorm was folded into the projection
+  if (row_ss != nullptr) {
+    float ssum = 0.f;
+    for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)t * ss_parts + p];
+    rs = rsqrtf(ssum * inv_h + eps);
+  }
   const int half = hd >> 1;
   const int tasks_per_head = half >> 3;
   const int width = (nh + 2 * nkv) * hd;
@@ -147,7 +208,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __re
     }
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf(a[j]);
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(a[j] * rs);
     return o;
   };
   const int pos = positions[t];
@@ -157,7 +218,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __re
   const int blk = slot >= 0 ? slot / block_size : 0, off = slot >= 0 ? slot % block_size : 0;
 
   const int rot_tasks = (nh + nkv) * tasks_per_head;
-  for (int task = tid; task < rot_tasks; task += 256) {
+  if (tid < rot_tasks) {
+    const int task = tid;
     const int head = task / tasks_per_head, d0 = (task % tasks_per_head) << 3;
     bf16x8 a = load8(head * hd + d0);
     bf16x8 b = load8(head * hd + half + d0);
@@ -182,7 +244,8 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(unsigned short* __re
   }
   if (slot >= 0) {
     const int v_tasks = nkv * (hd >> 3);
-    for (int task = tid; task < v_tasks; task += 256) {
+    const int task = tid - rot_tasks;
+    if (task >= 0 && task < v_tasks) {
       const int g = task / (hd >> 3), d0 = (task % (hd >> 3)) << 3;
       unsigned short* vp = v_cache + (((long long)blk * nkv + g) * block_size + off) * hd;
       *reinterpret_cast<bf16x8*>(vp + d0) = load8((nh + nkv) * hd + g * hd + d0);
@@ -420,12 +483,37 @@ int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride,
   return (int)hipGetLastError();
 }
 
+static inline int rope_grid_y(int nh, int nkv, int hd) {
+  const int tasks = (nh + nkv) * (hd >> 4) + nkv * (hd >> 3);
+  return (tasks + 63) / 64;
+}
+
+// row_ss (nullable): [T][ss_parts] partial sums of squares of the GEMM's input rows; when
+// given, the summed projection is scaled by rsqrt(sum/H_in + eps) (folded RMSNorm).
 int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_stride, void* q_out, const int* positions, const float* cos_t, const float* sin_t,
-                           void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, hipStream_t stream) {
+                           void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, const float* row_ss,
+                           int ss_parts, int h_in, float eps, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd % 16 || n_slabs < 1) return -1;
-  hipLaunchKernelGGL(rope_kv_write_kernel<true>, dim3(T), dim3(256), 0, stream, (unsigned short*)nullptr, slabs, n_slabs, slab_stride, (unsigned short*)q_out,
-                     positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size);
+  hipLaunchKernelGGL(rope_kv_write_kernel<true>, dim3(T, rope_grid_y(nh, nkv, hd)), dim3(64), 0, stream, (unsigned short*)nullptr, slabs, n_slabs, slab_stride,
+                     (unsigned short*)q_out, positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size,
+                     row_ss, ss_parts, h_in > 0 ? 1.f / (float)h_in : 0.f, eps);
+  return (int)hipGetLastError();
+}
+
+// x: bf16 [T, H] (n_slabs == 0) or fp32 slabs [n_slabs][T][H]; residual: bf16 [T, H] in/out
+// (has_residual == 0: treated as zero and only written); ss_part: float [T][ceil(H/512)].
+int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
+                       hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (H % 8) return -1;
+  dim3 grid((H + 511) / 512, T);
+  if (n_slabs > 0)
+    hipLaunchKernelGGL(residual_reduce_kernel<true>, grid, dim3(64), 0, stream, slabs, n_slabs, slab_stride, (const unsigned short*)nullptr,
+                       (unsigned short*)residual, has_residual, ss_part, H);
+  else
+    hipLaunchKernelGGL(residual_reduce_kernel<false>, grid, dim3(64), 0, stream, (const float*)nullptr, 0, 0LL, (const unsigned short*)x,
+                       (unsigned short*)residual, has_residual, ss_part, H);
   return (int)hipGetLastError();
 }
 
@@ -433,8 +521,9 @@ int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const 
                      int nh, int nkv, int hd, int block_size, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd % 16) return -1;
-  hipLaunchKernelGGL(rope_kv_write_kernel<false>, dim3(T), dim3(256), 0, stream, (unsigned short*)qkv, (const float*)nullptr, 0, 0LL, (unsigned short*)nullptr,
-                     positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size);
+  hipLaunchKernelGGL(rope_kv_write_kernel<false>, dim3(T, rope_grid_y(nh, nkv, hd)), dim3(64), 0, stream, (unsigned short*)qkv, (const float*)nullptr, 0, 0LL,
+                     (unsigned short*)nullptr, positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size,
+                     (const float*)nullptr, 0, 0.f, 0.f);
   return (int)hipGetLastError();
 }
 

@@ -45,7 +45,8 @@ enum Epilogue { EPI_BF16 = 0, EPI_SLAB = 1, EPI_SWIGLU = 2 };
 // KS = k-steps (of 32) per chunk.  grid = (N/64, splits).  chunks_per_split chunks per workgroup.
 template <int MT, int KS, int EPI>
 __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
-                                                          long long ldx, long long ldy, int chunks_per_split, long long slab_stride) {
+                                                          long long ldx, long long ldy, int chunks_per_split, long long slab_stride,
+                                                          const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps) {
   constexpr int XF = KS * MT;          // x fragment tiles (1 KiB each) per chunk
   constexpr int XL = (XF + 3) / 4;     // per-thread 16-byte x loads per chunk
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * XF * 1024 > 4 * 64 * 4 * 4 * MT ? 2 * XF * 1024 : 4 * 64 * 4 * 4 * MT];
@@ -118,6 +119,18 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
 
   // ---- epilogue.  Lane holds y[token j*16 + r][feature tile*16 + 4q + e], e = 0..3.
   const long long n_base = tile * 16 + q * 4;
+  // Folded RMSNorm: x is the un-normalised residual stream and W carries the norm gain,
+  // so rows are scaled by 1/rms(x[m]) here (slabs are scaled by their consumer).
+  if (EPI != EPI_SLAB && row_ss != nullptr) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      float ssum = 0.f;
+      for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)(j * 16 + r) * ss_parts + p];
+      const float rs = rsqrtf(ssum * inv_k + eps);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[j][e] *= rs;
+    }
+  }
   if (EPI == EPI_SLAB) {
     float* o = reinterpret_cast<float*>(out) + (long long)blockIdx.y * slab_stride;
 #pragma unroll
@@ -160,19 +173,21 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
 }
 
 template <int MT, int KS, int EPI>
-int launch(const void* Wp, const void* x, void* out, int N, int K, long long ldx, long long ldy, int splits, int cps, long long slab_stride, hipStream_t stream) {
+int launch(const void* Wp, const void* x, void* out, int N, int K, long long ldx, long long ldy, int splits, int cps, long long slab_stride,
+           const float* row_ss, int ss_parts, float eps, hipStream_t stream) {
   dim3 grid(N / 64, splits), block(256);
-  hipLaunchKernelGGL((stream_gemm_kernel<MT, KS, EPI>), grid, block, 0, stream, (const __bf16*)Wp, (const __bf16*)x, out, N, K, ldx, ldy, cps, slab_stride);
+  hipLaunchKernelGGL((stream_gemm_kernel<MT, KS, EPI>), grid, block, 0, stream, (const __bf16*)Wp, (const __bf16*)x, out, N, K, ldx, ldy, cps, slab_stride,
+                     row_ss, ss_parts, 1.f / (float)K, eps);
   return (int)hipGetLastError();
 }
 
 template <int MT, int KS>
 int dispatch_epi(int epi, const void* Wp, const void* x, void* out, int N, int K, long long ldx, long long ldy, int splits, int cps, long long slab_stride,
-                 hipStream_t stream) {
+                 const float* row_ss, int ss_parts, float eps, hipStream_t stream) {
   switch (epi) {
-    case EPI_BF16: return launch<MT, KS, EPI_BF16>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, stream);
-    case EPI_SLAB: return launch<MT, KS, EPI_SLAB>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, stream);
-    case EPI_SWIGLU: return launch<MT, KS, EPI_SWIGLU>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, stream);
+    case EPI_BF16: return launch<MT, KS, EPI_BF16>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, row_ss, ss_parts, eps, stream);
+    case EPI_SLAB: return launch<MT, KS, EPI_SLAB>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, row_ss, ss_parts, eps, stream);
+    case EPI_SWIGLU: return launch<MT, KS, EPI_SWIGLU>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, row_ss, ss_parts, eps, stream);
   }
   return -1;
 }
@@ -202,7 +217,7 @@ int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chu
 // ks_per_chunk: 4 or 8.  W must be packed (kv_pack_weight).  Requirements: M in {16,32,48,64},
 // N % 64 == 0 (N % 128 for SwiGLU), K % (32*ks_per_chunk) == 0.
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
-                   int chunks_per_split, long long slab_stride, hipStream_t stream) {
+                   int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, hipStream_t stream) {
   if (M <= 0 || M > 64 || (M & 15) || (N & 63) || (ks_per_chunk != 4 && ks_per_chunk != 8) || (K % (32 * ks_per_chunk))) return -1;
   if (epi == EPI_SWIGLU && (N & 127)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
@@ -210,8 +225,8 @@ int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K
   const int mt = M >> 4;
 #define KV_CASE(MTV)                                                                                                                 \
   case MTV:                                                                                                                          \
-    return ks_per_chunk == 4 ? dispatch_epi<MTV, 4>(epi, Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, stream)  \
-                             : dispatch_epi<MTV, 8>(epi, Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, stream);
+    return ks_per_chunk == 4 ? dispatch_epi<MTV, 4>(epi, Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, row_ss, ss_parts, eps, stream)  \
+                             : dispatch_epi<MTV, 8>(epi, Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, row_ss, ss_parts, eps, stream);
   switch (mt) {
     KV_CASE(1)
     KV_CASE(2)

@@ -155,7 +155,7 @@ class ModelRunner:
         bt = self._dev("block_tables").view(self.rcfg.max_num_seqs, self.max_blocks_per_seq)
 
         x = w.embed[tokens.long()] if w.embed.device.type == "cpu" else torch.index_select(w.embed, 0, tokens)
-        residual = torch.zeros_like(x)
+        residual = None  # the first residual add is a copy
         for li, lw in enumerate(w.layers):
             h, residual = ops.add_rmsnorm(x, residual, lw.attn_norm, cfg.rms_eps)
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
@@ -164,14 +164,16 @@ class ModelRunner:
             a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
             x = ops.linear(a, lw.wo, allow_slabs=self.tp_size == 1)
             if self.tp_size > 1:
+                x = x.contiguous()
                 torch.distributed.all_reduce(x, group=self.tp_group)
             h, residual = ops.add_rmsnorm(x, residual, lw.mlp_norm, cfg.rms_eps)
             act = ops.linear_swiglu(h, lw.wgu)
             x = ops.linear(act, lw.wdown, allow_slabs=self.tp_size == 1)
             if self.tp_size > 1:
+                x = x.contiguous()
                 torch.distributed.all_reduce(x, group=self.tp_group)
         h, residual = ops.add_rmsnorm(x, residual, w.final_norm, cfg.rms_eps)
-        hs = torch.index_select(h, 0, sample_idx[: self.sample_rows(t_pad)])
+        hs = ops.select_rows(h, sample_idx[: self.sample_rows(t_pad)])
         logits = ops.linear(hs, w.lm_head)
         self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
         return logits

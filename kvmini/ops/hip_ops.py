@@ -1,4 +1,12 @@
-"""Engine ops backed by the gfx950 HIP kernels (same signatures as ``torch_ops``).
+"""Engine ops backed by the gfx950 HIP kernels (same call surface as ``torch_ops``).
+
+RMSNorm is *folded*: at load time each norm's gain is multiplied into the
+columns of the projection that consumes it (``W' = W * diag(gain)``), so at run
+time ``add_rmsnorm`` only updates the residual stream and records per-row sums of
+squares (a fully parallel kernel), the projection reads the un-normalised
+residual, and the ``1/rms`` row scale is applied in the projection's epilogue
+(or by the consumer of its split-K slabs).  :class:`Normed` and :class:`Partial`
+carry that bookkeeping between ops.
 
 Linear layers run on the weight-streaming MFMA kernel (``csrc/stream_gemm.hip``)
 with weights re-ordered once, at load time, into MFMA fragment order
@@ -63,17 +71,55 @@ class PackedLinear:
 Weight = Union[torch.Tensor, PackedLinear]
 
 
+class Normed:
+    """Residual stream ``x`` (bf16 ``[T, H]``, NOT normalised) plus the per-row partial
+    sums of squares ``ss`` (``[T, ceil(H/512)]``) from which consumers derive 1/rms."""
+
+    __slots__ = ("x", "ss", "eps")
+
+    def __init__(self, x: torch.Tensor, ss: torch.Tensor, eps: float):
+        self.x, self.ss, self.eps = x, ss, eps
+
+
+class Partial:
+    """Split-K partial sums ``[S, T, N]`` (fp32) of a projection; ``ss``/``eps``/``h_in``
+    are set when the projection's input was a :class:`Normed` whose row scale has
+    not been applied yet."""
+
+    __slots__ = ("slabs", "ss", "eps", "h_in")
+
+    def __init__(self, slabs: torch.Tensor, ss: Optional[torch.Tensor] = None, eps: float = 0.0, h_in: int = 0):
+        self.slabs, self.ss, self.eps, self.h_in = slabs, ss, eps, h_in
+
+    def reduce(self) -> torch.Tensor:
+        """Materialise the bf16 result (tests / TP all-reduce path)."""
+        y = self.slabs.sum(0)
+        if self.ss is not None:
+            y = y * torch.rsqrt(self.ss.sum(-1, keepdim=True) / self.h_in + self.eps)
+        return y.to(torch.bfloat16)
+
+
 def prepare_weights(weights: Any) -> None:
-    """Pack every linear weight of a ``LlamaWeights`` in place (idempotent)."""
-    def pk(w: Weight) -> Weight:
-        return w if isinstance(w, PackedLinear) else PackedLinear(w)
+    """Fold every RMSNorm gain into the projection that consumes it and pack every
+    linear weight of a ``LlamaWeights`` into MFMA fragment order, in place."""
+    if getattr(weights, "_hip_prepared", False):
+        return
+
+    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor]) -> PackedLinear:
+        if gain is not None:
+            w = (w.float() * gain.float()[None, :]).to(torch.bfloat16)
+        return PackedLinear(w)
 
     for lw in weights.layers:
-        lw.wqkv, lw.wo, lw.wgu, lw.wdown = pk(lw.wqkv), pk(lw.wo), pk(lw.wgu), pk(lw.wdown)
-    if weights.lm_head is weights.embed:
-        weights.lm_head = PackedLinear(weights.embed.clone())
-    else:
-        weights.lm_head = pk(weights.lm_head)
+        lw.wqkv = fold_pack(lw.wqkv, lw.attn_norm)
+        lw.wgu = fold_pack(lw.wgu, lw.mlp_norm)
+        lw.wo = fold_pack(lw.wo, None)
+        lw.wdown = fold_pack(lw.wdown, None)
+        lw.attn_norm = torch.ones_like(lw.attn_norm)
+        lw.mlp_norm = torch.ones_like(lw.mlp_norm)
+    weights.lm_head = fold_pack(weights.lm_head, weights.final_norm)  # a tied embedding stays untouched: fold_pack copies
+    weights.final_norm = torch.ones_like(weights.final_norm)
+    weights._hip_prepared = True
     torch.cuda.empty_cache()
 
 
@@ -87,57 +133,70 @@ def _pad_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     return xp, m
 
 
-def _stream(w: PackedLinear, x: torch.Tensor, epi: int, allow_slabs: bool) -> torch.Tensor:
+def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_slabs: bool) -> Union[torch.Tensor, Partial]:
     C = native()
-    x, m = _pad_rows(x)
+    ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
+    x, m = _pad_rows(h.x if isinstance(h, Normed) else h)
     mp = x.shape[0]
+    if ss is not None and mp != m:
+        ss = torch.cat((ss, torch.ones((mp - m, ss.shape[1]), dtype=ss.dtype, device=ss.device)), 0)
     n_out = w.n_pad // 2 if epi == 2 else w.n_pad
+    nchunks = (w.k // 32) // w.ks
     if mp <= MAX_M:
         if allow_slabs and epi == 0:
             splits, cps = C.stream_gemm_plan(w.n_pad, w.k, w.ks, MAX_SPLITS)
-            if splits > 1:
+            if splits > 1 and m == mp and w.n == w.n_pad:
                 out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
-                C.stream_gemm(w.wp, w.n_pad, w.k, x, out, 1, w.ks, splits, cps)
-                return out[:, :m] if m != mp else out
-        nchunks = (w.k // 32) // w.ks
+                C.stream_gemm(w.wp, w.n_pad, w.k, x, out, 1, w.ks, splits, cps, None, 0.0)
+                return Partial(out, ss, eps, w.k)
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
-        C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, w.ks, 1, nchunks)
+        C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, w.ks, 1, nchunks, ss, eps)
     else:
-        nchunks = (w.k // 32) // w.ks
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         for r0 in range(0, mp, MAX_M):
             r1 = min(mp, r0 + MAX_M)
-            C.stream_gemm(w.wp, w.n_pad, w.k, x[r0:r1], out[r0:r1], epi, w.ks, 1, nchunks)
+            C.stream_gemm(w.wp, w.n_pad, w.k, x[r0:r1], out[r0:r1], epi, w.ks, 1, nchunks, None if ss is None else ss[r0:r1].contiguous(), eps)
     n_true = w.n // 2 if epi == 2 else w.n
     if m != mp or n_true != n_out:
         out = out[:m, :n_true]
     return out
 
 
-def add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, w: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``x``: bf16 ``[T, H]`` or fp32 slabs ``[S, T, H]``; ``residual`` is updated in place."""
-    y = torch.empty_like(residual)
-    if x.dim() == 3:
-        native().add_rmsnorm_slabs(x.contiguous(), residual, w, y, eps)
+def add_rmsnorm(x: Union[torch.Tensor, Partial], residual: Optional[torch.Tensor], w: torch.Tensor, eps: float) -> Tuple[Normed, torch.Tensor]:
+    """Residual update of the folded-norm pipeline.  ``x``: bf16 ``[T, H]`` or a
+    :class:`Partial` (split-K slabs of the previous projection); ``residual``: bf16
+    ``[T, H]`` updated in place, or None for the first layer.  ``w`` (the gain) must
+    already be folded into the consuming projection (:func:`prepare_weights`)."""
+    C = native()
+    if isinstance(x, Partial):
+        assert x.ss is None, "slabs that still need a row scale cannot feed a residual add"
+        src = x.slabs
+        t, hdim = src.shape[1], src.shape[2]
     else:
-        native().add_rmsnorm(x, residual, w, y, eps)
-    return y, residual
+        src = x if x.is_contiguous() else x.contiguous()
+        t, hdim = src.shape
+    has_res = residual is not None
+    if residual is None:
+        residual = torch.empty((t, hdim), dtype=torch.bfloat16, device=src.device)
+    ss = C.residual_reduce(src, residual, has_res)
+    return Normed(residual, ss, eps), residual
 
 
-def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
-    y, _ = add_rmsnorm(x, torch.zeros_like(x), w, eps)
-    return y
+def select_rows(h: Normed, idx: torch.Tensor) -> Normed:
+    return Normed(torch.index_select(h.x, 0, idx), torch.index_select(h.ss, 0, idx), h.eps)
 
 
-def linear(x: torch.Tensor, w: Weight, allow_slabs: bool = False) -> torch.Tensor:
+def linear(x: Union[torch.Tensor, Normed], w: Weight, allow_slabs: bool = False) -> Union[torch.Tensor, Partial]:
     if isinstance(w, PackedLinear):
         return _stream(w, x, 0, allow_slabs)
+    assert not isinstance(x, Normed)
     return F.linear(x, w)
 
 
-def linear_swiglu(x: torch.Tensor, wgu: Weight) -> torch.Tensor:
+def linear_swiglu(x: Union[torch.Tensor, Normed], wgu: Weight) -> torch.Tensor:
     if isinstance(wgu, PackedLinear):
-        return _stream(wgu, x, 2, False)
+        return _stream(wgu, x, 2, False)  # type: ignore[return-value]
+    assert not isinstance(x, Normed)
     gu = F.linear(x, wgu)
     act = torch.empty((gu.shape[0], gu.shape[1] // 2), dtype=gu.dtype, device=gu.device)
     native().swiglu_interleaved(gu, act)
@@ -151,7 +210,7 @@ def swiglu_interleaved(gu: torch.Tensor) -> torch.Tensor:
 
 
 def rope_kv_write(
-    qkv: torch.Tensor,
+    qkv: Union[torch.Tensor, Partial],
     positions: torch.Tensor,
     cos: torch.Tensor,
     sin: torch.Tensor,
@@ -163,11 +222,12 @@ def rope_kv_write(
     head_dim: int,
 ) -> torch.Tensor:
     """``qkv``: bf16 ``[T, W]`` (q is rotated in place and returned as a strided
-    view) or fp32 slabs ``[S, T, W]`` (q is written to a new ``[T, nh, hd]``)."""
-    if qkv.dim() == 3:
-        t = qkv.shape[1]
-        q = torch.empty((t, n_heads, head_dim), dtype=torch.bfloat16, device=qkv.device)
-        native().rope_kv_write_slabs(qkv.contiguous(), q, positions, cos, sin, k_cache, v_cache, slot_mapping, n_heads, n_kv, head_dim)
+    view) or a :class:`Partial` (slabs are summed, row-scaled, and q is written to a
+    new ``[T, nh, hd]``)."""
+    if isinstance(qkv, Partial):
+        t = qkv.slabs.shape[1]
+        q = torch.empty((t, n_heads, head_dim), dtype=torch.bfloat16, device=qkv.slabs.device)
+        native().rope_kv_write_slabs(qkv.slabs, q, positions, cos, sin, k_cache, v_cache, slot_mapping, n_heads, n_kv, head_dim, qkv.ss, qkv.h_in, qkv.eps)
         return q
     if not qkv.is_contiguous():
         qkv = qkv.contiguous()

@@ -29,10 +29,15 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return (y * w.float()).to(x.dtype)
 
 
-def add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, w: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """residual' = residual + x (kept in the activation dtype); y = rmsnorm(residual')."""
-    r = (residual.float() + x.float()).to(x.dtype)
+def add_rmsnorm(x: torch.Tensor, residual: "torch.Tensor | None", w: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """residual' = residual + x (kept in the activation dtype; ``residual=None`` means
+    zero, i.e. the first layer); y = rmsnorm(residual')."""
+    r = x if residual is None else (residual.float() + x.float()).to(x.dtype)
     return rmsnorm(r, w, eps), r
+
+
+def select_rows(h: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    return torch.index_select(h, 0, idx.long() if h.device.type == "cpu" else idx)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, allow_slabs: bool = False) -> torch.Tensor:

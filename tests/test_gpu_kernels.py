@@ -238,6 +238,7 @@ def test_engine_hip_matches_dense_reference(graphs):
     from kvmini.models.reference import dense_logits
 
     w = random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)
+    oracle = random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # the engine packs its copy in place
     eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, use_graphs=graphs, kernels="hip"), weights=w)
     if graphs:
         eng.warmup()
@@ -248,7 +249,7 @@ def test_engine_hip_matches_dense_reference(graphs):
     for p, o in zip(prompts, outs):
         ids = list(p)
         for tok in o:
-            lg = dense_logits(w, ids)[-1]
+            lg = dense_logits(oracle, ids)[-1]
             top = lg.max().item()
             assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05, (p, o)
             ids.append(tok)
@@ -271,8 +272,8 @@ def test_stream_gemm_bf16_and_slabs(M, N, K):
     assert y.shape == (M, N)
     assert (y.float() - ref).abs().max().item() <= tol
     s = hip_ops.linear(x, pw, allow_slabs=True)
-    if s.dim() == 3:
-        assert (s.sum(0) - ref).abs().max().item() <= tol
+    if isinstance(s, hip_ops.Partial):
+        assert (s.slabs.sum(0) - ref).abs().max().item() <= tol
     else:
         assert (s.float() - ref).abs().max().item() <= tol
 
@@ -293,30 +294,58 @@ def test_stream_gemm_swiglu(M):
     assert (act.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-2
 
 
-def test_slab_consumers_match_unsplit():
-    from kvmini.models.llama import get_config, rope_tables
+def test_folded_norm_pipeline_matches_reference():
+    """residual_reduce (slab sum + residual add + sum of squares) followed by projections
+    that apply 1/rms in their epilogue == rmsnorm(residual + x) * gain @ W^T."""
+    from kvmini.models.llama import get_config, interleave_gate_up, rope_tables
     from kvmini.ops import hip_ops, torch_ops
 
     torch.manual_seed(2)
-    T, H = 32, 4096
+    T, H, N = 32, 4096, 1024
     slabs = torch.randn(4, T, H, device=_dev())
     r = torch.randn(T, H, device=_dev()).bfloat16()
-    w = (1 + 0.1 * torch.randn(H, device=_dev())).bfloat16()
-    y_ref, r_ref = torch_ops.add_rmsnorm(slabs.sum(0).bfloat16(), r.clone(), w, 1e-5)
-    r2 = r.clone()
-    y, _ = hip_ops.add_rmsnorm(slabs, r2, w, 1e-5)
-    assert (r2.float() - r_ref.float()).abs().max().item() <= 6e-2  # one bf16 ulp of the fp32 slab sum
-    assert (y.float() - y_ref.float()).abs().max().item() <= 6e-2
+    gain = (1 + 0.1 * torch.randn(H, device=_dev())).bfloat16()
+    W = (torch.randn(N, H, device=_dev()) * 0.03).bfloat16()
+    y_norm, r_ref = torch_ops.add_rmsnorm(slabs.sum(0).bfloat16(), r.clone(), gain, 1e-5)
+    ref = y_norm.float() @ W.float().T
 
+    r2 = r.clone()
+    h, r_new = hip_ops.add_rmsnorm(hip_ops.Partial(slabs), r2, gain, 1e-5)
+    assert r_new is r2 and torch.equal(r2, r_ref)
+    assert torch.allclose(h.ss.sum(-1), r_ref.float().pow(2).sum(-1), rtol=1e-4)
+    Wf = hip_ops.PackedLinear((W.float() * gain.float()[None, :]).bfloat16())
+    y = hip_ops.linear(h, Wf)
+    tol = 3e-2 * ref.abs().max().item() + 2e-2
+    assert (y.float() - ref).abs().max().item() <= tol
+    # split-K slabs carry the row scale to their consumer
+    p = hip_ops.linear(h, hip_ops.PackedLinear((torch.cat([W] * 4).float() * gain.float()[None, :]).bfloat16()), allow_slabs=True)
+    assert isinstance(p, hip_ops.Partial) and p.ss is not None
+    assert (p.reduce().float()[:, :N] - ref).abs().max().item() <= tol
+    # first layer: no residual yet
+    x0 = torch.randn(T, H, device=_dev()).bfloat16()
+    h0, r0 = hip_ops.add_rmsnorm(x0, None, gain, 1e-5)
+    assert torch.equal(r0, x0)
+    # SwiGLU epilogue with the folded scale
+    I = 512
+    wg = (torch.randn(I, H, device=_dev()) * 0.03).bfloat16()
+    wu = (torch.randn(I, H, device=_dev()) * 0.03).bfloat16()
+    wgu = interleave_gate_up((wg.float() * gain.float()[None, :]).bfloat16(), (wu.float() * gain.float()[None, :]).bfloat16()).contiguous()
+    act = hip_ops.linear_swiglu(h, hip_ops.PackedLinear(wgu))
+    act_ref = torch.nn.functional.silu(y_norm.float() @ wg.float().T) * (y_norm.float() @ wu.float().T)
+    assert (act.float() - act_ref).abs().max().item() <= 3e-2 * act_ref.abs().max().item() + 2e-2
+
+    # RoPE consuming slabs (+ row scale)
     nh, nkv, hd, bs, nb = 8, 2, 128, 16, 32
     cos, sin = rope_tables(get_config("llama-3-8b"), 512, _dev())
     qs = torch.randn(3, T, (nh + 2 * nkv) * hd, device=_dev())
     pos = torch.randint(0, 512, (T,), device=_dev(), dtype=torch.int32)
     slots = torch.randperm(nb * bs, device=_dev())[:T].int()
-    kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
-    kc_ref, vc_ref = kc.clone(), vc.clone()
-    q_ref = torch_ops.rope_kv_write(qs.sum(0).bfloat16(), pos.long(), cos, sin, kc_ref, vc_ref, slots.long(), nh, nkv, hd)
-    q = hip_ops.rope_kv_write(qs, pos, cos, sin, kc, vc, slots, nh, nkv, hd)
-    assert (q.float() - q_ref.float()).abs().max().item() <= 6e-2
-    assert (kc.float() - kc_ref.float()).abs().max().item() <= 6e-2
-    assert (vc.float() - vc_ref.float()).abs().max().item() <= 6e-2
+    for ss in (None, h.ss):
+        kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
+        kc_ref, vc_ref = kc.clone(), vc.clone()
+        part = hip_ops.Partial(qs, ss, 1e-5, H)
+        q_ref = torch_ops.rope_kv_write(part.reduce(), pos.long(), cos, sin, kc_ref, vc_ref, slots.long(), nh, nkv, hd)
+        q = hip_ops.rope_kv_write(part, pos, cos, sin, kc, vc, slots, nh, nkv, hd)
+        assert (q.float() - q_ref.float()).abs().max().item() <= 6e-2
+        assert (kc.float() - kc_ref.float()).abs().max().item() <= 6e-2
+        assert (vc.float() - vc_ref.float()).abs().max().item() <= 6e-2
