@@ -27,7 +27,10 @@ import torch.nn.functional as F
 from . import gpu_available, native
 
 MAX_M = 64
-KS_PER_CHUNK = 8  # k-steps (of 32) per pipelined chunk: 8 KiB of weights in flight per wave
+# k-steps (of 32) per pipelined chunk.  Measured on MI355X (Llama-3-8B shapes): 8 (8 KiB of
+# weights in flight per wave) wins by ~2 % for a single 16-row token tile, 4 wins by 3-7 % from
+# 32 rows up (smaller LDS x-tiles, more workgroups resident per CU).
+KS_PER_CHUNK = 8
 MAX_SPLITS = 16
 
 
@@ -141,21 +144,22 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
     if ss is not None and mp != m:
         ss = torch.cat((ss, torch.ones((mp - m, ss.shape[1]), dtype=ss.dtype, device=ss.device)), 0)
     n_out = w.n_pad // 2 if epi == 2 else w.n_pad
-    nchunks = (w.k // 32) // w.ks
+    ks = w.ks if mp <= 16 else 4
+    nchunks = (w.k // 32) // ks
     if mp <= MAX_M:
         if allow_slabs and epi == 0:
-            splits, cps = C.stream_gemm_plan(w.n_pad, w.k, w.ks, MAX_SPLITS)
+            splits, cps = C.stream_gemm_plan(w.n_pad, w.k, ks, MAX_SPLITS)
             if splits > 1 and m == mp and w.n == w.n_pad:
                 out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
-                C.stream_gemm(w.wp, w.n_pad, w.k, x, out, 1, w.ks, splits, cps, None, 0.0)
+                C.stream_gemm(w.wp, w.n_pad, w.k, x, out, 1, ks, splits, cps, None, 0.0)
                 return Partial(out, ss, eps, w.k)
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
-        C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, w.ks, 1, nchunks, ss, eps)
+        C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, ks, 1, nchunks, ss, eps)
     else:
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         for r0 in range(0, mp, MAX_M):
             r1 = min(mp, r0 + MAX_M)
-            C.stream_gemm(w.wp, w.n_pad, w.k, x[r0:r1], out[r0:r1], epi, w.ks, 1, nchunks, None if ss is None else ss[r0:r1].contiguous(), eps)
+            C.stream_gemm(w.wp, w.n_pad, w.k, x[r0:r1], out[r0:r1], epi, ks, 1, nchunks, None if ss is None else ss[r0:r1].contiguous(), eps)
     n_true = w.n // 2 if epi == 2 else w.n
     if m != mp or n_true != n_out:
         out = out[:m, :n_true]
