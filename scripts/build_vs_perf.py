@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Entry-point shim kept at the path users of the flat-script layout expect:
+`python scripts/build_vs_perf.py ...` == `kvmini build-vs-perf ...`."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kvmini.cli import main  # noqa: E402
+
+if __name__ == "__main__":
+    sys.exit(main(["build-vs-perf"] + sys.argv[1:]))
