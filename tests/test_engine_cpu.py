@@ -1,0 +1,177 @@
+"""Engine on CPU (reference ops): paged KV, chunked prefill, prefix cache, preemption,
+sampling, the OpenAI server, and 2-rank tensor parallelism over gloo."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from kvmini.engine.engine import EngineConfig, LLMEngine
+from kvmini.engine.kv_cache import BlockManager
+from kvmini.engine.scheduler import SamplingParams, Scheduler, Sequence
+from kvmini.engine.tokenizer import SyntheticTokenizer
+from kvmini.models.llama import deinterleave_gate_up, get_config, interleave_gate_up, random_weights
+from kvmini.models.reference import dense_greedy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _engine(**kw):
+    w = random_weights(get_config("tiny"), "cpu", torch.float32, seed=1)
+    cfg = dict(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=16, max_model_len=128, num_blocks=64, block_size=4)
+    cfg.update(kw)
+    return LLMEngine(EngineConfig(**cfg), weights=w), w
+
+
+PROMPTS = [[1, 5, 9, 33, 47, 100, 21], [1] + list(range(60, 82)), [1, 5, 9, 33, 47, 100, 21, 99, 98]]
+
+
+def test_engine_matches_dense_reference_with_chunked_prefill_and_prefix_cache():
+    eng, w = _engine()
+    outs = eng.generate(PROMPTS, SamplingParams(max_tokens=10, ignore_eos=True))
+    for p, o in zip(PROMPTS, outs):
+        assert o == dense_greedy(w, p, 10)
+    m = eng.metrics()
+    assert m["prefix_cache_hits"] == 1 and m["kv_blocks_free"] == m["kv_blocks_total"] - 1  # block 0 is the scratch block
+    assert eng.generate(PROMPTS, SamplingParams(max_tokens=10, ignore_eos=True)) == outs
+    assert eng.metrics()["prefix_cache_hits"] == 4
+
+
+def test_preemption_recompute_is_transparent():
+    eng, w = _engine(num_blocks=14, max_num_seqs=4, enable_prefix_caching=False)
+    prompts = [[1] + list(range(10 + i, 22 + i)) for i in range(4)]
+    outs = eng.generate(prompts, SamplingParams(max_tokens=16, ignore_eos=True))
+    assert eng.scheduler.num_preemptions > 0
+    for p, o in zip(prompts, outs):
+        assert o == dense_greedy(w, p, 16)
+
+
+def test_eos_max_tokens_and_sampling_seed():
+    eng, w = _engine()
+    ref = dense_greedy(w, PROMPTS[0], 6)
+    eng.scheduler.eos_token_id = ref[2]
+    out = eng.generate([PROMPTS[0]], SamplingParams(max_tokens=6))[0]
+    assert out == ref[:3]  # stops at (and includes) EOS
+    a = eng.generate([PROMPTS[1]], SamplingParams(max_tokens=8, temperature=0.9, top_p=0.9, top_k=50, seed=7, ignore_eos=True))[0]
+    b = eng.generate([PROMPTS[1]], SamplingParams(max_tokens=8, temperature=0.9, top_p=0.9, top_k=50, seed=7, ignore_eos=True))[0]
+    assert a == b and len(a) == 8
+
+
+def test_block_manager_refcounts_and_eviction():
+    bm = BlockManager(8, 4, True)
+    toks = list(range(12))
+    blocks = bm.allocate(3)
+    assert bm.num_free == 4 and 0 not in blocks
+    assert bm.register_full_blocks(toks, blocks, 12, 0) == 3
+    bm.free(blocks)
+    assert bm.num_free == 7  # cached blocks stay evictable
+    hit, n = bm.match_prefix(toks + [99])
+    assert hit == blocks and n == 12
+    hit2, n2 = bm.match_prefix(toks)  # must leave one token to compute
+    assert n2 == 8
+    bm.free(hit)
+    bm.free(hit2)
+    got = bm.allocate(7)
+    assert got is not None and bm.allocate(1) is None
+    assert bm.match_prefix(toks + [99]) == ([], 0)  # evicted
+
+
+def test_scheduler_decode_first_and_budget():
+    bm = BlockManager(64, 4, False)
+    sch = Scheduler(bm, max_num_seqs=4, max_batched_tokens=8, max_model_len=64, eos_token_id=2)
+    a = Sequence(1, list(range(1, 6)), SamplingParams(max_tokens=4))
+    sch.add(a)
+    b1 = sch.schedule()
+    assert [(c.seq.req_id, c.start, c.n_tokens, c.sample) for c in b1.chunks] == [(1, 0, 5, True)]
+    sch.commit(b1.chunks[0], [7])
+    sch.add(Sequence(2, list(range(1, 20)), SamplingParams(max_tokens=4)))
+    b2 = sch.schedule()
+    assert [(c.seq.req_id, c.n_tokens, c.sample) for c in b2.chunks] == [(1, 1, True), (2, 7, False)]  # decode first, prefill chunk fills the budget
+
+
+def test_tokenizer_lengths():
+    tk = SyntheticTokenizer(128256, 128000, 128001)
+    ids = tk.apply_chat_template([{"role": "user", "content": "Hello, world!"}])
+    assert len(ids) == 14 and ids[0] == 128000 and max(ids) < 128256
+    assert tk.encode("a b c") == tk.encode("a b c") and len(tk.encode("a b, c")) == 4
+    assert tk.decode(tk.encode("x y")).count(" ") == 1
+
+
+def test_gate_up_interleave_roundtrip():
+    g, u = torch.randn(64, 8), torch.randn(64, 8)
+    gu = interleave_gate_up(g, u)
+    g2, u2 = deinterleave_gate_up(gu.T)
+    assert torch.equal(g2.T, g) and torch.equal(u2.T, u)
+    assert torch.equal(gu[:16], g[:16]) and torch.equal(gu[16:32], u[:16])
+
+
+def test_native_server_openai_and_tgi_endpoints(tmp_path):
+    from kvmini.loadgen.protocols import RequestSpec
+    from kvmini.loadgen.runner import LoadConfig, run_load_sync
+    from kvmini.server.native import start_native_in_thread
+
+    eng, _w = _engine(max_num_seqs=8, max_batched_tokens=32)
+    _ns, url, stop = start_native_in_thread(eng, model_name="tiny")
+    try:
+        res = run_load_sync(LoadConfig(url=url, run_dir=str(tmp_path / "r"), requests=16, concurrency=6, spec=RequestSpec(model="tiny", max_tokens=6), quiet=True))
+        assert all(r.status == 200 and r.completion_tokens == 6 and r.prompt_tokens == 14 and len(r.token_times_ms) == 6 for r in res)
+        assert all(r.ttfb_ms <= r.ttft_ms for r in res)
+        ns = run_load_sync(LoadConfig(url=url, requests=3, concurrency=3, spec=RequestSpec(model="tiny", max_tokens=5, stream=False), quiet=True))
+        assert all(r.status == 200 and r.total_tokens == 19 for r in ns)
+        tg = run_load_sync(LoadConfig(url=url, requests=3, concurrency=2, protocol="tgi", spec=RequestSpec(max_tokens=4), quiet=True))
+        assert all(r.status == 200 and r.completion_tokens == 4 for r in tg)
+        import urllib.request
+
+        metrics = urllib.request.urlopen(url + "/metrics").read().decode()
+        assert "vllm:generation_tokens_total" in metrics and "vllm:gpu_prefix_cache_hits_total" in metrics
+        models = json.loads(urllib.request.urlopen(url + "/v1/models").read())
+        assert models["data"][0]["id"] == "tiny"
+        req = urllib.request.Request(url + "/v1/chat/completions", data=b'{"messages": []}', headers={"Content-Type": "application/json"})
+        with pytest.raises(urllib.error.HTTPError) as ei:
+            urllib.request.urlopen(req)
+        assert ei.value.code == 400
+    finally:
+        stop()
+
+
+TP_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["KV_ROOT"])
+from kvmini.engine.engine import EngineConfig, LLMEngine
+from kvmini.engine.scheduler import SamplingParams
+from kvmini.models.llama import get_config, random_weights
+from kvmini.models.reference import dense_greedy
+from kvmini.parallel.telemetry_gather import TelemetryGather, table_to_power_json
+dist.init_process_group("gloo")
+r, ws = dist.get_rank(), dist.get_world_size()
+cfg = get_config("tiny")
+w = random_weights(cfg, "cpu", torch.float32, seed=5, tp_rank=r, tp_size=ws)
+eng = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=16, max_model_len=64, num_blocks=32, block_size=4, tp_size=ws, tp_rank=r), weights=w, tp_group=dist.group.WORLD)
+prompts = [[1, 4, 8, 15, 16, 23, 42], [1, 9, 9, 9]]
+outs = eng.generate(prompts, SamplingParams(max_tokens=6, ignore_eos=True))
+full = random_weights(cfg, "cpu", torch.float32, seed=5)
+ok = all(o == dense_greedy(full, p, 6) for p, o in zip(prompts, outs))
+# lock-step telemetry: per-tick and whole-table gathers
+tg = TelemetryGather()
+tick = tg.gather_tick({"ts_s": 100.0 + r, "watts": 500.0 + r, "gfx_util": 50.0})
+samples = [{"ts_s": 10.0 + 0.1 * i, "watts": 400.0 + 10 * r, "gfx_util": 70.0, "vram_used": 1e9} for i in range(30)]
+table = tg.gather_table(samples, 10.0, 12.0, 0.5)
+pj = table_to_power_json(table, 0.5)
+ok = ok and tick is not None and tick.shape == (ws, 16) and list(tick[:, 0]) == list(range(ws)) and table.shape == (ws, 5, 16)
+ok = ok and abs(pj["samples"][2]["watts"] - sum(400.0 + 10 * k for k in range(ws))) < 1e-9
+print(f"RANK{r} OK={ok}", flush=True)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_tensor_parallel_and_telemetry_gather_gloo_world2(tmp_path):
+    script = tmp_path / "tp.py"
+    script.write_text(TP_SCRIPT)
+    env = dict(os.environ, KV_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RANK0 OK=True" in r.stdout and "RANK1 OK=True" in r.stdout
