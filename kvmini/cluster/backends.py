@@ -114,6 +114,10 @@ class ClusterBackend:
     def inject_fault(self, fault: str, namespace: str, service: str) -> Dict[str, Any]:
         raise NotImplementedError(f"backend {self.name} cannot inject {fault}")
 
+    def clear_fault(self, fault: str, namespace: str, service: str) -> None:
+        """Undo a fault that persists until removed (network shaping); no-op otherwise."""
+        return None
+
     # --- derived ---------------------------------------------------------
     def cold_start_times(self, namespace: str, service: str, start: float, end: float) -> List[float]:
         """Epoch seconds at which a container of the service started inside
@@ -244,6 +248,16 @@ class KubectlBackend(ClusterBackend):
         else:
             raise ValueError(f"unknown fault {fault}")
         return {"fault": fault, "target": pod}
+
+    def clear_fault(self, fault: str, namespace: str, service: str) -> None:
+        if fault != "network-degrade":
+            return
+        pods = self.get_pods(namespace, service)
+        if pods:
+            try:
+                self._run(["-n", namespace, "exec", pods[0]["metadata"]["name"], "--", "sh", "-c", "tc qdisc del dev eth0 root"])
+            except (subprocess.SubprocessError, OSError):
+                pass
 
 
 class FakeBackend(ClusterBackend):

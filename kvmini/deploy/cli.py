@@ -66,6 +66,7 @@ def start_local_server(a: argparse.Namespace) -> Dict[str, Any]:
             cmd += ["--speculative-model", str(prof.native_engine["draft_model"]), "--num-speculative-tokens", str(prof.native_engine.get("num_speculative_tokens", 4))]
         if prof and prof.vllm_features.get("quantization") == "fp8":
             cmd += ["--quantization", "fp8"]
+    cmd += [str(x) for x in (getattr(a, "serve_args", None) or [])]
     log_dir = os.path.join("runs", ".local_logs")
     os.makedirs(log_dir, exist_ok=True)
     log = open(os.path.join(log_dir, f"{a.service}.log"), "ab")

@@ -1,0 +1,238 @@
+"""Backend A/B comparison (``kvmini ab-compare``).
+
+Deploys the same model on each serving backend (``vllm-rocm``, ``tgi-rocm``,
+``native`` — the in-tree MI355X engine — or any already-running endpoint given
+with ``--endpoints name=url``), runs the identical traffic profile against each,
+optionally once streaming and once non-streaming, and writes
+``ab_comparison.csv`` (``backend,streaming,requests,concurrency,mean_ttft_ms,
+p95_ttft_ms,mean_tpot_ms,p95_tpot_ms,throughput_req_s,gpu_util_avg,
+cost_per_1k_tokens``) plus ``comparison_report.json`` with the fastest-TTFT /
+highest-throughput / lowest-cost winners and the streaming deltas (reference
+``runners/ab-compare.sh:140-395``).
+"""
+
+from __future__ import annotations
+
+import argparse
+import csv
+import os
+import statistics
+import sys
+import time
+from typing import Any, Dict, List, Optional
+
+from kvmini.cluster import get_backend
+from kvmini.config.profiles import load_profile, resolve_load_settings
+from kvmini.deploy import manifests as mf
+from kvmini.utils import load_json, write_json
+
+CSV_COLS = ["backend", "streaming", "requests", "concurrency", "mean_ttft_ms", "p95_ttft_ms", "mean_tpot_ms", "p95_tpot_ms", "throughput_req_s", "gpu_util_avg", "cost_per_1k_tokens"]
+PROTOCOL = {"vllm-rocm": "openai", "vllm": "openai", "native": "openai", "mock": "openai", "tgi-rocm": "tgi", "tgi": "tgi"}
+
+
+def summarize_test(test_dir: str, backend: str, streaming: bool, requests: int, concurrency: int) -> Optional[Dict[str, Any]]:
+    req_csv = os.path.join(test_dir, "requests.csv")
+    if not os.path.exists(req_csv):
+        return None
+    ttft: List[float] = []
+    tpot: List[float] = []
+    with open(req_csv) as f:
+        for row in csv.DictReader(f):
+            if row.get("status") != "200":
+                continue
+            v = row.get("ttft_ms") or row.get("ttfb_ms")
+            if v:
+                ttft.append(float(v))
+            if row.get("tpot_ms"):
+                tpot.append(float(row["tpot_ms"]))
+
+    def p95(xs: List[float]) -> float:
+        return sorted(xs)[min(len(xs) - 1, int(0.95 * len(xs)))] if xs else 0.0
+
+    res_path = os.path.join(test_dir, "results.json")
+    summary = load_json(res_path) if os.path.exists(res_path) else {}
+    return {
+        "backend": backend,
+        "streaming": "true" if streaming else "false",
+        "requests": requests,
+        "concurrency": concurrency,
+        "mean_ttft_ms": round(statistics.mean(ttft), 1) if ttft else 0.0,
+        "p95_ttft_ms": round(p95(ttft), 1),
+        "mean_tpot_ms": round(statistics.mean(tpot), 1) if tpot else 0.0,
+        "p95_tpot_ms": round(p95(tpot), 1),
+        "throughput_req_s": round(float(summary.get("throughput_rps") or summary.get("throughput_req_per_sec") or 0.0), 2),
+        "gpu_util_avg": round(float(summary.get("gpu_util_avg") or summary.get("gpu_utilization_avg") or 0.0), 1),
+        "cost_per_1k_tokens": round(float(summary.get("cost_per_1k_tokens") or 0.0), 6),
+    }
+
+
+def build_report(rows: List[Dict[str, Any]], meta: Dict[str, Any]) -> Dict[str, Any]:
+    def f(r: Dict[str, Any], k: str) -> float:
+        return float(r[k])
+
+    best_ttft = min(rows, key=lambda r: f(r, "mean_ttft_ms"))
+    best_tp = max(rows, key=lambda r: f(r, "throughput_req_s"))
+    best_cost = min(rows, key=lambda r: f(r, "cost_per_1k_tokens"))
+    report: Dict[str, Any] = {
+        "comparison_metadata": meta,
+        "results": rows,
+        "winners": {
+            "fastest_ttft": {"backend": best_ttft["backend"], "streaming": best_ttft["streaming"], "value_ms": f(best_ttft, "mean_ttft_ms")},
+            "highest_throughput": {"backend": best_tp["backend"], "streaming": best_tp["streaming"], "value_req_s": f(best_tp, "throughput_req_s")},
+            "lowest_cost": {"backend": best_cost["backend"], "streaming": best_cost["streaming"], "value_per_1k": f(best_cost, "cost_per_1k_tokens")},
+        },
+    }
+    by: Dict[str, Dict[str, Dict[str, Any]]] = {}
+    for r in rows:
+        by.setdefault(r["backend"], {})[str(r["streaming"])] = r
+    deltas = {}
+    for b, modes in by.items():
+        if "true" in modes and "false" in modes:
+            deltas[b] = {
+                "ttft_advantage_ms": f(modes["false"], "mean_ttft_ms") - f(modes["true"], "mean_ttft_ms"),
+                "throughput_advantage_req_s": f(modes["true"], "throughput_req_s") - f(modes["false"], "throughput_req_s"),
+            }
+    if deltas:
+        report["streaming_vs_non_streaming"] = deltas
+    return report
+
+
+class ABRunner:
+    def __init__(self, a: argparse.Namespace, settings: Dict[str, Any]):
+        self.a = a
+        self.s = settings
+        self.cluster = get_backend(a.cluster_backend)
+        self.endpoints = dict(e.split("=", 1) for e in (a.endpoints or []))
+        self.rows: List[Dict[str, Any]] = []
+
+    def service(self, backend: str) -> str:
+        return f"{self.a.model}-{backend}".replace("_", "-").replace(".", "-").lower()
+
+    def deploy(self, backend: str) -> str:
+        if backend in self.endpoints:
+            return self.endpoints[backend]
+        if backend not in mf.BUILDERS:
+            raise RuntimeError(f"no deployer for backend '{backend}' (known: {sorted(mf.BUILDERS)}; or pass --endpoints {backend}=URL)")
+        name = self.service(backend)
+        if backend in ("tgi-rocm", "tgi"):
+            manifest = mf.tgi_rocm_isvc(name, self.a.namespace, self.a.model)
+        elif backend == "native":
+            manifest = mf.native_isvc(name, self.a.namespace, self.a.model)
+        else:
+            manifest = mf.vllm_rocm_isvc(name, self.a.namespace, model_name=self.a.model, model_uri=self.a.model_uri)
+        self.cluster.apply(manifest)
+        self.cluster.wait_ready(self.a.namespace, name, self.a.ready_timeout)
+        url = self.cluster.get_isvc_url(self.a.namespace, name)
+        if not url:
+            raise RuntimeError(f"could not get URL for {name}")
+        return url
+
+    def cleanup(self, backend: str) -> None:
+        if self.a.no_cleanup or backend in self.endpoints:
+            return
+        try:
+            self.cluster.delete_isvc(self.a.namespace, self.service(backend))
+        except Exception as e:
+            print(f"  cleanup warning: {e}", file=sys.stderr)
+
+    def test(self, backend: str, url: str, streaming: bool) -> None:
+        from kvmini.harness import bench
+
+        tag = f"{backend}_{'streaming' if streaming else 'nonstreaming'}"
+        test_dir = os.path.join(self.a.run_dir, tag)
+        print(f"Testing {backend} (streaming: {str(streaming).lower()}) -> {test_dir}")
+        argv = ["--namespace", self.a.namespace, "--service", self.service(backend), "--url", url, "--model", self.a.model, "--requests", str(self.s["requests"]), "--concurrency", str(self.s["concurrency"]), "--max-tokens", str(self.s["max_tokens"]), "--pattern", self.s["pattern"], "--run-dir", test_dir, "--protocol", PROTOCOL.get(backend, "openai"), "--cost-file", self.a.cost_file, "--no-energy"]
+        if not streaming:
+            argv.append("--no-stream")
+        if self.a.cluster_backend:
+            argv += ["--cluster-backend", self.a.cluster_backend]
+        try:
+            bench.main(argv)
+        except SystemExit:
+            pass
+        row = summarize_test(test_dir, backend, streaming, self.s["requests"], self.s["concurrency"])
+        if row is None:
+            print(f"WARNING: no results for {backend} test", file=sys.stderr)
+            return
+        self.rows.append(row)
+        self.write_csv()
+
+    def write_csv(self) -> str:
+        path = os.path.join(self.a.run_dir, "ab_comparison.csv")
+        with open(path, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=CSV_COLS)
+            w.writeheader()
+            w.writerows(self.rows)
+        return path
+
+    def run(self) -> Optional[Dict[str, Any]]:
+        backends = [b.strip() for b in self.a.backends.split(",") if b.strip()]
+        for i, b in enumerate(backends):
+            print(f"=== Testing backend: {b} ===")
+            try:
+                url = self.deploy(b)
+            except Exception as e:
+                print(f"ERROR: {b}: {e}", file=sys.stderr)
+                continue
+            try:
+                self.test(b, url, True)
+                if self.a.toggle_streaming:
+                    if self.a.wait_between > 0:
+                        time.sleep(self.a.wait_between)
+                    self.test(b, url, False)
+            finally:
+                self.cleanup(b)
+            if i + 1 < len(backends) and self.a.wait_between > 0:
+                time.sleep(self.a.wait_between)
+        if not self.rows:
+            print("No results to analyze", file=sys.stderr)
+            return None
+        meta = {"timestamp": time.strftime("%Y-%m-%dT%H:%M:%S", time.gmtime()), "profile": self.a.profile, "model": self.a.model, "requests": self.s["requests"], "concurrency": self.s["concurrency"], "streaming_tested": bool(self.a.toggle_streaming)}
+        report = build_report(self.rows, meta)
+        write_json(os.path.join(self.a.run_dir, "comparison_report.json"), report)
+        return report
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    ap = argparse.ArgumentParser(prog="kvmini ab-compare", description="Backend A/B testing for fair runtime comparisons")
+    ap.add_argument("--backends", required=True, help="comma-separated: vllm-rocm,tgi-rocm,native (or names given in --endpoints)")
+    ap.add_argument("--model", required=True)
+    ap.add_argument("--model-uri", default=None)
+    ap.add_argument("--profile", default="standard")
+    ap.add_argument("--namespace", default="ml-prod")
+    ap.add_argument("--toggle-streaming", action="store_true")
+    ap.add_argument("--requests", type=int, default=None)
+    ap.add_argument("--concurrency", type=int, default=None)
+    ap.add_argument("--run-dir", default=None)
+    ap.add_argument("--no-cleanup", action="store_true")
+    ap.add_argument("--wait-between", type=float, default=60.0)
+    ap.add_argument("--ready-timeout", type=float, default=600.0)
+    ap.add_argument("--endpoints", nargs="*", default=None, metavar="NAME=URL", help="already-running endpoints to compare (no deploy / cleanup)")
+    ap.add_argument("--cluster-backend", default=None, choices=["auto", "kubectl", "local", "fake"])
+    ap.add_argument("--cost-file", default="cost.yaml")
+    a = ap.parse_args(argv)
+    try:
+        profile = load_profile(a.profile)
+    except (FileNotFoundError, ValueError) as e:
+        print(f"ERROR: {e}", file=sys.stderr)
+        return 1
+    s = resolve_load_settings({"requests": a.requests, "concurrency": a.concurrency, "max_tokens": None, "pattern": None, "stream": None}, profile)
+    a.run_dir = a.run_dir or os.path.join("runs", "ab_compare_" + time.strftime("%Y-%m-%d_%H-%M-%S"))
+    os.makedirs(a.run_dir, exist_ok=True)
+    print(f"=== Backend A/B comparison ===\nBackends: {a.backends}\nModel: {a.model}\nProfile: {a.profile} (pattern {s['pattern']}, {s['requests']} requests, concurrency {s['concurrency']}, max tokens {s['max_tokens']})")
+    report = ABRunner(a, s).run()
+    if report is None:
+        return 1
+    w = report["winners"]
+    print("\n=== A/B comparison results ===")
+    print(f"  Fastest TTFT:       {w['fastest_ttft']['backend']} (streaming: {w['fastest_ttft']['streaming']}) - {w['fastest_ttft']['value_ms']} ms")
+    print(f"  Highest throughput: {w['highest_throughput']['backend']} - {w['highest_throughput']['value_req_s']} req/s")
+    print(f"  Lowest cost:        {w['lowest_cost']['backend']} - ${w['lowest_cost']['value_per_1k']} per 1K tokens")
+    for b, d in (report.get("streaming_vs_non_streaming") or {}).items():
+        print(f"  {b}: streaming TTFT advantage {d['ttft_advantage_ms']:+.1f} ms, throughput {d['throughput_advantage_req_s']:+.2f} req/s")
+    print(f"Results directory: {a.run_dir}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

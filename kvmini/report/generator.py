@@ -114,6 +114,35 @@ def svg_heatmap(rows: Sequence[Any], cols: Sequence[Any], values: Dict[Tuple[Any
     return "".join(out)
 
 
+def svg_scatter(points: Sequence[Tuple[Optional[float], Optional[float], str, bool]], title: str, xlabel: str, ylabel: str, width: int = 460, height: int = 320) -> str:
+    """Scatter of ``(x, y, label, highlighted)``; highlighted points (frontier
+    members) are drawn as labelled stars."""
+    pts = [(float(x), float(y), lab, hl) for x, y, lab, hl in points if x is not None and y is not None and x == x and y == y and abs(x) != float("inf") and abs(y) != float("inf")]
+    ml, mb, mt = 62, 44, 30
+    pw, ph = width - ml - 16, height - mb - mt
+    out = [f"<svg viewBox='0 0 {width} {height}' width='{width}' height='{height}' role='img'><text x='{width / 2}' y='18' text-anchor='middle' font-weight='600'>{html.escape(title)}</text>"]
+    out.append(f"<rect x='{ml}' y='{mt}' width='{pw}' height='{ph}' fill='none' stroke='#ced4da'/>")
+    out.append(f"<text x='{ml + pw / 2}' y='{height - 8}' text-anchor='middle' font-size='11'>{html.escape(xlabel)}</text>")
+    out.append(f"<text x='14' y='{mt + ph / 2}' text-anchor='middle' font-size='11' transform='rotate(-90 14 {mt + ph / 2})'>{html.escape(ylabel)}</text>")
+    if pts:
+        xs, ys = [p[0] for p in pts], [p[1] for p in pts]
+        x0, x1, y0, y1 = min(xs), max(xs), min(ys), max(ys)
+        dx, dy = (x1 - x0) or abs(x1) or 1.0, (y1 - y0) or abs(y1) or 1.0
+        x0, x1, y0, y1 = x0 - 0.08 * dx, x1 + 0.08 * dx, y0 - 0.08 * dy, y1 + 0.08 * dy
+        for i in range(5):
+            gx, gy = ml + pw * i / 4, mt + ph - ph * i / 4
+            out.append(f"<text x='{gx:.1f}' y='{mt + ph + 14}' text-anchor='middle' font-size='10'>{format_number(x0 + (x1 - x0) * i / 4, 2)}</text>")
+            out.append(f"<text x='{ml - 5}' y='{gy + 3:.1f}' text-anchor='end' font-size='10'>{format_number(y0 + (y1 - y0) * i / 4, 2)}</text>")
+        for x, y, lab, hl in pts:
+            cx, cy = ml + pw * (x - x0) / (x1 - x0), mt + ph - ph * (y - y0) / (y1 - y0)
+            if hl:
+                out.append(f"<text x='{cx:.1f}' y='{cy + 5:.1f}' text-anchor='middle' font-size='16' fill='#c92a2a'>★<title>{html.escape(lab)}</title></text><text x='{cx + 8:.1f}' y='{cy - 6:.1f}' font-size='10'>{html.escape(lab)}</text>")
+            else:
+                out.append(f"<circle cx='{cx:.1f}' cy='{cy:.1f}' r='5' fill='#1c7ed6' fill-opacity='.7'><title>{html.escape(lab)}</title></circle>")
+    out.append("</svg>")
+    return "".join(out)
+
+
 # ---- analysis helpers --------------------------------------------------------------------
 def compute_prewarm_breakeven(results: Dict[str, Any], cost_file: Optional[str] = None) -> Dict[str, Any]:
     """RPS at which keeping one replica warm costs as much as the cold starts it
