@@ -163,6 +163,8 @@ class BackendComparator:
             if rc != 0 or not os.path.exists(res_path):
                 raise RuntimeError(f"benchmark failed (exit {rc})")
             r.absorb(load_json(res_path))
+            if r.successful_requests == 0:
+                raise RuntimeError("no successful requests")
             r.success = True
         except (Exception, SystemExit) as e:
             r.error = str(e) or type(e).__name__

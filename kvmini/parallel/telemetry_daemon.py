@@ -107,7 +107,7 @@ def main(argv: Optional[List[str]] = None) -> int:
         except ValueError:
             pass
     # ticks are counted, not timed, so every rank issues the same number of collectives
-    n_ticks = int(a.duration / a.gather_every) if a.duration > 0 else 0
+    n_ticks = max(1, int(round(a.duration / a.gather_every))) if a.duration > 0 else 0
     tables: List[np.ndarray] = []
 
     def flush() -> None:

@@ -72,7 +72,7 @@ class MockLLM:
         return max(0.0, ms * (1.0 + self.rng.uniform(-j, j))) / 1000.0
 
     def _ttft_s(self, prompt: str) -> float:
-        ms = self.cfg.ttft_ms + self.extra_latency_ms
+        ms = self.cfg.ttft_ms
         if self.cfg.cold_seconds and time.time() - self.started_at < self.cfg.cold_seconds:
             ms *= self.cfg.cold_multiplier
         if self.cfg.prefix_cache:
@@ -85,7 +85,8 @@ class MockLLM:
                 self.seen_prompts.add(key)
         if self.cfg.max_concurrency and self.inflight > self.cfg.max_concurrency:
             ms *= self.inflight / self.cfg.max_concurrency
-        return self._jit(ms)
+        # injected (network-like) delay is not something a prefix cache can hide
+        return self._jit(ms) + self.extra_latency_ms / 1000.0
 
     def _gen_words(self, prompt: str, n: int, json_mode: bool = False) -> List[str]:
         if json_mode:
