@@ -65,9 +65,9 @@ def gemm_bench(out):
                     if slabs:
                         splits, cps = C.stream_gemm_plan(N, K, ks, 16)
                         out = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
-                        C.stream_gemm(wp, N, K, x, out, 1, ks, splits, cps)
+                        C.stream_gemm(wp, N, K, x, out, 1, ks, splits, cps, None, 0.0)
                     else:
-                        C.stream_gemm(wp, N, K, x, y, 0, ks, 1, (K // 32) // ks)
+                        C.stream_gemm(wp, N, K, x, y, 0, ks, 1, (K // 32) // ks, None, 0.0)
                 return f
 
             fns = {
