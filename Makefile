@@ -1,0 +1,121 @@
+SHELL := /bin/bash
+PY ?= python3
+CHART := charts/kserve-vllm-mini
+NS ?= ml-prod
+RELEASE ?= demo
+AIRGAP_DIR ?= airgap-bundle
+
+.PHONY: help demo build build-native native test test-gpu lint fmt fmt-check typecheck yaml-lint validate-configs dashboards \
+        helm-lint helm-install-minimal helm-install-with-kvmini helm-install-runtime helm-uninstall helm-package helm-test \
+        airgap airgap-clean airgap-images airgap-charts airgap-wheels airgap-artifacts airgap-docs airgap-dashboards airgap-finalize dev-setup clean
+
+help: ## Show this help
+	@grep -E '^[a-zA-Z_-]+:.*## ' $(MAKEFILE_LIST) | awk 'BEGIN{FS=":.*## "}{printf "  %-26s %s\n", $$1, $$2}'
+
+demo: ## Local end-to-end demo: mock server -> bench -> report (no cluster, no GPU)
+	$(PY) -m kvmini bench --serve mock --service demo-llm --requests 100 --concurrency 10 --max-tokens 32 --report
+	@echo "report: runs/latest/report.html"
+
+native: ## Compile the HIP extension for gfx950 (in-tree .so)
+	$(PY) build_native.py
+
+build: ## Build the harness container image
+	docker build -f Dockerfile.harness -t kvmini-harness:latest .
+
+build-native: ## Build the serving image (native engine)
+	docker build -f Dockerfile.native -t kvmini-native:latest .
+
+test: ## CPU test-suite
+	$(PY) -m pytest tests -x -q -m "not gpu"
+
+test-gpu: ## GPU test-suite (needs an MI355X)
+	$(PY) -u -m pytest tests -x -v -m gpu --timeout 120 --timeout-method thread
+
+lint: ## ruff + shellcheck (when installed)
+	@command -v ruff >/dev/null && ruff check kvmini tests bench.py || echo "ruff not installed; skipping"
+	@command -v shellcheck >/dev/null && shellcheck *.sh tools/*.sh sweeps/*.sh runners/*.sh scripts/*.sh || echo "shellcheck not installed; skipping"
+
+fmt: ## Auto-format
+	@command -v ruff >/dev/null && ruff format kvmini tests bench.py && ruff check --fix kvmini tests bench.py || echo "ruff not installed"
+	@command -v shfmt >/dev/null && shfmt -w -i 2 *.sh tools/*.sh || true
+
+fmt-check: ## Formatting check only
+	@command -v ruff >/dev/null && ruff format --check kvmini tests bench.py || echo "ruff not installed"
+
+typecheck: ## mypy (when installed)
+	@command -v mypy >/dev/null && mypy kvmini --ignore-missing-imports || echo "mypy not installed; skipping"
+
+yaml-lint: ## Parse every YAML file outside Helm templates
+	$(PY) -m kvmini validate --yaml-tree . --exclude charts/*/templates
+
+validate-configs: ## Validate profiles, cost file, SLO file, reference matrix, chart values vs schema
+	$(PY) -m kvmini validate --all
+
+dashboards: ## Regenerate dashboards/*.json
+	$(PY) -m kvmini.report.dashboards --out dashboards
+
+helm-lint: ## Lint both charts
+	helm dependency update $(CHART)
+	helm lint charts/kvmini
+	helm lint $(CHART) -f $(CHART)/examples/values-minimal.yaml
+
+helm-install-minimal: ## InferenceService only
+	helm upgrade --install $(RELEASE) $(CHART) -n $(NS) --create-namespace -f $(CHART)/examples/values-minimal.yaml
+
+helm-install-with-kvmini: ## InferenceService + harness pod
+	helm dependency update $(CHART)
+	helm upgrade --install $(RELEASE) $(CHART) -n $(NS) --create-namespace -f $(CHART)/examples/values-with-kvmini.yaml
+
+helm-install-runtime: ## Also install the vLLM-ROCm and native ServingRuntimes
+	helm upgrade --install $(RELEASE) $(CHART) -n $(NS) --create-namespace -f $(CHART)/examples/values-runtime.yaml
+
+helm-uninstall: ## Remove the release
+	helm uninstall $(RELEASE) -n $(NS)
+
+helm-package: ## Package the parent chart into dist/
+	helm dependency update $(CHART)
+	mkdir -p dist && helm package $(CHART) -d dist
+
+helm-test: ## helm test (smoke pod curls the endpoint)
+	helm test $(RELEASE) -n $(NS)
+
+airgap: airgap-images airgap-artifacts airgap-docs airgap-dashboards airgap-finalize ## Complete air-gapped bundle
+
+airgap-clean: ## Remove the bundle directory
+	rm -rf $(AIRGAP_DIR)
+
+airgap-images: airgap-clean ## Save container images (harness, native engine, vLLM-ROCm)
+	mkdir -p $(AIRGAP_DIR)/images
+	@for img in kvmini-harness:latest kvmini-native:latest rocm/vllm:latest; do \
+	  if docker image inspect $$img >/dev/null 2>&1; then docker save $$img | gzip > $(AIRGAP_DIR)/images/$$(echo $$img | tr '/:' '__').tar.gz; echo "saved $$img"; \
+	  else echo "image $$img not present locally; skipping"; fi; done
+
+airgap-charts: ## Package charts into the bundle
+	mkdir -p $(AIRGAP_DIR)/charts
+	@command -v helm >/dev/null && helm package charts/kvmini -d $(AIRGAP_DIR)/charts && helm dependency update $(CHART) && helm package $(CHART) -d $(AIRGAP_DIR)/charts || cp -r charts $(AIRGAP_DIR)/charts/src
+
+airgap-wheels: ## Download Python wheels
+	mkdir -p $(AIRGAP_DIR)/wheels
+	$(PY) -m pip wheel . -w $(AIRGAP_DIR)/wheels || echo "wheel build needs an index or a wheelhouse; skipping"
+
+airgap-artifacts: airgap-charts airgap-wheels ## Charts + wheels + configs
+	mkdir -p $(AIRGAP_DIR)/config
+	cp -r cost.yaml slo.json reference-matrix.yaml isvc.yaml example-config.yaml runners profiles policies $(AIRGAP_DIR)/config/
+
+airgap-docs: ## Documentation
+	mkdir -p $(AIRGAP_DIR)/docs && cp -r README.md docs/* $(AIRGAP_DIR)/docs/ 2>/dev/null || true
+
+airgap-dashboards: ## Grafana dashboards
+	mkdir -p $(AIRGAP_DIR)/dashboards && cp dashboards/*.json $(AIRGAP_DIR)/dashboards/
+
+airgap-finalize: ## Checksums + tarball
+	cd $(AIRGAP_DIR) && find . -type f ! -name SHA256SUMS -print0 | sort -z | xargs -0 sha256sum > SHA256SUMS
+	tar -czf $(AIRGAP_DIR).tar.gz $(AIRGAP_DIR) && echo "bundle: $(AIRGAP_DIR).tar.gz"
+
+dev-setup: ## Editable install + native build
+	$(PY) -m pip install -e ".[dev]" || true
+	$(PY) build_native.py
+
+clean: ## Remove build artifacts
+	rm -rf build dist *.egg-info .pytest_cache $(AIRGAP_DIR) $(AIRGAP_DIR).tar.gz
+	find . -name __pycache__ -type d -prune -exec rm -rf {} +

@@ -161,7 +161,21 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--gpu-memory-gb", type=int, help="Available GPU memory (GiB) for heuristic checks")
     ap.add_argument("--gpu-name", type=str, help="GPU product (default: detected)")
     ap.add_argument("--no-detect", action="store_true", help="do not query amd-smi")
+    ap.add_argument("--all", action="store_true", help="validate every config in the repository (profiles, pricing, SLO, matrix, chart values, dashboards)")
+    ap.add_argument("--yaml-tree", default=None, metavar="DIR", help="parse every YAML file under DIR")
+    ap.add_argument("--exclude", nargs="*", default=["charts/*/templates", "charts/*/templates/*"])
     a = ap.parse_args(argv)
+    if a.all or a.yaml_tree:
+        from kvmini.gates import repo_checks
+        from kvmini.utils import repo_root
+
+        if a.all:
+            n, sections = repo_checks.run_all(repo_root())
+        else:
+            errs = repo_checks.check_yaml_tree(a.yaml_tree, a.exclude)
+            n, sections = len(errs), {"yaml": errs}
+        repo_checks.report(sections)
+        return 1 if n else 0
     config: Dict[str, Any] = {}
     if a.profile:
         try:
