@@ -29,7 +29,8 @@ int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, l
 int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
-                   int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, hipStream_t stream);
+                   int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
+int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
                        hipStream_t stream);
 int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride, void* residual, const void* w, void* y, int T, int H, float eps,
@@ -189,6 +190,15 @@ at::Tensor pack_weight(at::Tensor W) {
   return Wp;
 }
 
+at::Tensor pack_weight_fp8(at::Tensor W) {
+  CHECK_DEV(W); CHECK_CONTIG(W);
+  TORCH_CHECK(W.dim() == 2 && W.scalar_type() == at::kByte, "W must be uint8 [N, K] (e4m3 bytes)");
+  TORCH_CHECK(W.size(0) % 16 == 0 && W.size(1) % 64 == 0, "N % 16 == 0 and K % 64 == 0 required");
+  auto Wp = at::empty_like(W);
+  check(kv_pack_weight_fp8(W.data_ptr(), Wp.data_ptr(), (int)W.size(0), (int)W.size(1), cur_stream()), "kv_pack_weight_fp8");
+  return Wp;
+}
+
 // ---- weight-streaming GEMM v2 (packed weights, LDS-shared x, split-K slabs) -------------
 std::pair<int64_t, int64_t> stream_gemm_plan(int64_t N, int64_t K, int64_t ks_per_chunk, int64_t max_splits) {
   int cps = 0;
@@ -206,9 +216,20 @@ const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* 
   return (const float*)t.data_ptr();
 }
 
+// Wp: bf16 packed weight, or uint8 (OCP e4m3 bytes, kv_pack_weight_fp8 order) with w_scale fp32 [N].
 void stream_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t ks_per_chunk, int64_t splits, int64_t chunks_per_split,
-                 c10::optional<at::Tensor> row_ss, double eps) {
-  CHECK_DEV(Wp); CHECK_BF16(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
+                 c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale) {
+  CHECK_DEV(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
+  const float* wsp = nullptr;
+  if (w_scale.has_value()) {
+    const at::Tensor& ws = *w_scale;
+    TORCH_CHECK(Wp.scalar_type() == at::kByte, "FP8 weights are passed as uint8 bytes");
+    TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kFloat && ws.is_contiguous() && ws.numel() == N, "w_scale must be contiguous fp32 [N]");
+    TORCH_CHECK(K % 64 == 0, "FP8 weights need K % 64 == 0");
+    wsp = (const float*)ws.data_ptr();
+  } else {
+    CHECK_BF16(Wp);
+  }
   TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
   const int64_t M = x.size(0);
@@ -226,7 +247,7 @@ void stream_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor o
     ldy = out.stride(0);
   }
   check(kv_stream_gemm(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)ks_per_chunk, (int)splits,
-                       (int)chunks_per_split, slab_stride, ssp, parts, (float)eps, cur_stream()),
+                       (int)chunks_per_split, slab_stride, ssp, parts, (float)eps, wsp, cur_stream()),
         "kv_stream_gemm");
 }
 
@@ -302,7 +323,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);
   m.def("stream_gemm_plan", &stream_gemm_plan);
-  m.def("stream_gemm", &stream_gemm);
+  m.def("stream_gemm", &stream_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("ks_per_chunk"), py::arg("splits"),
+        py::arg("chunks_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none());
+  m.def("pack_weight_fp8", &pack_weight_fp8);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs);
   m.def("residual_reduce", &residual_reduce);

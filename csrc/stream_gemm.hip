@@ -40,13 +40,39 @@ __device__ inline unsigned short f2bf(float f) {
   return (unsigned short)(u >> 16);
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int raw16;  // one 16-byte weight load
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
 enum Epilogue { EPI_BF16 = 0, EPI_SLAB = 1, EPI_SWIGLU = 2 };
 
+// A fragment for k-step u out of the raw weight registers.  bf16: one 16-byte load per
+// k-step.  FP8 (OCP e4m3, weight-only): one 16-byte load carries TWO k-steps (8 bytes each);
+// the bytes are widened to bf16 in registers (exact: e4m3 fits in bf16) with the packed
+// gfx950 conversion, and the per-output-row scale is applied once in the epilogue.
+template <bool W8>
+__device__ inline frag_ab a_frag(const raw16* raw, int u) {
+  if constexpr (!W8) {
+    return __builtin_bit_cast(frag_ab, raw[u]);
+  } else {
+    const raw16 v = raw[u >> 1];
+    const unsigned int lo = (u & 1) ? v[2] : v[0], hi = (u & 1) ? v[3] : v[1];
+    const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false);
+    const bf16x2 p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false);
+    const bf16x2 p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    frag_ab a;
+    a[0] = p0[0]; a[1] = p0[1]; a[2] = p1[0]; a[3] = p1[1]; a[4] = p2[0]; a[5] = p2[1]; a[6] = p3[0]; a[7] = p3[1];
+    return a;
+  }
+}
+
 // KS = k-steps (of 32) per chunk.  grid = (N/64, splits).  chunks_per_split chunks per workgroup.
-template <int MT, int KS, int EPI>
-__global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
+template <int MT, int KS, int EPI, bool W8>
+__global__ __launch_bounds__(256) void stream_gemm_kernel(const void* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
                                                           long long ldx, long long ldy, int chunks_per_split, long long slab_stride,
-                                                          const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps) {
+                                                          const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps,
+                                                          const float* __restrict__ w_scale) {
+  constexpr int AL = W8 ? KS / 2 : KS;  // 16-byte weight loads per chunk per lane
   constexpr int XF = KS * MT;          // x fragment tiles (1 KiB each) per chunk
   constexpr int XL = (XF + 3) / 4;     // per-thread 16-byte x loads per chunk
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * XF * 1024 > 4 * 64 * 4 * 4 * MT ? 2 * XF * 1024 : 4 * 64 * 4 * 4 * MT];
@@ -58,7 +84,8 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
   const int c0 = blockIdx.y * chunks_per_split;
   const int c1 = c0 + chunks_per_split < nchunks ? c0 + chunks_per_split : nchunks;
   const long long tile = (long long)blockIdx.x * 4 + wave;  // 16-row tile of W owned by this wave
-  const __bf16* wp = Wp + (tile * ksteps * 64 + lane) * 8;
+  // 16-byte units: bf16 [tile][kstep][lane], fp8 [tile][kstep pair][lane]
+  const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * (W8 ? ksteps / 2 : ksteps) * 64 + lane;
 
   // x fragment slot s = tid + 256*i  ->  tile f = s/64 (= wave + 4*i), ks = f / MT, j = f % MT
   const __bf16* xsrc[XL];
@@ -75,7 +102,8 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
 #pragma unroll
   for (int j = 0; j < MT; ++j) acc[j] = (frag_cd){0.f, 0.f, 0.f, 0.f};
 
-  frag_ab a_cur[KS], a_nxt[KS], xr[XL];
+  raw16 a_cur[AL], a_nxt[AL];
+  frag_ab xr[XL];
 
   // ---- prologue: chunk c0
   if (c0 < c1) {
@@ -83,7 +111,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
     for (int i = 0; i < XL; ++i)
       if (xok[i]) xr[i] = *reinterpret_cast<const frag_ab*>(xsrc[i] + (long long)c0 * KS * 32);
 #pragma unroll
-    for (int u = 0; u < KS; ++u) a_cur[u] = *reinterpret_cast<const frag_ab*>(wp + ((long long)c0 * KS + u) * 512);
+    for (int u = 0; u < AL; ++u) a_cur[u] = wp[((long long)c0 * AL + u) * 64];
 #pragma unroll
     for (int i = 0; i < XL; ++i)
       if (xok[i]) xs[(0 * XF + wave + 4 * i) * 64 + lane] = xr[i];
@@ -97,7 +125,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
       for (int i = 0; i < XL; ++i)
         if (xok[i]) xr[i] = *reinterpret_cast<const frag_ab*>(xsrc[i] + (long long)(c + 1) * KS * 32);
 #pragma unroll
-      for (int u = 0; u < KS; ++u) a_nxt[u] = *reinterpret_cast<const frag_ab*>(wp + ((long long)(c + 1) * KS + u) * 512);
+      for (int u = 0; u < AL; ++u) a_nxt[u] = wp[((long long)(c + 1) * AL + u) * 64];
     }
     __syncthreads();  // x chunk c is in LDS buffer `buf`; everyone is done reading buffer `buf^1`
 #pragma unroll
@@ -105,20 +133,29 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
       frag_ab b[MT];
 #pragma unroll
       for (int j = 0; j < MT; ++j) b[j] = xs[(buf * XF + u * MT + j) * 64 + lane];
+      const frag_ab a = a_frag<W8>(a_cur, u);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[u], b[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[j], 0, 0, 0);
     }
     if (more) {
 #pragma unroll
       for (int i = 0; i < XL; ++i)
         if (xok[i]) xs[((buf ^ 1) * XF + wave + 4 * i) * 64 + lane] = xr[i];
 #pragma unroll
-      for (int u = 0; u < KS; ++u) a_cur[u] = a_nxt[u];
+      for (int u = 0; u < AL; ++u) a_cur[u] = a_nxt[u];
     }
   }
 
   // ---- epilogue.  Lane holds y[token j*16 + r][feature tile*16 + 4q + e], e = 0..3.
   const long long n_base = tile * 16 + q * 4;
+  if constexpr (W8) {
+    // dequantise: one scale per output feature (weight row)
+    const frag_cd ws = *reinterpret_cast<const frag_cd*>(w_scale + n_base);
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[j][e] *= ws[e];
+  }
   // Folded RMSNorm: x is the un-normalised residual stream and W carries the norm gain,
   // so rows are scaled by 1/rms(x[m]) here (slabs are scaled by their consumer).
   if (EPI != EPI_SLAB && row_ss != nullptr) {
@@ -172,24 +209,53 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const __bf16* __restri
   }
 }
 
-template <int MT, int KS, int EPI>
-int launch(const void* Wp, const void* x, void* out, int N, int K, long long ldx, long long ldy, int splits, int cps, long long slab_stride,
-           const float* row_ss, int ss_parts, float eps, hipStream_t stream) {
-  dim3 grid(N / 64, splits), block(256);
-  hipLaunchKernelGGL((stream_gemm_kernel<MT, KS, EPI>), grid, block, 0, stream, (const __bf16*)Wp, (const __bf16*)x, out, N, K, ldx, ldy, cps, slab_stride,
-                     row_ss, ss_parts, 1.f / (float)K, eps);
+struct Args {
+  const void* Wp; const void* x; void* out; int N, K; long long ldx, ldy; int splits, cps; long long slab_stride;
+  const float* row_ss; int ss_parts; float eps; const float* w_scale; hipStream_t stream;
+};
+
+template <int MT, int KS, int EPI, bool W8>
+int launch(const Args& a) {
+  dim3 grid(a.N / 64, a.splits), block(256);
+  hipLaunchKernelGGL((stream_gemm_kernel<MT, KS, EPI, W8>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps, a.slab_stride,
+                     a.row_ss, a.ss_parts, 1.f / (float)a.K, a.eps, a.w_scale);
   return (int)hipGetLastError();
 }
 
-template <int MT, int KS>
-int dispatch_epi(int epi, const void* Wp, const void* x, void* out, int N, int K, long long ldx, long long ldy, int splits, int cps, long long slab_stride,
-                 const float* row_ss, int ss_parts, float eps, hipStream_t stream) {
+template <int MT, int KS, bool W8>
+int dispatch_epi(int epi, const Args& a) {
   switch (epi) {
-    case EPI_BF16: return launch<MT, KS, EPI_BF16>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, row_ss, ss_parts, eps, stream);
-    case EPI_SLAB: return launch<MT, KS, EPI_SLAB>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, row_ss, ss_parts, eps, stream);
-    case EPI_SWIGLU: return launch<MT, KS, EPI_SWIGLU>(Wp, x, out, N, K, ldx, ldy, splits, cps, slab_stride, row_ss, ss_parts, eps, stream);
+    case EPI_BF16: return launch<MT, KS, EPI_BF16, W8>(a);
+    case EPI_SLAB: return launch<MT, KS, EPI_SLAB, W8>(a);
+    case EPI_SWIGLU: return launch<MT, KS, EPI_SWIGLU, W8>(a);
   }
   return -1;
+}
+
+template <int MT>
+int dispatch_ks(int epi, int ks, bool w8, const Args& a) {
+  if (w8) return ks == 4 ? dispatch_epi<MT, 4, true>(epi, a) : dispatch_epi<MT, 8, true>(epi, a);
+  return ks == 4 ? dispatch_epi<MT, 4, false>(epi, a) : dispatch_epi<MT, 8, false>(epi, a);
+}
+
+// W[N, K] fp8 bytes (row-major) -> [N/16][K/64][64 lanes][16 bytes]: lane l of a tile holds
+// W[row l&15][k = 32*(2p+h) + 8*(l>>4) .. +8) for h = 0, 1 in its two 8-byte halves.
+__global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const unsigned char* __restrict__ W, unsigned char* __restrict__ Wp, int N, int K) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;  // one 16-byte unit per thread
+  const int kpairs = K >> 6;
+  const long long total = (long long)(N >> 4) * kpairs * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const long long t = idx >> 6;
+  const int p = (int)(t % kpairs);
+  const long long nt = t / kpairs;
+  const int r = lane & 15, q = lane >> 4;
+  const unsigned char* row = W + (nt * 16 + r) * (long long)K + (long long)p * 64 + q * 8;
+  const unsigned long long lo = *reinterpret_cast<const unsigned long long*>(row);
+  const unsigned long long hi = *reinterpret_cast<const unsigned long long*>(row + 32);
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(Wp + idx * 16);
+  dst[0] = lo;
+  dst[1] = hi;
 }
 
 }  // namespace
@@ -216,25 +282,30 @@ int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chu
 // epi: 0 = bf16 y[M, N] (single split), 1 = fp32 slabs out[splits][M][N], 2 = SwiGLU bf16 y[M, N/2].
 // ks_per_chunk: 4 or 8.  W must be packed (kv_pack_weight).  Requirements: M in {16,32,48,64},
 // N % 64 == 0 (N % 128 for SwiGLU), K % (32*ks_per_chunk) == 0.
+// w_scale != nullptr selects the FP8 weight path: Wp holds OCP e4m3 bytes packed by
+// kv_pack_weight_fp8 and w_scale[N] the per-row dequantisation scales.
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
-                   int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, hipStream_t stream) {
+                   int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream) {
   if (M <= 0 || M > 64 || (M & 15) || (N & 63) || (ks_per_chunk != 4 && ks_per_chunk != 8) || (K % (32 * ks_per_chunk))) return -1;
   if (epi == EPI_SWIGLU && (N & 127)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
   if (splits < 1 || chunks_per_split < 1 || (long long)splits * chunks_per_split < (K >> 5) / ks_per_chunk) return -1;
-  const int mt = M >> 4;
-#define KV_CASE(MTV)                                                                                                                 \
-  case MTV:                                                                                                                          \
-    return ks_per_chunk == 4 ? dispatch_epi<MTV, 4>(epi, Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, row_ss, ss_parts, eps, stream)  \
-                             : dispatch_epi<MTV, 8>(epi, Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, row_ss, ss_parts, eps, stream);
-  switch (mt) {
-    KV_CASE(1)
-    KV_CASE(2)
-    KV_CASE(3)
-    KV_CASE(4)
+  const Args a{Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, row_ss, ss_parts, eps, w_scale, stream};
+  const bool w8 = w_scale != nullptr;
+  switch (M >> 4) {
+    case 1: return dispatch_ks<1>(epi, ks_per_chunk, w8, a);
+    case 2: return dispatch_ks<2>(epi, ks_per_chunk, w8, a);
+    case 3: return dispatch_ks<3>(epi, ks_per_chunk, w8, a);
+    case 4: return dispatch_ks<4>(epi, ks_per_chunk, w8, a);
   }
-#undef KV_CASE
   return -1;
+}
+
+int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream) {
+  if ((N & 15) || (K & 63)) return -1;
+  const long long total = (long long)(N >> 4) * (K >> 6) * 64;
+  hipLaunchKernelGGL(pack_weight_fp8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const unsigned char*)W, (unsigned char*)Wp, N, K);
+  return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -114,10 +114,9 @@ class LLMEngine:
             kv_memory_fraction=ecfg.kv_memory_fraction,
             use_graphs=ecfg.use_graphs,
             kernels=ecfg.kernels,
+            quantization=ecfg.quantization,
         )
         self.runner = ModelRunner(weights, rcfg, tp_group)
-        if ecfg.quantization == "fp8":
-            self.runner.enable_fp8()
         self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)
         self.scheduler = Scheduler(self.bm, ecfg.max_num_seqs, ecfg.max_batched_tokens, ecfg.max_model_len, self.mcfg.eos_token_id)
         self.spec = None

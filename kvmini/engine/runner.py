@@ -41,6 +41,7 @@ class RunnerConfig:
     use_graphs: bool = True
     kernels: str = "auto"  # auto | hip | torch
     return_logits: bool = False
+    quantization: Optional[str] = None  # None | fp8 (weight-only, HIP kernels)
 
 
 def select_ops(kernels: str, device: torch.device) -> Any:
@@ -68,7 +69,12 @@ class ModelRunner:
         self.ops = select_ops(rcfg.kernels, self.device)
         if hasattr(self.ops, "prepare_weights"):
             # one-time re-order of every linear weight into MFMA fragment order
-            self.ops.prepare_weights(weights)
+            self.ops.prepare_weights(weights, rcfg.quantization)
+        elif rcfg.quantization == "fp8":
+            # reference ops: emulate weight-only FP8 by a quantise/dequantise round trip
+            from kvmini.models.llama import fake_quantize_fp8
+
+            fake_quantize_fp8(weights)
         cfg = self.cfg
         self.nh = cfg.num_heads // self.tp_size
         self.nkv = cfg.num_kv_heads // self.tp_size
@@ -248,6 +254,8 @@ class ModelRunner:
                 if seq.draft_ids and not seq.is_prefilling:
                     ids = ids + seq.draft_ids
                     first_sampled = max(0, seq.num_tokens - 1 - p0)
+                if ch.n_sample > 0:
+                    first_sampled = max(0, n - ch.n_sample)
                 pos = np.arange(p0, p0 + n, dtype=np.int32)
                 st[o_tok + i : o_tok + i + n] = ids[p0 : p0 + n]
                 st[o_pos + i : o_pos + i + n] = pos

@@ -78,6 +78,9 @@ class ScheduledChunk:
     start: int  # first position computed in this step
     n_tokens: int  # number of positions computed in this step
     sample: bool  # the chunk ends at the sequence's last known token -> sample next
+    # trailing positions to sample; -1 = the last one, or with draft tokens to verify
+    # every position from the last accepted token on
+    n_sample: int = -1
 
 
 @dataclass

@@ -279,3 +279,17 @@ def quantize_fp8_rows(w: torch.Tensor) -> "tuple[torch.Tensor, torch.Tensor]":
     scale = amax / 448.0
     q = (w.float() / scale[:, None]).to(torch.float8_e4m3fn)
     return q, scale.float()
+
+
+def fake_quantize_fp8(weights: "LlamaWeights") -> None:
+    """Round every layer projection through per-row e4m3 and back (in place): the
+    numerics of weight-only FP8 for the reference (non-HIP) ops, and the oracle the
+    FP8 kernel tests compare against.  The LM head is left in full precision."""
+    if getattr(weights, "quantization", None) == "fp8":
+        return
+    for lw in weights.layers:
+        for name in ("wqkv", "wo", "wgu", "wdown"):
+            w = getattr(lw, name)
+            q, scale = quantize_fp8_rows(w)
+            setattr(lw, name, (q.float() * scale[:, None]).to(w.dtype))
+    weights.quantization = "fp8"

@@ -45,9 +45,12 @@ class PackedLinear:
     """A bf16 ``[N, K]`` weight re-ordered into MFMA fragment order
     ``[N/16][K/32][64][8]`` (N zero-padded to a multiple of 64)."""
 
-    __slots__ = ("wp", "n", "k", "n_pad", "ks")
+    __slots__ = ("wp", "n", "k", "n_pad", "ks", "wscale")
 
-    def __init__(self, w: torch.Tensor):
+    def __init__(self, w: torch.Tensor, fp8: bool = False):
+        """``fp8=True`` stores the weight as OCP e4m3 bytes with one fp32 scale per
+        output row (weight-only quantisation: activations and accumulation stay
+        bf16 / fp32), halving the bytes the decode GEMM streams from HBM."""
         n, k = w.shape
         if w.dtype != torch.bfloat16 or not w.is_cuda:
             raise ValueError("PackedLinear needs a bf16 GPU weight")
@@ -57,7 +60,15 @@ class PackedLinear:
         n_pad = (n + 63) // 64 * 64
         if n_pad != n:
             w = torch.cat((w, torch.zeros(n_pad - n, k, dtype=w.dtype, device=w.device)), 0)
-        self.wp = native().pack_weight(w.contiguous())
+        self.wscale: Optional[torch.Tensor] = None
+        if fp8:
+            from kvmini.models.llama import quantize_fp8_rows
+
+            q, scale = quantize_fp8_rows(w)
+            self.wp = native().pack_weight_fp8(q.view(torch.uint8).contiguous())
+            self.wscale = scale.contiguous()
+        else:
+            self.wp = native().pack_weight(w.contiguous())
         self.n, self.k, self.n_pad, self.ks = n, k, n_pad, ks
 
     @property
@@ -102,16 +113,21 @@ class Partial:
         return y.to(torch.bfloat16)
 
 
-def prepare_weights(weights: Any) -> None:
+def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
     """Fold every RMSNorm gain into the projection that consumes it and pack every
-    linear weight of a ``LlamaWeights`` into MFMA fragment order, in place."""
+    linear weight of a ``LlamaWeights`` into MFMA fragment order, in place.
+    ``quantization='fp8'`` stores the layer projections as e4m3 (the LM head stays
+    bf16, as serving stacks do, to keep the logits exact)."""
     if getattr(weights, "_hip_prepared", False):
         return
+    if quantization not in (None, "none", "fp8"):
+        raise ValueError(f"unsupported quantization {quantization!r} (native engine: fp8)")
+    fp8 = quantization == "fp8"
 
-    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor]) -> PackedLinear:
+    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor], q: bool = fp8) -> PackedLinear:
         if gain is not None:
             w = (w.float() * gain.float()[None, :]).to(torch.bfloat16)
-        return PackedLinear(w)
+        return PackedLinear(w, fp8=q and w.shape[1] % 64 == 0)
 
     for lw in weights.layers:
         lw.wqkv = fold_pack(lw.wqkv, lw.attn_norm)
@@ -120,9 +136,10 @@ def prepare_weights(weights: Any) -> None:
         lw.wdown = fold_pack(lw.wdown, None)
         lw.attn_norm = torch.ones_like(lw.attn_norm)
         lw.mlp_norm = torch.ones_like(lw.mlp_norm)
-    weights.lm_head = fold_pack(weights.lm_head, weights.final_norm)  # a tied embedding stays untouched: fold_pack copies
+    weights.lm_head = fold_pack(weights.lm_head, weights.final_norm, False)  # a tied embedding stays untouched: fold_pack copies
     weights.final_norm = torch.ones_like(weights.final_norm)
     weights._hip_prepared = True
+    weights.quantization = "fp8" if fp8 else None
     torch.cuda.empty_cache()
 
 
@@ -151,15 +168,15 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
             splits, cps = C.stream_gemm_plan(w.n_pad, w.k, ks, MAX_SPLITS)
             if splits > 1 and m == mp and w.n == w.n_pad:
                 out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
-                C.stream_gemm(w.wp, w.n_pad, w.k, x, out, 1, ks, splits, cps, None, 0.0)
+                C.stream_gemm(w.wp, w.n_pad, w.k, x, out, 1, ks, splits, cps, None, 0.0, w.wscale)
                 return Partial(out, ss, eps, w.k)
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
-        C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, ks, 1, nchunks, ss, eps)
+        C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, ks, 1, nchunks, ss, eps, w.wscale)
     else:
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         for r0 in range(0, mp, MAX_M):
             r1 = min(mp, r0 + MAX_M)
-            C.stream_gemm(w.wp, w.n_pad, w.k, x[r0:r1], out[r0:r1], epi, ks, 1, nchunks, None if ss is None else ss[r0:r1].contiguous(), eps)
+            C.stream_gemm(w.wp, w.n_pad, w.k, x[r0:r1], out[r0:r1], epi, ks, 1, nchunks, None if ss is None else ss[r0:r1].contiguous(), eps, w.wscale)
     n_true = w.n // 2 if epi == 2 else w.n
     if m != mp or n_true != n_out:
         out = out[:m, :n_true]

@@ -175,3 +175,30 @@ def test_tensor_parallel_and_telemetry_gather_gloo_world2(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RANK0 OK=True" in r.stdout and "RANK1 OK=True" in r.stdout
+
+
+def test_speculative_decoding_matches_plain_greedy():
+    """Greedy verification must reproduce the target's own greedy output exactly,
+    whatever the draft proposes (random draft: ~0 accepted; identical draft: all accepted)."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
+    prompts = [[1, 5, 9, 200, 31], [1, 77], [1] + list(range(40, 75))]
+    params = SamplingParams(max_tokens=12, ignore_eos=True)
+    base = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=32, max_model_len=128, num_blocks=64))
+    want = base.generate(prompts, params)
+
+    spec = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=32, max_model_len=128, num_blocks=64, draft_model="tiny-draft", num_speculative_tokens=3))
+    got = spec.generate(prompts, params)
+    assert got == want
+    assert spec.stats.spec_proposed > 0
+
+    same = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=32, max_model_len=128, num_blocks=64, draft_model="tiny", num_speculative_tokens=3))
+    same.spec.load_draft_weights(random_weights(get_config("tiny"), same.device, torch.float32, 0))
+    got2 = same.generate(prompts, params)
+    assert got2 == want
+    st = same.stats
+    assert st.spec_accepted == st.spec_proposed > 0  # the target agrees with itself
+    assert st.steps < base.stats.steps  # fewer target passes for the same tokens
+    assert same.bm.num_free == same.bm.num_blocks - 1 or same.bm.num_free > 0
