@@ -85,6 +85,9 @@ def main() -> int:
     ap.add_argument("--target-rps", type=float, default=0.0, help="0 = saturate (closed loop at --concurrency)")
     ap.add_argument("--kernels", default="hip", choices=["hip", "torch"])
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--quantization", default=None, choices=["fp8"], help="weight-only FP8 (NOT the headline configuration: the headline is bf16)")
+    ap.add_argument("--speculative-model", default=None, help="draft preset for speculative decoding (not the headline configuration)")
+    ap.add_argument("--num-speculative-tokens", type=int, default=2)
     ap.add_argument("--max-num-seqs", type=int, default=32)
     ap.add_argument("--max-batched-tokens", type=int, default=256)
     ap.add_argument("--max-model-len", type=int, default=2048)
@@ -123,6 +126,9 @@ def main() -> int:
             max_batched_tokens=args.max_batched_tokens,
             max_model_len=args.max_model_len,
             use_graphs=not args.no_graphs,
+            quantization=args.quantization,
+            draft_model=args.speculative_model,
+            num_speculative_tokens=args.num_speculative_tokens if args.speculative_model else 0,
             kernels=args.kernels,
             kv_memory_fraction=0.3,
         )
@@ -255,7 +261,7 @@ def main() -> int:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": round(rps / BASELINE["rps"], 4),
-            "dtype": "bf16",
+            "dtype": "bf16" if not args.quantization else f"bf16 activations, {args.quantization} weights",
             "data": "synthetic prompts ('Hello, world!' chat, 14 prompt tokens), random-init weights, synthetic tokenizer",
             "config": {
                 "model": args.model,

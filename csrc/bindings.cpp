@@ -30,6 +30,7 @@ int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
                    int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
+int kv_prefetch(const void* p, long long bytes, int workgroups, unsigned int* sink, hipStream_t stream);
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
                        hipStream_t stream);
@@ -161,6 +162,13 @@ void argmax(at::Tensor logits, at::Tensor out) {
   TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1, "logits must be [S, V] with unit inner stride");
   TORCH_CHECK(out.scalar_type() == at::kLong && out.numel() >= logits.size(0), "out must be int64 with >= S elements");
   check(kv_argmax(logits.data_ptr(), logits.stride(0), (int)logits.size(0), (int)logits.size(1), (long long*)out.data_ptr(), cur_stream()), "kv_argmax");
+}
+
+void prefetch(at::Tensor t, int64_t workgroups, at::Tensor sink) {
+  CHECK_DEV(t); CHECK_CONTIG(t); CHECK_DEV(sink);
+  TORCH_CHECK(sink.scalar_type() == at::kInt && sink.numel() >= 1, "sink must be an int32 tensor");
+  TORCH_CHECK(((uintptr_t)t.data_ptr() & 15) == 0, "tensor must be 16-byte aligned");
+  check(kv_prefetch(t.data_ptr(), (long long)t.numel() * t.element_size(), (int)workgroups, (unsigned int*)sink.data_ptr(), cur_stream()), "kv_prefetch");
 }
 
 void swiglu_interleaved(at::Tensor gu, at::Tensor act) {
@@ -326,6 +334,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_gemm", &stream_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("ks_per_chunk"), py::arg("splits"),
         py::arg("chunks_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none());
   m.def("pack_weight_fp8", &pack_weight_fp8);
+  m.def("prefetch", &prefetch);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs);
   m.def("residual_reduce", &residual_reduce);

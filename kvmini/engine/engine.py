@@ -43,6 +43,7 @@ class EngineConfig:
     enable_prefix_caching: bool = True
     weights_path: Optional[str] = None
     quantization: Optional[str] = None  # None | fp8
+    prefill_gemm: str = "library"  # library | stream (see RunnerConfig)
     # speculative decoding
     draft_model: Optional[str] = None
     num_speculative_tokens: int = 0
@@ -115,6 +116,7 @@ class LLMEngine:
             use_graphs=ecfg.use_graphs,
             kernels=ecfg.kernels,
             quantization=ecfg.quantization,
+            prefill_gemm=ecfg.prefill_gemm,
         )
         self.runner = ModelRunner(weights, rcfg, tp_group)
         self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)

@@ -42,6 +42,10 @@ class RunnerConfig:
     kernels: str = "auto"  # auto | hip | torch
     return_logits: bool = False
     quantization: Optional[str] = None  # None | fp8 (weight-only, HIP kernels)
+    # GEMM for token batches wider than 64: "library" keeps a row-major weight copy for
+    # hipBLASLt (2x weight memory, fast prefill), "stream" re-streams the packed weights
+    # once per 64 tokens (no extra memory)
+    prefill_gemm: str = "library"
 
 
 def select_ops(kernels: str, device: torch.device) -> Any:
@@ -69,7 +73,7 @@ class ModelRunner:
         self.ops = select_ops(rcfg.kernels, self.device)
         if hasattr(self.ops, "prepare_weights"):
             # one-time re-order of every linear weight into MFMA fragment order
-            self.ops.prepare_weights(weights, rcfg.quantization)
+            self.ops.prepare_weights(weights, rcfg.quantization, keep_full=rcfg.prefill_gemm == "library" and rcfg.max_batched_tokens > 64)
         elif rcfg.quantization == "fp8":
             # reference ops: emulate weight-only FP8 by a quantise/dequantise round trip
             from kvmini.models.llama import fake_quantize_fp8

@@ -45,9 +45,9 @@ class PackedLinear:
     """A bf16 ``[N, K]`` weight re-ordered into MFMA fragment order
     ``[N/16][K/32][64][8]`` (N zero-padded to a multiple of 64)."""
 
-    __slots__ = ("wp", "n", "k", "n_pad", "ks", "wscale")
+    __slots__ = ("wp", "n", "k", "n_pad", "ks", "wscale", "w_full")
 
-    def __init__(self, w: torch.Tensor, fp8: bool = False):
+    def __init__(self, w: torch.Tensor, fp8: bool = False, keep_full: bool = False):
         """``fp8=True`` stores the weight as OCP e4m3 bytes with one fp32 scale per
         output row (weight-only quantisation: activations and accumulation stay
         bf16 / fp32), halving the bytes the decode GEMM streams from HBM."""
@@ -61,14 +61,22 @@ class PackedLinear:
         if n_pad != n:
             w = torch.cat((w, torch.zeros(n_pad - n, k, dtype=w.dtype, device=w.device)), 0)
         self.wscale: Optional[torch.Tensor] = None
+        # row-major copy for the library GEMM that serves token batches wider than the
+        # streaming kernel's 64-token tile (prefill chunks); FP8 keeps the dequantised values
+        # so both paths compute with the same weights
+        self.w_full: Optional[torch.Tensor] = None
         if fp8:
             from kvmini.models.llama import quantize_fp8_rows
 
             q, scale = quantize_fp8_rows(w)
             self.wp = native().pack_weight_fp8(q.view(torch.uint8).contiguous())
             self.wscale = scale.contiguous()
+            if keep_full:
+                self.w_full = (q.float() * scale[:, None]).to(torch.bfloat16)
         else:
             self.wp = native().pack_weight(w.contiguous())
+            if keep_full:
+                self.w_full = w.contiguous()
         self.n, self.k, self.n_pad, self.ks = n, k, n_pad, ks
 
     @property
@@ -113,7 +121,7 @@ class Partial:
         return y.to(torch.bfloat16)
 
 
-def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
+def prepare_weights(weights: Any, quantization: Optional[str] = None, keep_full: bool = False) -> None:
     """Fold every RMSNorm gain into the projection that consumes it and pack every
     linear weight of a ``LlamaWeights`` into MFMA fragment order, in place.
     ``quantization='fp8'`` stores the layer projections as e4m3 (the LM head stays
@@ -124,10 +132,10 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
         raise ValueError(f"unsupported quantization {quantization!r} (native engine: fp8)")
     fp8 = quantization == "fp8"
 
-    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor], q: bool = fp8) -> PackedLinear:
+    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor], q: bool = fp8, full: bool = keep_full) -> PackedLinear:
         if gain is not None:
             w = (w.float() * gain.float()[None, :]).to(torch.bfloat16)
-        return PackedLinear(w, fp8=q and w.shape[1] % 64 == 0)
+        return PackedLinear(w, fp8=q and w.shape[1] % 64 == 0, keep_full=full)
 
     for lw in weights.layers:
         lw.wqkv = fold_pack(lw.wqkv, lw.attn_norm)
@@ -136,7 +144,7 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
         lw.wdown = fold_pack(lw.wdown, None)
         lw.attn_norm = torch.ones_like(lw.attn_norm)
         lw.mlp_norm = torch.ones_like(lw.mlp_norm)
-    weights.lm_head = fold_pack(weights.lm_head, weights.final_norm, False)  # a tied embedding stays untouched: fold_pack copies
+    weights.lm_head = fold_pack(weights.lm_head, weights.final_norm, False, False)  # a tied embedding stays untouched: fold_pack copies
     weights.final_norm = torch.ones_like(weights.final_norm)
     weights._hip_prepared = True
     weights.quantization = "fp8" if fp8 else None
@@ -172,6 +180,17 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
                 return Partial(out, ss, eps, w.k)
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, ks, 1, nchunks, ss, eps, w.wscale)
+    elif w.w_full is not None:
+        # wide token batch (prefill): compute-bound, served by the library GEMM on the
+        # row-major copy; the epilogues the streaming kernel fuses run as small kernels here
+        y = F.linear(x[:m], w.w_full[: w.n])
+        if ss is not None:
+            y = (y.float() * torch.rsqrt(ss[:m].sum(-1, keepdim=True) / w.k + eps)).to(torch.bfloat16)
+        if epi == 2:
+            act = torch.empty((m, w.n // 2), dtype=torch.bfloat16, device=x.device)
+            C.swiglu_interleaved(y.contiguous(), act)
+            return act
+        return y
     else:
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         for r0 in range(0, mp, MAX_M):

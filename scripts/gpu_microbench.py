@@ -87,13 +87,13 @@ def gemm_bench(out):
         torch.cuda.empty_cache()
 
 
-def step_bench(out, model, batch, kernels_list):
+def step_bench(out, model, batch, kernels_list, quantization=None):
     kernels_list = [k for k in kernels_list if k == "hip"]  # the torch ops are not graph-capturable
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
 
     for kernels in kernels_list:
-        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=256, max_model_len=512 if kernels == "torch" else 2048, kernels=kernels, kv_memory_fraction=0.2))
+        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=256, max_model_len=512 if kernels == "torch" else 2048, kernels=kernels, kv_memory_fraction=0.2, quantization=quantization))
         eng.warmup()
         prompts = [[1] + list(range(100 + i, 113 + i)) for i in range(batch)]
         for rep in range(2):
@@ -109,7 +109,92 @@ def step_bench(out, model, batch, kernels_list):
                 n += 1
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / max(1, n)
-        row = {"bench": "decode_step", "model": model, "batch": batch, "kernels": kernels, "ms_per_step": dt * 1e3, "steps": n, "weight_GB": eng.weights.nbytes() / 1e9, "eff_TBps": eng.weights.nbytes() / dt / 1e12, "load_s": eng.load_s, "warm_s": eng.warm_s}
+        row = {"bench": "decode_step", "model": model, "batch": batch, "kernels": kernels, "quantization": quantization, "ms_per_step": dt * 1e3, "steps": n, "weight_GB": eng.weights.nbytes() / 1e9, "eff_TBps": eng.weights.nbytes() / dt / 1e12, "load_s": eng.load_s, "warm_s": eng.warm_s}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+        del eng
+        torch.cuda.empty_cache()
+
+
+def mall_bench(out):
+    """Does touching a weight matrix ahead of time (reads allocate in the 256 MiB
+    memory-side cache) make the GEMM that streams it next faster?  cold = rotating
+    copies, warm = same copy back to back, prefetched = prefetch kernel then GEMM
+    (GEMM time only), plus the prefetch kernel's own time at several widths."""
+    from kvmini.ops import native
+
+    C = native()
+    dev = torch.device("cuda:0")
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    shapes = {"o": (4096, 4096), "qkv": (6144, 4096), "down": (4096, 14336), "gate_up": (28672, 4096)}
+    M = 32
+    for name, (N, K) in shapes.items():
+        copies = max(3, int(800e6 // (N * K * 2)) + 1)
+        Wps = [C.pack_weight((torch.randn(N, K, device=dev) * 0.02).bfloat16()) for _ in range(copies)]
+        x = torch.randn(M, K, device=dev).bfloat16()
+        ks = 4
+        splits, cps = C.stream_gemm_plan(N, K, ks, 16)
+        slab = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
+
+        def gemm(wp):
+            C.stream_gemm(wp, N, K, x, slab, 1, ks, splits, cps)
+
+        def timed(pre, n=40):
+            ts = []
+            for i in range(n):
+                wp = Wps[i % copies]
+                if pre:
+                    pre(wp)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gemm(wp)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            return statistics.median(ts)
+
+        row = {"bench": "mall", "shape": name, "MB": N * K * 2 / 1e6, "gemm_cold_us": timed(None), "gemm_warm_us": timed(lambda wp: gemm(wp))}
+        for wgs in (64, 256, 1024):
+            row[f"gemm_after_prefetch{wgs}_us"] = timed(lambda wp: C.prefetch(wp, wgs, sink))
+            ts = []
+            for i in range(20):
+                wp = Wps[i % copies]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                C.prefetch(wp, wgs, sink)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            row[f"prefetch{wgs}_us"] = statistics.median(ts)
+        print(json.dumps(row), flush=True)
+        out.append(row)
+        del Wps
+        torch.cuda.empty_cache()
+
+
+def prefill_bench(out, model):
+    """One engine step that prefills 256 prompt tokens, with the library GEMM vs the
+    re-streamed packed weights, plus a 2048-token prompt end to end."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    for mode in ("library", "stream"):
+        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=256, max_model_len=4096, kernels="hip", kv_memory_fraction=0.2, prefill_gemm=mode))
+        eng.warmup()
+        res = {}
+        for plen in (256, 2048):
+            ts = []
+            for rep in range(3):
+                seq = eng.make_sequence([1] + [(7 * i + rep) % 1000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=1, ignore_eos=True))
+                eng.scheduler.add(seq)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                while eng.scheduler.has_work():
+                    eng.step()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            res[plen] = min(ts) * 1e3
+        row = {"bench": "prefill", "model": model, "prefill_gemm": mode, "ms_256_tokens": res[256], "ms_2048_tokens": res[2048], "tok_per_s_2048": 2048 / res[2048] * 1e3, "mem_GB": torch.cuda.memory_allocated() / 1e9}
         print(json.dumps(row), flush=True)
         out.append(row)
         del eng
@@ -123,12 +208,17 @@ def main():
     ap.add_argument("--batch", type=int, default=20)
     ap.add_argument("--kernels", default="hip,torch")
     ap.add_argument("--out", default="gpurun_out/microbench.json")
+    ap.add_argument("--quantization", default=None)
     a = ap.parse_args()
     out = []
     if "gemm" in a.what:
         gemm_bench(out)
+    if "mall" in a.what:
+        mall_bench(out)
+    if "prefill" in a.what:
+        prefill_bench(out, a.model)
     if "step" in a.what:
-        step_bench(out, a.model, a.batch, a.kernels.split(","))
+        step_bench(out, a.model, a.batch, a.kernels.split(","), a.quantization)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)

@@ -444,3 +444,28 @@ def test_speculative_decoding_on_gpu_matches_plain_greedy():
     assert [len(o) for o in got] == [len(o) for o in want]
     assert all(g[:3] == w[:3] for g, w in zip(got, want)), (got, want)
     assert spec.stats.spec_proposed > 0
+
+
+@pytest.mark.parametrize("mode", ["library", "stream"])
+def test_engine_wide_prefill_paths_match_oracle(mode):
+    """A 200-token prompt is prefilled in chunks wider than the streaming GEMM's
+    64-token tile: both wide-batch paths must agree with the dense oracle."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.models.reference import dense_logits
+
+    cfg = get_config("small-hd128")
+    w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
+    oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
+    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=256, max_model_len=512, num_blocks=256, kernels="hip", prefill_gemm=mode), weights=w)
+    eng.warmup()
+    assert (eng.weights.layers[0].wqkv.w_full is not None) == (mode == "library")
+    prompt = [1] + [(13 * i) % 900 + 20 for i in range(199)]
+    out = eng.generate([prompt, [1, 2, 3]], SamplingParams(max_tokens=4, ignore_eos=True))[0]
+    ids = list(prompt)
+    for tok in out:
+        lg = dense_logits(oracle, ids)[-1]
+        top = lg.max().item()
+        assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05
+        ids.append(tok)
