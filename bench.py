@@ -113,7 +113,7 @@ def main() -> int:
 
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.server.native import start_native_in_thread
-    from kvmini.telemetry.amdsmi_sampler import TelemetrySampler
+    from kvmini.telemetry.native_rt import make_sampler
 
     proc_start = time.time()
     engine = LLMEngine(
@@ -136,7 +136,7 @@ def main() -> int:
     engine.warmup()
     _srv, url, stop_server = start_native_in_thread(engine, model_name=args.model)
     child = LoadChild()
-    sampler = TelemetrySampler(0.1, gpu_indices=[local_rank]).start()
+    sampler = make_sampler(0.05, gpu_indices=[local_rank]).start()  # native C++ sampling thread when available
 
     target = args.target_rps if args.target_rps > 0 else 1e6
     cmd = {

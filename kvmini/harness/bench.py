@@ -172,9 +172,9 @@ def main(argv: Optional[List[str]] = None) -> int:
 
     sampler = None
     if not a.no_energy:
-        from kvmini.telemetry.amdsmi_sampler import TelemetrySampler
+        from kvmini.telemetry.native_rt import make_sampler
 
-        sampler = TelemetrySampler(0.1)
+        sampler = make_sampler(0.1)
         if sampler.working():
             sampler.start()
         else:

@@ -1,0 +1,218 @@
+"""ctypes bindings for ``libkvmini_rt.so`` — the native runtime pieces:
+
+* :class:`NativeSampler` — a C++ thread polling the AMD SMI library into a ring
+  buffer (``csrc/amdsmi_sampler.cpp``); same interface as
+  :class:`kvmini.telemetry.amdsmi_sampler.TelemetrySampler`, but the cadence does
+  not depend on the GIL.
+* :class:`NativeGather` — one ``ncclAllGather`` (RCCL) of 128-byte snapshots on a
+  private communicator and stream (``csrc/telemetry_gather.cpp``).
+
+The reference samples power by shelling out to ``nvidia-smi`` once per second
+(``energy/collector.py:103-145``) and aggregates multi-GPU telemetry through
+Prometheus scrapes (``analyze.py:259-299``); both are replaced by these.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+_LIB: Optional[ctypes.CDLL] = None
+_TRIED = False
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libkvmini_rt.so")
+
+
+def load() -> Optional[ctypes.CDLL]:
+    """The runtime library, or None when it is not built / not loadable here
+    (it links RCCL and the HIP runtime, which a CPU-only host may lack)."""
+    global _LIB, _TRIED
+    if _TRIED:
+        return _LIB
+    _TRIED = True
+    try:
+        lib = ctypes.CDLL(lib_path())
+    except OSError:
+        return None
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.kvs_gpu_count.restype = ctypes.c_int
+    lib.kvs_start.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_longlong]
+    lib.kvs_start.restype = ctypes.c_int
+    lib.kvs_count.restype = ctypes.c_longlong
+    lib.kvs_read.argtypes = [dp, ctypes.c_longlong]
+    lib.kvs_read.restype = ctypes.c_longlong
+    lib.kvs_stop.restype = ctypes.c_int
+    lib.kvs_trapz_wh.argtypes = [dp, dp, ctypes.c_longlong]
+    lib.kvs_trapz_wh.restype = ctypes.c_double
+    lib.kvt_unique_id_bytes.restype = ctypes.c_int
+    lib.kvt_unique_id.argtypes = [ctypes.c_void_p]
+    lib.kvt_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib.kvt_gather_many.argtypes = [dp, dp, ctypes.c_longlong]
+    lib.kvt_gather.argtypes = [dp, dp]
+    _LIB = lib
+    return lib
+
+
+def _dp(a: np.ndarray) -> Any:
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def trapz_wh(t_s: Sequence[float], watts: Sequence[float]) -> float:
+    """Trapezoidal energy through the native runtime (NaN samples skipped)."""
+    lib = load()
+    t = np.ascontiguousarray(t_s, dtype=np.float64)
+    w = np.ascontiguousarray(watts, dtype=np.float64)
+    if lib is None:
+        ok = ~(np.isnan(t) | np.isnan(w))
+        return float(np.trapezoid(w[ok], t[ok]) / 3600.0) if ok.sum() > 1 else 0.0
+    return float(lib.kvs_trapz_wh(_dp(t), _dp(w), len(t)))
+
+
+def native_gpu_count() -> int:
+    lib = load()
+    if lib is None:
+        return 0
+    return max(0, int(lib.kvs_gpu_count()))
+
+
+class NativeSampler:
+    """Drop-in for ``TelemetrySampler`` backed by the C++ sampling thread."""
+
+    RECORD = 8  # ts_s, gpu, watts, gfx_util, vram_used_bytes, temp_c, sclk_mhz, energy_uj
+
+    def __init__(self, interval_s: float = 0.05, gpu_indices: Optional[Sequence[int]] = None, capacity: int = 1 << 20):
+        self.interval_s = max(0.001, float(interval_s))
+        self.gpu_indices = list(gpu_indices) if gpu_indices is not None else None
+        self.capacity = capacity
+        self.samples: List[Dict[str, Any]] = []
+        self._lib = load()
+        self._started = False
+
+    def working(self) -> bool:
+        return self._lib is not None and native_gpu_count() > 0
+
+    def start(self) -> "NativeSampler":
+        if not self.working():
+            raise RuntimeError("native telemetry runtime unavailable (library missing or no AMD GPU visible)")
+        idx = self.gpu_indices or []
+        arr = (ctypes.c_int * max(1, len(idx)))(*idx)
+        rc = self._lib.kvs_start(self.interval_s, arr, len(idx), self.capacity)
+        if rc != 0:
+            raise RuntimeError(f"kvs_start failed: {rc}")
+        self._started = True
+        return self
+
+    def _drain(self) -> List[Dict[str, Any]]:
+        n = int(self._lib.kvs_count())
+        n = min(n, self.capacity)
+        if n <= 0:
+            return []
+        buf = np.empty((n, self.RECORD), dtype=np.float64)
+        got = int(self._lib.kvs_read(_dp(buf), n))
+        return records_to_samples(buf[:got])
+
+    def latest(self) -> Optional[Dict[str, Any]]:
+        s = self._drain()
+        return s[-1] if s else None
+
+    def stop(self) -> List[Dict[str, Any]]:
+        if self._started:
+            self.samples = self._drain()
+            self._lib.kvs_stop()
+            self._started = False
+        return self.samples
+
+    def to_power_json(self) -> Dict[str, Any]:
+        return {"samples": self.samples, "interval_s": self.interval_s, "source": "amd-smi (native sampler thread)"}
+
+
+def records_to_samples(rec: np.ndarray) -> List[Dict[str, Any]]:
+    """Group per-(tick, gpu) records into per-tick samples in the collector's schema
+    (watts summed over GPUs, utilisation averaged).  A tick = a run of records with
+    distinct GPU ids."""
+    out: List[Dict[str, Any]] = []
+    cur: List[np.ndarray] = []
+    seen: set = set()
+
+    def flush() -> None:
+        if not cur:
+            return
+
+        def agg(col: int, how: str) -> Optional[float]:
+            vals = [float(r[col]) for r in cur if not math.isnan(r[col])]
+            if not vals:
+                return None
+            return sum(vals) if how == "sum" else sum(vals) / len(vals)
+
+        per = [{"index": int(r[1]), "watts": None if math.isnan(r[2]) else float(r[2]), "gfx_util": None if math.isnan(r[3]) else float(r[3]), "vram_used": None if math.isnan(r[4]) else float(r[4]),
+                "temp_c": None if math.isnan(r[5]) else float(r[5]), "sclk_mhz": None if math.isnan(r[6]) else float(r[6]), "energy_uj": None if math.isnan(r[7]) else float(r[7])} for r in cur]
+        out.append({"ts_s": float(cur[0][0]), "watts": agg(2, "sum"), "gfx_util": agg(3, "avg"), "vram_used": agg(4, "sum"), "temp_c": agg(5, "avg"), "sclk_mhz": agg(6, "avg"), "per_gpu": per})
+
+    for r in rec:
+        gid = int(r[1])
+        if gid in seen:
+            flush()
+            cur, seen = [], set()
+        cur.append(r)
+        seen.add(gid)
+    flush()
+    return out
+
+
+class NativeGather:
+    """``ncclAllGather`` of telemetry snapshots through the native runtime.  The
+    unique id travels over the already-initialised ``torch.distributed`` group."""
+
+    def __init__(self, device_index: int):
+        import torch
+        import torch.distributed as dist
+
+        lib = load()
+        if lib is None:
+            raise RuntimeError("libkvmini_rt.so not available")
+        self._lib = lib
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        nbytes = int(lib.kvt_unique_id_bytes())
+        buf = ctypes.create_string_buffer(nbytes)
+        if self.rank == 0:
+            if lib.kvt_unique_id(buf) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            if dist.get_backend() == "nccl":
+                t = t.cuda(device_index)
+            dist.broadcast(t, 0)
+            buf = ctypes.create_string_buffer(bytes(t.cpu().numpy().tobytes()), nbytes)
+        rc = lib.kvt_init(self.rank, self.world, buf, device_index)
+        if rc != 0:
+            raise RuntimeError(f"kvt_init failed: {rc}")
+
+    def gather(self, local: np.ndarray) -> np.ndarray:
+        """``local``: ``[n_ticks, 16]`` float64 -> ``[world, n_ticks, 16]``."""
+        local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1, 16)
+        n = local.shape[0]
+        table = np.empty((self.world, n, 16), dtype=np.float64)
+        rc = self._lib.kvt_gather_many(_dp(local), _dp(table), n)
+        if rc != 0:
+            raise RuntimeError(f"kvt_gather_many failed: {rc}")
+        return table
+
+    def close(self) -> None:
+        self._lib.kvt_destroy()
+
+
+def make_sampler(interval_s: float = 0.05, gpu_indices: Optional[Sequence[int]] = None) -> Any:
+    """Native sampler when the runtime and a GPU are available, else the Python one."""
+    ns = NativeSampler(interval_s, gpu_indices)
+    if ns.working():
+        return ns
+    from .amdsmi_sampler import TelemetrySampler
+
+    return TelemetrySampler(interval_s=interval_s, gpu_indices=gpu_indices)

@@ -219,3 +219,19 @@ def test_every_shipped_profile_validates_and_loads():
     assert s["concurrency"] == 3 and s["requests"] == 200 and s["max_tokens"] == 128  # CLI > profile > default
     assert load_profile("fp8").name == "fp8" and load_profile("tool-calling").openai_tools()[0]["function"]["name"] == "get_weather"
     assert load_profile("structured-output").test_schema["required"] == ["name", "age"]
+
+
+def test_native_runtime_bindings_cpu_side():
+    """The parts of libkvmini_rt.so that need no GPU: record grouping, trapezoid."""
+    import numpy as np
+
+    from kvmini.telemetry import native_rt as rt
+
+    rec = np.array([[1.0, 0, 100, 50, 1e9, 60, 2000, 5], [1.0, 1, 110, 70, 2e9, 62, 2100, 6], [2.0, 0, 120, float("nan"), 1e9, 61, 2000, 7], [2.0, 1, 130, 75, 2e9, 63, 2100, 8]])
+    s = rt.records_to_samples(rec)
+    assert len(s) == 2 and s[0]["watts"] == 210.0 and s[0]["gfx_util"] == 60.0 and s[1]["gfx_util"] == 75.0
+    assert [g["index"] for g in s[1]["per_gpu"]] == [0, 1] and s[1]["per_gpu"][0]["gfx_util"] is None
+    # 100 W for 3 s with a NaN hole = 300 J
+    assert rt.trapz_wh([0, 1, 2, 3], [100, 100, float("nan"), 100]) == pytest.approx(300 / 3600)
+    sampler = rt.make_sampler(0.05)
+    assert hasattr(sampler, "start") and hasattr(sampler, "stop") and hasattr(sampler, "to_power_json")

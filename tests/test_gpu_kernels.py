@@ -469,3 +469,31 @@ def test_engine_wide_prefill_paths_match_oracle(mode):
         top = lg.max().item()
         assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05
         ids.append(tok)
+
+
+def test_native_sampler_and_rccl_gather_on_gpu():
+    import time
+
+    import numpy as np
+
+    from kvmini.telemetry import native_rt as rt
+
+    assert rt.load() is not None, "libkvmini_rt.so must be built in-tree"
+    assert rt.native_gpu_count() >= 1
+    s = rt.NativeSampler(0.01, gpu_indices=[0]).start()
+    x = torch.randn(4096, 4096, device="cuda:0")
+    t0 = time.time()
+    while time.time() - t0 < 0.3:
+        (x @ x).sum().item()
+    samples = s.stop()
+    assert len(samples) >= 10, len(samples)
+    dts = np.diff([p["ts_s"] for p in samples])
+    assert np.median(dts) < 0.03  # the C++ thread keeps its cadence while Python is busy
+    watts = [p["watts"] for p in samples if p["watts"] is not None]
+    assert watts and 10 < max(watts) < 2000
+    assert any(p["per_gpu"][0]["vram_used"] for p in samples)
+    g = rt.NativeGather(0)  # world of one: the collective still runs through RCCL
+    local = np.arange(32, dtype=np.float64).reshape(2, 16)
+    table = g.gather(local)
+    g.close()
+    assert table.shape == (1, 2, 16) and np.array_equal(table[0], local)
