@@ -112,10 +112,13 @@ class BlockManager:
         n_full = num_computed // bs
         if n_full <= already:
             return already
-        parent = 0
-        # recompute the chain up to ``already`` (cheap: hashing small tuples)
-        for i in range(already):
-            parent = self.chain_hash(parent, token_ids[i * bs : (i + 1) * bs])
+        # chain hash of the last published block: remembered per canonical block; only a
+        # sequence whose previous block duplicated an already cached one recomputes the chain
+        parent = self._hash_of.get(blocks[already - 1]) if already > 0 else 0
+        if parent is None:
+            parent = 0
+            for i in range(already):
+                parent = self.chain_hash(parent, token_ids[i * bs : (i + 1) * bs])
         for i in range(already, n_full):
             h = self.chain_hash(parent, token_ids[i * bs : (i + 1) * bs])
             b = blocks[i]

@@ -39,7 +39,7 @@ class SamplingParams:
     stop_token_ids: List[int] = field(default_factory=list)
 
 
-@dataclass
+@dataclass(eq=False)  # identity semantics: sequences live in lists / sets and are compared per step
 class Sequence:
     req_id: int
     prompt_ids: List[int]
@@ -237,7 +237,9 @@ class Scheduler:
         the tokens actually appended (after max_tokens / EOS truncation)."""
         seq = chunk.seq
         seq.num_computed = chunk.start + (chunk.n_tokens if num_accepted_positions is None else num_accepted_positions)
-        seq.published_blocks = self.bm.register_full_blocks(seq.all_ids, seq.blocks, min(seq.num_computed, seq.num_tokens), seq.published_blocks)
+        n_done = min(seq.num_computed, seq.num_tokens)
+        if n_done // self.bm.block_size > seq.published_blocks:  # a block filled up in this step
+            seq.published_blocks = self.bm.register_full_blocks(seq.all_ids, seq.blocks, n_done, seq.published_blocks)
         appended: List[int] = []
         if not chunk.sample:
             return appended

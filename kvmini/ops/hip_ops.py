@@ -171,7 +171,19 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
     n_out = w.n_pad // 2 if epi == 2 else w.n_pad
     ks = w.ks if mp <= 16 else 4
     nchunks = (w.k // 32) // ks
-    if mp <= MAX_M:
+    if mp <= MAX_M and w.k % 256 == 0:
+        # deep-pipeline kernel (v3).  Measured on MI355X: split-K shapes run best with
+        # 2-chunk groups, unsplit ones (gate/up, LM head) with 4-chunk groups up to 32 rows.
+        if allow_slabs and epi == 0 and m == mp and w.n == w.n_pad:
+            splits, gps = C.stream_gemm3_plan(w.n_pad, w.k, 2, MAX_SPLITS, 512)
+            if splits > 1:
+                out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
+                C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, 2, splits, gps, None, 0.0, w.wscale)
+                return Partial(out, ss, eps, w.k)
+        nb = 4 if (mp <= 32 and w.k % 512 == 0) else 2
+        out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
+        C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, nb, 1, w.k // (128 * nb), ss, eps, w.wscale)
+    elif mp <= MAX_M:
         if allow_slabs and epi == 0:
             splits, cps = C.stream_gemm_plan(w.n_pad, w.k, ks, MAX_SPLITS)
             if splits > 1 and m == mp and w.n == w.n_pad:

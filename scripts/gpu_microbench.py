@@ -70,7 +70,28 @@ def gemm_bench(out):
                         C.stream_gemm(wp, N, K, x, y, 0, ks, 1, (K // 32) // ks, None, 0.0)
                 return f
 
+            def sg3(nb, slabs, target=512):
+                def f():
+                    wp = nxt(Wps)
+                    if slabs:
+                        splits, gps = C.stream_gemm3_plan(N, K, nb, 32, target)
+                        out = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
+                        C.stream_gemm3(wp, N, K, x, out, 1, nb, splits, gps, None, 0.0)
+                    else:
+                        C.stream_gemm3(wp, N, K, x, y, 0, nb, 1, K // (128 * nb), None, 0.0)
+                return f
+
+            v3 = {}
+            for nb in (2, 4):
+                if K % (128 * nb):
+                    continue
+                if N > 8192:
+                    v3[f"v3_nb{nb}"] = sg3(nb, False)
+                else:
+                    for target in (512, 768):
+                        v3[f"v3_nb{nb}_slab{target}"] = sg3(nb, True, target)
             fns = {
+                **v3,
                 "v2_ks4": sg(4, False),
                 "v2_ks8": sg(8, False),
                 "v2_ks4_slab": sg(4, True),

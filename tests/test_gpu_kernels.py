@@ -278,6 +278,30 @@ def test_stream_gemm_bf16_and_slabs(M, N, K):
         assert (s.float() - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("nb", [2, 4])
+@pytest.mark.parametrize("M", [16, 48])
+def test_stream_gemm3_every_group_depth(nb, M):
+    """The deep-pipeline kernel at both ring depths, unsplit and split-K, against fp32."""
+    from kvmini.ops import native
+
+    C = native()
+    torch.manual_seed(4)
+    N, K = 512, 2048
+    W = (torch.randn(N, K, device=_dev()) * 0.05).bfloat16()
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    ref = x.float() @ W.float().T
+    tol = 2e-2 * ref.abs().max().item() + 1e-2
+    wp = C.pack_weight(W)
+    y = torch.empty(M, N, device=_dev(), dtype=torch.bfloat16)
+    C.stream_gemm3(wp, N, K, x, y, 0, nb, 1, K // (128 * nb))
+    assert (y.float() - ref).abs().max().item() <= tol
+    splits, gps = C.stream_gemm3_plan(N, K, nb, 16, 512)
+    assert splits > 1 and (splits - 1) * gps < K // (128 * nb) <= splits * gps
+    slabs = torch.empty(splits, M, N, device=_dev())
+    C.stream_gemm3(wp, N, K, x, slabs, 1, nb, splits, gps)
+    assert (slabs.sum(0) - ref).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("M", [16, 64, 33])
 def test_stream_gemm_swiglu(M):
     from kvmini.models.llama import interleave_gate_up
