@@ -93,6 +93,7 @@ def main() -> int:
     ap.add_argument("--max-model-len", type=int, default=2048)
     ap.add_argument("--out-dir", default=None, help="write run artifacts (requests.csv, power.json, results.json) here")
     ap.add_argument("--gpu-hourly", type=float, default=None, help="$/GPU-hour (default: cost.yaml MI355X entry)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = rehearsal of the multi-rank flow over gloo with the reference ops (not a benchmark)")
     args = ap.parse_args()
 
     import numpy as np
@@ -102,14 +103,22 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        print("bench.py needs a ROCm GPU", file=sys.stderr)
+    on_gpu = args.device == "cuda"
+    if on_gpu and not torch.cuda.is_available():
+        print("bench.py needs a ROCm GPU (use --device cpu only to rehearse the multi-rank flow)", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+        args.kernels, args.no_graphs = "torch", True
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.server.native import start_native_in_thread
@@ -120,7 +129,7 @@ def main() -> int:
         EngineConfig(
             model=args.model,
             device=str(device),
-            dtype="bf16",
+            dtype="bf16" if on_gpu else "fp32",
             seed=rank,
             max_num_seqs=args.max_num_seqs,
             max_batched_tokens=args.max_batched_tokens,
@@ -136,7 +145,7 @@ def main() -> int:
     engine.warmup()
     _srv, url, stop_server = start_native_in_thread(engine, model_name=args.model)
     child = LoadChild()
-    sampler = make_sampler(0.05, gpu_indices=[local_rank]).start()  # native C++ sampling thread when available
+    sampler = make_sampler(0.05, gpu_indices=[local_rank]).start()  # native C++ sampling thread when available (no-op readings without a GPU)
 
     target = args.target_rps if args.target_rps > 0 else 1e6
     cmd = {
@@ -155,7 +164,8 @@ def main() -> int:
     def barrier() -> None:
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if on_gpu:
+            torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
         child.call(cmd)
@@ -222,8 +232,14 @@ def main() -> int:
         lat = torch.where(ok, mat_all[0], torch.full_like(mat_all[0], float("nan")))
         ttfb = torch.where(ok, mat_all[1], torch.full_like(mat_all[1], float("nan")))
         ttft = torch.where(ok, mat_all[2], torch.full_like(mat_all[2], float("nan")))
-        q, stats = hq.batched_quantiles(torch.stack([lat, ttfb, ttft]), (0.5, 0.95, 0.99), return_stats=True)
-        qi, istats = hq.batched_quantiles(itl_all, (0.5, 0.95, 0.99), return_stats=True)
+        if on_gpu:
+            q, stats = hq.batched_quantiles(torch.stack([lat, ttfb, ttft]), (0.5, 0.95, 0.99), return_stats=True)
+            qi, _ = hq.batched_quantiles(itl_all, (0.5, 0.95, 0.99), return_stats=True)
+        else:  # rehearsal: the same reduction on the host
+            m3 = torch.stack([lat, ttfb, ttft]).numpy()
+            q = np.nanquantile(m3, (0.5, 0.95, 0.99), axis=1).T
+            stats = [{"mean": float(np.nanmean(r))} for r in m3]
+            qi = np.nanquantile(itl_all.numpy(), (0.5, 0.95, 0.99), axis=1).T
         n_ok = int(ok.sum().item())
         n_total = int(status.numel())
         completion = float(mat_all[4][ok].sum().item())
@@ -261,7 +277,7 @@ def main() -> int:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": round(rps / BASELINE["rps"], 4),
-            "dtype": "bf16" if not args.quantization else f"bf16 activations, {args.quantization} weights",
+            "dtype": ("bf16" if on_gpu else "fp32 (cpu rehearsal)") if not args.quantization else f"bf16 activations, {args.quantization} weights",
             "data": "synthetic prompts ('Hello, world!' chat, 14 prompt tokens), random-init weights, synthetic tokenizer",
             "config": {
                 "model": args.model,
@@ -304,7 +320,7 @@ def main() -> int:
                 "cost_per_1k_tokens": round(cost_1k / BASELINE["cost_per_1k_tokens"], 4) if cost_1k else None,
                 "wh_per_1k_tokens": round(wh_1k / BASELINE["wh_per_1k_tokens"], 5) if wh_1k else None,
             },
-            "quantile_engine": "hip:kv_radix_select",
+            "quantile_engine": "hip:kv_radix_select" if on_gpu else "numpy (cpu rehearsal)",
             "telemetry": pj["source"] if watts else "unavailable",
         }
         if n_ok == 0:
