@@ -2,8 +2,8 @@
 """Build the native (HIP/C++) parts of kvmini in-tree for gfx950.
 
 * ``kvmini/_C.<abi>.so``       torch extension: HIP kernels (csrc/*.hip) + bindings.cpp
-* ``kvmini/libkvmini_rt.so``    torch-free runtime library (amd-smi sampler thread,
-                                RCCL telemetry gather) loaded through ctypes
+* ``kvmini/libkvmini_rt.so``      torch-free amd-smi sampler thread, loaded through ctypes
+* ``kvmini/libkvmini_gather.so``  RCCL telemetry all-gather (binds to the process's HIP/RCCL at load)
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs on a CPU-only build
 host; objects are cached under ``build/`` by source mtime.  ``python build_native.py``
@@ -25,10 +25,10 @@ CSRC = ROOT / "csrc"
 BUILD = ROOT / "build"
 ARCH = os.environ.get("KVMINI_GPU_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXX = os.environ.get("CXX", "g++")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 KERNEL_SOURCES = ["hist_quantile.hip", "energy_trapz.hip", "engine_kernels.hip", "skinny_gemm.hip", "stream_gemm.hip"]
-RT_SOURCES = ["amdsmi_sampler.cpp", "telemetry_gather.cpp"]
 
 
 def run(cmd: list[str]) -> None:
@@ -79,7 +79,10 @@ def build_ext(force: bool = False) -> Path:
         link = []
         for d in libdirs:
             link += [f"-L{d}", f"-Wl,-rpath,{d}"]
-        run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *map(str, objs), *link, f"-L{ROCM}/lib", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-lamdhip64", "-o", str(out)])
+        # linked with the host C++ driver, not hipcc: hipcc would add the SYSTEM libamdhip64 next
+        # to the one bundled with torch, and a process with two HIP runtimes fails in odd ways
+        # (kernel launches of the second one report "no ROCm-capable device")
+        run([CXX, "-shared", "-fPIC", *map(str, objs), *link, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-lamdhip64", "-o", str(out)])
     return out
 
 
@@ -87,15 +90,26 @@ def rt_path() -> Path:
     return ROOT / "kvmini" / "libkvmini_rt.so"
 
 
+def gather_path() -> Path:
+    return ROOT / "kvmini" / "libkvmini_gather.so"
+
+
 def build_rt(force: bool = False) -> Path:
+    """Two torch-free libraries.  ``libkvmini_rt.so`` (amd-smi sampler thread; opens
+    libamd_smi with dlopen) links no GPU runtime at all, so it can be loaded into any process
+    at any time.  ``libkvmini_gather.so`` (RCCL telemetry all-gather) uses HIP + RCCL but is
+    linked WITHOUT them: its loader (kvmini/telemetry/native_rt.py) first makes the process's
+    one HIP runtime and RCCL global — the copies bundled with torch when torch is imported,
+    the system ones otherwise — so a process never ends up with two HIP runtimes."""
     BUILD.mkdir(exist_ok=True)
-    srcs = [CSRC / s for s in RT_SOURCES if (CSRC / s).exists()]
     out = rt_path()
-    if not srcs:
-        return out
-    if force or stale(out, srcs):
-        run([HIPCC, f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", *map(str, srcs), f"-I{ROCM}/include", f"-L{ROCM}/lib", f"-Wl,-rpath,{ROCM}/lib",
-             "-lamdhip64", "-lrccl", "-lpthread", "-ldl", "-o", str(out)])
+    src = CSRC / "amdsmi_sampler.cpp"
+    if src.exists() and (force or stale(out, [src])):
+        run([CXX, "-O2", "-std=c++17", "-fPIC", "-shared", str(src), "-lpthread", "-ldl", "-o", str(out)])
+    gout = gather_path()
+    gsrc = CSRC / "telemetry_gather.cpp"
+    if gsrc.exists() and (force or stale(gout, [gsrc])):
+        run([CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", f"-I{ROCM}/include", str(gsrc), "-lpthread", "-o", str(gout)])
     return out
 
 

@@ -46,7 +46,13 @@ int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_strid
 
 namespace {
 
-hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+// Every wrapper evaluates cur_stream() as an argument of its launcher, i.e. right before the
+// launch: clear the thread's sticky HIP error here so that the launcher's hipGetLastError()
+// reports its own launch and not a stale error of an unrelated earlier runtime call.
+hipStream_t cur_stream() {
+  (void)hipGetLastError();
+  return c10::hip::getCurrentHIPStream().stream();
+}
 
 void check(int rc, const char* what) {
   TORCH_CHECK(rc == 0, what, " failed: ", rc < 0 ? "unsupported shape/arguments" : hipGetErrorString((hipError_t)rc));

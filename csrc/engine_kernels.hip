@@ -257,20 +257,24 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
 // Ragged paged attention.  One workgroup per (token, kv head); the REP = nh/nkv query
 // heads of the group share every K/V load.  Each of the 4 waves walks KV blocks
 // w, w+4, ... of the token's sequence with an online softmax, then the waves merge
-// through LDS.  Specialised for head_dim 128, block_size 16, REP <= 8 (host checks).
+// through LDS.  Specialised for head_dim 64 / 128, block_size 16, REP <= 8 (host checks).
 //
 // Lane roles inside a wave, per 16-token KV block:
-//   QK: lane = 4*token + c; the lane dots dims [32c, 32c+32) of the 16-B-vector K row
+//   QK: lane = 4*token + c; the lane dots a quarter of the head dims of the K row
 //       against the REP query heads; two xor-shuffles finish the 128-dim dot.
-//   PV: lane = 16*tg + dv; it owns output dims [8dv, 8dv+8) and tokens {tg, tg+4, tg+8,
+//   PV: lane = 16*tg + dv; it owns 1/16 of the output dims and tokens {tg, tg+4, tg+8,
 //       tg+12} of the block; the 4 token groups are summed once at the end.
-template <int REP>
+template <int REP, int HD>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
                                                               const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
                                                               const int* __restrict__ block_tables, int max_blocks_per_seq,
                                                               const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
                                                               unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
-  constexpr int HD = 128, BS = 16;
+  constexpr int BS = 16;
+  constexpr int DQ = HD / 4;   // dims of the QK dot owned by a lane
+  constexpr int NV = DQ / 8;   // 16-byte K loads per lane
+  constexpr int DP = HD / 16;  // output dims owned by a lane in PV
+  static_assert(HD == 64 || HD == 128, "head_dim 64 or 128");
   __shared__ float p_lds[4][REP][BS];        // per-wave probabilities of the current block
   __shared__ float m_lds[4][REP], l_lds[4][REP];
   __shared__ float o_lds[4][REP][HD];
@@ -285,48 +289,49 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
   const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
   const int n_blocks = (ctx + BS - 1) / BS;
 
-  // this lane's 32-dim slice of the REP query heads, pre-scaled by scale*log2(e)
+  // this lane's DQ-dim slice of the REP query heads, pre-scaled by scale*log2(e)
   const int qk_tok = lane >> 2, qk_c = lane & 3;
-  float qf[REP][32];
+  float qf[REP][DQ];
   {
-    const unsigned short* qrow = q + (long long)t * q_row_stride + (long long)g * REP * HD + qk_c * 32;
+    const unsigned short* qrow = q + (long long)t * q_row_stride + (long long)g * REP * HD + qk_c * DQ;
 #pragma unroll
     for (int h = 0; h < REP; ++h)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < NV; ++v) {
         bf16x8 a = *reinterpret_cast<const bf16x8*>(qrow + h * HD + v * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) qf[h][v * 8 + j] = bf2f(a[j]) * scale_log2e;
       }
   }
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
-  float acc[REP][8];
+  float acc[REP][DP];
   float m_run[REP], l_run[REP];
 #pragma unroll
   for (int h = 0; h < REP; ++h) {
     m_run[h] = -1e30f; l_run[h] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+    for (int j = 0; j < DP; ++j) acc[h][j] = 0.f;
   }
 
   for (int b = wave; b < n_blocks; b += 4) {
     const long long base = ((long long)bt[b] * nkv + g) * BS * HD;
     // ---- QK^T
-    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
-    bf16x8 kv[4];
+    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * DQ;
+    bf16x8 kv[NV];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+    for (int v = 0; v < NV; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
     // V loads issued early: they do not depend on the softmax
-    bf16x8 vv[4];
-    const unsigned short* vp = v_cache + base + pv_dv * 8;
+    typedef __attribute__((ext_vector_type(DP))) unsigned short vrow_t;  // 16 B (HD 128) or 8 B (HD 64)
+    vrow_t vv[4];
+    const unsigned short* vp = v_cache + base + pv_dv * DP;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
     float s[REP];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
       float d = 0.f;
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
+      for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int j = 0; j < 8; ++j) d += qf[h][v * 8 + j] * bf2f(kv[v][j]);
       d += __shfl_xor(d, 1, 64);
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
       l_run[h] = l_run[h] * corr + ps;
       m_run[h] = m_new;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[h][j] *= corr;
+      for (int j = 0; j < DP; ++j) acc[h][j] *= corr;
       if (qk_c == 0) p_lds[wave][h][qk_tok] = p;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): p_lds visible to the wave (single wave: no barrier needed)
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
       for (int h = 0; h < REP; ++h) {
         const float p = p_lds[wave][h][tok];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[h][j] += p * bf2f(vv[i][j]);
+        for (int j = 0; j < DP; ++j) acc[h][j] += p * bf2f(vv[i][j]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
 #pragma unroll
   for (int h = 0; h < REP; ++h)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < DP; ++j) {
       float v = acc[h][j];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
 #pragma unroll
     for (int h = 0; h < REP; ++h)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o_lds[wave][h][pv_dv * 8 + j] = acc[h][j];
+      for (int j = 0; j < DP; ++j) o_lds[wave][h][pv_dv * DP + j] = acc[h][j];
   }
   if (lane == 0) {
 #pragma unroll
@@ -553,20 +558,23 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
                        const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale,
                        hipStream_t stream) {
   if (T <= 0) return 0;
-  if (hd != 128 || block_size != 16 || nh % nkv) return -1;
+  if ((hd != 128 && hd != 64) || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
   dim3 grid(T, nkv), block(256);
-#define KV_LAUNCH(R)                                                                                                                          \
-  hipLaunchKernelGGL(paged_attention_kernel<R>, grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
+#define KV_LAUNCH(R, D)                                                                                                                          \
+  hipLaunchKernelGGL((paged_attention_kernel<R, D>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
                      (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, sl)
-  switch (rep) {
-    case 1: KV_LAUNCH(1); break;
-    case 2: KV_LAUNCH(2); break;
-    case 4: KV_LAUNCH(4); break;
-    case 8: KV_LAUNCH(8); break;
-    default: return -1;
+#define KV_BY_REP(D)              \
+  switch (rep) {                  \
+    case 1: KV_LAUNCH(1, D); break; \
+    case 2: KV_LAUNCH(2, D); break; \
+    case 4: KV_LAUNCH(4, D); break; \
+    case 8: KV_LAUNCH(8, D); break; \
+    default: return -1;           \
   }
+  if (hd == 128) { KV_BY_REP(128) } else { KV_BY_REP(64) }
+#undef KV_BY_REP
 #undef KV_LAUNCH
   return (int)hipGetLastError();
 }

@@ -27,8 +27,12 @@ def is_success(row: Dict[str, Any]) -> bool:
 
 
 def classify_requests_cold_warm(
-    rows: List[Dict[str, Any]], cold_start_times: Sequence[float], cold_window_sec: float = 30.0
+    rows: List[Dict[str, Any]], cold_start_times: Sequence[float], cold_window_sec: float = 30.0, spanning: bool = True
 ) -> List[Dict[str, Any]]:
+    """``spanning`` (an addition): a request that was already in flight when a cold start
+    happened (``start < t_cold < start + latency``: it sat in the activator / waited for the
+    restarted server) is cold as well — under the reference's predicate the request that
+    paid for the whole cold start counts as warm."""
     cold_sorted = sorted(float(t) for t in cold_start_times)
     for row in rows:
         t = float(row.get("start_ms", 0) or 0) / 1000.0
@@ -38,6 +42,14 @@ def classify_requests_cold_warm(
             i = bisect.bisect_right(cold_sorted, t) - 1
             if i >= 0 and t <= cold_sorted[i] + cold_window_sec:
                 cold = True
+            elif spanning:
+                try:
+                    lat = float(row.get("latency_ms", 0) or 0) / 1000.0
+                except (TypeError, ValueError):
+                    lat = 0.0
+                j = bisect.bisect_right(cold_sorted, t)  # first cold start after the request began
+                if lat > 0 and j < len(cold_sorted) and cold_sorted[j] < t + lat:
+                    cold = True
         row["is_cold_start"] = cold
     return rows
 

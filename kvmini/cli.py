@@ -51,6 +51,7 @@ COMMANDS: Dict[str, Tuple[str, str, str]] = {
     "fairness": ("kvmini.harness.fairness", "main", "dual-tenant fairness / backpressure harness"),
     "parity": ("kvmini.harness.parity_probe", "main", "OpenAI API parity probe"),
     "chaos": ("kvmini.harness.chaos", "main", "fault injection + MTTR table"),
+    "spec-delta": ("kvmini.harness.spec_delta", "main", "speculative decoding TTFT / inter-token delta report"),
     "quality": ("kvmini.harness.quality", "main", "quality mini-eval + Pareto bucket"),
     "telemetry": ("kvmini.parallel.telemetry_daemon", "main", "lock-step multi-GPU telemetry over RCCL"),
     # servers

@@ -45,8 +45,11 @@ class EngineConfig:
     quantization: Optional[str] = None  # None | fp8
     prefill_gemm: str = "library"  # library | stream (see RunnerConfig)
     # speculative decoding
-    draft_model: Optional[str] = None
+    draft_model: Optional[str] = None  # preset name, or "self:<K>" = early exit after K layers of the target
     num_speculative_tokens: int = 0
+    # random-init only: damp the residual branches of layers >= K by this factor (see
+    # kvmini.models.llama.random_weights); K is the early-exit depth of a "self:<K>" draft
+    tail_damping: float = 0.0
     tp_size: int = 1
     tp_rank: int = 0
 
@@ -104,7 +107,10 @@ class LLMEngine:
 
                 weights = load_hf_safetensors(ecfg.weights_path, self.mcfg, self.device, dtype, ecfg.tp_rank, ecfg.tp_size)
             else:
-                weights = random_weights(self.mcfg, self.device, dtype, ecfg.seed, ecfg.tp_rank, ecfg.tp_size)
+                damp = None
+                if ecfg.tail_damping > 0 and ecfg.draft_model and ecfg.draft_model.startswith("self:"):
+                    damp = (int(ecfg.draft_model.split(":", 1)[1]), float(ecfg.tail_damping))
+                weights = random_weights(self.mcfg, self.device, dtype, ecfg.seed, ecfg.tp_rank, ecfg.tp_size, tail_damping=damp)
         self.weights = weights
         rcfg = RunnerConfig(
             max_num_seqs=ecfg.max_num_seqs,

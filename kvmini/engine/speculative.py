@@ -22,11 +22,12 @@ counterpart, reported through ``spec_proposed`` / ``spec_accepted``.
 from __future__ import annotations
 
 import time
+from dataclasses import replace
 from typing import TYPE_CHECKING, Dict, List
 
 import torch
 
-from kvmini.models.llama import get_config, random_weights
+from kvmini.models.llama import LlamaWeights, get_config, random_weights
 
 from .runner import ModelRunner, RunnerConfig
 from .scheduler import Batch, ScheduledChunk, SeqStatus, Sequence
@@ -40,13 +41,26 @@ class SpeculativeDecoder:
         self.engine = engine
         self.k = int(k)
         tgt = engine.runner
-        dcfg = get_config(draft_model)
-        if dcfg.vocab_size != engine.mcfg.vocab_size:
-            raise ValueError(f"draft vocab {dcfg.vocab_size} != target vocab {engine.mcfg.vocab_size}")
         ecfg = engine.ecfg
         if ecfg.tp_size > 1:
             raise ValueError("speculative decoding is single-GPU in this engine (the draft is not sharded)")
-        dw = random_weights(dcfg, engine.device, engine.weights.embed.dtype, ecfg.seed + 1)
+        if draft_model.startswith("self:"):
+            # early-exit self-speculation: the draft is the target's first K layers followed by
+            # the target's own final norm and LM head.  It shares the (already packed) weight
+            # tensors, so it costs no extra weight memory — only a K-layer KV cache.
+            depth = int(draft_model.split(":", 1)[1])
+            if not 0 < depth < engine.mcfg.num_layers:
+                raise ValueError(f"self-draft depth must be in 1..{engine.mcfg.num_layers - 1}")
+            tw = engine.weights
+            dw = LlamaWeights(replace(engine.mcfg, name=f"{engine.mcfg.name}-exit{depth}", num_layers=depth), tw.embed, tw.layers[:depth], tw.final_norm, tw.lm_head, tw.tp_rank, tw.tp_size)
+            for attr in ("_hip_prepared", "quantization"):
+                if hasattr(tw, attr):
+                    setattr(dw, attr, getattr(tw, attr))
+        else:
+            dcfg = get_config(draft_model)
+            if dcfg.vocab_size != engine.mcfg.vocab_size:
+                raise ValueError(f"draft vocab {dcfg.vocab_size} != target vocab {engine.mcfg.vocab_size}")
+            dw = random_weights(dcfg, engine.device, engine.weights.embed.dtype, ecfg.seed + 1)
         rcfg = RunnerConfig(max_num_seqs=ecfg.max_num_seqs, max_batched_tokens=ecfg.max_batched_tokens, max_model_len=ecfg.max_model_len, block_size=ecfg.block_size,
                             num_blocks=tgt.num_blocks, use_graphs=ecfg.use_graphs, kernels=ecfg.kernels)
         self.draft = ModelRunner(dw, rcfg)
@@ -129,6 +143,18 @@ class SpeculativeDecoder:
         # keep the verify pass within the token budget
         room = max(0, sch.max_batched_tokens - len(sch.running))
         cands = cands[: room // max(1, k)]
+        # the draft writes K/V for positions up to num_tokens + k - 1: those blocks must exist
+        # before proposing (after a fully accepted step the previous allocation is used up)
+        ready = []
+        for s in cands:
+            need = sch._blocks_needed(s, s.num_tokens + k)
+            if need:
+                got = sch.bm.allocate(need) if sch.bm.can_allocate(need) else None
+                if got is None:
+                    continue  # decode this one without drafts in this step
+                s.blocks += got
+            ready.append(s)
+        cands = ready
         with torch.no_grad():
             if cands:
                 self._propose(cands)

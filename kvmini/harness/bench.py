@@ -207,6 +207,9 @@ def main(argv: Optional[List[str]] = None) -> int:
                 threading.Thread(target=_restart, daemon=True).start()
 
         cfg_l.on_result = on_result
+        # requests that arrive while the server restarts wait for it (as behind Knative's
+        # activator) instead of failing fast: their latency carries the cold start
+        cfg_l.connect_retry_s = max(cfg_l.connect_retry_s, 300.0)
 
     t0 = time.time()
     try:

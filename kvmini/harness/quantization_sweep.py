@@ -177,7 +177,9 @@ class QuantizationSweepRunner:
             return self.error_result(config, f"unsupported_quantization:{q}")
         cmd = [sys.executable, "-m", "kvmini", "bench", "--namespace", b["namespace"], "--service", self.service_name(config), "--model", b["model"], "--requests", str(b["requests"]), "--concurrency", str(b["concurrency"]), "--max-tokens", str(config.get("max_tokens", 64)), "--run-id", run_id, "--run-dir", run_dir, "--cost-file", self.cost_file]
         if self.local:
-            cmd += ["--cluster-backend", "local", "--no-energy"]
+            cmd += ["--cluster-backend", "local"]
+            if self.local == "mock":
+                cmd += ["--no-energy"]  # a mock burns no GPU power worth integrating
         lt = loadtest_args_for(config.get("decoding") or {}, self.output_dir, config["name"])
         if lt:
             cmd += ["--loadtest-args", " ".join(lt)]

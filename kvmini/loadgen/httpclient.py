@@ -14,6 +14,7 @@ from __future__ import annotations
 import asyncio
 import json
 import ssl
+import time
 import urllib.parse
 from dataclasses import dataclass, field
 from typing import Any, AsyncIterator, Dict, List, Optional, Tuple
@@ -106,10 +107,13 @@ class Response:
 
 
 class HttpClient:
-    def __init__(self, pooled: bool = True, verify_tls: bool = True, connect_timeout: float = 10.0, max_idle_per_origin: int = 256):
+    def __init__(self, pooled: bool = True, verify_tls: bool = True, connect_timeout: float = 10.0, max_idle_per_origin: int = 256, connect_retry_s: float = 0.0):
         self.pooled = pooled
         self.verify_tls = verify_tls
         self.connect_timeout = connect_timeout
+        # keep knocking on a refused port for this long: what Knative's activator does for a
+        # scaled-to-zero / restarting revision (the request waits, its latency shows the cold start)
+        self.connect_retry_s = connect_retry_s
         self.max_idle = max_idle_per_origin
         self._idle: Dict[Tuple[str, int, bool], List[_Conn]] = {}
         self.connections_opened = 0
@@ -122,7 +126,15 @@ class HttpClient:
             if not self.verify_tls:
                 ctx.check_hostname = False
                 ctx.verify_mode = ssl.CERT_NONE
-        reader, writer = await asyncio.wait_for(asyncio.open_connection(host, port, ssl=ctx, limit=1 << 20), self.connect_timeout)
+        deadline = time.monotonic() + self.connect_retry_s
+        while True:
+            try:
+                reader, writer = await asyncio.wait_for(asyncio.open_connection(host, port, ssl=ctx, limit=1 << 20), self.connect_timeout)
+                break
+            except (ConnectionRefusedError, ConnectionResetError):
+                if time.monotonic() >= deadline:
+                    raise
+                await asyncio.sleep(0.05)
         sock = writer.get_extra_info("socket")
         if sock is not None:
             import socket

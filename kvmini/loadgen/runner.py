@@ -112,6 +112,7 @@ class LoadConfig:
     api_key: Optional[str] = None
     insecure: bool = False
     pooled: bool = True
+    connect_retry_s: float = 0.0  # wait this long for a refused port (cold-starting server)
     timeout_s: float = 60.0
     seed: Optional[int] = None
     prompts: Optional[List[str]] = None
@@ -325,7 +326,7 @@ async def run_load(cfg: LoadConfig, tracer: Optional[TraceCollector] = None, cli
         tracer = TraceCollector()
     own_client = client is None
     if own_client:
-        client = HttpClient(pooled=cfg.pooled, verify_tls=not cfg.insecure)
+        client = HttpClient(pooled=cfg.pooled, verify_tls=not cfg.insecure, connect_retry_s=cfg.connect_retry_s)
     sem = asyncio.Semaphore(cfg.concurrency)
     results: List[ReqResult] = []
     tasks: List[asyncio.Task] = []
@@ -436,6 +437,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
     ap.add_argument("--prompt-tokens", type=int, default=None, help="Synthesise a prompt of about N tokens")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-pool", action="store_true", help="New TCP/TLS connection per request (reference behaviour)")
+    ap.add_argument("--connect-retry-s", type=float, default=0.0, help="Keep retrying a refused connection for this long (requests wait out a server cold start)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--timeout", type=float, default=60.0)
     ap.add_argument("--header", action="append", default=[], help="Extra header 'Name: value' (repeatable)")
@@ -499,6 +501,7 @@ def config_from_args(args: argparse.Namespace) -> LoadConfig:
         api_key=args.api_key,
         insecure=args.insecure,
         pooled=not args.no_pool,
+        connect_retry_s=args.connect_retry_s,
         timeout_s=args.timeout,
         seed=args.seed,
         prompts=prompts,

@@ -164,12 +164,19 @@ def random_weights(
     seed: int = 0,
     tp_rank: int = 0,
     tp_size: int = 1,
+    tail_damping: "Optional[tuple[int, float]]" = None,
 ) -> LlamaWeights:
     """Random-init weights (N(0, 0.02) like HF initialisation, norms = 1).  Every
     TP rank draws the *full* matrix from the same seed and keeps its shard, so a
     TP=k model equals the TP=1 model of the same seed (what the multi-process
     tests check).  Generation happens on ``device`` layer by layer, so the 16 GB of
-    an 8B model never exist on the host."""
+    an 8B model never exist on the host.
+
+    ``tail_damping=(first_layer, eps)`` multiplies the residual-branch outputs (``wo``,
+    ``wdown``) of layers ``>= first_layer`` by ``eps``: a synthetic stand-in for a trained
+    model whose early layers already decide most tokens, so that an early-exit draft
+    (speculative decoding with ``draft_model="self:<first_layer>"``) agrees with the full
+    model at a controllable rate.  The full model still streams every layer's weights."""
     assert cfg.num_heads % tp_size == 0 and cfg.num_kv_heads % tp_size == 0 and cfg.intermediate_size % (tp_size * GU_GROUP) == 0
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
@@ -189,7 +196,8 @@ def random_weights(
 
     embed = rnd(cfg.vocab_size, h)
     layers: List[LayerWeights] = []
-    for _ in range(cfg.num_layers):
+    for li in range(cfg.num_layers):
+        damp = tail_damping[1] if tail_damping is not None and li >= tail_damping[0] else None
         wq = shard_rows(rnd(cfg.q_size, h), nh_l * hd)
         wk = shard_rows(rnd(cfg.kv_size, h), nkv_l * hd)
         wv = shard_rows(rnd(cfg.kv_size, h), nkv_l * hd)
@@ -197,6 +205,8 @@ def random_weights(
         wg = shard_rows(rnd(cfg.intermediate_size, h), i_l)
         wu = shard_rows(rnd(cfg.intermediate_size, h), i_l)
         wd = shard_cols(rnd(h, cfg.intermediate_size), i_l)
+        if damp is not None:
+            wo, wd = (wo.float() * damp).to(dtype), (wd.float() * damp).to(dtype)
         layers.append(
             LayerWeights(
                 attn_norm=torch.ones(h, device=dev, dtype=dtype),

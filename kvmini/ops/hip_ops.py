@@ -298,7 +298,7 @@ def paged_attention(
     max_blocks: Optional[int] = None,
 ) -> torch.Tensor:
     t, nh, hd = q.shape
-    if hd != 128 or k_cache.shape[2] != 16:
+    if hd not in (64, 128) or k_cache.shape[2] != 16 or nh // k_cache.shape[1] not in (1, 2, 4, 8):
         # shapes outside the kernel's specialisation (test-sized models): reference path
         from . import torch_ops
 

@@ -348,7 +348,8 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--kernels", default="auto", choices=["auto", "hip", "torch"])
     ap.add_argument("--no-prefix-caching", action="store_true")
     ap.add_argument("--quantization", default=None, choices=[None, "fp8"])
-    ap.add_argument("--speculative-model", default=None, help="draft model preset for speculative decoding")
+    ap.add_argument("--speculative-model", default=None, help="draft model preset for speculative decoding, or self:<K> (early exit after K layers of the served model)")
+    ap.add_argument("--tail-damping", type=float, default=0.0, help="random-init + self:<K> only: damp layers >= K so the early-exit draft agrees with the full model (synthetic)")
     ap.add_argument("--num-speculative-tokens", type=int, default=0)
     ap.add_argument("--honor-eos", action="store_true", help="stop at EOS (default: ignore EOS with random-init weights)")
 
@@ -371,6 +372,7 @@ def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
         weights_path=a.weights,
         quantization=a.quantization,
         draft_model=a.speculative_model,
+        tail_damping=a.tail_damping,
         num_speculative_tokens=a.num_speculative_tokens,
     )
 

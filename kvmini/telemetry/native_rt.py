@@ -30,8 +30,9 @@ def lib_path() -> str:
 
 
 def load() -> Optional[ctypes.CDLL]:
-    """The runtime library, or None when it is not built / not loadable here
-    (it links RCCL and the HIP runtime, which a CPU-only host may lack)."""
+    """The sampler library, or None when it is not built.  It links no GPU runtime (amd-smi is
+    opened with dlopen inside), so loading it never brings a second HIP runtime into a
+    process that also imports torch."""
     global _LIB, _TRIED
     if _TRIED:
         return _LIB
@@ -50,12 +51,56 @@ def load() -> Optional[ctypes.CDLL]:
     lib.kvs_stop.restype = ctypes.c_int
     lib.kvs_trapz_wh.argtypes = [dp, dp, ctypes.c_longlong]
     lib.kvs_trapz_wh.restype = ctypes.c_double
+    _LIB = lib
+    return lib
+
+
+_GATHER: Optional[ctypes.CDLL] = None
+
+
+def gather_lib_path() -> str:
+    return os.path.join(os.path.dirname(lib_path()), "libkvmini_gather.so")
+
+
+def _gpu_runtime_global() -> None:
+    """``libkvmini_gather.so`` is linked without HIP / RCCL; make the process's copies of
+    them global first.  With torch imported those are the ones bundled with torch (a second,
+    system HIP runtime in the same process breaks kernel launches); otherwise the system's."""
+    import sys
+
+    cands: List[List[str]] = []
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        d = os.path.join(os.path.dirname(torch.__file__), "lib")
+        cands = [[os.path.join(d, "libamdhip64.so")], [os.path.join(d, "librccl.so")]]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    sysl = [[os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"], [os.path.join(rocm, "lib", "librccl.so"), "librccl.so"]]
+    for i in range(2):
+        for name in (cands[i] if cands else []) + sysl[i]:
+            try:
+                ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+
+
+def load_gather() -> Optional[ctypes.CDLL]:
+    """The RCCL telemetry-gather library bound to this process's HIP runtime and RCCL."""
+    global _GATHER
+    if _GATHER is not None:
+        return _GATHER
+    _gpu_runtime_global()
+    try:
+        lib = ctypes.CDLL(gather_lib_path())
+    except OSError:
+        return None
+    dp = ctypes.POINTER(ctypes.c_double)
     lib.kvt_unique_id_bytes.restype = ctypes.c_int
     lib.kvt_unique_id.argtypes = [ctypes.c_void_p]
     lib.kvt_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     lib.kvt_gather_many.argtypes = [dp, dp, ctypes.c_longlong]
     lib.kvt_gather.argtypes = [dp, dp]
-    _LIB = lib
+    _GATHER = lib
     return lib
 
 
@@ -173,9 +218,9 @@ class NativeGather:
         import torch
         import torch.distributed as dist
 
-        lib = load()
+        lib = load_gather()
         if lib is None:
-            raise RuntimeError("libkvmini_rt.so not available")
+            raise RuntimeError("libkvmini_gather.so not available")
         self._lib = lib
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1

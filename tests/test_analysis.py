@@ -100,7 +100,13 @@ def test_analyze_run_with_fake_cluster(tmp_path):
     (run / "io_probe.json").write_text(json.dumps({"rtt": {"p50_ms": 1.5, "p95_ms": 2.5}, "s3": {"avg_MBps": 90.0}}))
     (run / "power.json").write_text(json.dumps({"samples": [{"ts_s": 1.0 + 0.1 * i, "watts": 700.0, "gfx_util": 88.0, "vram_used": 2e10} for i in range(10)]}))
     res = analyze_run(str(run), "ns", "demo-llm", backend=fb, quiet=True)
-    assert res["cold_start_count"] == 1 and res["cold_count"] == 3  # requests starting at/after 1.2 s
+    # 3 requests start at/after 1.2 s (the reference's predicate) + 1 that was in flight across it
+    assert res["cold_start_count"] == 1 and res["cold_count"] == 4
+    from kvmini.analysis.coldwarm import classify_requests_cold_warm
+    from kvmini.analysis.reduce import read_requests_csv
+
+    rows = read_requests_csv(str(run / "requests.csv"))
+    assert sum(r["is_cold_start"] for r in classify_requests_cold_warm(rows, [1.2], spanning=False)) == 3
     assert res["network_rtt_p95_ms"] == 2.5 and res["s3_avg_MBps"] == 90.0
     assert res["gpu_power_watts_avg"] == pytest.approx(700.0) and res["gpu_util_avg"] == pytest.approx(88.0)
     assert res["energy_wh"] == pytest.approx(700.0 * 0.8 / 3600)

@@ -202,3 +202,30 @@ def test_speculative_decoding_matches_plain_greedy():
     assert st.spec_accepted == st.spec_proposed > 0  # the target agrees with itself
     assert st.steps < base.stats.steps  # fewer target passes for the same tokens
     assert same.bm.num_free == same.bm.num_blocks - 1 or same.bm.num_free > 0
+
+
+def test_self_speculation_early_exit_draft_is_exact_and_accepts_with_damped_tail():
+    """``self:<K>`` drafts with the target's first K layers.  Output must equal plain greedy
+    decoding; with the tail layers damped the draft agrees most of the time."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import LlamaConfig, random_weights
+
+    cfg = LlamaConfig("tiny4", 512, 128, 256, 4, 4, 2, 32)
+    prompts = [[1, 5, 9, 200, 31], [1, 77], [1] + list(range(40, 60))]
+    params = SamplingParams(max_tokens=16, ignore_eos=True)
+    common = dict(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=32, max_model_len=128, num_blocks=64)
+
+    def weights():
+        return random_weights(cfg, "cpu", torch.float32, seed=11, tail_damping=(2, 0.02))
+
+    base = LLMEngine(EngineConfig(**common), weights=weights())
+    want = base.generate(prompts, params)
+    spec = LLMEngine(EngineConfig(**common, draft_model="self:2", num_speculative_tokens=3), weights=weights())
+    assert spec.spec.draft.cfg.num_layers == 2 and spec.spec.draft.w.layers[0] is spec.weights.layers[0]
+    got = spec.generate(prompts, params)
+    assert got == want
+    st = spec.stats
+    assert st.spec_proposed > 0 and st.spec_accepted / st.spec_proposed > 0.5, (st.spec_proposed, st.spec_accepted)
+    # fewer target passes than tokens generated
+    assert st.steps < sum(len(o) for o in got)

@@ -1,10 +1,13 @@
 """Numerics of the gfx950 HIP kernels against plain PyTorch / numpy fp32-fp64 references."""
 
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -103,11 +106,12 @@ def test_rope_kv_write(C):
 
 
 @pytest.mark.parametrize("rep", [1, 4, 8])
-def test_paged_attention(C, rep):
+@pytest.mark.parametrize("hd", [128, 64])
+def test_paged_attention(C, rep, hd):
     from kvmini.ops import torch_ops
 
     torch.manual_seed(4)
-    nkv, hd, bs, nb = 2, 128, 16, 64
+    nkv, bs, nb = 2, 16, 64
     nh = nkv * rep
     n_seqs, max_blocks = 4, 12
     T = 9
@@ -521,3 +525,28 @@ def test_native_sampler_and_rccl_gather_on_gpu():
     table = g.gather(local)
     g.close()
     assert table.shape == (1, 2, 16) and np.array_equal(table[0], local)
+
+
+def test_sampler_loaded_before_torch_keeps_one_hip_runtime():
+    """The harness starts the C++ sampler before anything imports torch; HIP kernels of the
+    extension must still launch afterwards (a sampler library that dragged the system HIP
+    runtime in made them fail with 'no ROCm-capable device')."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from kvmini.telemetry import native_rt as rt\n"
+        "s = rt.NativeSampler(0.01, gpu_indices=[0]).start()\n"
+        "import torch\n"
+        "from kvmini.telemetry.energy import PowerSample, integrate_series_batched\n"
+        "series = {0: [PowerSample(float(t), 360.0) for t in range(0, 11)]}\n"
+        "out = integrate_series_batched(series, 0.0, 10.0, engine='hip')\n"
+        "s.stop()\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "n_hip = len({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l})\n"
+        "print('WH', out[0], 'NHIP', n_hip)\n"
+    ) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert "WH 1.0" in r.stdout and "NHIP 1" in r.stdout, r.stdout
