@@ -52,6 +52,7 @@ class EngineConfig:
     tail_damping: float = 0.0
     tp_size: int = 1
     tp_rank: int = 0
+    tp_graphs: bool = False
 
 
 # (request id, new token ids, finished?, finish reason, sequence)
@@ -92,6 +93,32 @@ def _sample_row(logits: torch.Tensor, p: SamplingParams, gen: Optional[torch.Gen
     return int(torch.multinomial(probs, 1, generator=gen).item())
 
 
+def _sample_rows(logits: torch.Tensor, params: List[SamplingParams]) -> List[int]:
+    """The same sampler for many rows at once (``logits``: ``[R, V]``, one SamplingParams per
+    row, unseeded): one softmax / sort / multinomial over the batch and ONE device
+    synchronisation, instead of R of each — at 20 sampled rows per step the per-row form
+    costs more than the whole forward pass."""
+    dev = logits.device
+    temps = torch.tensor([max(p.temperature, 1e-5) for p in params], dtype=torch.float32, device=dev)
+    x = logits.float() / temps[:, None]
+    ks = [min(p.top_k, x.shape[1]) if p.top_k and p.top_k > 0 else 0 for p in params]
+    if any(ks):
+        vals = torch.topk(x, max(ks), dim=-1).values
+        kidx = torch.tensor([max(k, 1) - 1 for k in ks], device=dev)
+        kth = vals.gather(1, kidx[:, None])
+        use = torch.tensor([k > 0 for k in ks], device=dev)[:, None]
+        x = torch.where(use & (x < kth), torch.full_like(x, float("-inf")), x)
+    probs = torch.softmax(x, dim=-1)
+    if any(p.top_p < 1.0 for p in params):
+        tp = torch.tensor([p.top_p for p in params], dtype=torch.float32, device=dev)
+        sp, si = torch.sort(probs, dim=-1, descending=True)
+        keep = (torch.cumsum(sp, -1) - sp) < tp[:, None]
+        sp = sp * keep
+        probs = torch.zeros_like(probs).scatter_(1, si, sp)
+        probs = probs / probs.sum(-1, keepdim=True)
+    return torch.multinomial(probs, 1).view(-1).tolist()
+
+
 class LLMEngine:
     def __init__(self, ecfg: EngineConfig, weights: Optional[LlamaWeights] = None, tp_group: Any = None):
         self.ecfg = ecfg
@@ -123,6 +150,7 @@ class LLMEngine:
             kernels=ecfg.kernels,
             quantization=ecfg.quantization,
             prefill_gemm=ecfg.prefill_gemm,
+            tp_graphs=ecfg.tp_graphs,
         )
         self.runner = ModelRunner(weights, rcfg, tp_group)
         self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)
@@ -178,6 +206,14 @@ class LLMEngine:
 
     def _commit(self, batch: Batch, ids: List[int], logits: Optional[torch.Tensor]) -> List[TokenEvent]:
         events: List[TokenEvent] = []
+        # unseeded temperature sampling: all such rows of the step in one batched call
+        batched: Dict[int, int] = {}
+        if logits is not None:
+            rows_b = [r for r, ch in enumerate(c for c in batch.chunks if c.sample) if ch.seq.params.temperature > 0 and ch.seq.params.seed is None]
+            if rows_b:
+                plist = [ch.seq.params for ch in batch.chunks if ch.sample]
+                toks = _sample_rows(logits[torch.tensor(rows_b, device=logits.device)], [plist[r] for r in rows_b])
+                batched = dict(zip(rows_b, toks))
         row = 0
         for ch in batch.chunks:
             seq = ch.seq
@@ -188,14 +224,14 @@ class LLMEngine:
                 continue
             tok = ids[row]
             p = seq.params
-            if p.temperature > 0 and logits is not None:
-                gen = None
-                if p.seed is not None:
-                    gen = self._gens.get(seq.req_id)
-                    if gen is None:
-                        gen = torch.Generator(device=logits.device)
-                        gen.manual_seed(p.seed)
-                        self._gens[seq.req_id] = gen
+            if row in batched:
+                tok = batched[row]
+            elif p.temperature > 0 and logits is not None:
+                gen = self._gens.get(seq.req_id)
+                if gen is None:
+                    gen = torch.Generator(device=logits.device)
+                    gen.manual_seed(p.seed)
+                    self._gens[seq.req_id] = gen
                 tok = _sample_row(logits[row], p, gen)
             row += 1
             new = self.scheduler.commit(ch, [tok])
@@ -231,6 +267,18 @@ class LLMEngine:
         if self._thread is not None:
             self._thread.join(10)
             self._thread = None
+        self.release_followers()
+
+    # --- tensor parallelism: rank 0 of the TP group schedules, the others follow -------------
+    def follow(self) -> int:
+        """Serve as a tensor-parallel follower until the scheduling rank stops (blocking)."""
+        with torch.no_grad():
+            return self.runner.follow()
+
+    def release_followers(self) -> None:
+        if self.ecfg.tp_size > 1 and self.ecfg.tp_rank == 0 and not getattr(self, "_followers_released", False):
+            self._followers_released = True
+            self.runner.stop_followers()
 
     def submit(self, prompt_ids: List[int], params: SamplingParams, user: Any = None) -> int:
         seq = self.make_sequence(prompt_ids, params, user)

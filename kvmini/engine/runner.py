@@ -46,6 +46,7 @@ class RunnerConfig:
     # hipBLASLt (2x weight memory, fast prefill), "stream" re-streams the packed weights
     # once per 64 tokens (no extra memory)
     prefill_gemm: str = "library"
+    tp_graphs: bool = False  # capture HIP graphs (with the RCCL all-reduces inside) under tensor parallelism
 
 
 def select_ops(kernels: str, device: torch.device) -> Any:
@@ -105,11 +106,16 @@ class ModelRunner:
             off += n
         self._off["block_tables"] = (off, smax * self.max_blocks_per_seq)
         off += smax * self.max_blocks_per_seq
+        # step header (tensor parallelism: rank 0 broadcasts the whole staging buffer, followers
+        # read the step shape from here): t_pad, n_samples, max_ctx, command (0 = run, 1 = stop)
+        self._off["header"] = (off, 8)
+        off += 8
         pin = self.device.type == "cuda"
         self.stage_cpu = torch.zeros(off, dtype=torch.int32, pin_memory=pin)
         self.stage_np = self.stage_cpu.numpy()
         self.stage_dev = torch.zeros(off, dtype=torch.int32, device=self.device)
-        self.bt_np = self.stage_np[self._off["block_tables"][0] :].reshape(smax, self.max_blocks_per_seq)
+        o_bt = self._off["block_tables"][0]
+        self.bt_np = self.stage_np[o_bt : o_bt + smax * self.max_blocks_per_seq].reshape(smax, self.max_blocks_per_seq)
         self.out_ids = torch.zeros(tmax, dtype=torch.int64, device=self.device)
         self.out_ids_cpu = torch.zeros(tmax, dtype=torch.int64, pin_memory=pin)
         self.logits_buf: Optional[torch.Tensor] = None
@@ -194,6 +200,8 @@ class ModelRunner:
         ones share its memory pool)."""
         if self.device.type != "cuda" or not self.rcfg.use_graphs:
             return
+        if self.tp_size > 1 and not self.rcfg.tp_graphs:
+            return  # collectives inside captured graphs are opt-in (every rank must capture in step)
         self._stage_dummy()
         for b in sorted(buckets or self.buckets, reverse=True):
             if b in self.graphs:
@@ -213,6 +221,46 @@ class ModelRunner:
                 self._graph_pool = g.pool()
             self.graphs[b] = (g, logits)
         torch.cuda.synchronize(self.device)
+
+    def _run_staged(self, t_pad: int, max_ctx: int) -> torch.Tensor:
+        entry = self.graphs.get(t_pad)
+        if entry is not None:
+            g, logits = entry
+            g.replay()
+        else:
+            with torch.no_grad():
+                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size)
+        self.steps += 1
+        return logits
+
+    def _tp_src(self) -> int:
+        """Global rank of the tensor-parallel group's first member (the scheduling rank)."""
+        g = self.tp_group
+        return 0 if g is None else torch.distributed.get_global_rank(g, 0)
+
+    def follow(self) -> int:
+        """Tensor-parallel follower loop (ranks > 0 of the TP group): receive the staging
+        buffer that the scheduling rank broadcasts each step, run the same pass on the local
+        weight shard (the all-reduces inside ``forward`` pair up with the other ranks'), until
+        a stop command arrives.  Returns the number of steps served."""
+        o_h = self._off["header"][0]
+        n = 0
+        while True:
+            torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
+            t_pad, _n_samples, max_ctx, cmd = self.stage_dev[o_h : o_h + 4].tolist()
+            if cmd == 1:
+                return n
+            self._run_staged(int(t_pad), int(max_ctx))
+            n += 1
+
+    def stop_followers(self) -> None:
+        """Scheduling rank: release the followers from :meth:`follow`."""
+        if self.tp_size <= 1:
+            return
+        o_h = self._off["header"][0]
+        self.stage_np[o_h : o_h + 4] = (0, 0, 0, 1)
+        self.stage_dev.copy_(self.stage_cpu)
+        torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
 
     def _stage_dummy(self) -> None:
         """Inputs that are safe for warm-up/capture: every token is padding."""
@@ -282,15 +330,13 @@ class ModelRunner:
             st[o_ctx + t : o_ctx + t_pad] = 0
         st[o_smp + n_samples : o_smp + t_pad] = 0
 
+        o_h = self._off["header"][0]
+        st[o_h : o_h + 4] = (t_pad, n_samples, max_ctx, 0)
         self.stage_dev.copy_(self.stage_cpu, non_blocking=True)
-        entry = self.graphs.get(t_pad)
-        if entry is not None:
-            g, logits = entry
-            g.replay()
-        else:
-            with torch.no_grad():
-                logits = self.forward(t_pad, max_blocks=(max_ctx + bs - 1) // bs)
-        self.steps += 1
+        if self.tp_size > 1:
+            # every rank runs the same step: ship the staged inputs to the followers (see follow())
+            torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
+        logits = self._run_staged(t_pad, max_ctx)
         if self.device.type == "cuda":
             self.out_ids_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()

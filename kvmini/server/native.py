@@ -351,6 +351,8 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--speculative-model", default=None, help="draft model preset for speculative decoding, or self:<K> (early exit after K layers of the served model)")
     ap.add_argument("--tail-damping", type=float, default=0.0, help="random-init + self:<K> only: damp layers >= K so the early-exit draft agrees with the full model (synthetic)")
     ap.add_argument("--num-speculative-tokens", type=int, default=0)
+    ap.add_argument("--tensor-parallel-size", type=int, default=1, help="shard the model over this many GPUs; launch with torchrun --nproc-per-node N (one rank per GPU, RCCL)")
+    ap.add_argument("--tp-graphs", action="store_true", help="capture HIP graphs under tensor parallelism (the RCCL all-reduces are recorded inside them)")
     ap.add_argument("--honor-eos", action="store_true", help="stop at EOS (default: ignore EOS with random-init weights)")
 
 
@@ -374,7 +376,31 @@ def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
         draft_model=a.speculative_model,
         tail_damping=a.tail_damping,
         num_speculative_tokens=a.num_speculative_tokens,
+        tp_size=getattr(a, "tensor_parallel_size", 1),
+        tp_rank=getattr(a, "tp_rank", 0),
+        tp_graphs=getattr(a, "tp_graphs", False),
     )
+
+
+def init_tensor_parallel(a: argparse.Namespace) -> Any:
+    """One process per GPU (torchrun): join the RCCL world, pin this rank to its GPU and
+    return the TP process group.  ``--device cpu`` uses gloo (tests)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.tensor_parallel_size:
+        raise SystemExit(f"--tensor-parallel-size {a.tensor_parallel_size} needs torchrun --nproc-per-node {a.tensor_parallel_size} (WORLD_SIZE is {world})")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if a.device == "cpu":
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        a.device = f"cuda:{local_rank}"
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    a.tp_rank = dist.get_rank()
+    return dist.group.WORLD
 
 
 def main(argv: Optional[List[str]] = None) -> int:
@@ -389,24 +415,43 @@ def main(argv: Optional[List[str]] = None) -> int:
     add_engine_args(ap)
     a = ap.parse_args(argv)
     proc_start = time.time()
-    engine = LLMEngine(engine_config_from_args(a))
+    import signal
+
+    def _term(*_: Any) -> None:  # SIGTERM = orderly shutdown (the finally block releases TP followers)
+        raise KeyboardInterrupt
+
+    signal.signal(signal.SIGTERM, _term)
+    tp_group = init_tensor_parallel(a) if a.tensor_parallel_size > 1 else None
+    engine = LLMEngine(engine_config_from_args(a), tp_group=tp_group)
     engine.warmup()
+    if tp_group is not None and a.tp_rank != 0:
+        # follower rank: no HTTP server, no scheduler — run the steps rank 0 broadcasts
+        import torch.distributed as dist
+
+        served = engine.follow()
+        print(f"[tp rank {a.tp_rank}] served {served} steps", flush=True)
+        dist.destroy_process_group()
+        return 0
     ns = NativeServer(engine, a.served_model_name or a.model, a.tokenizer, ignore_eos=not a.honor_eos, api_key=a.api_key)
     ns.started_at = proc_start
     if not a.no_register:
         from kvmini.cluster import LocalBackend
 
-        LocalBackend().register_server(a.service, f"http://{a.host}:{a.port}", os.getpid(), proc_start, namespace=a.namespace, gpus=1 if engine.device.type == "cuda" else 0)
+        LocalBackend().register_server(a.service, f"http://{a.host}:{a.port}", os.getpid(), proc_start, namespace=a.namespace, gpus=a.tensor_parallel_size if engine.device.type == "cuda" else 0)
     try:
         asyncio.run(ns.serve(a.host, a.port))
     except KeyboardInterrupt:
         pass
     finally:
-        engine.stop()
+        engine.stop()  # also releases tensor-parallel followers
         if not a.no_register:
             from kvmini.cluster import LocalBackend
 
             LocalBackend().mark_finished(os.getpid())
+        if tp_group is not None:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
     return 0
 
 

@@ -34,11 +34,13 @@ for what in $WHAT; do
 case "$what" in
 headline)  # config 2: 500 req / c20 with a cold restart half-way -> cold/warm split, report, SLO gate
   timeout -k 10 500 python -m kvmini bench --profile headline --model "$MODEL" --serve native --serve-model "$MODEL" --serve-port 8101 --cluster-backend local \
-    --cold-restart-at 0.5 --report --slo slo.json --run-dir "$OUT/headline" > "$OUT/headline.log" 2>&1 || { tail -30 "$OUT/headline.log"; exit 1; }
-  tail -14 "$OUT/headline.log" ;;
+    --cold-restart-at 0.5 --report --run-dir "$OUT/headline" > "$OUT/headline.log" 2>&1 || { tail -30 "$OUT/headline.log"; exit 1; }
+  # the gate is expected to flag the provoked cold start (exit 3): record its verdict, do not stop
+  python -m kvmini gate --results "$OUT/headline/results.json" --slo slo.json > "$OUT/headline_gate.log" 2>&1; echo "gate exit code: $?" >> "$OUT/headline_gate.log"
+  tail -14 "$OUT/headline.log"; tail -12 "$OUT/headline_gate.log" ;;
 grid)      # config 4 (single-GPU part): concurrency 1..64 grid with the energy per 1k tokens column
   start_server grid 8102 --model "$MODEL" --max-num-seqs 64 || exit 1
-  timeout -k 10 900 python -m kvmini grid-sweep --url http://127.0.0.1:8102 --model "$MODEL" --cluster-backend local --requests 200 --concurrency 1,2,4,8,16,32,64 \
+  timeout -k 10 900 python -m kvmini grid-sweep --url http://127.0.0.1:8102 --model "$MODEL" --service grid --namespace local --cluster-backend local --requests 200 --concurrency 1,2,4,8,16,32,64 \
     --max-tokens 64 --patterns steady --runs-root "$OUT/grid_runs" --output "$OUT/grid_sweep.csv" --report > "$OUT/grid.log" 2>&1 || { tail -30 "$OUT/grid.log"; exit 1; }
   stop_server; tail -12 "$OUT/grid.log" ;;
 quant)     # config 4: bf16 vs fp8 quantization sweep on the native engine
@@ -47,7 +49,7 @@ quant)     # config 4: bf16 vs fp8 quantization sweep on the native engine
   tail -12 "$OUT/quant.log" ;;
 70b)       # Llama-3-70B bf16 on ONE 288 GB GPU (TP=8 needs the 8-GPU node): 141 GB of weights resident
   start_server l70 8104 --model llama-3-70b --max-num-seqs 32 --max-batched-tokens 64 --max-model-len 1024 --kv-memory-fraction 0.5 || exit 1
-  timeout -k 10 600 python -m kvmini bench --url http://127.0.0.1:8104 --model llama-3-70b --cluster-backend local --service l70 --requests 60 --concurrency 20 --max-tokens 64 \
+  timeout -k 10 600 python -m kvmini bench --url http://127.0.0.1:8104 --model llama-3-70b --cluster-backend local --service l70 --namespace local --requests 60 --concurrency 20 --max-tokens 64 \
     --report --run-dir "$OUT/llama70b_1gpu" > "$OUT/llama70b.log" 2>&1 || { tail -30 "$OUT/llama70b.log"; exit 1; }
   stop_server; tail -14 "$OUT/llama70b.log" ;;
 ab)        # config 5 (single-box part): native engine vs protocol mocks of the two cluster backends

@@ -151,9 +151,15 @@ cfg = get_config("tiny")
 w = random_weights(cfg, "cpu", torch.float32, seed=5, tp_rank=r, tp_size=ws)
 eng = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=16, max_model_len=64, num_blocks=32, block_size=4, tp_size=ws, tp_rank=r), weights=w, tp_group=dist.group.WORLD)
 prompts = [[1, 4, 8, 15, 16, 23, 42], [1, 9, 9, 9]]
-outs = eng.generate(prompts, SamplingParams(max_tokens=6, ignore_eos=True))
-full = random_weights(cfg, "cpu", torch.float32, seed=5)
-ok = all(o == dense_greedy(full, p, 6) for p, o in zip(prompts, outs))
+if r == 0:
+    # rank 0 schedules and samples; the other rank only follows the broadcast steps
+    outs = eng.generate(prompts, SamplingParams(max_tokens=6, ignore_eos=True))
+    eng.release_followers()
+    full = random_weights(cfg, "cpu", torch.float32, seed=5)
+    ok = all(o == dense_greedy(full, p, 6) for p, o in zip(prompts, outs))
+else:
+    served = eng.follow()
+    ok = served >= 6
 # lock-step telemetry: per-tick and whole-table gathers
 tg = TelemetryGather()
 tick = tg.gather_tick({"ts_s": 100.0 + r, "watts": 500.0 + r, "gfx_util": 50.0})
@@ -229,3 +235,65 @@ def test_self_speculation_early_exit_draft_is_exact_and_accepts_with_damped_tail
     assert st.spec_proposed > 0 and st.spec_accepted / st.spec_proposed > 0.5, (st.spec_proposed, st.spec_accepted)
     # fewer target passes than tokens generated
     assert st.steps < sum(len(o) for o in got)
+
+
+def test_batched_sampling_matches_greedy_under_top_k_1_and_respects_top_p():
+    """The batched sampler (all unseeded sampled rows of a step in one call) with top_k=1 is
+    greedy decoding; top_p keeps only the head of the distribution; mixed batches work."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine, _sample_rows
+    from kvmini.engine.scheduler import SamplingParams
+
+    common = dict(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=32, max_model_len=128, num_blocks=64)
+    prompts = [[1, 5, 9, 200, 31], [1, 77], [1, 3, 3, 7]]
+    want = LLMEngine(EngineConfig(**common)).generate(prompts, SamplingParams(max_tokens=8, ignore_eos=True))
+    got = LLMEngine(EngineConfig(**common)).generate(prompts, SamplingParams(max_tokens=8, ignore_eos=True, temperature=0.8, top_k=1))
+    assert got == want
+    torch.manual_seed(0)
+    logits = torch.tensor([[5.0, 4.0, 0.0, -1.0], [0.0, 0.0, 10.0, 0.0], [1.0, 0.9, 0.5, 0.4]]).repeat(200, 1)
+    params = [SamplingParams(temperature=1.0, top_p=0.6), SamplingParams(temperature=0.5), SamplingParams(temperature=1.0, top_k=2)] * 200
+    toks = _sample_rows(logits, params)
+    assert set(toks[0::3]) == {0}          # top_p 0.6: only the first token (p = 0.72) survives
+    assert set(toks[1::3]) == {2}          # a 10-logit lead at T = 0.5 is certain
+    assert set(toks[2::3]) == {0, 1}       # top_k 2 of a nearly flat row: exactly the two best ids, both drawn
+
+
+def test_tensor_parallel_serving_two_ranks_gloo_matches_single_rank(tmp_path):
+    """``kvmini serve --tensor-parallel-size 2`` under torchrun: rank 0 serves HTTP and
+    schedules, rank 1 follows the broadcast steps; the greedy answer equals the single-rank
+    server's, and SIGTERM ends every rank (no one is left blocked in a broadcast)."""
+    import json
+    import signal
+    import time
+    import urllib.request
+
+    def ask(port):
+        body = json.dumps({"model": "tiny", "messages": [{"role": "user", "content": "hello tensor parallel world"}], "max_tokens": 8}).encode()
+        req = urllib.request.Request(f"http://127.0.0.1:{port}/v1/chat/completions", data=body, headers={"Content-Type": "application/json"})
+        return json.loads(urllib.request.urlopen(req, timeout=30).read())["choices"][0]["message"]["content"]
+
+    def wait_ready(port, proc):
+        for _ in range(300):
+            assert proc.poll() is None, "server exited early"
+            try:
+                urllib.request.urlopen(f"http://127.0.0.1:{port}/health", timeout=1)
+                return
+            except Exception:
+                time.sleep(0.2)
+        raise AssertionError("server not ready")
+
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    common = ["--model", "tiny", "--device", "cpu", "--dtype", "fp32", "--max-model-len", "128", "--no-register"]
+    tp = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29771", "-m", "kvmini", "serve",
+                           "--tensor-parallel-size", "2", "--port", "8331", *common], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    one = subprocess.Popen([sys.executable, "-m", "kvmini", "serve", "--port", "8332", *common], env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        wait_ready(8331, tp)
+        wait_ready(8332, one)
+        a, b = ask(8331), ask(8332)
+        assert a == b and len(a.split()) == 8
+    finally:
+        one.terminate()
+        os.killpg(tp.pid, signal.SIGTERM)  # launcher and both ranks: nobody may be left waiting in a collective
+        tp.communicate(timeout=60)
+        one.wait(30)
+    assert tp.returncode is not None
