@@ -22,6 +22,10 @@ int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const 
                      int nh, int nkv, int hd, int block_size, hipStream_t stream);
 int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                        const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale, hipStream_t stream);
+int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
+                              void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
+                              void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
+                              hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
 int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
@@ -164,6 +168,34 @@ void paged_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::T
                            (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(), out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd,
                            (int)k_cache.size(2), (float)scale, cur_stream()),
         "kv_paged_attention");
+}
+
+const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* parts);
+
+// RoPE + KV write + paged attention in one launch (decode-only steps; see engine_kernels.hip)
+void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
+                            at::Tensor slot_mapping, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor out, int64_t nh,
+                            c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale) {
+  CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_I32(positions); CHECK_I32(slot_mapping); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
+  CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_BF16(out); CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(out); CHECK_CONTIG(block_tables);
+  CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping); CHECK_CONTIG(tok_seq); CHECK_CONTIG(ctx_lens); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t);
+  TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3, "slabs must be fp32 [S, T, W]");
+  TORCH_CHECK(cos_t.scalar_type() == at::kFloat && sin_t.scalar_type() == at::kFloat, "cos/sin tables must be fp32");
+  const int64_t T = slabs.size(1), W = slabs.size(2);
+  TORCH_CHECK(k_cache.dim() == 4 && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  const int64_t nkv = k_cache.size(1), hd = k_cache.size(3);
+  TORCH_CHECK(W == (nh + 2 * nkv) * hd, "slab width must be (nh + 2 nkv) * head_dim");
+  TORCH_CHECK(cos_t.dim() == 2 && cos_t.size(1) == hd / 2 && sin_t.sizes() == cos_t.sizes(), "cos/sin tables must be [max_pos, hd/2]");
+  TORCH_CHECK(positions.numel() >= T && slot_mapping.numel() >= T && tok_seq.numel() >= T && ctx_lens.numel() >= T, "per-token index tensors shorter than T");
+  TORCH_CHECK(block_tables.dim() == 2 && out.dim() == 2 && out.size(0) == T && out.size(1) == nh * hd, "bad block_tables/out shape");
+  int parts = 0;
+  const float* ssp = ss_ptr(row_ss, T, &parts);
+  check(kv_decode_attention_fused((const float*)slabs.data_ptr(), (int)slabs.size(0), T * W, (const int*)positions.data_ptr(), (const float*)cos_t.data_ptr(),
+                                  (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(),
+                                  (const int*)block_tables.data_ptr(), (int)block_tables.size(1), (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(),
+                                  out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps, (float)scale,
+                                  cur_stream()),
+        "kv_decode_attention_fused");
 }
 
 void argmax(at::Tensor logits, at::Tensor out) {
@@ -376,6 +408,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("add_rmsnorm", &add_rmsnorm);
   m.def("rope_kv_write", &rope_kv_write);
   m.def("paged_attention", &paged_attention);
+  m.def("decode_attention_fused", &decode_attention_fused);
   m.def("argmax", &argmax);
   m.def("swiglu_interleaved", &swiglu_interleaved);
   m.def("skinny_gemm", &skinny_gemm);

@@ -406,6 +406,229 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
 }
 
 // ---------------------------------------------------------------------------------
+// Decode-step fusion: RoPE + KV write + paged attention in ONE launch, for steps in which
+// every token is the only new token of its sequence (plain decoding: no prompt chunk needs
+// keys that another workgroup of the same launch is still producing).  One workgroup per
+// (token, kv head):
+//   phase A  sum the split-K slabs of this head group's q rows (REP heads), k row and v row,
+//            apply the folded RMSNorm row scale and RoPE, round to bf16 like the two-kernel
+//            path; q (pre-scaled) and the token's own k / v stay in LDS, k / v also go to
+//            the paged cache for later steps;
+//   phase B  the 4 waves walk the sequence's EARLIER positions in the cache (online softmax,
+//            same lane roles as paged_attention_kernel) and wave 0 folds in the token's own
+//            key / value from LDS — nothing written in phase A is read back from memory.
+// Saves one kernel boundary and one slab -> q round trip per layer.  head_dim 128, block 16.
+template <int REP>
+__global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+                                                                     const int* __restrict__ positions, const float* __restrict__ cos_t,
+                                                                     const float* __restrict__ sin_t, unsigned short* __restrict__ k_cache,
+                                                                     unsigned short* __restrict__ v_cache, const int* __restrict__ slot_mapping,
+                                                                     const int* __restrict__ block_tables, int max_blocks_per_seq,
+                                                                     const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
+                                                                     unsigned short* __restrict__ out, int nh, int nkv,
+                                                                     const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
+                                                                     float scale_log2e) {
+  constexpr int HD = 128, BS = 16, HALF = 64;
+  __shared__ float q_lds[REP][HD];            // RoPE'd q, bf16-rounded, times scale*log2(e)
+  __shared__ float kown_lds[HD], vown_lds[HD];  // this token's key / value (bf16-rounded)
+  __shared__ float p_lds[4][REP][BS];
+  __shared__ float m_lds[4][REP], l_lds[4][REP];
+  __shared__ float o_lds[4][REP][HD];
+  const int t = blockIdx.x, g = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ctx = ctx_lens[t];
+  unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
+  if (ctx <= 0) {  // padding token: no KV write (slot -1), zero output
+    for (int i = tid; i < REP * HD; i += 256) orow[i] = 0;
+    return;
+  }
+  // ---- phase A
+  {
+    float rs = 1.f;
+    if (row_ss != nullptr) {
+      float ssum = 0.f;
+      for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)t * ss_parts + p];
+      rs = rsqrtf(ssum * inv_h + eps);
+    }
+    const int width = (nh + 2 * nkv) * HD;
+    const float* row0 = slabs + (long long)t * width;
+    auto load8 = [&](int col, float* a) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      for (int sidx = 0; sidx < n_slabs; ++sidx) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(row0 + (long long)sidx * slab_stride + col);
+        f32x4 lo = p[0], hi = p[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += lo[j]; a[4 + j] += hi[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = bf2f(f2bf(a[j] * rs));  // the GEMM output as bf16
+    };
+    const int pos = positions[t];
+    const int slot = slot_mapping[t];
+    const float* cs = cos_t + (long long)pos * HALF;
+    const float* sn = sin_t + (long long)pos * HALF;
+    const long long cache_row = slot >= 0 ? (((long long)(slot / BS) * nkv + g) * BS + slot % BS) * HD : -1;
+    // rotation tasks: (REP q heads + 1 k head) x 8 pieces of 8 dims (first half + its partner)
+    constexpr int ROT = (REP + 1) * 8;
+    if (tid < ROT) {
+      const int hsel = tid >> 3, d0 = (tid & 7) << 3;
+      const int col = hsel < REP ? (g * REP + hsel) * HD : (nh + g) * HD;
+      float a[8], b[8];
+      load8(col + d0, a);
+      load8(col + HALF + d0, b);
+      bf16x8 oa, ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = cs[d0 + j], sv = sn[d0 + j];
+        oa[j] = f2bf(a[j] * c - b[j] * sv);
+        ob[j] = f2bf(b[j] * c + a[j] * sv);
+      }
+      if (hsel < REP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q_lds[hsel][d0 + j] = bf2f(oa[j]) * scale_log2e; q_lds[hsel][HALF + d0 + j] = bf2f(ob[j]) * scale_log2e; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kown_lds[d0 + j] = bf2f(oa[j]); kown_lds[HALF + d0 + j] = bf2f(ob[j]); }
+        if (cache_row >= 0) {
+          *reinterpret_cast<bf16x8*>(k_cache + cache_row + d0) = oa;
+          *reinterpret_cast<bf16x8*>(k_cache + cache_row + HALF + d0) = ob;
+        }
+      }
+    } else if (tid < ROT + 16) {
+      const int d0 = (tid - ROT) << 3;
+      float a[8];
+      load8((nh + nkv + g) * HD + d0, a);
+      bf16x8 ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ov[j] = f2bf(a[j]); vown_lds[d0 + j] = a[j]; }
+      if (cache_row >= 0) *reinterpret_cast<bf16x8*>(v_cache + cache_row + d0) = ov;
+    }
+  }
+  __syncthreads();
+  // ---- phase B: earlier positions from the cache
+  const int prev = ctx - 1;
+  const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
+  const int n_blocks = (prev + BS - 1) / BS;
+  const int qk_tok = lane >> 2, qk_c = lane & 3;
+  float qf[REP][32];
+#pragma unroll
+  for (int h = 0; h < REP; ++h)
+#pragma unroll
+    for (int j = 0; j < 32; ++j) qf[h][j] = q_lds[h][qk_c * 32 + j];
+  const int pv_tg = lane >> 4, pv_dv = lane & 15;
+  float acc[REP][8];
+  float m_run[REP], l_run[REP];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) {
+    m_run[h] = -1e30f; l_run[h] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+  }
+  for (int b = wave; b < n_blocks; b += 4) {
+    const long long base = ((long long)bt[b] * nkv + g) * BS * HD;
+    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
+    bf16x8 kv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+    bf16x8 vv[4];
+    const unsigned short* vp = v_cache + base + pv_dv * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+    float s[REP];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += qf[h][v * 8 + j] * bf2f(kv[v][j]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      s[h] = (b * BS + qk_tok < prev) ? d : -1e30f;
+    }
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float mx = s[h];
+      for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float m_new = fmaxf(m_run[h], mx);
+      const float p = exp2f(s[h] - m_new);
+      float ps = p;
+      for (int o = 4; o < 64; o <<= 1) ps += __shfl_xor(ps, o, 64);
+      const float corr = exp2f(m_run[h] - m_new);
+      l_run[h] = l_run[h] * corr + ps;
+      m_run[h] = m_new;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[h][j] *= corr;
+      if (qk_c == 0) p_lds[wave][h][qk_tok] = p;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tok = pv_tg + 4 * i;
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float p = p_lds[wave][h][tok];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[h][j] += p * bf2f(vv[i][j]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- the token's own key / value (wave 0; one token group adds the value)
+  if (wave == 0) {
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) d += qf[h][j] * kown_lds[qk_c * 32 + j];
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      const float m_new = fmaxf(m_run[h], d);
+      const float p = exp2f(d - m_new);
+      const float corr = exp2f(m_run[h] - m_new);
+      l_run[h] = l_run[h] * corr + p;
+      m_run[h] = m_new;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * corr + (pv_tg == 0 ? p * vown_lds[pv_dv * 8 + j] : 0.f);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < REP; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = acc[h][j];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[h][j] = v;
+    }
+  if (pv_tg == 0) {
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o_lds[wave][h][pv_dv * 8 + j] = acc[h][j];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int h = 0; h < REP; ++h) { m_lds[wave][h] = m_run[h]; l_lds[wave][h] = l_run[h]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < REP * HD; i += 256) {
+    const int h = i / HD, d = i % HD;
+    float m = fmaxf(fmaxf(m_lds[0][h], m_lds[1][h]), fmaxf(m_lds[2][h], m_lds[3][h]));
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float c = exp2f(m_lds[w][h] - m);
+      num += o_lds[w][h][d] * c;
+      den += l_lds[w][h] * c;
+    }
+    orow[i] = f2bf(den > 0.f ? num / den : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Row-wise argmax of bf16 logits [S, V] -> int64 ids.  One 1024-thread workgroup per row.
 __global__ __launch_bounds__(1024) void argmax_kernel(const unsigned short* __restrict__ logits, long long row_stride, int V, long long* __restrict__ out) {
   __shared__ float bv[16];
@@ -575,6 +798,33 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
   }
   if (hd == 128) { KV_BY_REP(128) } else { KV_BY_REP(64) }
 #undef KV_BY_REP
+#undef KV_LAUNCH
+  return (int)hipGetLastError();
+}
+
+// slabs: fp32 [n_slabs][T][(nh + 2 nkv) * 128] split-K partial sums of the fused QKV projection.
+// Valid only when every token of the step is the sole new token of its sequence.
+int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
+                              void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
+                              void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
+                              hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1) return -1;
+  const int rep = nh / nkv;
+  const float sl = scale * 1.4426950408889634f;
+  const float inv_h = h_in > 0 ? 1.f / (float)h_in : 0.f;
+  dim3 grid(T, nkv), block(256);
+#define KV_LAUNCH(R)                                                                                                                                   \
+  hipLaunchKernelGGL(decode_attention_fused_kernel<R>, grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t,                   \
+                     (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens,            \
+                     (unsigned short*)out, nh, nkv, row_ss, ss_parts, inv_h, eps, sl)
+  switch (rep) {
+    case 1: KV_LAUNCH(1); break;
+    case 2: KV_LAUNCH(2); break;
+    case 4: KV_LAUNCH(4); break;
+    case 8: KV_LAUNCH(8); break;
+    default: return -1;
+  }
 #undef KV_LAUNCH
   return (int)hipGetLastError();
 }

@@ -345,7 +345,7 @@ class LLMEngine:
             "preemptions": self.scheduler.num_preemptions,
             "spec_proposed": st.spec_proposed,
             "spec_accepted": st.spec_accepted,
-            "graphs": sorted(self.runner.graphs),
+            "graphs": sorted({b for b, _ in self.runner.graphs}),
             "load_s": self.load_s,
             "warm_s": self.warm_s,
         }

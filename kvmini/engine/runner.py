@@ -122,7 +122,7 @@ class ModelRunner:
         self.spec_width = 1  # positions sampled per sequence per step (k+1 with speculation)
         self.s_cap = tmax
         self.set_spec_width(1)
-        self.graphs: Dict[int, Any] = {}
+        self.graphs: Dict[Tuple[int, bool], Any] = {}  # (token bucket, decode-only variant) -> (graph, logits)
         self._graph_pool = None
         self.steps = 0
 
@@ -158,9 +158,11 @@ class ModelRunner:
         raise ValueError(f"{t} tokens exceed max_batched_tokens={self.buckets[-1]}")
 
     # ------------------------------------------------------------------
-    def forward(self, t_pad: int, max_blocks: Optional[int] = None) -> torch.Tensor:
+    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: bool = False) -> torch.Tensor:
         """The ragged forward pass over the first ``t_pad`` staged tokens; writes
-        sampled ids into ``out_ids[:t_pad]`` and returns the logits ``[t_pad, V]``."""
+        sampled ids into ``out_ids[:t_pad]`` and returns the logits ``[t_pad, V]``.
+        ``decode_only``: every staged token is the only new token of its sequence, which
+        allows RoPE + KV write + attention to run as one kernel."""
         ops, cfg, w = self.ops, self.cfg, self.w
         tokens = self._dev("tokens", t_pad)
         positions = self._dev("positions", t_pad)
@@ -176,8 +178,11 @@ class ModelRunner:
             h, residual = ops.add_rmsnorm(x, residual, lw.attn_norm, cfg.rms_eps)
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
-            q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
-            a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
+            if decode_only and self._fused_ok(qkv, kc):
+                a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale)
+            else:
+                q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
+                a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
             x = ops.linear(a, lw.wo, allow_slabs=self.tp_size == 1)
             if self.tp_size > 1:
                 x = x.contiguous()
@@ -194,6 +199,10 @@ class ModelRunner:
         self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
         return logits
 
+    def _fused_ok(self, qkv: Any, k_cache: torch.Tensor) -> bool:
+        fn = getattr(self.ops, "supports_fused_decode_attention", None)
+        return fn is not None and fn(qkv, self.nh, k_cache)
+
     # ------------------------------------------------------------------
     def capture_graphs(self, buckets: Optional[Sequence[int]] = None) -> None:
         """Capture one HIP graph per token bucket (largest first so the smaller
@@ -203,33 +212,37 @@ class ModelRunner:
         if self.tp_size > 1 and not self.rcfg.tp_graphs:
             return  # collectives inside captured graphs are opt-in (every rank must capture in step)
         self._stage_dummy()
-        for b in sorted(buckets or self.buckets, reverse=True):
-            if b in self.graphs:
+        variants = [(b, False) for b in sorted(buckets or self.buckets, reverse=True)]
+        # decode-sized buckets also get the decode-only variant (fused RoPE + attention kernel)
+        variants += [(b, True) for b, _ in variants if b <= self.rcfg.max_num_seqs and b <= 64 and hasattr(self.ops, "rope_attention_fused")]
+        for b, dec in variants:
+            key = (b, dec)
+            if key in self.graphs:
                 continue
             # warm-up on a side stream (allocator + lazy init), then capture
             s = torch.cuda.Stream(self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(s):
                 for _ in range(2):
-                    self.forward(b)
+                    self.forward(b, decode_only=dec)
             torch.cuda.current_stream(self.device).wait_stream(s)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._graph_pool):
-                logits = self.forward(b)
+                logits = self.forward(b, decode_only=dec)
             if self._graph_pool is None:
                 self._graph_pool = g.pool()
-            self.graphs[b] = (g, logits)
+            self.graphs[key] = (g, logits)
         torch.cuda.synchronize(self.device)
 
-    def _run_staged(self, t_pad: int, max_ctx: int) -> torch.Tensor:
-        entry = self.graphs.get(t_pad)
+    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: bool = False) -> torch.Tensor:
+        entry = self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, False))
         if entry is not None:
             g, logits = entry
             g.replay()
         else:
             with torch.no_grad():
-                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size)
+                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size, decode_only=decode_only)
         self.steps += 1
         return logits
 
@@ -247,10 +260,10 @@ class ModelRunner:
         n = 0
         while True:
             torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
-            t_pad, _n_samples, max_ctx, cmd = self.stage_dev[o_h : o_h + 4].tolist()
+            t_pad, _n_samples, max_ctx, cmd, dec = self.stage_dev[o_h : o_h + 5].tolist()
             if cmd == 1:
                 return n
-            self._run_staged(int(t_pad), int(max_ctx))
+            self._run_staged(int(t_pad), int(max_ctx), bool(dec))
             n += 1
 
     def stop_followers(self) -> None:
@@ -258,7 +271,7 @@ class ModelRunner:
         if self.tp_size <= 1:
             return
         o_h = self._off["header"][0]
-        self.stage_np[o_h : o_h + 4] = (0, 0, 0, 1)
+        self.stage_np[o_h : o_h + 5] = (0, 0, 0, 1, 0)
         self.stage_dev.copy_(self.stage_cpu)
         torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
 
@@ -330,13 +343,15 @@ class ModelRunner:
             st[o_ctx + t : o_ctx + t_pad] = 0
         st[o_smp + n_samples : o_smp + t_pad] = 0
 
+        # plain decoding step: every chunk is one token (no prompt chunk, no drafts to verify)
+        decode_only = all(ch.n_tokens == 1 for ch in batch.chunks)
         o_h = self._off["header"][0]
-        st[o_h : o_h + 4] = (t_pad, n_samples, max_ctx, 0)
+        st[o_h : o_h + 5] = (t_pad, n_samples, max_ctx, 0, int(decode_only))
         self.stage_dev.copy_(self.stage_cpu, non_blocking=True)
         if self.tp_size > 1:
             # every rank runs the same step: ship the staged inputs to the followers (see follow())
             torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
-        logits = self._run_staged(t_pad, max_ctx)
+        logits = self._run_staged(t_pad, max_ctx, decode_only)
         if self.device.type == "cuda":
             self.out_ids_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()

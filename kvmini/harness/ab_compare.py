@@ -36,50 +36,85 @@ def summarize_test(test_dir: str, backend: str, streaming: bool, requests: int, 
         return None
     ttft: List[float] = []
     tpot: List[float] = []
+    lat: List[float] = []
+
+    def num(row: Dict[str, str], key: str) -> Optional[float]:
+        try:
+            v = float(row.get(key) or "")
+        except ValueError:
+            return None
+        return None if v != v else v
+
     with open(req_csv) as f:
         for row in csv.DictReader(f):
             if row.get("status") != "200":
                 continue
-            v = row.get("ttft_ms") or row.get("ttfb_ms")
-            if v:
-                ttft.append(float(v))
-            if row.get("tpot_ms"):
-                tpot.append(float(row["tpot_ms"]))
+            if num(row, "latency_ms") is not None:
+                lat.append(num(row, "latency_ms"))
+            if streaming:  # a non-streamed response has no first token: its "first byte" is the whole answer
+                v = num(row, "ttft_ms")
+                v = num(row, "ttfb_ms") if v is None else v
+                if v is not None:
+                    ttft.append(v)
+            # time per output token: the column when a producer wrote it (the reference's
+            # ab-compare.sh:209 expects one nobody writes), else decode time / decoded tokens
+            t = num(row, "tpot_ms")
+            if t is None:
+                first = num(row, "ttft_ms")
+                first = num(row, "ttfb_ms") if first is None else first
+                last, n = num(row, "tllt_ms"), num(row, "completion_tokens")
+                if streaming and first is not None and last is not None and n and n > 1:
+                    t = (last - first) / (n - 1)
+                elif not streaming and n and num(row, "latency_ms") is not None:
+                    t = num(row, "latency_ms") / n  # whole-request time per token (includes prefill)
+            if t is not None:
+                tpot.append(t)
 
-    def p95(xs: List[float]) -> float:
-        return sorted(xs)[min(len(xs) - 1, int(0.95 * len(xs)))] if xs else 0.0
+    def p95(xs: List[float]) -> Optional[float]:
+        return sorted(xs)[min(len(xs) - 1, int(0.95 * len(xs)))] if xs else None
+
+    def r(v: Optional[float], nd: int) -> Optional[float]:
+        return None if v is None else round(float(v), nd)
 
     res_path = os.path.join(test_dir, "results.json")
     summary = load_json(res_path) if os.path.exists(res_path) else {}
+    # a metric nobody measured stays empty (None): a 0.0 placeholder would win every "lowest" ranking
     return {
         "backend": backend,
         "streaming": "true" if streaming else "false",
         "requests": requests,
         "concurrency": concurrency,
-        "mean_ttft_ms": round(statistics.mean(ttft), 1) if ttft else 0.0,
-        "p95_ttft_ms": round(p95(ttft), 1),
-        "mean_tpot_ms": round(statistics.mean(tpot), 1) if tpot else 0.0,
-        "p95_tpot_ms": round(p95(tpot), 1),
-        "throughput_req_s": round(float(summary.get("throughput_rps") or summary.get("throughput_req_per_sec") or 0.0), 2),
-        "gpu_util_avg": round(float(summary.get("gpu_util_avg") or summary.get("gpu_utilization_avg") or 0.0), 1),
-        "cost_per_1k_tokens": round(float(summary.get("cost_per_1k_tokens") or 0.0), 6),
+        "mean_ttft_ms": r(statistics.mean(ttft), 1) if ttft else None,
+        "p95_ttft_ms": r(p95(ttft), 1),
+        "mean_tpot_ms": r(statistics.mean(tpot), 2) if tpot else None,
+        "p95_tpot_ms": r(p95(tpot), 2),
+        "throughput_req_s": r(summary.get("throughput_rps") or summary.get("throughput_req_per_sec"), 2),
+        "gpu_util_avg": r(summary.get("gpu_util_avg") if summary.get("gpu_util_avg") is not None else summary.get("gpu_utilization_avg"), 1),
+        "cost_per_1k_tokens": r(summary.get("cost_per_1k_tokens"), 6),
+        "mean_latency_ms": r(statistics.mean(lat), 1) if lat else None,  # JSON report only; the CSV keeps the reference's columns
     }
 
 
 def build_report(rows: List[Dict[str, Any]], meta: Dict[str, Any]) -> Dict[str, Any]:
-    def f(r: Dict[str, Any], k: str) -> float:
-        return float(r[k])
+    def f(r: Dict[str, Any], k: str) -> Optional[float]:
+        v = r.get(k)
+        return None if v in (None, "") else float(v)
 
-    best_ttft = min(rows, key=lambda r: f(r, "mean_ttft_ms"))
-    best_tp = max(rows, key=lambda r: f(r, "throughput_req_s"))
-    best_cost = min(rows, key=lambda r: f(r, "cost_per_1k_tokens"))
+    def best(k: str, pick: Any, unit_key: str) -> Optional[Dict[str, Any]]:
+        cands = [r for r in rows if f(r, k) is not None]
+        if not cands:
+            return None
+        w = pick(cands, key=lambda r: f(r, k))
+        return {"backend": w["backend"], "streaming": w["streaming"], unit_key: f(w, k)}
+
     report: Dict[str, Any] = {
         "comparison_metadata": meta,
         "results": rows,
         "winners": {
-            "fastest_ttft": {"backend": best_ttft["backend"], "streaming": best_ttft["streaming"], "value_ms": f(best_ttft, "mean_ttft_ms")},
-            "highest_throughput": {"backend": best_tp["backend"], "streaming": best_tp["streaming"], "value_req_s": f(best_tp, "throughput_req_s")},
-            "lowest_cost": {"backend": best_cost["backend"], "streaming": best_cost["streaming"], "value_per_1k": f(best_cost, "cost_per_1k_tokens")},
+            "fastest_ttft": best("mean_ttft_ms", min, "value_ms"),
+            "fastest_tpot": best("mean_tpot_ms", min, "value_ms"),
+            "highest_throughput": best("throughput_req_s", max, "value_req_s"),
+            "lowest_cost": best("cost_per_1k_tokens", min, "value_per_1k"),
         },
     }
     by: Dict[str, Dict[str, Dict[str, Any]]] = {}
@@ -88,9 +123,13 @@ def build_report(rows: List[Dict[str, Any]], meta: Dict[str, Any]) -> Dict[str, 
     deltas = {}
     for b, modes in by.items():
         if "true" in modes and "false" in modes:
+            # what streaming buys: the first token arrives this much earlier than the complete
+            # non-streamed answer (mean request latency), at this throughput difference
+            lat_ns, ttft_s = f(modes["false"], "mean_latency_ms"), f(modes["true"], "mean_ttft_ms")
+            tp_s, tp_ns = f(modes["true"], "throughput_req_s"), f(modes["false"], "throughput_req_s")
             deltas[b] = {
-                "ttft_advantage_ms": f(modes["false"], "mean_ttft_ms") - f(modes["true"], "mean_ttft_ms"),
-                "throughput_advantage_req_s": f(modes["true"], "throughput_req_s") - f(modes["false"], "throughput_req_s"),
+                "ttft_advantage_ms": None if lat_ns is None or ttft_s is None else lat_ns - ttft_s,
+                "throughput_advantage_req_s": None if tp_s is None or tp_ns is None else tp_s - tp_ns,
             }
     if deltas:
         report["streaming_vs_non_streaming"] = deltas
@@ -141,7 +180,9 @@ class ABRunner:
         tag = f"{backend}_{'streaming' if streaming else 'nonstreaming'}"
         test_dir = os.path.join(self.a.run_dir, tag)
         print(f"Testing {backend} (streaming: {str(streaming).lower()}) -> {test_dir}")
-        argv = ["--namespace", self.a.namespace, "--service", self.service(backend), "--url", url, "--model", self.a.model, "--requests", str(self.s["requests"]), "--concurrency", str(self.s["concurrency"]), "--max-tokens", str(self.s["max_tokens"]), "--pattern", self.s["pattern"], "--run-dir", test_dir, "--protocol", PROTOCOL.get(backend, "openai"), "--cost-file", self.a.cost_file, "--no-energy"]
+        argv = ["--namespace", self.a.namespace, "--service", self.service(backend), "--url", url, "--model", self.a.model, "--requests", str(self.s["requests"]), "--concurrency", str(self.s["concurrency"]), "--max-tokens", str(self.s["max_tokens"]), "--pattern", self.s["pattern"], "--run-dir", test_dir, "--protocol", PROTOCOL.get(backend, "openai"), "--cost-file", self.a.cost_file]
+        if backend == "mock" or self.a.no_energy:
+            argv.append("--no-energy")
         if not streaming:
             argv.append("--no-stream")
         if self.a.cluster_backend:
@@ -160,9 +201,9 @@ class ABRunner:
     def write_csv(self) -> str:
         path = os.path.join(self.a.run_dir, "ab_comparison.csv")
         with open(path, "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=CSV_COLS)
+            w = csv.DictWriter(f, fieldnames=CSV_COLS, extrasaction="ignore")
             w.writeheader()
-            w.writerows(self.rows)
+            w.writerows({k: ("" if v is None else v) for k, v in r.items()} for r in self.rows)
         return path
 
     def run(self) -> Optional[Dict[str, Any]]:
@@ -210,6 +251,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--endpoints", nargs="*", default=None, metavar="NAME=URL", help="already-running endpoints to compare (no deploy / cleanup)")
     ap.add_argument("--cluster-backend", default=None, choices=["auto", "kubectl", "local", "fake"])
     ap.add_argument("--cost-file", default="cost.yaml")
+    ap.add_argument("--no-energy", action="store_true", help="do not sample amd-smi power during the tests")
     a = ap.parse_args(argv)
     try:
         profile = load_profile(a.profile)
@@ -225,11 +267,18 @@ def main(argv: Optional[List[str]] = None) -> int:
         return 1
     w = report["winners"]
     print("\n=== A/B comparison results ===")
-    print(f"  Fastest TTFT:       {w['fastest_ttft']['backend']} (streaming: {w['fastest_ttft']['streaming']}) - {w['fastest_ttft']['value_ms']} ms")
-    print(f"  Highest throughput: {w['highest_throughput']['backend']} - {w['highest_throughput']['value_req_s']} req/s")
-    print(f"  Lowest cost:        {w['lowest_cost']['backend']} - ${w['lowest_cost']['value_per_1k']} per 1K tokens")
+
+    def line(title: str, key: str, val_key: str, unit: str) -> None:
+        x = w.get(key)
+        print(f"  {title:<20}" + ("not measured" if not x else f"{x['backend']} (streaming: {x['streaming']}) - {x[val_key]} {unit}"))
+
+    line("Fastest TTFT:", "fastest_ttft", "value_ms", "ms")
+    line("Fastest per token:", "fastest_tpot", "value_ms", "ms/token")
+    line("Highest throughput:", "highest_throughput", "value_req_s", "req/s")
+    line("Lowest cost:", "lowest_cost", "value_per_1k", "$ per 1K tokens")
     for b, d in (report.get("streaming_vs_non_streaming") or {}).items():
-        print(f"  {b}: streaming TTFT advantage {d['ttft_advantage_ms']:+.1f} ms, throughput {d['throughput_advantage_req_s']:+.2f} req/s")
+        ta, tp = d["ttft_advantage_ms"], d["throughput_advantage_req_s"]
+        print(f"  {b}: first token {'n/a' if ta is None else f'{ta:.1f} ms'} earlier than the complete non-streamed answer, throughput {'n/a' if tp is None else f'{tp:+.2f} req/s'}")
     print(f"Results directory: {a.run_dir}")
     return 0
 

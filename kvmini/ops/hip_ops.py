@@ -308,6 +308,36 @@ def paged_attention(
     return out
 
 
+def supports_fused_decode_attention(qkv: Any, n_heads: int, k_cache: torch.Tensor) -> bool:
+    """Shapes the one-launch RoPE + KV write + attention kernel covers."""
+    nkv, bs, hd = k_cache.shape[1], k_cache.shape[2], k_cache.shape[3]
+    return isinstance(qkv, Partial) and hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in (1, 2, 4, 8)
+
+
+def rope_attention_fused(
+    qkv: Partial,
+    positions: torch.Tensor,
+    cos: torch.Tensor,
+    sin: torch.Tensor,
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    slot_mapping: torch.Tensor,
+    block_tables: torch.Tensor,
+    tok_seq: torch.Tensor,
+    ctx_lens: torch.Tensor,
+    n_heads: int,
+    scale: float,
+) -> torch.Tensor:
+    """RoPE + paged-KV write + attention for a step in which every token is the only new
+    token of its sequence (plain decoding).  ``qkv`` must be the split-K slabs of the QKV
+    projection; returns the attention output ``[T, nh*hd]``."""
+    t = qkv.slabs.shape[1]
+    hd = k_cache.shape[3]
+    out = torch.empty((t, n_heads * hd), dtype=torch.bfloat16, device=qkv.slabs.device)
+    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale)
+    return out
+
+
 def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
     out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
     native().argmax(logits, out)

@@ -53,11 +53,11 @@ quant)     # config 4: bf16 vs fp8 quantization sweep on the native engine
     --report --run-dir "$OUT/llama70b_1gpu" > "$OUT/llama70b.log" 2>&1 || { tail -30 "$OUT/llama70b.log"; exit 1; }
   stop_server; tail -14 "$OUT/llama70b.log" ;;
 ab)        # config 5 (single-box part): native engine vs protocol mocks of the two cluster backends
-  start_server abn 8105 --model "$MODEL" || exit 1
-  python -m kvmini mock --port 8106 --model mock-vllm > "$OUT/mock_vllm.log" 2>&1 & M1=$!
-  python -m kvmini mock --port 8107 --model mock-tgi > "$OUT/mock_tgi.log" 2>&1 & M2=$!
+  start_server "$MODEL-native" 8105 --model "$MODEL" --namespace ab || exit 1
+  python -m kvmini mock --port 8106 --model mock-vllm --service "$MODEL-vllm-rocm" --register > "$OUT/mock_vllm.log" 2>&1 & M1=$!
+  python -m kvmini mock --port 8107 --model mock-tgi --service "$MODEL-tgi-rocm" --register > "$OUT/mock_tgi.log" 2>&1 & M2=$!
   sleep 2
-  timeout -k 10 600 python -m kvmini ab-compare --backends native,vllm-rocm,tgi-rocm --model "$MODEL" --profile standard --toggle-streaming --cluster-backend local \
+  timeout -k 10 600 python -m kvmini ab-compare --backends native,vllm-rocm,tgi-rocm --model "$MODEL" --profile standard --toggle-streaming --cluster-backend local --namespace ab \
     --endpoints native=http://127.0.0.1:8105 vllm-rocm=http://127.0.0.1:8106 tgi-rocm=http://127.0.0.1:8107 --run-dir "$OUT/ab" > "$OUT/ab.log" 2>&1 || { kill $M1 $M2; tail -30 "$OUT/ab.log"; exit 1; }
   kill $M1 $M2 2>/dev/null; stop_server; tail -14 "$OUT/ab.log" ;;
 spec)      # config 3: speculative decoding TTFT / inter-token delta report

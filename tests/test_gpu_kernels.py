@@ -550,3 +550,40 @@ def test_sampler_loaded_before_torch_keeps_one_hip_runtime():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
     assert "WH 1.0" in r.stdout and "NHIP 1" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("rep", [1, 4, 8])
+def test_fused_decode_attention_matches_two_kernel_path(rep):
+    """RoPE + KV write + attention in one launch == rope_kv_write_slabs followed by
+    paged_attention, for a decode-only step (one new token per sequence, padding rows included)."""
+    from kvmini.models.llama import LlamaConfig, rope_tables
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(7)
+    nkv, hd, bs, nb = 2, 128, 16, 96
+    nh = nkv * rep
+    n_seqs, max_blocks, T, S, h_in = 16, 6, 16, 5, 512
+    width = (nh + 2 * nkv) * hd
+    cos, sin = rope_tables(LlamaConfig(head_dim=hd), 128, _dev())
+    ctx = torch.tensor([1, 2, 16, 17, 33, 64, 80, 0, 5, 48, 96, 31, 32, 0, 9, 65], device=_dev(), dtype=torch.int32)
+    positions = (ctx - 1).clamp(min=0)
+    tok_seq = torch.arange(T, device=_dev(), dtype=torch.int32)
+    bt = torch.randperm(nb, device=_dev())[: n_seqs * max_blocks].view(n_seqs, max_blocks).int()
+    slots = torch.where(ctx > 0, bt[torch.arange(T, device=_dev()), (positions // bs).long()] * bs + positions % bs, torch.full_like(ctx, -1)).int()
+    slabs = torch.randn(S, T, width, device=_dev()) * 0.4
+    ss = torch.rand(T, 1, device=_dev()) * h_in + 1.0
+
+    def caches():
+        g = torch.Generator(device=_dev()); g.manual_seed(1)
+        return (torch.randn(nb, nkv, bs, hd, device=_dev(), generator=g).bfloat16(), torch.randn(nb, nkv, bs, hd, device=_dev(), generator=g).bfloat16())
+
+    kc1, vc1 = caches()
+    part = hip_ops.Partial(slabs, ss, 1e-5, h_in)
+    q = hip_ops.rope_kv_write(part, positions, cos, sin, kc1, vc1, slots, nh, nkv, hd)
+    ref = hip_ops.paged_attention(q, kc1, vc1, bt, tok_seq, ctx, 1 / math.sqrt(hd))
+    kc2, vc2 = caches()
+    assert hip_ops.supports_fused_decode_attention(part, nh, kc2)
+    out = hip_ops.rope_attention_fused(part, positions, cos, sin, kc2, vc2, slots, bt, tok_seq, ctx, nh, 1 / math.sqrt(hd))
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)  # identical cache writes
+    assert (out.float() - ref.float()).abs().max().item() <= 2e-2
+    assert out[7].abs().max().item() == 0 and out[13].abs().max().item() == 0  # padding rows
