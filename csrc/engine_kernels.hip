@@ -136,12 +136,28 @@ __global__ __launch_bounds__(64) void residual_reduce_kernel(const float* __rest
     if (SLAB) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = 0.f;
-#pragma unroll 4
-      for (int sidx = 0; sidx < n_slabs; ++sidx) {
-        const f32x4* q = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + off);
-        f32x4 lo = q[0], hi = q[1];
+      // all slab loads of the lane are issued before the first add (one memory round trip
+      // instead of n_slabs / 4); the sum runs in slab order
+      constexpr int MAX_S = 16;
+      f32x4 lo[MAX_S], hi[MAX_S];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] += lo[j]; a[4 + j] += hi[j]; }
+      for (int sidx = 0; sidx < MAX_S; ++sidx)
+        if (sidx < n_slabs) {
+          const f32x4* q = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + off);
+          lo[sidx] = q[0];
+          hi[sidx] = q[1];
+        }
+#pragma unroll
+      for (int sidx = 0; sidx < MAX_S; ++sidx)
+        if (sidx < n_slabs) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] += lo[sidx][j]; a[4 + j] += hi[sidx][j]; }
+        }
+      for (int sidx = MAX_S; sidx < n_slabs; ++sidx) {  // more than 16 splits: the rare tail
+        const f32x4* q = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + off);
+        f32x4 l2 = q[0], h2 = q[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += l2[j]; a[4 + j] += h2[j]; }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = bf2f(f2bf(a[j]));
@@ -200,11 +216,27 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    for (int sidx = 0; sidx < n_slabs; ++sidx) {
-      const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + (long long)t * width + col);
-      f32x4 lo = p[0], hi = p[1];
+    // loads of up to 16 slabs in flight together, summed in slab order
+    constexpr int MAX_S = 16;
+    f32x4 lo[MAX_S], hi[MAX_S];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] += lo[j]; a[4 + j] += hi[j]; }
+    for (int sidx = 0; sidx < MAX_S; ++sidx)
+      if (sidx < n_slabs) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + (long long)t * width + col);
+        lo[sidx] = p[0];
+        hi[sidx] = p[1];
+      }
+#pragma unroll
+    for (int sidx = 0; sidx < MAX_S; ++sidx)
+      if (sidx < n_slabs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += lo[sidx][j]; a[4 + j] += hi[sidx][j]; }
+      }
+    for (int sidx = MAX_S; sidx < n_slabs; ++sidx) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (long long)sidx * slab_stride + (long long)t * width + col);
+      f32x4 l2 = p[0], h2 = p[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] += l2[j]; a[4 + j] += h2[j]; }
     }
     bf16x8 o;
 #pragma unroll
@@ -410,10 +442,10 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
 // every token is the only new token of its sequence (plain decoding: no prompt chunk needs
 // keys that another workgroup of the same launch is still producing).  One workgroup per
 // (token, kv head):
-//   phase A  sum the split-K slabs of this head group's q rows (REP heads), k row and v row,
-//            apply the folded RMSNorm row scale and RoPE, round to bf16 like the two-kernel
-//            path; q (pre-scaled) and the token's own k / v stay in LDS, k / v also go to
-//            the paged cache for later steps;
+//   phase A  sum the split-K slabs of this head group's q rows (REP heads), k row and v row
+//            (all slab loads of a thread in flight at once), apply the folded RMSNorm row
+//            scale and RoPE, round to bf16 like the two-kernel path; q (pre-scaled) and the
+//            token's own k / v stay in LDS, k / v also go to the paged cache for later steps;
 //   phase B  the 4 waves walk the sequence's EARLIER positions in the cache (online softmax,
 //            same lane roles as paged_attention_kernel) and wave 0 folds in the token's own
 //            key / value from LDS — nothing written in phase A is read back from memory.
@@ -429,8 +461,9 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
                                                                      const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
                                                                      float scale_log2e) {
   constexpr int HD = 128, BS = 16, HALF = 64;
-  __shared__ float q_lds[REP][HD];            // RoPE'd q, bf16-rounded, times scale*log2(e)
-  __shared__ float kown_lds[HD], vown_lds[HD];  // this token's key / value (bf16-rounded)
+  // rows 0..REP-1: q (after A.2: RoPE'd, bf16-rounded, times scale*log2(e)); row REP: this
+  // token's key (RoPE'd); row REP+1: its value — all bf16-rounded like the cache contents
+  __shared__ float x_lds[REP + 2][HD];
   __shared__ float p_lds[4][REP][BS];
   __shared__ float m_lds[4][REP], l_lds[4][REP];
   __shared__ float o_lds[4][REP][HD];
@@ -442,7 +475,37 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
     for (int i = tid; i < REP * HD; i += 256) orow[i] = 0;
     return;
   }
-  // ---- phase A
+  // The keys / values of earlier positions do not depend on phase A: each wave loads its
+  // first KV block now, so that round trip overlaps the slab loads and the RoPE phase.
+  const int prev = ctx - 1;
+  const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
+  const int n_blocks = (prev + BS - 1) / BS;
+  const int qk_tok = lane >> 2, qk_c = lane & 3;
+  const int pv_tg = lane >> 4, pv_dv = lane & 15;
+  bf16x8 kv[4], vv[4];
+  if (wave < n_blocks) {
+    const long long base = ((long long)bt[wave] * nkv + g) * BS * HD;
+    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+    const unsigned short* vp = v_cache + base + pv_dv * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+  }
+  // likewise the RoPE table row of this token (needed in A.2)
+  constexpr int ROT = (REP + 1) * 8;  // (q heads + k) x 8 pieces of 8 dims and their partners
+  const int pos = positions[t];
+  const int slot = slot_mapping[t];
+  f32x4 csr[2], snr[2];
+  if (tid < ROT) {
+    const int d0 = (tid & 7) << 3;
+    const f32x4* cp = reinterpret_cast<const f32x4*>(cos_t + (long long)pos * HALF + d0);
+    const f32x4* sp = reinterpret_cast<const f32x4*>(sin_t + (long long)pos * HALF + d0);
+    csr[0] = cp[0]; csr[1] = cp[1]; snr[0] = sp[0]; snr[1] = sp[1];
+  }
+  // ---- phase A.1: every thread sums ONE 4-column piece of this head group's q / k / v rows
+  // over all slabs.  The slab loads are independent and issued together (one memory round
+  // trip instead of n_slabs), and summed in slab order — the order of the two-kernel path.
   {
     float rs = 1.f;
     if (row_ss != nullptr) {
@@ -452,71 +515,67 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
     }
     const int width = (nh + 2 * nkv) * HD;
     const float* row0 = slabs + (long long)t * width;
-    auto load8 = [&](int col, float* a) {
+    constexpr int PIECES = (REP + 2) * (HD / 4);  // q heads, then k, then v; 32 pieces per row
+    constexpr int MAX_S = 16;
+    for (int pc = tid; pc < PIECES; pc += 256) {
+      const int r = pc >> 5, c4 = (pc & 31) << 2;
+      const int col = (r < REP ? (g * REP + r) * HD : r == REP ? (nh + g) * HD : (nh + nkv + g) * HD) + c4;
+      f32x4 v[MAX_S];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = 0.f;
-      for (int sidx = 0; sidx < n_slabs; ++sidx) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(row0 + (long long)sidx * slab_stride + col);
-        f32x4 lo = p[0], hi = p[1];
+      for (int sidx = 0; sidx < MAX_S; ++sidx)
+        if (sidx < n_slabs) v[sidx] = *reinterpret_cast<const f32x4*>(row0 + (long long)sidx * slab_stride + col);
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] += lo[j]; a[4 + j] += hi[j]; }
-      }
+      for (int sidx = 0; sidx < MAX_S; ++sidx)
+        if (sidx < n_slabs) a += v[sidx];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = bf2f(f2bf(a[j] * rs));  // the GEMM output as bf16
-    };
-    const int pos = positions[t];
-    const int slot = slot_mapping[t];
-    const float* cs = cos_t + (long long)pos * HALF;
-    const float* sn = sin_t + (long long)pos * HALF;
+      for (int j = 0; j < 4; ++j) x_lds[r][c4 + j] = bf2f(f2bf(a[j] * rs));  // the GEMM output as bf16
+    }
+  }
+  __syncthreads();
+  // ---- phase A.2: RoPE on q and k (pairs d, d + 64), cache write of k and v
+  {
     const long long cache_row = slot >= 0 ? (((long long)(slot / BS) * nkv + g) * BS + slot % BS) * HD : -1;
-    // rotation tasks: (REP q heads + 1 k head) x 8 pieces of 8 dims (first half + its partner)
-    constexpr int ROT = (REP + 1) * 8;
-    if (tid < ROT) {
-      const int hsel = tid >> 3, d0 = (tid & 7) << 3;
-      const int col = hsel < REP ? (g * REP + hsel) * HD : (nh + g) * HD;
-      float a[8], b[8];
-      load8(col + d0, a);
-      load8(col + HALF + d0, b);
-      bf16x8 oa, ob;
+    static_assert(ROT + 16 <= 256, "one task per thread");
+    {
+      const int task = tid;
+      if (task < ROT) {
+        const int hsel = task >> 3, d0 = (task & 7) << 3;
+        bf16x8 oa, ob;
+        float fa[8], fb[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float c = cs[d0 + j], sv = sn[d0 + j];
-        oa[j] = f2bf(a[j] * c - b[j] * sv);
-        ob[j] = f2bf(b[j] * c + a[j] * sv);
-      }
-      if (hsel < REP) {
+        for (int j = 0; j < 8; ++j) {
+          const float c = csr[j >> 2][j & 3], sv = snr[j >> 2][j & 3];
+          const float x1 = x_lds[hsel][d0 + j], x2 = x_lds[hsel][HALF + d0 + j];
+          oa[j] = f2bf(x1 * c - x2 * sv);
+          ob[j] = f2bf(x2 * c + x1 * sv);
+          fa[j] = bf2f(oa[j]);
+          fb[j] = bf2f(ob[j]);
+        }
+        // in-place is safe: this task owns dims d0..d0+7 and HALF+d0.. of row hsel
+        const float sc = hsel < REP ? scale_log2e : 1.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { q_lds[hsel][d0 + j] = bf2f(oa[j]) * scale_log2e; q_lds[hsel][HALF + d0 + j] = bf2f(ob[j]) * scale_log2e; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { kown_lds[d0 + j] = bf2f(oa[j]); kown_lds[HALF + d0 + j] = bf2f(ob[j]); }
-        if (cache_row >= 0) {
+        for (int j = 0; j < 8; ++j) { x_lds[hsel][d0 + j] = fa[j] * sc; x_lds[hsel][HALF + d0 + j] = fb[j] * sc; }
+        if (hsel == REP && cache_row >= 0) {
           *reinterpret_cast<bf16x8*>(k_cache + cache_row + d0) = oa;
           *reinterpret_cast<bf16x8*>(k_cache + cache_row + HALF + d0) = ob;
         }
-      }
-    } else if (tid < ROT + 16) {
-      const int d0 = (tid - ROT) << 3;
-      float a[8];
-      load8((nh + nkv + g) * HD + d0, a);
-      bf16x8 ov;
+      } else if (task < ROT + 16 && cache_row >= 0) {
+        const int d0 = (task - ROT) << 3;
+        bf16x8 ov;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ov[j] = f2bf(a[j]); vown_lds[d0 + j] = a[j]; }
-      if (cache_row >= 0) *reinterpret_cast<bf16x8*>(v_cache + cache_row + d0) = ov;
+        for (int j = 0; j < 8; ++j) ov[j] = f2bf(x_lds[REP + 1][d0 + j]);
+        *reinterpret_cast<bf16x8*>(v_cache + cache_row + d0) = ov;
+      }
     }
   }
   __syncthreads();
   // ---- phase B: earlier positions from the cache
-  const int prev = ctx - 1;
-  const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
-  const int n_blocks = (prev + BS - 1) / BS;
-  const int qk_tok = lane >> 2, qk_c = lane & 3;
   float qf[REP][32];
 #pragma unroll
   for (int h = 0; h < REP; ++h)
 #pragma unroll
-    for (int j = 0; j < 32; ++j) qf[h][j] = q_lds[h][qk_c * 32 + j];
-  const int pv_tg = lane >> 4, pv_dv = lane & 15;
+    for (int j = 0; j < 32; ++j) qf[h][j] = x_lds[h][qk_c * 32 + j];
   float acc[REP][8];
   float m_run[REP], l_run[REP];
 #pragma unroll
@@ -526,15 +585,18 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
     for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
   }
   for (int b = wave; b < n_blocks; b += 4) {
-    const long long base = ((long long)bt[b] * nkv + g) * BS * HD;
-    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
-    bf16x8 kv[4];
+    // this block's K / V are in registers (loaded before phase A, or by the previous
+    // iteration); start the next block's loads before computing on this one
+    bf16x8 kn[4], vn[4];
+    if (b + 4 < n_blocks) {
+      const long long nbase = ((long long)bt[b + 4] * nkv + g) * BS * HD;
+      const unsigned short* kp = k_cache + nbase + qk_tok * HD + qk_c * 32;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-    bf16x8 vv[4];
-    const unsigned short* vp = v_cache + base + pv_dv * 8;
+      for (int v = 0; v < 4; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+      const unsigned short* vp = v_cache + nbase + pv_dv * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+      for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+    }
     float s[REP];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
@@ -575,6 +637,10 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (b + 4 < n_blocks) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { kv[v] = kn[v]; vv[v] = vn[v]; }
+    }
   }
   // ---- the token's own key / value (wave 0; one token group adds the value)
   if (wave == 0) {
@@ -582,7 +648,7 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
     for (int h = 0; h < REP; ++h) {
       float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) d += qf[h][j] * kown_lds[qk_c * 32 + j];
+      for (int j = 0; j < 32; ++j) d += qf[h][j] * x_lds[REP][qk_c * 32 + j];
       d += __shfl_xor(d, 1, 64);
       d += __shfl_xor(d, 2, 64);
       const float m_new = fmaxf(m_run[h], d);
@@ -591,7 +657,7 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
       l_run[h] = l_run[h] * corr + p;
       m_run[h] = m_new;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * corr + (pv_tg == 0 ? p * vown_lds[pv_dv * 8 + j] : 0.f);
+      for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * corr + (pv_tg == 0 ? p * x_lds[REP + 1][pv_dv * 8 + j] : 0.f);
     }
   }
 #pragma unroll
@@ -809,7 +875,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
                               hipStream_t stream) {
   if (T <= 0) return 0;
-  if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1) return -1;
+  if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1 || n_slabs > 16) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
   const float inv_h = h_in > 0 ? 1.f / (float)h_in : 0.f;
