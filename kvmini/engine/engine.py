@@ -53,6 +53,7 @@ class EngineConfig:
     tp_size: int = 1
     tp_rank: int = 0
     tp_graphs: bool = False
+    tp_force_collectives: bool = False
 
 
 # (request id, new token ids, finished?, finish reason, sequence)
@@ -151,6 +152,7 @@ class LLMEngine:
             quantization=ecfg.quantization,
             prefill_gemm=ecfg.prefill_gemm,
             tp_graphs=ecfg.tp_graphs,
+            tp_force_collectives=ecfg.tp_force_collectives,
         )
         self.runner = ModelRunner(weights, rcfg, tp_group)
         self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)

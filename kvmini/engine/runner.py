@@ -47,6 +47,7 @@ class RunnerConfig:
     # once per 64 tokens (no extra memory)
     prefill_gemm: str = "library"
     tp_graphs: bool = False  # capture HIP graphs (with the RCCL all-reduces inside) under tensor parallelism
+    tp_force_collectives: bool = False  # run the TP collectives even for a group of one rank (tests)
 
 
 def select_ops(kernels: str, device: torch.device) -> Any:
@@ -71,6 +72,9 @@ class ModelRunner:
         self.device = weights.device
         self.tp_group = tp_group
         self.tp_size = weights.tp_size
+        # the collective code path runs whenever a group is given — also for a group of one
+        # (tests: the RCCL all-reduce and its capture into HIP graphs on a single GPU)
+        self.tp_active = tp_group is not None and (weights.tp_size > 1 or rcfg.tp_force_collectives)
         self.ops = select_ops(rcfg.kernels, self.device)
         if hasattr(self.ops, "prepare_weights"):
             # one-time re-order of every linear weight into MFMA fragment order
@@ -183,21 +187,30 @@ class ModelRunner:
             else:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
-            x = ops.linear(a, lw.wo, allow_slabs=self.tp_size == 1)
-            if self.tp_size > 1:
-                x = x.contiguous()
-                torch.distributed.all_reduce(x, group=self.tp_group)
+            x = ops.linear(a, lw.wo, allow_slabs=True)
+            if self.tp_active:
+                x = self._tp_all_reduce(x)
             h, residual = ops.add_rmsnorm(x, residual, lw.mlp_norm, cfg.rms_eps)
             act = ops.linear_swiglu(h, lw.wgu)
-            x = ops.linear(act, lw.wdown, allow_slabs=self.tp_size == 1)
-            if self.tp_size > 1:
-                x = x.contiguous()
-                torch.distributed.all_reduce(x, group=self.tp_group)
+            x = ops.linear(act, lw.wdown, allow_slabs=True)
+            if self.tp_active:
+                x = self._tp_all_reduce(x)
         h, residual = ops.add_rmsnorm(x, residual, w.final_norm, cfg.rms_eps)
         hs = ops.select_rows(h, sample_idx[: self.sample_rows(t_pad)])
         logits = ops.linear(hs, w.lm_head)
         self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
         return logits
+
+    def _tp_all_reduce(self, x: Any) -> torch.Tensor:
+        """Sum a row-parallel projection's partial output over the TP ranks.  Split-K slabs are
+        first summed locally into one bf16 ``[T, H]`` tensor, so that ONE message per
+        projection crosses xGMI (T x H x 2 bytes: 0.5 MiB at 32 tokens of a 70B model) instead
+        of one per slab; the all-reduce itself is RCCL's."""
+        if hasattr(x, "reduce"):  # hip_ops.Partial
+            x = x.reduce()
+        x = x.contiguous()
+        torch.distributed.all_reduce(x, group=self.tp_group)
+        return x
 
     def _fused_ok(self, qkv: Any, k_cache: torch.Tensor) -> bool:
         fn = getattr(self.ops, "supports_fused_decode_attention", None)
@@ -209,7 +222,7 @@ class ModelRunner:
         ones share its memory pool)."""
         if self.device.type != "cuda" or not self.rcfg.use_graphs:
             return
-        if self.tp_size > 1 and not self.rcfg.tp_graphs:
+        if self.tp_active and not self.rcfg.tp_graphs:
             return  # collectives inside captured graphs are opt-in (every rank must capture in step)
         self._stage_dummy()
         variants = [(b, False) for b in sorted(buckets or self.buckets, reverse=True)]

@@ -587,3 +587,30 @@ def test_fused_decode_attention_matches_two_kernel_path(rep):
     assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)  # identical cache writes
     assert (out.float() - ref.float()).abs().max().item() <= 2e-2
     assert out[7].abs().max().item() == 0 and out[13].abs().max().item() == 0  # padding rows
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_engine_tp_collective_path_on_one_gpu_through_rccl(graphs):
+    """The tensor-parallel code path (slab reduce -> RCCL all-reduce, optionally captured in
+    HIP graphs) with a one-rank RCCL group must reproduce the plain engine's tokens."""
+    import torch.distributed as dist
+
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29793")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip")
+    prompts = [[1, 50, 60, 70, 80], list(range(1, 30))]
+    params = SamplingParams(max_tokens=8, ignore_eos=True)
+    base = LLMEngine(EngineConfig(**common, use_graphs=False), weights=random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3))
+    want = base.generate(prompts, params)
+    eng = LLMEngine(EngineConfig(**common, use_graphs=graphs, tp_graphs=graphs, tp_force_collectives=True), weights=random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3), tp_group=dist.group.WORLD)
+    assert eng.runner.tp_active
+    if graphs:
+        eng.warmup()
+        assert eng.runner.graphs, "graphs with RCCL all-reduces inside were not captured"
+    assert eng.generate(prompts, params) == want
