@@ -120,6 +120,7 @@ class ModelRunner:
         self.stage_dev = torch.zeros(off, dtype=torch.int32, device=self.device)
         o_bt = self._off["block_tables"][0]
         self.bt_np = self.stage_np[o_bt : o_bt + smax * self.max_blocks_per_seq].reshape(smax, self.max_blocks_per_seq)
+        self._bt_owner: List[Tuple[Any, int]] = [(None, 0)] * smax  # per slot: ((request id, blocks epoch), block ids already staged)
         self.out_ids = torch.zeros(tmax, dtype=torch.int64, device=self.device)
         self.out_ids_cpu = torch.zeros(tmax, dtype=torch.int64, pin_memory=pin)
         self.logits_buf: Optional[torch.Tensor] = None
@@ -291,6 +292,7 @@ class ModelRunner:
     def _stage_dummy(self) -> None:
         """Inputs that are safe for warm-up/capture: every token is padding."""
         self.stage_np[:] = 0
+        self._bt_owner = [(None, 0)] * len(self._bt_owner)
         o, n = self._off["slots"]
         self.stage_np[o : o + n] = -1
         self.stage_dev.copy_(self.stage_cpu)
@@ -313,7 +315,13 @@ class ModelRunner:
             seq = ch.seq
             n = ch.n_tokens
             blocks = seq.blocks
-            self.bt_np[seq.slot, : len(blocks)] = blocks
+            # block tables only grow while a sequence keeps its slot: write the new tail
+            key = (seq.req_id, seq.blocks_epoch)
+            owner = self._bt_owner[seq.slot]
+            nb_have = owner[1] if owner[0] == key and owner[1] <= len(blocks) else 0
+            if nb_have < len(blocks):
+                self.bt_np[seq.slot, nb_have : len(blocks)] = blocks[nb_have:]
+            self._bt_owner[seq.slot] = (key, len(blocks))
             p0 = ch.start
             if n == 1 and not seq.draft_ids:
                 npmt = len(seq.prompt_ids)

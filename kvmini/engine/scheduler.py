@@ -49,6 +49,7 @@ class Sequence:
     status: SeqStatus = SeqStatus.WAITING
     num_computed: int = 0  # tokens whose K/V are in the cache
     blocks: List[int] = field(default_factory=list)
+    blocks_epoch: int = 0  # bumped whenever ``blocks`` is replaced (not merely extended)
     published_blocks: int = 0
     slot: int = -1  # row in the block-table tensor
     cached_prefix_tokens: int = 0
@@ -146,6 +147,7 @@ class Scheduler:
                 continue
             self.bm.free(victim.blocks)
             victim.blocks = []
+            victim.blocks_epoch += 1
             victim.published_blocks = 0
             victim.num_computed = 0
             victim.draft_ids = []
@@ -197,6 +199,7 @@ class Scheduler:
             if not seq.blocks:
                 cached_blocks, cached_tokens = self.bm.match_prefix(seq.all_ids)
                 seq.blocks = list(cached_blocks)
+                seq.blocks_epoch += 1
                 seq.num_computed = cached_tokens
                 seq.cached_prefix_tokens = cached_tokens
                 seq.published_blocks = len(cached_blocks)
@@ -207,6 +210,7 @@ class Scheduler:
                 # give the cached prefix back; retry when blocks free up
                 self.bm.free(seq.blocks)
                 seq.blocks, seq.num_computed, seq.published_blocks = [], 0, 0
+                seq.blocks_epoch += 1
                 break
             if need:
                 seq.blocks += self.bm.allocate(need) or []
