@@ -22,6 +22,9 @@ int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const 
                      int nh, int nkv, int hd, int block_size, hipStream_t stream);
 int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                        const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale, hipStream_t stream);
+int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                         const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
+                         int block_size, float scale, hipStream_t stream);
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
@@ -168,6 +171,23 @@ void paged_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::T
                            (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(), out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd,
                            (int)k_cache.size(2), (float)scale, cur_stream()),
         "kv_paged_attention");
+}
+
+// Tiled MFMA attention for prompt chunks; `tiles` is int32 [4, n_tiles]: row0, n, pos0, block-table row
+void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tiles, at::Tensor out, double scale) {
+  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tiles);
+  CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tiles);
+  TORCH_CHECK(q.dim() == 3 && q.stride(2) == 1 && q.stride(1) == q.size(2) && q.stride(0) % 8 == 0, "q must be [T, nh, hd] with contiguous heads and 16-byte aligned rows");
+  const int64_t T = q.size(0), nh = q.size(1), hd = q.size(2);
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  TORCH_CHECK(tiles.dim() == 2 && tiles.size(0) == 4, "tiles must be int32 [4, n_tiles]");
+  TORCH_CHECK(block_tables.dim() == 2 && out.dim() == 2 && out.size(0) == T && out.size(1) == nh * hd, "bad block_tables/out shape");
+  const int64_t n_tiles = tiles.size(1);
+  const int* tp = (const int*)tiles.data_ptr();
+  check(kv_prefill_attention(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1), tp,
+                             tp + n_tiles, tp + 2 * n_tiles, tp + 3 * n_tiles, out.data_ptr(), (int)n_tiles, (int)nh, (int)k_cache.size(1), (int)hd,
+                             (int)k_cache.size(2), (float)scale, cur_stream()),
+        "kv_prefill_attention");
 }
 
 const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* parts);
@@ -408,6 +428,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("add_rmsnorm", &add_rmsnorm);
   m.def("rope_kv_write", &rope_kv_write);
   m.def("paged_attention", &paged_attention);
+  m.def("prefill_attention", &prefill_attention);
   m.def("decode_attention_fused", &decode_attention_fused);
   m.def("argmax", &argmax);
   m.def("swiglu_interleaved", &swiglu_interleaved);

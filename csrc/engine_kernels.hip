@@ -438,6 +438,163 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
 }
 
 // ---------------------------------------------------------------------------------
+// Tiled (flash-style) causal attention for prompt chunks on the paged cache, on MFMA.
+// paged_attention_kernel gives every query token its own workgroup and re-reads the whole
+// prefix per token: fine for decode, quadratic L2 traffic for a prompt.  Here one workgroup
+// serves a tile of 16 consecutive query tokens of ONE chunk for one kv head (all REP query
+// heads of the group: wave w owns heads w, w+4, ...), walking the keys 32 at a time:
+//   S = Q K^T   mfma_f32_16x16x32_bf16, A = Q rows (registers, loaded once), B = K rows read
+//               straight from the paged cache (a lane's 8 dims of one key are 16 contiguous
+//               bytes: no staging needed);
+//   softmax     online, in the accumulator layout (lane l, reg r = query 4*(l>>4)+r, key l&15);
+//   O += P V    P goes through a per-wave LDS tile to become an A operand; V^T is the B
+//               operand, so the workgroup stages the 32 value rows once per step into LDS
+//               TRANSPOSED ([dim][key]), shared by all heads of the group.
+// Tiles are described by host-staged arrays (first token row, valid queries, first position,
+// block-table row); tile_n == 0 marks an unused tile.  K/V of the chunk's own tokens must be
+// in the cache already (rope_kv_write runs first).  head_dim 128, block_size 16.
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_ab;
+typedef __attribute__((ext_vector_type(4))) float mfma_cd;
+
+template <int REP>
+__global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
+                                                                const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
+                                                                const int* __restrict__ block_tables, int max_blocks_per_seq,
+                                                                const int* __restrict__ tile_row0, const int* __restrict__ tile_n,
+                                                                const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq,
+                                                                unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
+  constexpr int HD = 128, BS = 16, KSTEP = 32, VT_STRIDE = 40;  // 80-byte rows: 16-byte aligned fragments
+  constexpr int HPW = (REP + 3) / 4;                           // query heads per wave
+  __shared__ __attribute__((aligned(16))) unsigned short vt_lds[HD * VT_STRIDE];        // V^T [dim][key]
+  __shared__ __attribute__((aligned(16))) unsigned short p_lds[4][HPW][16 * KSTEP];     // P [query][key] per wave and head
+  const int tile = blockIdx.x, g = blockIdx.y;
+  const int n_q = tile_n[tile];
+  if (n_q <= 0) return;
+  const int row0 = tile_row0[tile], pos0 = tile_pos0[tile];
+  const int* bt = block_tables + (long long)tile_seq[tile] * max_blocks_per_seq;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int last_key = pos0 + n_q - 1;  // highest key index any query of the tile may see
+
+  // Q fragments: A lane = Q[query lr][dims 32*ks + 8*lq .. +8]
+  mfma_ab qa[HPW][4];
+  const int qrow = row0 + (lr < n_q ? lr : n_q - 1);
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+    const int h = wave + 4 * hh;
+    if (h < REP) {
+      const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + h) * HD + lq * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qa[hh][ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 32);
+    }
+  }
+  mfma_cd o[HPW][8];
+  float m_run[HPW][4], l_run[HPW][4];
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[hh][r] = -1e30f; l_run[hh][r] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) o[hh][nt] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
+  }
+  // V staging role: key = tid & 31, 16 dims starting at (tid >> 5) * 16
+  const int sv_key = tid & 31, sv_d0 = (tid >> 5) << 4;
+
+  for (int kb = 0; kb <= last_key; kb += KSTEP) {
+    // ---- stage V^T for keys kb .. kb+31 (keys past the end read a valid block and are masked)
+    {
+      int key = kb + sv_key;
+      if (key > last_key) key = last_key;
+      const unsigned short* vp = v_cache + (((long long)bt[key >> 4] * nkv + g) * BS + (key & 15)) * HD + sv_d0;
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vp);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vp + 8);
+      __syncthreads();  // every wave is done with the previous step's V^T
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        vt_lds[(sv_d0 + j) * VT_STRIDE + sv_key] = v0[j];
+        vt_lds[(sv_d0 + 8 + j) * VT_STRIDE + sv_key] = v1[j];
+      }
+    }
+    // ---- K fragments for the two key blocks: B lane = K[key lr][dims 32*ks + 8*lq .. +8]
+    mfma_ab kf[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      int key = kb + b * 16 + lr;
+      if (key > last_key) key = last_key;
+      const unsigned short* kp = k_cache + (((long long)bt[key >> 4] * nkv + g) * BS + (key & 15)) * HD + lq * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = *reinterpret_cast<const mfma_ab*>(kp + ks * 32);
+    }
+    __syncthreads();  // V^T is staged
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h >= REP) continue;
+      // ---- S = Q K^T for 2 x 16 keys
+      mfma_cd sacc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        sacc[b] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[hh][ks], kf[b][ks], sacc[b], 0, 0, 0);
+      }
+      // ---- causal mask + online softmax; this lane: queries 4*lq + r, keys kb + 16*b + lr
+      float p[2][4], corr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qpos = pos0 + 4 * lq + r;
+        float s0 = (kb + lr <= qpos) ? sacc[0][r] * scale_log2e : -1e30f;
+        float s1 = (kb + 16 + lr <= qpos) ? sacc[1][r] * scale_log2e : -1e30f;
+        float mx = fmaxf(s0, s1);
+        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float m_new = fmaxf(m_run[hh][r], mx);
+        p[0][r] = exp2f(s0 - m_new);
+        p[1][r] = exp2f(s1 - m_new);
+        float ps = p[0][r] + p[1][r];
+        for (int off = 1; off < 16; off <<= 1) ps += __shfl_xor(ps, off, 64);
+        corr[r] = exp2f(m_run[hh][r] - m_new);
+        l_run[hh][r] = l_run[hh][r] * corr[r] + ps;
+        m_run[hh][r] = m_new;
+      }
+      // ---- P -> LDS [query][key] (bf16), then back as an A operand
+      unsigned short* pw = p_lds[wave][hh];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pw[(4 * lq + r) * KSTEP + lr] = f2bf(p[0][r]);
+        pw[(4 * lq + r) * KSTEP + 16 + lr] = f2bf(p[1][r]);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+      __builtin_amdgcn_wave_barrier();
+      const mfma_ab pa = *reinterpret_cast<const mfma_ab*>(pw + lr * KSTEP + lq * 8);
+      // ---- O = O * corr + P V   (B lane = V^T[dim 16*nt + lr][keys 8*lq .. +8])
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[hh][nt][r] *= corr[r];
+        const mfma_ab vb = *reinterpret_cast<const mfma_ab*>(vt_lds + (nt * 16 + lr) * VT_STRIDE + lq * 8);
+        o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[hh][nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // ---- normalise and store: lane holds O[query 4*lq + r][dim 16*nt + lr]
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+    const int h = wave + 4 * hh;
+    if (h >= REP) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = 4 * lq + r;
+      if (qi >= n_q) continue;
+      const float inv = l_run[hh][r] > 0.f ? 1.f / l_run[hh][r] : 0.f;
+      unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + lr;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) op[nt * 16] = f2bf(o[hh][nt][r] * inv);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Decode-step fusion: RoPE + KV write + paged attention in ONE launch, for steps in which
 // every token is the only new token of its sequence (plain decoding: no prompt chunk needs
 // keys that another workgroup of the same launch is still producing).  One workgroup per
@@ -864,6 +1021,30 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
   }
   if (hd == 128) { KV_BY_REP(128) } else { KV_BY_REP(64) }
 #undef KV_BY_REP
+#undef KV_LAUNCH
+  return (int)hipGetLastError();
+}
+
+// Tiled causal attention for prompt chunks (see prefill_attention_kernel).  Tile arrays have
+// n_tiles entries; rows of `out` not covered by a tile are left untouched.
+int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                         const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
+                         int block_size, float scale, hipStream_t stream) {
+  if (n_tiles <= 0) return 0;
+  if (hd != 128 || block_size != 16 || nh % nkv) return -1;
+  const int rep = nh / nkv;
+  const float sl = scale * 1.4426950408889634f;
+  dim3 grid(n_tiles, nkv), block(256);
+#define KV_LAUNCH(R)                                                                                                                              \
+  hipLaunchKernelGGL(prefill_attention_kernel<R>, grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
+                     (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, (unsigned short*)out, nh, nkv, sl)
+  switch (rep) {
+    case 1: KV_LAUNCH(1); break;
+    case 2: KV_LAUNCH(2); break;
+    case 4: KV_LAUNCH(4); break;
+    case 8: KV_LAUNCH(8); break;
+    default: return -1;
+  }
 #undef KV_LAUNCH
   return (int)hipGetLastError();
 }

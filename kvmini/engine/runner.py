@@ -110,6 +110,15 @@ class ModelRunner:
             off += n
         self._off["block_tables"] = (off, smax * self.max_blocks_per_seq)
         off += smax * self.max_blocks_per_seq
+        # prompt chunks (more than one token of a sequence in the step) are served by the tiled
+        # attention kernel: 16-query tiles (first row, valid queries, first position, block-table
+        # row), and a context-length array that is zero for those tokens so that the per-token
+        # kernel skips them
+        self.max_tiles = tmax // 16 + smax
+        self._off["ctx_decode"] = (off, tmax)
+        off += tmax
+        self._off["tiles"] = (off, 4 * self.max_tiles)
+        off += 4 * self.max_tiles
         # step header (tensor parallelism: rank 0 broadcasts the whole staging buffer, followers
         # read the step shape from here): t_pad, n_samples, max_ctx, command (0 = run, 1 = stop)
         self._off["header"] = (off, 8)
@@ -185,6 +194,11 @@ class ModelRunner:
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             if decode_only and self._fused_ok(qkv, kc):
                 a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale)
+            elif not decode_only and self._tiled_ok(kc):
+                # decode tokens: one workgroup per token; prompt chunks: 16-query MFMA tiles
+                q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
+                a = ops.paged_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self.scale, max_blocks)
+                ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale)
             else:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
@@ -213,6 +227,10 @@ class ModelRunner:
         torch.distributed.all_reduce(x, group=self.tp_group)
         return x
 
+    def _tiled_ok(self, k_cache: torch.Tensor) -> bool:
+        fn = getattr(self.ops, "supports_prefill_attention", None)
+        return fn is not None and fn(self.nh, k_cache)
+
     def _fused_ok(self, qkv: Any, k_cache: torch.Tensor) -> bool:
         fn = getattr(self.ops, "supports_fused_decode_attention", None)
         return fn is not None and fn(qkv, self.nh, k_cache)
@@ -226,6 +244,23 @@ class ModelRunner:
         if self.tp_active and not self.rcfg.tp_graphs:
             return  # collectives inside captured graphs are opt-in (every rank must capture in step)
         self._stage_dummy()
+        # Nothing may free device memory while a stream is capturing: a garbage-collection pass
+        # that drops an older engine's graphs (and their private memory pool) in the middle of a
+        # capture aborts the process.  Collect first, then keep the collector off until done.
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize(self.device)
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_all(buckets)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+        torch.cuda.synchronize(self.device)
+
+    def _capture_all(self, buckets: Optional[Sequence[int]]) -> None:
         variants = [(b, False) for b in sorted(buckets or self.buckets, reverse=True)]
         # decode-sized buckets also get the decode-only variant (fused RoPE + attention kernel)
         variants += [(b, True) for b, _ in variants if b <= self.rcfg.max_num_seqs and b <= 64 and hasattr(self.ops, "rope_attention_fused")]
@@ -242,12 +277,13 @@ class ModelRunner:
             torch.cuda.current_stream(self.device).wait_stream(s)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pool):
+            # thread_local: other threads of the process (HTTP front-end, RCCL watchdog) may
+            # touch the HIP runtime while this thread captures
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
                 logits = self.forward(b, decode_only=dec)
             if self._graph_pool is None:
                 self._graph_pool = g.pool()
             self.graphs[key] = (g, logits)
-        torch.cuda.synchronize(self.device)
 
     def _run_staged(self, t_pad: int, max_ctx: int, decode_only: bool = False) -> torch.Tensor:
         entry = self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, False))
@@ -307,6 +343,8 @@ class ModelRunner:
         t_pad = self.bucket_for(t)
         st = self.stage_np
         o_tok, o_pos, o_slot, o_seq, o_ctx, o_smp = (self._off[k][0] for k in ("tokens", "positions", "slots", "tok_seq", "ctx", "sample_idx"))
+        o_cd, o_tl, mt = self._off["ctx_decode"][0], self._off["tiles"][0], self.max_tiles
+        n_tiles = 0
         bs = self.block_size
         i = 0
         n_samples = 0
@@ -330,6 +368,7 @@ class ModelRunner:
                 st[o_slot + i] = blocks[p0 // bs] * bs + p0 % bs
                 st[o_seq + i] = seq.slot
                 st[o_ctx + i] = p0 + 1
+                st[o_cd + i] = p0 + 1
                 if ch.sample:
                     st[o_smp + n_samples] = i
                     n_samples += 1
@@ -349,6 +388,10 @@ class ModelRunner:
                 st[o_slot + i : o_slot + i + n] = blk * bs + pos % bs
                 st[o_seq + i : o_seq + i + n] = seq.slot
                 st[o_ctx + i : o_ctx + i + n] = pos + 1
+                st[o_cd + i : o_cd + i + n] = 0
+                for off in range(0, n, 16):
+                    st[o_tl + n_tiles], st[o_tl + mt + n_tiles], st[o_tl + 2 * mt + n_tiles], st[o_tl + 3 * mt + n_tiles] = i + off, min(16, n - off), p0 + off, seq.slot
+                    n_tiles += 1
                 if ch.sample:
                     k = n - first_sampled
                     st[o_smp + n_samples : o_smp + n_samples + k] = np.arange(i + first_sampled, i + n, dtype=np.int32)
@@ -362,7 +405,9 @@ class ModelRunner:
             st[o_slot + t : o_slot + t_pad] = -1
             st[o_seq + t : o_seq + t_pad] = 0
             st[o_ctx + t : o_ctx + t_pad] = 0
+            st[o_cd + t : o_cd + t_pad] = 0
         st[o_smp + n_samples : o_smp + t_pad] = 0
+        st[o_tl + mt + n_tiles : o_tl + 2 * mt] = 0  # unused tiles: zero valid queries
 
         # plain decoding step: every chunk is one token (no prompt chunk, no drafts to verify)
         decode_only = all(ch.n_tokens == 1 for ch in batch.chunks)

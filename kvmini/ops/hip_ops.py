@@ -338,6 +338,20 @@ def rope_attention_fused(
     return out
 
 
+def supports_prefill_attention(n_heads: int, k_cache: torch.Tensor) -> bool:
+    nkv, bs, hd = k_cache.shape[1], k_cache.shape[2], k_cache.shape[3]
+    return hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in (1, 2, 4, 8)
+
+
+def prefill_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor, tiles: torch.Tensor, out: torch.Tensor, scale: float) -> torch.Tensor:
+    """Tiled MFMA causal attention for prompt chunks, written into ``out`` ``[T, nh*hd]``
+    in place (rows not covered by a tile keep their content).  ``tiles``: int32
+    ``[4, n_tiles]`` = first token row, valid queries (0 = unused), first position,
+    block-table row of each 16-query tile; K/V of the chunk must be in the cache already."""
+    native().prefill_attention(q, k_cache, v_cache, block_tables, tiles, out, scale)
+    return out
+
+
 def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
     out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
     native().argmax(logits, out)

@@ -339,7 +339,7 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--weights", default=None, help="directory with HF *.safetensors")
     ap.add_argument("--tokenizer", default=None, help="tokenizer.json (default: synthetic tokenizer)")
     ap.add_argument("--max-num-seqs", type=int, default=64)
-    ap.add_argument("--max-batched-tokens", type=int, default=256)
+    ap.add_argument("--max-batched-tokens", type=int, default=1024, help="token budget of one engine step (decode tokens + prompt chunk); larger = faster long-prompt prefill, longer worst-case step")
     ap.add_argument("--max-model-len", type=int, default=8192)
     ap.add_argument("--block-size", type=int, default=16)
     ap.add_argument("--num-blocks", type=int, default=0)

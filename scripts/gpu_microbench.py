@@ -199,8 +199,8 @@ def prefill_bench(out, model):
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
 
-    for mode in ("library", "stream"):
-        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=256, max_model_len=4096, kernels="hip", kv_memory_fraction=0.2, prefill_gemm=mode))
+    for mode, budget in (("library", 256), ("library", 1024), ("library", 2048), ("stream", 256)):
+        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=budget, max_model_len=4096, kernels="hip", kv_memory_fraction=0.2, prefill_gemm=mode))
         eng.warmup()
         res = {}
         for plen in (256, 2048):
@@ -215,7 +215,7 @@ def prefill_bench(out, model):
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
             res[plen] = min(ts) * 1e3
-        row = {"bench": "prefill", "model": model, "prefill_gemm": mode, "ms_256_tokens": res[256], "ms_2048_tokens": res[2048], "tok_per_s_2048": 2048 / res[2048] * 1e3, "mem_GB": torch.cuda.memory_allocated() / 1e9}
+        row = {"bench": "prefill", "model": model, "prefill_gemm": mode, "max_batched_tokens": budget, "ms_256_tokens": res[256], "ms_2048_tokens": res[2048], "tok_per_s_2048": 2048 / res[2048] * 1e3, "mem_GB": torch.cuda.memory_allocated() / 1e9}
         print(json.dumps(row), flush=True)
         out.append(row)
         del eng

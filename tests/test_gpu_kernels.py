@@ -599,10 +599,25 @@ def test_engine_tp_collective_path_on_one_gpu_through_rccl(graphs):
     from kvmini.engine.scheduler import SamplingParams
     from kvmini.models.llama import get_config, random_weights
 
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29793")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29793")
+    own_pg = not dist.is_initialized()
+    if own_pg:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        _tp_one_rank_body(graphs)
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+
+
+def _tp_one_rank_body(graphs):
+    import torch.distributed as dist
+
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
     common = dict(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip")
     prompts = [[1, 50, 60, 70, 80], list(range(1, 30))]
     params = SamplingParams(max_tokens=8, ignore_eos=True)
@@ -614,3 +629,43 @@ def test_engine_tp_collective_path_on_one_gpu_through_rccl(graphs):
         eng.warmup()
         assert eng.runner.graphs, "graphs with RCCL all-reduces inside were not captured"
     assert eng.generate(prompts, params) == want
+
+
+@pytest.mark.parametrize("rep", [1, 2, 4, 8])
+def test_prefill_attention_tiles_match_reference(rep):
+    """The tiled MFMA prompt-attention kernel against the per-token reference: chunks that
+    start at position 0, mid-block continuations of an earlier chunk, short chunks, and rows
+    that belong to no tile (left untouched)."""
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(11)
+    nkv, hd, bs, nb = 2, 128, 16, 200
+    nh = nkv * rep
+    n_seqs, max_blocks = 4, 24
+    kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
+    bt = torch.randperm(nb, device=_dev())[: n_seqs * max_blocks].view(n_seqs, max_blocks).int()
+    # (block-table row, first position, tokens): flat rows in this order, one decode row between
+    chunks = [(0, 0, 40), (1, 37, 23), (2, 0, 5), (3, 300, 33)]
+    rows, tok_seq, ctx, tiles = 0, [], [], []
+    for k, (seq, p0, n) in enumerate(chunks):
+        if k == 2:  # a row owned by nobody: must keep its sentinel value
+            tok_seq.append(0); ctx.append(0); rows += 1
+        for off in range(0, n, 16):
+            tiles.append((rows + off, min(16, n - off), p0 + off, seq))
+        tok_seq += [seq] * n
+        ctx += [p0 + j + 1 for j in range(n)]
+        rows += n
+    tiles += [(0, 0, 0, 0)] * 3  # unused tiles
+    T = rows
+    q = torch.randn(T, nh, hd, device=_dev()).bfloat16()
+    tok_seq_t = torch.tensor(tok_seq, device=_dev(), dtype=torch.int32)
+    ctx_t = torch.tensor(ctx, device=_dev(), dtype=torch.int32)
+    scale = 1 / math.sqrt(hd)
+    ref = torch_ops.paged_attention(q, kc, vc, bt, tok_seq_t, ctx_t, scale)
+    out = torch.full((T, nh * hd), 7.0, device=_dev(), dtype=torch.bfloat16)
+    tiles_t = torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous()
+    assert hip_ops.supports_prefill_attention(nh, kc)
+    hip_ops.prefill_attention(q, kc, vc, bt, tiles_t, out, scale)
+    owned = ctx_t > 0
+    assert (out[owned].float() - ref[owned].float()).abs().max().item() <= 2.5e-2
+    assert (out[~owned] == 7.0).all()
