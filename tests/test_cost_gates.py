@@ -235,3 +235,16 @@ def test_native_runtime_bindings_cpu_side():
     assert rt.trapz_wh([0, 1, 2, 3], [100, 100, float("nan"), 100]) == pytest.approx(300 / 3600)
     sampler = rt.make_sampler(0.05)
     assert hasattr(sampler, "start") and hasattr(sampler, "stop") and hasattr(sampler, "to_power_json")
+
+
+def test_long_name_alias_package_resolves_to_kvmini():
+    import kserve_vllm_mini_amd as alias
+    import kvmini.models.llama as real_llama
+    from kserve_vllm_mini_amd.models import llama
+    from kserve_vllm_mini_amd.parallel import telemetry_gather
+
+    import kvmini.parallel.telemetry_gather as real_tg
+
+    assert llama is real_llama and telemetry_gather is real_tg
+    assert alias.ops.gpu_available is __import__("kvmini.ops").ops.gpu_available
+    assert alias.utils.parse_k8s_quantity("500m") == 0.5
