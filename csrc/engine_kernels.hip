@@ -467,7 +467,10 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
   constexpr int HPW = (REP + 3) / 4;                           // query heads per wave
   __shared__ __attribute__((aligned(16))) unsigned short vt_lds[HD * VT_STRIDE];        // V^T [dim][key]
   __shared__ __attribute__((aligned(16))) unsigned short p_lds[4][HPW][16 * KSTEP];     // P [query][key] per wave and head
-  const int tile = blockIdx.x, g = blockIdx.y;
+  // grid = (kv heads, tiles): consecutive workgroup ids differ in the kv head, so with the
+  // round-robin placement of workgroups on the 8 XCDs every tile of kv head g (when nkv is a
+  // multiple of 8) runs on XCD g % 8 and that head's K/V stay in ONE XCD's L2
+  const int g = blockIdx.x, tile = blockIdx.y;
   const int n_q = tile_n[tile];
   if (n_q <= 0) return;
   const int row0 = tile_row0[tile], pos0 = tile_pos0[tile];
@@ -1034,7 +1037,7 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   if (hd != 128 || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
-  dim3 grid(n_tiles, nkv), block(256);
+  dim3 grid(nkv, n_tiles), block(256);
 #define KV_LAUNCH(R)                                                                                                                              \
   hipLaunchKernelGGL(prefill_attention_kernel<R>, grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
                      (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, (unsigned short*)out, nh, nkv, sl)
