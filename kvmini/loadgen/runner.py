@@ -436,6 +436,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
     ap.add_argument("--prompts-file", default=None, help="One prompt per line (or a JSON list); rotated per request")
     ap.add_argument("--prompt-tokens", type=int, default=None, help="Synthesise a prompt of about N tokens")
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--procs", type=int, default=1, help="Generator processes (requests, concurrency and rate are split evenly; artifacts are merged)")
     ap.add_argument("--no-pool", action="store_true", help="New TCP/TLS connection per request (reference behaviour)")
     ap.add_argument("--connect-retry-s", type=float, default=0.0, help="Keep retrying a refused connection for this long (requests wait out a server cold start)")
     ap.add_argument("--no-trace", action="store_true")
@@ -511,8 +512,85 @@ def config_from_args(args: argparse.Namespace) -> LoadConfig:
     )
 
 
+def run_sharded(argv: List[str], args: argparse.Namespace) -> int:
+    """``--procs N``: N generator processes, each with 1/N of the requests, of the
+    concurrency and of the target rate, started together against the same endpoint; their
+    run directories (``<run-dir>/shard<k>``) are merged into the canonical artifacts
+    (request ids renumbered, token events and trace spans concatenated).  One asyncio
+    process tops out around 10^5 token events per second; shards scale that with cores."""
+    import json
+    import subprocess
+
+    import numpy as np
+
+    n = args.procs
+    base = [a for a in (argv if argv is not None else sys.argv[1:])]
+
+    def strip(flag: str, has_value: bool = True) -> None:
+        while flag in base:
+            i = base.index(flag)
+            del base[i : i + (2 if has_value else 1)]
+
+    for flag in ("--procs", "--requests", "--concurrency", "--run-dir", "--target-rps", "--seed"):
+        strip(flag)
+    procs = []
+    for k in range(n):
+        req = args.requests // n + (1 if k < args.requests % n else 0)
+        conc = max(1, args.concurrency // n + (1 if k < args.concurrency % n else 0))
+        shard = ["--requests", str(req), "--concurrency", str(conc), "--run-dir", os.path.join(args.run_dir, f"shard{k}"), "--seed", str((args.seed or 0) * 1000 + k)]
+        if args.target_rps:
+            shard += ["--target-rps", str(args.target_rps / n)]
+        procs.append(subprocess.Popen([sys.executable, "-m", "kvmini.loadgen.runner", *base, *shard, "--quiet"]))
+    rc = max(p.wait() for p in procs)
+    rows: List[List[str]] = []
+    events, spans, metas = [], [], []
+    for k in range(n):
+        d = os.path.join(args.run_dir, f"shard{k}")
+        off = len(rows)
+        with open(os.path.join(d, "requests.csv"), newline="") as f:
+            rd = csv.reader(f)
+            header = next(rd)
+            for r in rd:
+                r[0] = str(int(r[0]) + off)
+                rows.append(r)
+        ev_path = os.path.join(d, "token_events.npy")
+        if os.path.exists(ev_path):
+            ev = np.load(ev_path)
+            ev[:, 0] += off
+            events.append(ev)
+        tr = os.path.join(d, "traces", "traces.json")
+        if os.path.exists(tr):
+            with open(tr) as f:
+                doc = json.load(f)
+            spans += doc["resourceSpans"][0]["scopeSpans"][0]["spans"]
+        with open(os.path.join(d, "meta.json")) as f:
+            metas.append(json.load(f))
+    os.makedirs(args.run_dir, exist_ok=True)
+    with open(os.path.join(args.run_dir, "requests.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(header)
+        w.writerows(rows)
+    if events:
+        np.save(os.path.join(args.run_dir, "token_events.npy"), np.concatenate(events))
+    if spans:
+        doc["resourceSpans"][0]["scopeSpans"][0]["spans"] = spans
+        os.makedirs(os.path.join(args.run_dir, "traces"), exist_ok=True)
+        with open(os.path.join(args.run_dir, "traces", "traces.json"), "w") as f:
+            json.dump(doc, f)
+    meta = dict(metas[0])
+    meta.update({"requests": args.requests, "concurrency": args.concurrency, "target_rps": sum(m.get("target_rps") or 0 for m in metas), "duration_sec": max(m.get("duration_sec") or 0 for m in metas),
+                 "test_start_time": min(m.get("test_start_time") or 0 for m in metas), "connections_opened": sum(m.get("connections_opened") or 0 for m in metas), "generator_processes": n})
+    write_json(os.path.join(args.run_dir, "meta.json"), meta)
+    if not args.quiet:
+        ok = sum(1 for r in rows if r[header.index("status")] == "200")
+        print(f"Completed {len(rows)} requests ({ok} ok) in {n} generator processes -> {args.run_dir}")
+    return rc
+
+
 def main(argv: Optional[List[str]] = None) -> int:
     args = build_arg_parser().parse_args(argv)
+    if getattr(args, "procs", 1) > 1:
+        return run_sharded(list(argv) if argv is not None else sys.argv[1:], args)
     cfg = config_from_args(args)
     try:
         results = run_load_sync(cfg)

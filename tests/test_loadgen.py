@@ -151,3 +151,29 @@ def test_cli_args_and_files(tmp_path, mock_server):
     assert len(synthetic_prompt(100).split()) == 100
     with pytest.raises(SystemExit):  # unknown flags are rejected, not silently forwarded
         build_arg_parser().parse_args(["--url", url, "--run-dir", "x", "--speculative-model", "foo"])
+
+
+def test_sharded_load_generation_merges_artifacts(mock_server, tmp_path):
+    """``--procs 2``: two generator processes, one merged run directory that the analyzer reads."""
+    import csv
+    import json
+
+    import numpy as np
+
+    from kvmini.analysis.reduce import analyze_run
+    from kvmini.cluster import FakeBackend
+    from kvmini.loadgen import runner
+
+    _mock, url = mock_server
+    run = tmp_path / "sharded"
+    rc = runner.main(["--url", url, "--model", "m", "--requests", "21", "--concurrency", "5", "--max-tokens", "6", "--run-dir", str(run), "--procs", "2", "--quiet", "--target-rps", "500"])
+    assert rc == 0
+    rows = list(csv.DictReader(open(run / "requests.csv")))
+    assert len(rows) == 21 and sorted(int(r["id"]) for r in rows) == list(range(1, 22))  # ids stay 1-based and unique after the merge
+    assert all(r["status"] == "200" and int(float(r["completion_tokens"])) == 6 for r in rows)
+    ev = np.load(run / "token_events.npy")
+    assert ev.shape == (21 * 6, 3) and set(ev[:, 0].astype(int)) == set(range(1, 22))
+    meta = json.load(open(run / "meta.json"))
+    assert meta["generator_processes"] == 2 and meta["requests"] == 21 and meta["concurrency"] == 5
+    res = analyze_run(str(run), "ns", "svc", backend=FakeBackend(), quiet=True)
+    assert res["requests"] == {"total": 21, "success": 21} and res["itl_samples"] == 21 * 5
