@@ -24,7 +24,7 @@ from typing import Any, Dict, List, Optional
 from kvmini.cluster import get_backend
 from kvmini.config.profiles import load_profile, resolve_load_settings
 from kvmini.deploy import manifests as mf
-from kvmini.utils import load_json, write_json
+from kvmini.utils import load_yaml, load_json, write_json
 
 CSV_COLS = ["backend", "streaming", "requests", "concurrency", "mean_ttft_ms", "p95_ttft_ms", "mean_tpot_ms", "p95_tpot_ms", "throughput_req_s", "gpu_util_avg", "cost_per_1k_tokens"]
 PROTOCOL = {"vllm-rocm": "openai", "vllm": "openai", "native": "openai", "mock": "openai", "tgi-rocm": "tgi", "tgi": "tgi"}
@@ -91,7 +91,11 @@ def summarize_test(test_dir: str, backend: str, streaming: bool, requests: int, 
         "throughput_req_s": r(summary.get("throughput_rps") or summary.get("throughput_req_per_sec"), 2),
         "gpu_util_avg": r(summary.get("gpu_util_avg") if summary.get("gpu_util_avg") is not None else summary.get("gpu_utilization_avg"), 1),
         "cost_per_1k_tokens": r(summary.get("cost_per_1k_tokens"), 6),
-        "mean_latency_ms": r(statistics.mean(lat), 1) if lat else None,  # JSON report only; the CSV keeps the reference's columns
+        # JSON / HTML report only; the CSV keeps the reference's columns
+        "mean_latency_ms": r(statistics.mean(lat), 1) if lat else None,
+        "p95_latency_ms": r(summary.get("p95_ms"), 1),
+        "energy_wh_per_1k_tokens": r(summary.get("energy_wh_per_1k_tokens"), 5),
+        "gpu_power_watts_avg": r(summary.get("gpu_power_watts_avg"), 1),
     }
 
 
@@ -115,6 +119,7 @@ def build_report(rows: List[Dict[str, Any]], meta: Dict[str, Any]) -> Dict[str, 
             "fastest_tpot": best("mean_tpot_ms", min, "value_ms"),
             "highest_throughput": best("throughput_req_s", max, "value_req_s"),
             "lowest_cost": best("cost_per_1k_tokens", min, "value_per_1k"),
+            "lowest_energy": best("energy_wh_per_1k_tokens", min, "value_wh_per_1k"),
         },
     }
     by: Dict[str, Dict[str, Dict[str, Any]]] = {}
@@ -136,12 +141,50 @@ def build_report(rows: List[Dict[str, Any]], meta: Dict[str, Any]) -> Dict[str, 
     return report
 
 
+def write_html_report(path: str, report: Dict[str, Any]) -> str:
+    """Cost + energy + latency report of an A/B run: one bar chart per metric (backends on the
+    x axis, streaming / non-streaming as series), the result table and the winners."""
+    import html
+
+    from kvmini.report.generator import format_number, svg_bar_chart
+
+    rows = report["results"]
+    backends = list(dict.fromkeys(r["backend"] for r in rows))
+    modes = list(dict.fromkeys(str(r["streaming"]) for r in rows))
+
+    def series(key: str) -> Dict[str, List[Optional[float]]]:
+        by = {(r["backend"], str(r["streaming"])): r.get(key) for r in rows}
+        return {("streaming" if m == "true" else "non-streaming"): [None if by.get((b, m)) in (None, "") else float(by[(b, m)]) for b in backends] for m in modes}
+
+    charts = [
+        ("mean_ttft_ms", "Time to first token (mean)", " ms"), ("mean_tpot_ms", "Time per output token (mean)", " ms"), ("p95_latency_ms", "Request latency p95", " ms"),
+        ("throughput_req_s", "Throughput", " req/s"), ("cost_per_1k_tokens", "Cost per 1K tokens", " $"), ("energy_wh_per_1k_tokens", "Energy per 1K tokens", " Wh"),
+    ]
+    meta = report["comparison_metadata"]
+    out = ["<!doctype html><html><head><meta charset='utf-8'><title>Backend A/B comparison</title><style>body{font-family:system-ui,sans-serif;margin:2em;max-width:84em}"
+           "table{border-collapse:collapse;margin:1em 0}td,th{border:1px solid #ced4da;padding:.3em .6em;text-align:right}td:first-child,th:first-child{text-align:left}"
+           ".grid{display:grid;grid-template-columns:repeat(auto-fill,minmax(640px,1fr));gap:1em}.win{color:#2b8a3e;font-weight:700}</style></head><body>"]
+    out.append(f"<h1>Backend A/B comparison</h1><p>Model <b>{html.escape(str(meta.get('model')))}</b>, profile <b>{html.escape(str(meta.get('profile')))}</b>, {meta.get('requests')} requests at concurrency {meta.get('concurrency')}"
+               + (f", partition profile <b>{html.escape(str(meta.get('partition_profile')))}</b>" if meta.get("partition_profile") else "") + f" &middot; {html.escape(str(meta.get('timestamp')))}</p>")
+    w = report.get("winners") or {}
+    names = {"fastest_ttft": "Fastest first token", "fastest_tpot": "Fastest per token", "highest_throughput": "Highest throughput", "lowest_cost": "Lowest cost", "lowest_energy": "Lowest energy"}
+    out.append("<ul>" + "".join(f"<li>{names.get(k, k)}: " + ("not measured" if not v else f"<span class='win'>{html.escape(v['backend'])}</span> (streaming: {v['streaming']}) &mdash; {format_number(next(x for kk, x in v.items() if kk.startswith('value')), 6)}") + "</li>" for k, v in w.items()) + "</ul>")
+    out.append("<div class='grid'>" + "".join(svg_bar_chart(backends, series(k), title, unit) for k, title, unit in charts if any(v is not None for s_ in series(k).values() for v in s_)) + "</div>")
+    cols = ["backend", "streaming", "mean_ttft_ms", "p95_ttft_ms", "mean_tpot_ms", "p95_tpot_ms", "mean_latency_ms", "p95_latency_ms", "throughput_req_s", "gpu_util_avg", "gpu_power_watts_avg", "cost_per_1k_tokens", "energy_wh_per_1k_tokens"]
+    out.append("<table><tr>" + "".join(f"<th>{c}</th>" for c in cols) + "</tr>" + "".join("<tr>" + "".join(f"<td>{'' if r.get(c) is None else html.escape(str(r.get(c)))}</td>" for c in cols) + "</tr>" for r in rows) + "</table>")
+    out.append("<p>Empty cells were not measured (for example: no GPU power for an endpoint that runs on another machine; no first token for a non-streamed response).</p></body></html>")
+    with open(path, "w") as f:
+        f.write("".join(out))
+    return path
+
+
 class ABRunner:
     def __init__(self, a: argparse.Namespace, settings: Dict[str, Any]):
         self.a = a
         self.s = settings
         self.cluster = get_backend(a.cluster_backend)
         self.endpoints = dict(e.split("=", 1) for e in (a.endpoints or []))
+        self.partition = load_yaml(a.partition_profile) if getattr(a, "partition_profile", None) else None
         self.rows: List[Dict[str, Any]] = []
 
     def service(self, backend: str) -> str:
@@ -159,6 +202,8 @@ class ABRunner:
             manifest = mf.native_isvc(name, self.a.namespace, self.a.model)
         else:
             manifest = mf.vllm_rocm_isvc(name, self.a.namespace, model_name=self.a.model, model_uri=self.a.model_uri)
+        if self.partition is not None:
+            manifest = mf.apply_partition_profile(manifest, self.partition)
         self.cluster.apply(manifest)
         self.cluster.wait_ready(self.a.namespace, name, self.a.ready_timeout)
         url = self.cluster.get_isvc_url(self.a.namespace, name)
@@ -228,9 +273,12 @@ class ABRunner:
         if not self.rows:
             print("No results to analyze", file=sys.stderr)
             return None
-        meta = {"timestamp": time.strftime("%Y-%m-%dT%H:%M:%S", time.gmtime()), "profile": self.a.profile, "model": self.a.model, "requests": self.s["requests"], "concurrency": self.s["concurrency"], "streaming_tested": bool(self.a.toggle_streaming)}
+        meta = {"timestamp": time.strftime("%Y-%m-%dT%H:%M:%S", time.gmtime()), "profile": self.a.profile, "model": self.a.model, "requests": self.s["requests"], "concurrency": self.s["concurrency"], "streaming_tested": bool(self.a.toggle_streaming),
+                "partition_profile": getattr(self.a, "partition_profile", None)}
         report = build_report(self.rows, meta)
         write_json(os.path.join(self.a.run_dir, "comparison_report.json"), report)
+        if not getattr(self.a, "no_report", False):
+            print("Report:", write_html_report(os.path.join(self.a.run_dir, "ab_report.html"), report))
         return report
 
 
@@ -252,6 +300,8 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--cluster-backend", default=None, choices=["auto", "kubectl", "local", "fake"])
     ap.add_argument("--cost-file", default="cost.yaml")
     ap.add_argument("--no-energy", action="store_true", help="do not sample amd-smi power during the tests")
+    ap.add_argument("--partition-profile", default=None, help="MI355X partition profile YAML applied to every deployed InferenceService (profiles/partition/*.yaml)")
+    ap.add_argument("--no-report", action="store_true", help="skip ab_report.html")
     a = ap.parse_args(argv)
     try:
         profile = load_profile(a.profile)

@@ -1,6 +1,7 @@
 """CPU tests for the harness tools, driven against the in-tree mock server and
 the fake / local cluster backends (no cluster, no GPU)."""
 
+import argparse
 import csv
 import json
 import os
@@ -9,6 +10,8 @@ import numpy as np
 import pytest
 
 from kvmini.utils import load_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture()
@@ -288,6 +291,31 @@ def test_ab_compare_endpoints(in_tmp):
     assert rep["winners"]["fastest_ttft"]["backend"] == "fast"
     assert set(rep["streaming_vs_non_streaming"]) == {"fast", "slow"}
     assert rep["comparison_metadata"]["streaming_tested"] is True
+    # measured per-token time (the reference's tpot_ms column was always empty); no zero placeholders
+    assert all(float(r["mean_tpot_ms"]) > 0 for r in rows)
+    assert all(r["mean_ttft_ms"] == "" for r in rows if r["streaming"] == "false")  # a non-streamed answer has no first token
+    assert rep["winners"]["fastest_ttft"]["streaming"] == "true" and rep["winners"]["fastest_tpot"] is not None
+    assert all(d["ttft_advantage_ms"] > 0 for d in rep["streaming_vs_non_streaming"].values())
+    page = open("ab/ab_report.html").read()
+    assert "<svg" in page and "Time per output token" in page and "fast" in page
+
+
+def test_ab_compare_applies_partition_profile_to_deployed_manifests(in_tmp):
+    from kvmini.cluster import FakeBackend
+    from kvmini.harness import ab_compare
+
+    ns = argparse.Namespace(backends="vllm-rocm", model="llama-3-8b", model_uri=None, namespace="ml", endpoints=None, cluster_backend="fake", ready_timeout=1.0,
+                            partition_profile=os.path.join(ROOT, "profiles", "partition", "mi355x-cpx-nps4.yaml"), no_cleanup=True)
+    runner = ab_compare.ABRunner(ns, {"requests": 1, "concurrency": 1, "max_tokens": 1, "pattern": "steady"})
+    assert isinstance(runner.cluster, FakeBackend)
+    applied = []
+    runner.cluster.apply = lambda m: applied.append(m)
+    runner.cluster.wait_ready = lambda *a, **k: None
+    runner.cluster.get_isvc_url = lambda *a, **k: "http://x"
+    assert runner.deploy("vllm-rocm") == "http://x"
+    res = applied[0]["spec"]["predictor"]["model"]["resources"] if "model" in applied[0]["spec"]["predictor"] else applied[0]["spec"]["predictor"]["containers"][0]["resources"]
+    gpu_keys = [k for k in res["limits"] if k.startswith("amd.com/")]
+    assert gpu_keys and all("cpx" in k for k in gpu_keys), res
 
 
 def test_compare_backends_reports(in_tmp, mock_server):
