@@ -137,8 +137,7 @@ __global__ __launch_bounds__(KV_THREADS) void stream_hist_kernel(const T* __rest
   const bool aligned = (((uintptr_t)row) & 15) == 0;
   if (aligned) {
     const Pack* pv = reinterpret_cast<const Pack*>(row);
-    for (long long i = (long long)blockIdx.x * KV_THREADS + tid; i < nvec; i += stride) {
-      Pack p = pv[i];
+    auto consume = [&](const Pack& p) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         T v = p.v[j];
@@ -149,7 +148,15 @@ __global__ __launch_bounds__(KV_THREADS) void stream_hist_kernel(const T* __rest
           kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
         }
       }
+    };
+    // four 16-byte loads in flight per lane: the LDS atomics of one pack hide the latency of
+    // the next loads instead of serialising load -> bin -> load
+    long long i = (long long)blockIdx.x * KV_THREADS + tid;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+      const Pack p0 = pv[i], p1 = pv[i + stride], p2 = pv[i + 2 * stride], p3 = pv[i + 3 * stride];
+      consume(p0); consume(p1); consume(p2); consume(p3);
     }
+    for (; i < nvec; i += stride) consume(pv[i]);
   }
   // tail (or everything, when the row is not 16-byte aligned)
   for (long long i = (aligned ? nvec * VEC : 0) + (long long)blockIdx.x * KV_THREADS + tid; i < n; i += stride) {
@@ -240,7 +247,19 @@ __global__ __launch_bounds__(KV_THREADS) void radix_hist_kernel(const T* __restr
   };
   if (aligned) {
     const Pack* pv = reinterpret_cast<const Pack*>(row);
-    for (long long i = (long long)blockIdx.x * KV_THREADS + tid; i < nvec; i += stride) {
+    long long i = (long long)blockIdx.x * KV_THREADS + tid;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {  // four loads in flight per lane
+      const Pack p0 = pv[i], p1 = pv[i + stride], p2 = pv[i + 2 * stride], p3 = pv[i + 3 * stride];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) visit(p0.v[j]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) visit(p1.v[j]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) visit(p2.v[j]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) visit(p3.v[j]);
+    }
+    for (; i < nvec; i += stride) {
       Pack p = pv[i];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) visit(p.v[j]);
@@ -392,7 +411,10 @@ __global__ __launch_bounds__(KV_THREADS) void equal_hist_kernel(const T* __restr
 inline int grid_x(long long n, int per_thread) {
   long long blocks = (n + (long long)KV_THREADS * per_thread - 1) / ((long long)KV_THREADS * per_thread);
   if (blocks < 1) blocks = 1;
-  if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks; grid-stride covers the rest
+  // 256 CUs x 2 blocks; grid-stride covers the rest.  Every block ends with one global atomic
+  // per non-empty bin on the SAME few hundred addresses: with 2048 blocks that flush (about a
+  // million contended atomics) cost more than streaming the samples.
+  if (blocks > 512) blocks = 512;
   return (int)blocks;
 }
 
