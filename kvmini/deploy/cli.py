@@ -71,7 +71,11 @@ def start_local_server(a: argparse.Namespace) -> Dict[str, Any]:
     os.makedirs(log_dir, exist_ok=True)
     log = open(os.path.join(log_dir, f"{a.service}.log"), "ab")
     t0 = time.time()
-    proc = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
+    # the child must import this very package, whatever the caller's working directory is
+    pkg_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    proc = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, start_new_session=True, env=env)
     lb = LocalBackend()
     url = f"http://127.0.0.1:{port}"
     deadline = t0 + a.timeout

@@ -413,3 +413,21 @@ def test_every_cli_subcommand_resolves_and_prints_help(capsys):
         main(["fairness", "--help"])
     assert e.value.code == 0
     assert "--tenant-a-requests" in capsys.readouterr().out
+
+
+def test_spec_delta_report_with_self_speculation_on_cpu(in_tmp):
+    """`kvmini spec-delta`: serves the tiny model twice on CPU (plain, then early-exit
+    self-speculation on damped weights), writes the delta report with the acceptance rate."""
+    from kvmini.harness import spec_delta
+
+    rc = spec_delta.main(["--model", "tiny", "--draft", "self:1", "--tail-damping", "0.02", "--num-speculative-tokens", "3", "--requests", "12", "--concurrency", "3", "--max-tokens", "10",
+                          "--port", "8471", "--serve-args", "--device cpu --dtype fp32 --max-model-len 128", "--output-dir", "spec"])
+    assert rc == 0
+    doc = load_json("spec/spec_delta.json")
+    assert doc["draft"] == "self:1" and doc["baseline"]["spec_proposed"] == 0
+    assert doc["speculative"]["spec_proposed"] > 0 and doc["speculative"]["acceptance_rate"] > 0.5
+    assert doc["baseline"]["error_rate"] == 0.0 and doc["speculative"]["error_rate"] == 0.0
+    keys = {d["metric"] for d in doc["deltas"]}
+    assert {"time_to_first_token_ms", "itl_p50_ms", "p95_ms", "tokens_per_sec"} <= keys
+    page = open("spec/spec_delta.html").read()
+    assert "acceptance rate" in page.lower() and "self:1" in page
