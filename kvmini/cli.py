@@ -56,6 +56,7 @@ COMMANDS: Dict[str, Tuple[str, str, str]] = {
     "telemetry": ("kvmini.parallel.telemetry_daemon", "main", "lock-step multi-GPU telemetry over RCCL"),
     # servers
     "serve": ("kvmini.server.native", "main", "native MI355X OpenAI-compatible server"),
+    "router": ("kvmini.server.router", "main", "data-parallel front-end over N engine replicas"),
     "mock": ("kvmini.server.mock", "main", "deterministic mock LLM endpoint"),
 }
 

@@ -297,3 +297,40 @@ def test_tensor_parallel_serving_two_ranks_gloo_matches_single_rank(tmp_path):
         tp.communicate(timeout=60)
         one.wait(30)
     assert tp.returncode is not None
+
+
+def test_data_parallel_router_two_cpu_replicas(tmp_path):
+    """`kvmini router --replicas 2`: two engine processes behind one port; streamed and
+    non-streamed requests are spread over both, metrics carry a replica label."""
+    import signal
+    import time
+    import urllib.request
+
+    from kvmini.loadgen.protocols import RequestSpec
+    from kvmini.loadgen.runner import LoadConfig, run_load_sync
+
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    p = subprocess.Popen([sys.executable, "-m", "kvmini", "router", "--replicas", "2", "--port", "8350", "--device", "cpu", "--no-register", "--", "--model", "tiny", "--dtype", "fp32", "--max-model-len", "128"],
+                         env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    url = "http://127.0.0.1:8350"
+    try:
+        for _ in range(400):
+            assert p.poll() is None, p.stdout.read()[-2000:]
+            try:
+                urllib.request.urlopen(url + "/health", timeout=1)
+                break
+            except Exception:
+                time.sleep(0.2)
+        res = run_load_sync(LoadConfig(url=url, requests=16, concurrency=4, spec=RequestSpec(model="tiny", max_tokens=6, stream=True), quiet=True, trace=False))
+        assert all(r.status == 200 and r.completion_tokens == 6 for r in res)
+        res2 = run_load_sync(LoadConfig(url=url, requests=4, concurrency=2, spec=RequestSpec(model="tiny", max_tokens=4, stream=False), quiet=True, trace=False))
+        assert all(r.status == 200 and r.completion_tokens == 4 for r in res2)
+        metrics = urllib.request.urlopen(url + "/metrics").read().decode()
+        served = {ln.split("{")[1].split("}")[0]: float(ln.rsplit(" ", 1)[1]) for ln in metrics.splitlines() if ln.startswith("kvmini_router_requests_total{")}
+        assert len(served) == 2 and all(v > 0 for v in served.values()) and sum(served.values()) == 20, served
+        assert 'vllm:generation_tokens_total{replica="0"}' in metrics.replace(' ', '') or 'replica="0"' in metrics
+        models = json.loads(urllib.request.urlopen(url + "/v1/models").read())
+        assert models["data"][0]["id"] == "tiny"
+    finally:
+        os.killpg(p.pid, signal.SIGTERM)
+        p.communicate(timeout=60)
