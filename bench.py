@@ -91,6 +91,7 @@ def main() -> int:
     ap.add_argument("--max-num-seqs", type=int, default=32)
     ap.add_argument("--max-batched-tokens", type=int, default=256)
     ap.add_argument("--max-model-len", type=int, default=2048)
+    ap.add_argument("--no-async-scheduling", action="store_true", help="one step at a time: read the sampled ids back before launching the next step")
     ap.add_argument("--out-dir", default=None, help="write run artifacts (requests.csv, power.json, results.json) here")
     ap.add_argument("--gpu-hourly", type=float, default=None, help="$/GPU-hour (default: cost.yaml MI355X entry)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = rehearsal of the multi-rank flow over gloo with the reference ops (not a benchmark)")
@@ -140,6 +141,7 @@ def main() -> int:
             num_speculative_tokens=args.num_speculative_tokens if args.speculative_model else 0,
             kernels=args.kernels,
             kv_memory_fraction=0.3,
+            async_scheduling=not args.no_async_scheduling,
         )
     )
     engine.warmup()
@@ -292,6 +294,7 @@ def main() -> int:
                 "parallelism": f"dp{world}",
                 "kernels": args.kernels,
                 "hip_graphs": not args.no_graphs,
+                "async_scheduling": not args.no_async_scheduling,
             },
             "p50_ms": float(q[0][0]),
             "p95_ms": p95,

@@ -29,6 +29,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
                               hipStream_t stream);
+int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
 int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
@@ -216,6 +217,18 @@ void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor c
                                   out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps, (float)scale,
                                   cur_stream()),
         "kv_decode_attention_fused");
+}
+
+void embed_fed(at::Tensor table, at::Tensor tokens, at::Tensor feed, at::Tensor prev_ids, at::Tensor out) {
+  CHECK_DEV(table); CHECK_BF16(table); CHECK_CONTIG(table); CHECK_DEV(out); CHECK_BF16(out); CHECK_CONTIG(out);
+  CHECK_DEV(tokens); CHECK_DEV(feed); CHECK_DEV(prev_ids); CHECK_CONTIG(tokens); CHECK_CONTIG(feed); CHECK_CONTIG(prev_ids);
+  TORCH_CHECK(table.dim() == 2 && out.dim() == 2 && out.size(1) == table.size(1) && table.size(1) % 8 == 0, "table [V, H], out [T, H], H % 8 == 0");
+  const int64_t T = out.size(0);
+  TORCH_CHECK(tokens.scalar_type() == at::kInt && feed.scalar_type() == at::kInt && tokens.numel() >= T && feed.numel() >= T, "tokens/feed must be int32 with >= T elements");
+  TORCH_CHECK(prev_ids.scalar_type() == at::kLong && prev_ids.numel() >= 1, "prev_ids must be a non-empty int64 tensor");
+  check(kv_embed_fed(table.data_ptr(), (const int*)tokens.data_ptr(), (const int*)feed.data_ptr(), (const long long*)prev_ids.data_ptr(), (int)prev_ids.numel(), out.data_ptr(), (int)T,
+                     (int)table.size(1), (int)table.size(0), cur_stream()),
+        "kv_embed_fed");
 }
 
 void argmax(at::Tensor logits, at::Tensor out) {
@@ -431,6 +444,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("prefill_attention", &prefill_attention);
   m.def("decode_attention_fused", &decode_attention_fused);
   m.def("argmax", &argmax);
+  m.def("embed_fed", &embed_fed);
   m.def("swiglu_interleaved", &swiglu_interleaved);
   m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);

@@ -895,6 +895,21 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const unsigned short* __re
   }
 }
 
+// Embedding lookup whose token id may come from the previous step's sampled ids instead of
+// the staged token array: feed[i] = r + 1 selects prev_ids[r] (the host launched this step
+// before it had read that id back), feed[i] = 0 selects tokens[i].  One workgroup per row,
+// 16 bytes per thread per trip; ids outside [0, V) read row 0.
+__global__ __launch_bounds__(256) void embed_fed_kernel(const unsigned short* __restrict__ table, const int* __restrict__ tokens, const int* __restrict__ feed,
+                                                        const long long* __restrict__ prev_ids, int n_prev, unsigned short* __restrict__ out, int H, int V) {
+  const int i = blockIdx.x;
+  const int f = feed[i];
+  long long tok = (f > 0 && f <= n_prev) ? prev_ids[f - 1] : (long long)tokens[i];
+  if (tok < 0 || tok >= V) tok = 0;
+  const bf16x8* src = reinterpret_cast<const bf16x8*>(table + tok * H);
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out + (long long)i * H);
+  for (int c = threadIdx.x; c < (H >> 3); c += 256) dst[c] = src[c];
+}
+
 // silu(gate) * up for the group-of-16 interleaved layout: gu [T, 2I] -> act [T, I]
 __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ act, int I) {
   const int t = blockIdx.y;
@@ -1082,6 +1097,13 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream) {
   if (S <= 0) return 0;
   hipLaunchKernelGGL(argmax_kernel, dim3(S), dim3(1024), 0, stream, (const unsigned short*)logits, row_stride, V, out);
+  return (int)hipGetLastError();
+}
+
+int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (H % 8) return -1;
+  hipLaunchKernelGGL(embed_fed_kernel, dim3(T), dim3(256), 0, stream, (const unsigned short*)table, tokens, feed, prev_ids, n_prev, (unsigned short*)out, H, V);
   return (int)hipGetLastError();
 }
 

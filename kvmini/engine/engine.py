@@ -50,6 +50,8 @@ class EngineConfig:
     # random-init only: damp the residual branches of layers >= K by this factor (see
     # kvmini.models.llama.random_weights); K is the early-exit depth of a "self:<K>" draft
     tail_damping: float = 0.0
+    # launch step n+1 before reading step n's tokens back (greedy requests, no KV pressure)
+    async_scheduling: bool = True
     tp_size: int = 1
     tp_rank: int = 0
     tp_graphs: bool = False
@@ -172,6 +174,8 @@ class LLMEngine:
         self.on_tokens: Optional[Callable[[List[TokenEvent]], None]] = None
         self._gens: Dict[int, torch.Generator] = {}
         self.warm_s = 0.0
+        self._pending: Optional[Tuple[Batch, Any]] = None  # (batch, runner handle) of the step in flight
+        self.pipelined_steps = 0
 
     # ------------------------------------------------------------------
     def warmup(self) -> float:
@@ -189,21 +193,86 @@ class LLMEngine:
         return Sequence(next(self._ids), list(prompt_ids), params or SamplingParams(), user=user)
 
     def step(self) -> List[TokenEvent]:
-        """One engine iteration.  Empty list when nothing is schedulable."""
+        """One engine iteration.  Empty list when nothing is schedulable (or, pipelined, when
+        the first step of a burst has been launched and none was in flight before it)."""
         if self.spec is not None:
             return self.spec.step()
-        batch = self.scheduler.schedule()
-        if not batch.chunks:
-            return []
         t0 = time.perf_counter()
-        with torch.no_grad():
-            ids, logits = self.runner.execute(batch)
-        events = self._commit(batch, ids, logits)
-        dt = time.perf_counter() - t0
-        st = self.stats
-        st.steps += 1
-        st.busy_s += dt
-        st.step_ms_ewma = dt * 1e3 if st.step_ms_ewma == 0 else 0.9 * st.step_ms_ewma + 0.1 * dt * 1e3
+        launched = False
+        if self.ecfg.async_scheduling and self._can_pipeline():
+            # launch the next step on top of the one in flight, THEN read that one's tokens:
+            # the device never waits for the host between steps
+            batch = self.scheduler.schedule()
+            handle = None
+            if batch.chunks:
+                with torch.no_grad():
+                    handle = self.runner.launch(batch)
+                self.scheduler.launch_commit(batch)
+                launched = True
+                self.pipelined_steps += 1
+            events = self._finalize_pending()
+            self._pending = (batch, handle) if handle is not None else None
+        else:
+            events = self._finalize_pending()
+            batch = self.scheduler.schedule()
+            if batch.chunks:
+                with torch.no_grad():
+                    ids, logits = self.runner.execute(batch)
+                events += self._commit(batch, ids, logits)
+                launched = True
+        if launched:
+            dt = time.perf_counter() - t0
+            st = self.stats
+            st.steps += 1
+            st.busy_s += dt
+            st.step_ms_ewma = dt * 1e3 if st.step_ms_ewma == 0 else 0.9 * st.step_ms_ewma + 0.1 * dt * 1e3
+        self._progress = launched or bool(events)
+        return events
+
+    def _can_pipeline(self) -> bool:
+        """Pipelined stepping needs every token of the next step to be either known or the
+        argmax the device already holds (greedy requests only), and no preemption (a preempted
+        sequence is rescheduled from its token list, which may not hold placeholders)."""
+        r, sch = self.runner, self.scheduler
+        if r.tp_active or r.tp_size > 1:
+            return False
+        for s in sch.running:
+            if s.params.temperature > 0 or s.params.logprobs:
+                return False
+        room = sch.max_num_seqs - len(sch.running)
+        if room > 0 and sch.waiting:
+            for s in itertools.islice(sch.waiting, room):
+                if s.params.temperature > 0 or s.params.logprobs:
+                    return False
+        return self.bm.num_free >= len(sch.running) + sch.max_batched_tokens // self.bm.block_size + 2
+
+    def _finalize_pending(self) -> List[TokenEvent]:
+        """Read back the step in flight (if any) and commit its tokens."""
+        if self._pending is None:
+            return []
+        batch, handle = self._pending
+        self._pending = None
+        ids, _ = self.runner.collect(handle)
+        events: List[TokenEvent] = []
+        row = 0
+        for ch in batch.chunks:
+            seq = ch.seq
+            if ch.start < len(seq.prompt_ids):
+                self.stats.prompt_tokens += min(ch.n_tokens, len(seq.prompt_ids) - ch.start)
+            tok = None
+            if ch.sample:
+                tok = ids[row]
+                row += 1
+            if seq.status != SeqStatus.RUNNING:
+                continue
+            new = self.scheduler.finalize(ch, tok)
+            if not ch.sample:
+                continue
+            self.stats.generation_tokens += len(new)
+            done = seq.status == SeqStatus.FINISHED
+            if done:
+                self.stats.requests_finished += 1
+            events.append((seq.req_id, new, done, seq.finish_reason, seq))
         return events
 
     def _commit(self, batch: Batch, ids: List[int], logits: Optional[torch.Tensor]) -> List[TokenEvent]:
@@ -251,7 +320,7 @@ class LLMEngine:
         for s in seqs:
             self.scheduler.add(s)
         while self.scheduler.has_work():
-            if not self.step() and not self.scheduler.running and self.scheduler.waiting:
+            if not self.step() and self._pending is None and not self.scheduler.running and self.scheduler.waiting:
                 raise RuntimeError("scheduler cannot make progress (KV cache too small for the prompt?)")
         return [s.output_ids for s in seqs]
 
@@ -319,12 +388,13 @@ class LLMEngine:
 
                 traceback.print_exc()
                 events = []
+                self._pending = None
                 for s in list(self.scheduler.running):
                     self.scheduler._finish(s, "error")
                     events.append((s.req_id, [], True, f"error: {e}", s))
             if events and self.on_tokens is not None:
                 self.on_tokens(events)
-            elif not events:
+            elif not events and not getattr(self, "_progress", False):
                 # nothing schedulable right now (e.g. waiting for KV blocks)
                 time.sleep(0.0005)
 
@@ -348,6 +418,7 @@ class LLMEngine:
             "spec_proposed": st.spec_proposed,
             "spec_accepted": st.spec_accepted,
             "graphs": sorted({b for b, _ in self.runner.graphs}),
+            "pipelined_steps": self.pipelined_steps,
             "load_s": self.load_s,
             "warm_s": self.warm_s,
         }

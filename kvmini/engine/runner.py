@@ -25,7 +25,7 @@ import torch
 
 from kvmini.models.llama import LlamaConfig, LlamaWeights, rope_tables
 
-from .scheduler import Batch
+from .scheduler import PLACEHOLDER, Batch
 
 DEFAULT_BUCKETS = (16, 32, 48, 64, 128, 256, 512, 1024, 2048)
 
@@ -62,6 +62,28 @@ def select_ops(kernels: str, device: torch.device) -> Any:
 
     hip_ops.require()
     return hip_ops
+
+
+class _Stage:
+    """One pinned host image of the step inputs (+ the host copy of the sampled ids)."""
+
+    def __init__(self, n_ints: int, o_bt: int, smax: int, max_blocks_per_seq: int, tmax: int, pin: bool):
+        self.cpu = torch.zeros(n_ints, dtype=torch.int32, pin_memory=pin)
+        self.np = self.cpu.numpy()
+        self.bt_np = self.np[o_bt : o_bt + smax * max_blocks_per_seq].reshape(smax, max_blocks_per_seq)
+        # per slot: ((request id, blocks epoch), block ids already staged in THIS image)
+        self.bt_owner: List[Tuple[Any, int]] = [(None, 0)] * smax
+        self.out_cpu = torch.zeros(tmax, dtype=torch.int64, pin_memory=pin)
+        self.event: Any = None
+
+
+@dataclass
+class StepHandle:
+    """A launched step whose sampled ids have not been read back yet."""
+
+    n_samples: int
+    logits: Optional[torch.Tensor]
+    stage: _Stage
 
 
 class ModelRunner:
@@ -123,15 +145,17 @@ class ModelRunner:
         # read the step shape from here): t_pad, n_samples, max_ctx, command (0 = run, 1 = stop)
         self._off["header"] = (off, 8)
         off += 8
+        # token feed (pipelined stepping): feed[i] = r + 1 -> token i is row r of the previous
+        # step's sampled ids, read on the device; 0 -> the staged token
+        self._off["feed"] = (off, tmax)
+        off += tmax
         pin = self.device.type == "cuda"
-        self.stage_cpu = torch.zeros(off, dtype=torch.int32, pin_memory=pin)
-        self.stage_np = self.stage_cpu.numpy()
+        # two host staging buffers, used alternately: a step can be staged while the copy of the
+        # previous one may still be in flight
+        self.stages = [_Stage(off, self._off["block_tables"][0], smax, self.max_blocks_per_seq, tmax, pin) for _ in range(2)]
+        self._cur = 0
         self.stage_dev = torch.zeros(off, dtype=torch.int32, device=self.device)
-        o_bt = self._off["block_tables"][0]
-        self.bt_np = self.stage_np[o_bt : o_bt + smax * self.max_blocks_per_seq].reshape(smax, self.max_blocks_per_seq)
-        self._bt_owner: List[Tuple[Any, int]] = [(None, 0)] * smax  # per slot: ((request id, blocks epoch), block ids already staged)
         self.out_ids = torch.zeros(tmax, dtype=torch.int64, device=self.device)
-        self.out_ids_cpu = torch.zeros(tmax, dtype=torch.int64, pin_memory=pin)
         self.logits_buf: Optional[torch.Tensor] = None
         self.spec_width = 1  # positions sampled per sequence per step (k+1 with speculation)
         self.s_cap = tmax
@@ -186,7 +210,7 @@ class ModelRunner:
         sample_idx = self._dev("sample_idx", t_pad)
         bt = self._dev("block_tables").view(self.rcfg.max_num_seqs, self.max_blocks_per_seq)
 
-        x = w.embed[tokens.long()] if w.embed.device.type == "cpu" else torch.index_select(w.embed, 0, tokens)
+        x = ops.embed_tokens(w.embed, tokens, self._dev("feed", t_pad), self.out_ids)
         residual = None  # the first residual add is a copy
         for li, lw in enumerate(w.layers):
             h, residual = ops.add_rmsnorm(x, residual, lw.attn_norm, cfg.rms_eps)
@@ -321,17 +345,19 @@ class ModelRunner:
         if self.tp_size <= 1:
             return
         o_h = self._off["header"][0]
-        self.stage_np[o_h : o_h + 5] = (0, 0, 0, 1, 0)
-        self.stage_dev.copy_(self.stage_cpu)
+        sb = self.stages[0]
+        sb.np[o_h : o_h + 5] = (0, 0, 0, 1, 0)
+        self.stage_dev.copy_(sb.cpu)
         torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
 
     def _stage_dummy(self) -> None:
         """Inputs that are safe for warm-up/capture: every token is padding."""
-        self.stage_np[:] = 0
-        self._bt_owner = [(None, 0)] * len(self._bt_owner)
         o, n = self._off["slots"]
-        self.stage_np[o : o + n] = -1
-        self.stage_dev.copy_(self.stage_cpu)
+        for sb in self.stages:
+            sb.np[:] = 0
+            sb.bt_owner = [(None, 0)] * len(sb.bt_owner)
+            sb.np[o : o + n] = -1
+        self.stage_dev.copy_(self.stages[0].cpu)
 
     # ------------------------------------------------------------------
     def execute(self, batch: Batch) -> Tuple[List[int], Optional[torch.Tensor]]:
@@ -339,9 +365,26 @@ class ModelRunner:
         flagged for sampling, in chunk order: a chunk flagged ``sample`` contributes
         its last position — or, when it carries draft tokens to verify, every
         position from the last accepted token on."""
+        return self.collect(self.launch(batch))
+
+    def collect(self, h: StepHandle) -> Tuple[List[int], Optional[torch.Tensor]]:
+        """Wait for a launched step and read its sampled ids."""
+        if h.stage.event is not None:
+            h.stage.event.synchronize()
+        n = h.n_samples
+        return h.stage.out_cpu[:n].tolist(), (h.logits[:n] if h.logits is not None else None)
+
+    def launch(self, batch: Batch) -> StepHandle:
+        """Stage and enqueue one step without waiting for it.  A one-token chunk whose token
+        is still a placeholder (``PLACEHOLDER``: sampled by the previous step, which the host
+        has not read back) is fed on the device from row ``seq.pending_row`` of that step's
+        ids.  At most one launched step may be uncollected when the next one is launched."""
         t = batch.num_tokens
         t_pad = self.bucket_for(t)
-        st = self.stage_np
+        sb = self.stages[self._cur]
+        self._cur ^= 1
+        st = sb.np
+        o_fd = self._off["feed"][0]
         o_tok, o_pos, o_slot, o_seq, o_ctx, o_smp = (self._off[k][0] for k in ("tokens", "positions", "slots", "tok_seq", "ctx", "sample_idx"))
         o_cd, o_tl, mt = self._off["ctx_decode"][0], self._off["tiles"][0], self.max_tiles
         n_tiles = 0
@@ -355,15 +398,21 @@ class ModelRunner:
             blocks = seq.blocks
             # block tables only grow while a sequence keeps its slot: write the new tail
             key = (seq.req_id, seq.blocks_epoch)
-            owner = self._bt_owner[seq.slot]
+            owner = sb.bt_owner[seq.slot]
             nb_have = owner[1] if owner[0] == key and owner[1] <= len(blocks) else 0
             if nb_have < len(blocks):
-                self.bt_np[seq.slot, nb_have : len(blocks)] = blocks[nb_have:]
-            self._bt_owner[seq.slot] = (key, len(blocks))
+                sb.bt_np[seq.slot, nb_have : len(blocks)] = blocks[nb_have:]
+            sb.bt_owner[seq.slot] = (key, len(blocks))
             p0 = ch.start
             if n == 1 and not seq.draft_ids:
                 npmt = len(seq.prompt_ids)
-                st[o_tok + i] = seq.prompt_ids[p0] if p0 < npmt else seq.output_ids[p0 - npmt]
+                tok = seq.prompt_ids[p0] if p0 < npmt else seq.output_ids[p0 - npmt]
+                if tok == PLACEHOLDER:
+                    st[o_tok + i] = 0
+                    st[o_fd + i] = seq.pending_row + 1
+                else:
+                    st[o_tok + i] = tok
+                    st[o_fd + i] = 0
                 st[o_pos + i] = p0
                 st[o_slot + i] = blocks[p0 // bs] * bs + p0 % bs
                 st[o_seq + i] = seq.slot
@@ -389,6 +438,7 @@ class ModelRunner:
                 st[o_seq + i : o_seq + i + n] = seq.slot
                 st[o_ctx + i : o_ctx + i + n] = pos + 1
                 st[o_cd + i : o_cd + i + n] = 0
+                st[o_fd + i : o_fd + i + n] = 0
                 for off in range(0, n, 16):
                     st[o_tl + n_tiles], st[o_tl + mt + n_tiles], st[o_tl + 2 * mt + n_tiles], st[o_tl + 3 * mt + n_tiles] = i + off, min(16, n - off), p0 + off, seq.slot
                     n_tiles += 1
@@ -406,6 +456,7 @@ class ModelRunner:
             st[o_seq + t : o_seq + t_pad] = 0
             st[o_ctx + t : o_ctx + t_pad] = 0
             st[o_cd + t : o_cd + t_pad] = 0
+            st[o_fd + t : o_fd + t_pad] = 0
         st[o_smp + n_samples : o_smp + t_pad] = 0
         st[o_tl + mt + n_tiles : o_tl + 2 * mt] = 0  # unused tiles: zero valid queries
 
@@ -413,15 +464,15 @@ class ModelRunner:
         decode_only = all(ch.n_tokens == 1 for ch in batch.chunks)
         o_h = self._off["header"][0]
         st[o_h : o_h + 5] = (t_pad, n_samples, max_ctx, 0, int(decode_only))
-        self.stage_dev.copy_(self.stage_cpu, non_blocking=True)
+        self.stage_dev.copy_(sb.cpu, non_blocking=True)
         if self.tp_size > 1:
             # every rank runs the same step: ship the staged inputs to the followers (see follow())
             torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
         logits = self._run_staged(t_pad, max_ctx, decode_only)
+        # the ids leave the device right behind the step, before a later launch overwrites them
+        sb.out_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
         if self.device.type == "cuda":
-            self.out_ids_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
-            torch.cuda.current_stream(self.device).synchronize()
-            ids_out = self.out_ids_cpu[:n_samples].tolist()
-        else:
-            ids_out = self.out_ids[:n_samples].tolist()
-        return ids_out, (logits[:n_samples] if logits is not None else None)
+            if sb.event is None:
+                sb.event = torch.cuda.Event()
+            sb.event.record(torch.cuda.current_stream(self.device))
+        return StepHandle(n_samples, logits, sb)

@@ -21,6 +21,11 @@ from typing import Any, Deque, Dict, List, Optional
 from .kv_cache import BlockManager
 
 
+# stands in ``Sequence.output_ids`` for a token that a launched step has sampled but the host has
+# not read back yet (pipelined stepping: the next step is launched first)
+PLACEHOLDER = -1
+
+
 class SeqStatus(Enum):
     WAITING = 0
     RUNNING = 1
@@ -59,6 +64,10 @@ class Sequence:
     # speculative decoding state: draft tokens proposed for the next verify step
     draft_ids: List[int] = field(default_factory=list)
     preemptions: int = 0
+    # pipelined stepping: row of this sequence's sample in the step in flight; set when the
+    # in-flight sample is known (by length) to be the sequence's last
+    pending_row: int = -1
+    pending_finish: bool = False
 
     @property
     def all_ids(self) -> List[int]:
@@ -82,6 +91,7 @@ class ScheduledChunk:
     # trailing positions to sample; -1 = the last one, or with draft tokens to verify
     # every position from the last accepted token on
     n_sample: int = -1
+    out_index: int = -1  # pipelined stepping: index in ``output_ids`` of the placeholder this chunk fills
 
 
 @dataclass
@@ -175,6 +185,8 @@ class Scheduler:
                 break
             if seq not in self.running:  # preempted while serving an earlier sequence
                 continue
+            if seq.pending_finish:  # its last token is in flight
+                continue
             known = seq.num_tokens + (len(seq.draft_ids) if not seq.is_prefilling else 0)
             n_new = known - seq.num_computed
             if n_new <= 0:
@@ -234,6 +246,61 @@ class Scheduler:
             seq.slot = -1
         if seq in self.running:
             self.running.remove(seq)
+
+    # --- pipelined stepping: account for a step at LAUNCH, fill in its tokens later ----------
+    def launch_commit(self, batch: Batch) -> None:
+        """Advance every sequence of a step that has just been enqueued as if it had finished:
+        its positions count as computed and a sampled token is a ``PLACEHOLDER`` until
+        :meth:`finalize`.  A sequence that reaches its length limit with this token is not
+        scheduled again (``pending_finish``); it keeps its blocks and slot until finalized."""
+        row = 0
+        bs = self.bm.block_size
+        for ch in batch.chunks:
+            seq = ch.seq
+            seq.num_computed = ch.start + ch.n_tokens
+            # blocks whose tokens are all known (prompt chunks above all) are published now: a
+            # request admitted by the very next launch may reuse them, its step runs behind this
+            # one on the stream
+            known = seq.num_tokens - (1 if seq.output_ids and seq.output_ids[-1] == PLACEHOLDER else 0)
+            n_reg = min(seq.num_computed, known)
+            if n_reg // bs > seq.published_blocks:
+                seq.published_blocks = self.bm.register_full_blocks(seq.all_ids, seq.blocks, n_reg, seq.published_blocks)
+            if not ch.sample:
+                continue
+            seq.pending_row = row
+            row += 1
+            ch.out_index = len(seq.output_ids)
+            seq.output_ids.append(PLACEHOLDER)
+            if len(seq.output_ids) >= seq.params.max_tokens or seq.num_tokens >= self.max_model_len:
+                seq.pending_finish = True
+
+    def finalize(self, chunk: ScheduledChunk, token: Optional[int]) -> List[int]:
+        """The launched step of ``chunk`` has finished and ``token`` is its sample (None for a
+        chunk that did not sample).  Returns the tokens appended.  A stop token ends the
+        sequence here, one step late: the token a later launch computed for it meanwhile is
+        dropped (its KV write went to blocks the sequence still owned)."""
+        seq = chunk.seq
+        if seq.status != SeqStatus.RUNNING:  # aborted while the step was in flight
+            return []
+        n_done = chunk.start + chunk.n_tokens  # every token below this position is known by now
+        if chunk.sample:
+            assert token is not None
+            seq.output_ids[chunk.out_index] = token
+        if n_done // self.bm.block_size > seq.published_blocks:
+            seq.published_blocks = self.bm.register_full_blocks(seq.all_ids, seq.blocks, n_done, seq.published_blocks)
+        if not chunk.sample:
+            return []
+        if seq.first_token_time is None:
+            seq.first_token_time = time.perf_counter()
+        n_out = chunk.out_index + 1
+        if (not seq.params.ignore_eos and token == self.eos_token_id) or token in seq.params.stop_token_ids:
+            del seq.output_ids[n_out:]
+            seq.pending_finish = False
+            self._finish(seq, "stop")
+        elif n_out >= seq.params.max_tokens or len(seq.prompt_ids) + n_out >= self.max_model_len:
+            seq.pending_finish = False
+            self._finish(seq, "length")
+        return [token]
 
     def commit(self, chunk: ScheduledChunk, new_tokens: List[int], num_accepted_positions: Optional[int] = None) -> List[int]:
         """Account for a finished step.  ``new_tokens`` are the tokens to append

@@ -234,6 +234,18 @@ def add_rmsnorm(x: Union[torch.Tensor, Partial], residual: Optional[torch.Tensor
     return Normed(residual, ss, eps), residual
 
 
+def embed_tokens(table: torch.Tensor, tokens: torch.Tensor, feed: torch.Tensor, prev_ids: torch.Tensor) -> torch.Tensor:
+    """Embedding lookup with device-side token feed (see ``torch_ops.embed_tokens``): one
+    kernel, so a step can be launched before the host has read the previous step's ids."""
+    if table.dtype != torch.bfloat16 or table.shape[1] % 8:
+        from . import torch_ops
+
+        return torch_ops.embed_tokens(table, tokens, feed, prev_ids)
+    out = torch.empty((tokens.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
+    native().embed_fed(table, tokens, feed, prev_ids, out)
+    return out
+
+
 def select_rows(h: Normed, idx: torch.Tensor) -> Normed:
     return Normed(torch.index_select(h.x, 0, idx), torch.index_select(h.ss, 0, idx), h.eps)
 

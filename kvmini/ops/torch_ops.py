@@ -36,6 +36,16 @@ def add_rmsnorm(x: torch.Tensor, residual: "torch.Tensor | None", w: torch.Tenso
     return rmsnorm(r, w, eps), r
 
 
+def embed_tokens(table: torch.Tensor, tokens: torch.Tensor, feed: torch.Tensor, prev_ids: torch.Tensor) -> torch.Tensor:
+    """Embedding rows of a step's tokens.  ``feed[i] = r + 1`` takes the id from
+    ``prev_ids[r]`` (the previous step's sampled ids, still on the device) instead of
+    ``tokens[i]``; 0 = use ``tokens[i]``.  Ids outside the vocabulary read row 0."""
+    fed = prev_ids[(feed.long() - 1).clamp(0, prev_ids.numel() - 1)]
+    tok = torch.where((feed > 0) & (feed <= prev_ids.numel()), fed, tokens.long())
+    tok = torch.where((tok < 0) | (tok >= table.shape[0]), torch.zeros_like(tok), tok)
+    return table[tok]
+
+
 def select_rows(h: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return torch.index_select(h, 0, idx.long() if h.device.type == "cpu" else idx)
 

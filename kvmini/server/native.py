@@ -352,6 +352,7 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--tail-damping", type=float, default=0.0, help="random-init + self:<K> only: damp layers >= K so the early-exit draft agrees with the full model (synthetic)")
     ap.add_argument("--num-speculative-tokens", type=int, default=0)
     ap.add_argument("--tensor-parallel-size", type=int, default=1, help="shard the model over this many GPUs; launch with torchrun --nproc-per-node N (one rank per GPU, RCCL)")
+    ap.add_argument("--no-async-scheduling", action="store_true", help="read every step's tokens back before launching the next one (default: launch ahead; greedy requests only)")
     ap.add_argument("--tp-graphs", action="store_true", help="capture HIP graphs under tensor parallelism (the RCCL all-reduces are recorded inside them)")
     ap.add_argument("--honor-eos", action="store_true", help="stop at EOS (default: ignore EOS with random-init weights)")
 
@@ -379,6 +380,7 @@ def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
         tp_size=getattr(a, "tensor_parallel_size", 1),
         tp_rank=getattr(a, "tp_rank", 0),
         tp_graphs=getattr(a, "tp_graphs", False),
+        async_scheduling=not getattr(a, "no_async_scheduling", False),
     )
 
 

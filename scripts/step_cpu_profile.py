@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Host-side cost of one engine step, phase by phase (GPU box): schedule, staging up to the
-graph launch, wait for the GPU, commit.  Prints mean microseconds per phase."""
+"""Host-side cost of one engine step (GPU box), one-step-at-a-time against pipelined stepping
+(the next step launched before the previous one's ids are read back).  Prints ms per step of a
+20-sequence decode for both, and for the synchronous mode the mean microseconds per phase:
+schedule, staging up to the graph launch, wait for the GPU, commit."""
 import os
 import sys
 import time
@@ -17,7 +19,8 @@ eng.warmup()
 T = {"schedule": 0.0, "stage+launch": 0.0, "gpu wait": 0.0, "commit": 0.0}
 sched, runner = eng.scheduler, eng.runner
 _schedule, _commit, _run = sched.schedule, eng._commit, runner._run_staged
-sync = torch.cuda.Stream.synchronize
+_finalize = eng._finalize_pending
+sync = torch.cuda.Event.synchronize
 marks = {}
 
 
@@ -37,35 +40,41 @@ def commit(*a, **k):
     t = time.perf_counter(); r = _commit(*a, **k); T["commit"] += time.perf_counter() - t; return r
 
 
-sched.schedule, eng._commit, runner._run_staged = schedule, commit, run_staged
-torch.cuda.Stream.synchronize = synchronize
+def finalize(*a, **k):
+    t = time.perf_counter(); w0 = T["gpu wait"]; r = _finalize(*a, **k); T["commit"] += time.perf_counter() - t - (T["gpu wait"] - w0); return r
+
+
+sched.schedule, eng._commit, runner._run_staged, eng._finalize_pending = schedule, commit, run_staged, finalize
+torch.cuda.Event.synchronize = synchronize
 prompts = [[1] + list(range(100 + i, 113 + i)) for i in range(20)]
-for rep in range(2):
-    for k in T:
-        T[k] = 0.0
-    for p in prompts:
-        sched.add(eng.make_sequence(p, SamplingParams(max_tokens=64, ignore_eos=True)))
-    eng.step()
-    torch.cuda.synchronize()
-    for k in T:
-        T[k] = 0.0
-    t0 = time.perf_counter()
-    n = 0
-    while sched.has_work():
+for mode in (False, True):
+    eng.ecfg.async_scheduling = mode
+    for rep in range(2):
+        for p in prompts:
+            sched.add(eng.make_sequence(p, SamplingParams(max_tokens=64, ignore_eos=True)))
         eng.step()
-        n += 1
-    wall = time.perf_counter() - t0
-print("steps", n, "ms/step", round(wall / n * 1e3, 4))
-for k, v in T.items():
-    print(f"  {k:<14} {v / n * 1e6:8.1f} us/step")
-print(f"  {'other':<14} {(wall - sum(T.values())) / n * 1e6:8.1f} us/step")
+        eng.step()
+        torch.cuda.synchronize()
+        for k in T:
+            T[k] = 0.0
+        t0 = time.perf_counter()
+        n = 0
+        while sched.has_work():
+            eng.step()
+            n += 1
+        wall = time.perf_counter() - t0
+    print("pipelined" if mode else "synchronous", "steps", n, "ms/step", round(wall / n * 1e3, 4))
+    for k, v in T.items():
+        print(f"  {k:<14} {v / n * 1e6:8.1f} us/step")
+    print(f"  {'other':<14} {(wall - sum(T.values())) / n * 1e6:8.1f} us/step")
 
 # ---- the pieces of "stage+launch" in isolation
 g, _ = runner.graphs[(32, True)]
+sb = runner.stages[0]
 torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(200):
-    runner.stage_dev.copy_(runner.stage_cpu, non_blocking=True)
+    runner.stage_dev.copy_(sb.cpu, non_blocking=True)
 h2d = (time.perf_counter() - t) / 200
 torch.cuda.synchronize()
 rep = []
@@ -76,7 +85,7 @@ for _ in range(30):
     torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(200):
-    runner.out_ids_cpu[:20].copy_(runner.out_ids[:20], non_blocking=True)
+    sb.out_cpu[:20].copy_(runner.out_ids[:20], non_blocking=True)
 d2h = (time.perf_counter() - t) / 200
 torch.cuda.synchronize()
-print(f"  h2d enqueue {h2d * 1e6:.1f} us, graph replay call {sorted(rep)[len(rep) // 2] * 1e6:.1f} us, d2h enqueue {d2h * 1e6:.1f} us, stage ints {runner.stage_cpu.numel()}")
+print(f"  h2d enqueue {h2d * 1e6:.1f} us, graph replay call {sorted(rep)[len(rep) // 2] * 1e6:.1f} us, d2h enqueue {d2h * 1e6:.1f} us, stage ints {sb.cpu.numel()}")

@@ -334,3 +334,72 @@ def test_data_parallel_router_two_cpu_replicas(tmp_path):
     finally:
         os.killpg(p.pid, signal.SIGTERM)
         p.communicate(timeout=60)
+
+
+def test_pipelined_stepping_equals_synchronous_stepping():
+    """Launch-ahead stepping (step n+1 enqueued before step n's ids are read, token fed on the
+    device) must produce the same tokens, finish reasons, prefix-cache state and block
+    accounting as one-step-at-a-time, with arrivals in mid-flight, stop tokens that take effect
+    one step late, an abort of a sequence whose step is in flight, and a length cap."""
+
+    def run(async_on):
+        eng, w = _engine(async_scheduling=async_on, max_num_seqs=4, max_batched_tokens=16, num_blocks=128)
+        ref = dense_greedy(w, PROMPTS[0], 12)
+        plan = [  # (arrival step, prompt, params)
+            (0, PROMPTS[0], SamplingParams(max_tokens=12, ignore_eos=True)),
+            (0, PROMPTS[1], SamplingParams(max_tokens=9, ignore_eos=True)),
+            (2, PROMPTS[2], SamplingParams(max_tokens=7, ignore_eos=True, stop_token_ids=[dense_greedy(w, PROMPTS[2], 7)[3]])),
+            (3, PROMPTS[0], SamplingParams(max_tokens=12, ignore_eos=True, stop_token_ids=[ref[5]])),
+            (5, [1, 7, 8, 9], SamplingParams(max_tokens=30, ignore_eos=True)),  # aborted below
+            (6, [1] + list(range(40, 70)), SamplingParams(max_tokens=5, ignore_eos=True)),
+            (9, PROMPTS[1], SamplingParams(max_tokens=3, ignore_eos=True)),
+        ]
+        seqs, events, step = [], [], 0
+        while step < 200:
+            for at, prompt, sp in plan:
+                if at == step:
+                    s = eng.make_sequence(prompt, sp)
+                    seqs.append(s)
+                    eng.scheduler.add(s)
+            if step == 9:
+                eng.scheduler.abort(seqs[4].req_id)
+            ev = eng.step()
+            events += [(e[0], tuple(e[1]), e[2], e[3]) for e in ev]
+            step += 1
+            if step > 10 and not eng.scheduler.has_work() and eng._pending is None:
+                break
+        assert not eng.scheduler.has_work()
+        m = eng.metrics()
+        assert m["kv_blocks_free"] == m["kv_blocks_total"] - 1
+        outs = [(s.output_ids, s.finish_reason) for i, s in enumerate(seqs) if i != 4]
+        assert all(-1 not in o for o, _ in outs)
+        return outs, events, eng, w
+
+    sync_out, sync_ev, eng_s, w = run(False)
+    pipe_out, pipe_ev, eng_p, _ = run(True)
+    assert eng_s.pipelined_steps == 0 and eng_p.pipelined_steps > 10
+    assert pipe_out == sync_out
+    assert sync_out[0] == (dense_greedy(w, PROMPTS[0], 12), "length")
+    assert sync_out[2][1] == "stop" and len(sync_out[2][0]) == 4
+    ref = dense_greedy(w, PROMPTS[0], 12)
+    assert sync_out[3][1] == "stop" and len(sync_out[3][0]) == ref.index(ref[5]) + 1
+    # per request the streamed events carry the same tokens in the same order
+    for rid in {e[0] for e in sync_ev}:
+        if rid == 5:
+            continue
+        assert [e[1:] for e in pipe_ev if e[0] == rid] == [e[1:] for e in sync_ev if e[0] == rid]
+
+
+def test_pipelined_stepping_hands_over_to_synchronous_for_sampled_requests():
+    eng, w = _engine(max_num_seqs=4)
+    a = eng.make_sequence(PROMPTS[0], SamplingParams(max_tokens=10, ignore_eos=True))
+    eng.scheduler.add(a)
+    for _ in range(4):
+        eng.step()
+    assert eng._pending is not None and eng.pipelined_steps == 4
+    b = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=5, temperature=0.8, seed=3, ignore_eos=True))
+    eng.scheduler.add(b)
+    while eng.scheduler.has_work():
+        eng.step()
+    assert eng._pending is None
+    assert a.output_ids == dense_greedy(w, PROMPTS[0], 10) and len(b.output_ids) == 5 and -1 not in b.output_ids

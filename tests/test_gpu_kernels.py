@@ -669,3 +669,46 @@ def test_prefill_attention_tiles_match_reference(rep):
     owned = ctx_t > 0
     assert (out[owned].float() - ref[owned].float()).abs().max().item() <= 2.5e-2
     assert (out[~owned] == 7.0).all()
+
+
+@pytest.mark.gpu
+def test_embed_fed_matches_reference_and_pipelined_engine_matches_sync():
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(0)
+    V, H, T = 1000, 512, 48
+    table = torch.randn(V, H, device="cuda", dtype=torch.bfloat16)
+    tokens = torch.randint(0, V, (T,), device="cuda", dtype=torch.int32)
+    prev = torch.randint(0, V, (64,), device="cuda", dtype=torch.int64)
+    feed = torch.zeros(T, device="cuda", dtype=torch.int32)
+    feed[::3] = torch.randint(1, 65, (len(feed[::3]),), device="cuda", dtype=torch.int32)
+    feed[5] = 65 + 7  # beyond prev: falls back to the staged token
+    tokens[7] = V + 3  # outside the vocabulary: row 0
+    got = hip_ops.embed_tokens(table, tokens, feed, prev)
+    want = torch_ops.embed_tokens(table, tokens, feed, prev)
+    assert torch.equal(got, want)
+    assert torch.equal(got[3], table[prev[feed[3] - 1]]) and torch.equal(got[7], table[0]) and torch.equal(got[5], table[tokens[5]])
+
+    # engine level: launch-ahead stepping (graphs, device-side token feed) = one step at a time
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    prompts = [[1] + list(range(100 + 3 * i, 110 + 4 * i)) for i in range(6)] + [[1] + list(range(300, 420))]
+    outs = {}
+    for mode in (False, True):
+        eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=512, kernels="hip", async_scheduling=mode, num_blocks=256))
+        eng.warmup()
+        seqs = [eng.make_sequence(p, SamplingParams(max_tokens=24 + 3 * i, ignore_eos=True)) for i, p in enumerate(prompts)]
+        for s in seqs[:3]:
+            eng.scheduler.add(s)
+        step = 0
+        while eng.scheduler.has_work() or step < 8:
+            if step == 4:
+                for s in seqs[3:]:
+                    eng.scheduler.add(s)
+            eng.step()
+            step += 1
+        outs[mode] = [s.output_ids for s in seqs]
+        assert (eng.pipelined_steps > 20) == mode
+        assert all(len(s.output_ids) == 24 + 3 * i for i, s in enumerate(seqs))
+    assert outs[True] == outs[False]
