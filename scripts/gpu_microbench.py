@@ -108,6 +108,36 @@ def gemm_bench(out):
         torch.cuda.empty_cache()
 
 
+def balance_bench(out):
+    """Unsplit v3 GEMM (K = 4096, M = 32) over widths that give 1, 1.5, 1.75, 2, 2.5, 3 and 7.8
+    workgroups per CU: is the gate/up projection (448 workgroups on 256 CUs) paying for the
+    uneven last round?"""
+    from kvmini.ops import native
+
+    C = native()
+    dev = torch.device("cuda:0")
+    K, M = 4096, 32
+    x = torch.randn(M, K, device=dev).bfloat16()
+    for N in (16384, 24576, 28672, 32768, 40960, 49152, 128256):
+        copies = max(3, int(800e6 // (N * K * 2)) + 1)
+        Wps = [C.pack_weight((torch.randn(N, K, device=dev) * 0.02).bfloat16()) for _ in range(copies)]
+        y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        st = {"i": 0}
+
+        def mk(nb):
+            def f():
+                st["i"] = (st["i"] + 1) % copies
+                C.stream_gemm3(Wps[st["i"]], N, K, x, y, 0, nb, 1, K // (128 * nb), None, 0.0)
+            return f
+
+        t = time_fns({"nb4": mk(4), "nb2": mk(2)})
+        row = {"bench": "balance", "N": N, "wgs": N // 64, "wgs_per_cu": N / 64 / 256, "us": t, "TBps": {k: N * K * 2 / (v * 1e-6) / 1e12 for k, v in t.items()}}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+        del Wps
+        torch.cuda.empty_cache()
+
+
 def step_bench(out, model, batch, kernels_list, quantization=None):
     kernels_list = [k for k in kernels_list if k == "hip"]  # the torch ops are not graph-capturable
     from kvmini.engine.engine import EngineConfig, LLMEngine
@@ -236,6 +266,8 @@ def main():
         gemm_bench(out)
     if "mall" in a.what:
         mall_bench(out)
+    if "balance" in a.what:
+        balance_bench(out)
     if "prefill" in a.what:
         prefill_bench(out, a.model)
     if "step" in a.what:
