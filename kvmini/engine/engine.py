@@ -52,6 +52,10 @@ class EngineConfig:
     tail_damping: float = 0.0
     # launch step n+1 before reading step n's tokens back (greedy requests, no KV pressure)
     async_scheduling: bool = True
+    # pipelined stepping launches the next step this long before the step in flight is expected
+    # to end (not right away), so that requests arriving meanwhile still make that launch; 0 =
+    # launch immediately
+    launch_margin_ms: float = 0.7
     tp_size: int = 1
     tp_rank: int = 0
     tp_graphs: bool = False
@@ -176,6 +180,8 @@ class LLMEngine:
         self.warm_s = 0.0
         self._pending: Optional[Tuple[Batch, Any]] = None  # (batch, runner handle) of the step in flight
         self.pipelined_steps = 0
+        self._step_dur: Dict[Tuple[int, bool], float] = {}  # measured device time of a step, by runner key
+        self._t_collect = 0.0  # when the previous step's ids arrived = when the step in flight started
 
     # ------------------------------------------------------------------
     def warmup(self) -> float:
@@ -202,6 +208,7 @@ class LLMEngine:
         if self.ecfg.async_scheduling and self._can_pipeline():
             # launch the next step on top of the one in flight, THEN read that one's tokens:
             # the device never waits for the host between steps
+            self._hold_launch()
             batch = self.scheduler.schedule()
             handle = None
             if batch.chunks:
@@ -210,8 +217,11 @@ class LLMEngine:
                 self.scheduler.launch_commit(batch)
                 launched = True
                 self.pipelined_steps += 1
+            had_pending = self._pending is not None
             events = self._finalize_pending()
             self._pending = (batch, handle) if handle is not None else None
+            if not had_pending:  # nothing was in flight: the new step starts now
+                self._t_collect = time.perf_counter()
         else:
             events = self._finalize_pending()
             batch = self.scheduler.schedule()
@@ -228,6 +238,23 @@ class LLMEngine:
             st.step_ms_ewma = dt * 1e3 if st.step_ms_ewma == 0 else 0.9 * st.step_ms_ewma + 0.1 * dt * 1e3
         self._progress = launched or bool(events)
         return events
+
+    def _hold_launch(self) -> None:
+        """Just-in-time launch: sleep until shortly before the step in flight should end (its
+        duration is known from earlier steps of the same shape), then take in what arrived.  A
+        request that arrives during a step thus rides the very next one instead of the one
+        after.  Unknown shapes launch immediately; a late launch only costs idle time, so the
+        margin is generous next to the ~0.2 ms of host work a launch takes."""
+        margin = self.ecfg.launch_margin_ms * 1e-3
+        if self._pending is None or margin <= 0:
+            return
+        dur = self._step_dur.get(self._pending[1].key)
+        if dur is None:
+            return
+        wait = self._t_collect + dur - margin - time.perf_counter()
+        if wait > 50e-6:
+            time.sleep(wait)
+            self._drain_inbox()
 
     def _can_pipeline(self) -> bool:
         """Pipelined stepping needs every token of the next step to be either known or the
@@ -253,6 +280,11 @@ class LLMEngine:
         batch, handle = self._pending
         self._pending = None
         ids, _ = self.runner.collect(handle)
+        d = handle.device_seconds()  # device-side timing: idle time in front of a late launch does not count
+        if d is not None:
+            old = self._step_dur.get(handle.key)
+            self._step_dur[handle.key] = d if old is None else 0.5 * (old + d)
+        self._t_collect = time.perf_counter()
         events: List[TokenEvent] = []
         row = 0
         for ch in batch.chunks:
