@@ -38,8 +38,8 @@ int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
                    int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
-int kv_stream_gemm3_plan(int N, int K, int nb, int max_splits, int target_wgs, int* groups_per_split);
-int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int splits,
+int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int target_wgs, int* groups_per_split);
+int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
 int kv_prefetch(const void* p, long long bytes, int workgroups, unsigned int* sink, hipStream_t stream);
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
@@ -334,15 +334,15 @@ void stream_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor o
 }
 
 // ---- weight-streaming GEMM v3 (deep register pipeline; bf16 or FP8 weights) ----------------------
-std::pair<int64_t, int64_t> stream_gemm3_plan(int64_t N, int64_t K, int64_t nb, int64_t max_splits, int64_t target_wgs) {
+std::pair<int64_t, int64_t> stream_gemm3_plan(int64_t N, int64_t K, int64_t nb, int64_t max_splits, int64_t target_wgs, int64_t nw) {
   int gps = 0;
-  int splits = kv_stream_gemm3_plan((int)N, (int)K, (int)nb, (int)max_splits, (int)target_wgs, &gps);
+  int splits = kv_stream_gemm3_plan((int)N, (int)K, (int)nb, (int)nw, (int)max_splits, (int)target_wgs, &gps);
   TORCH_CHECK(splits > 0, "stream_gemm3: K must be a multiple of 128*nb");
   return {splits, gps};
 }
 
 void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t nb, int64_t splits, int64_t groups_per_split,
-                  c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale) {
+                  c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale, int64_t nw) {
   CHECK_DEV(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
   const float* wsp = nullptr;
   if (w_scale.has_value()) {
@@ -354,6 +354,8 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
     CHECK_BF16(Wp);
   }
   TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
+  TORCH_CHECK(nw == 4 || nw == 7 || nw == 8, "nw (waves per workgroup) must be 4, 7 or 8");
+  TORCH_CHECK(N % (16 * nw) == 0, "N must be a multiple of 16 * nw");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
   const int64_t M = x.size(0);
   int parts = 0;
@@ -369,7 +371,7 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
     TORCH_CHECK(splits == 1, "bf16 / SwiGLU epilogues need a single split");
     ldy = out.stride(0);
   }
-  check(kv_stream_gemm3(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)nb, (int)splits,
+  check(kv_stream_gemm3(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)nb, (int)nw, (int)splits,
                         (int)groups_per_split, slab_stride, ssp, parts, (float)eps, wsp, cur_stream()),
         "kv_stream_gemm3");
 }
@@ -452,9 +454,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_gemm", &stream_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("ks_per_chunk"), py::arg("splits"),
         py::arg("chunks_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none());
   m.def("pack_weight_fp8", &pack_weight_fp8);
-  m.def("stream_gemm3_plan", &stream_gemm3_plan, py::arg("N"), py::arg("K"), py::arg("nb"), py::arg("max_splits"), py::arg("target_wgs") = 512);
+  m.def("stream_gemm3_plan", &stream_gemm3_plan, py::arg("N"), py::arg("K"), py::arg("nb"), py::arg("max_splits"), py::arg("target_wgs") = 512, py::arg("nw") = 4);
   m.def("stream_gemm3", &stream_gemm3, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("nb"), py::arg("splits"),
-        py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none());
+        py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4);
   m.def("prefetch", &prefetch);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs);

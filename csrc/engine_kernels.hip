@@ -910,23 +910,22 @@ __global__ __launch_bounds__(256) void embed_fed_kernel(const unsigned short* __
   for (int c = threadIdx.x; c < (H >> 3); c += 256) dst[c] = src[c];
 }
 
-// silu(gate) * up for the group-of-16 interleaved layout: gu [T, 2I] -> act [T, I]
+// silu(gate) * up for the group-of-8 interleaved layout: gu [T, 2I] -> act [T, I]
 __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ act, int I) {
   const int t = blockIdx.y;
-  const int grp = blockIdx.x * 256 + threadIdx.x;  // one thread = 8 outputs (half a 16-group)
+  const int grp = blockIdx.x * 256 + threadIdx.x;  // one thread = one group: 8 gate values, then their 8 up values
   const int n_tasks = I >> 3;
   if (grp >= n_tasks) return;
-  const int g16 = grp >> 1, hsel = grp & 1;
-  const unsigned short* src = gu + (long long)t * 2 * I + g16 * 32 + hsel * 8;
+  const unsigned short* src = gu + (long long)t * 2 * I + (long long)grp * 16;
   bf16x8 a = *reinterpret_cast<const bf16x8*>(src);
-  bf16x8 b = *reinterpret_cast<const bf16x8*>(src + 16);
+  bf16x8 b = *reinterpret_cast<const bf16x8*>(src + 8);
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float gte = bf2f(a[j]), up = bf2f(b[j]);
     o[j] = f2bf(gte / (1.f + __expf(-gte)) * up);
   }
-  *reinterpret_cast<bf16x8*>(act + (long long)t * I + g16 * 16 + hsel * 8) = o;
+  *reinterpret_cast<bf16x8*>(act + (long long)t * I + (long long)grp * 8) = o;
 }
 
 }  // namespace
@@ -1109,7 +1108,7 @@ int kv_embed_fed(const void* table, const int* tokens, const int* feed, const lo
 
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream) {
   if (T <= 0) return 0;
-  if (I % 16) return -1;
+  if (I % 8) return -1;
   dim3 grid(((I >> 3) + 255) / 256, T);
   hipLaunchKernelGGL(swiglu_interleaved_kernel, grid, dim3(256), 0, stream, (const unsigned short*)gu, (unsigned short*)act, I);
   return (int)hipGetLastError();

@@ -14,7 +14,7 @@
 //    (in-workgroup split-K) and each keeps U k-steps of loads in flight in a two-deep
 //    register pipeline, so a CU holds >= 32 KiB of outstanding weight reads — what it
 //    takes to cover HBM latency at ~6 TB/s over 256 CUs.  Partial sums meet in LDS.
-//  * Optional SwiGLU epilogue: with gate/up rows interleaved in groups of 16 (NR = 2:
+//  * Optional SwiGLU epilogue: with gate/up rows interleaved in groups of 8 (NR = 2:
 //    tile 0 = gate, tile 1 = up of the same 16 intermediate features) the workgroup writes
 //    silu(gate) * up directly, so the [M, 2I] intermediate never reaches memory.
 //  * PACKED weight layout (optional): W re-ordered offline into MFMA fragment order
@@ -141,14 +141,18 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const __bf16* _
       }
     const long long row = (long long)(j * 16 + r) * ldy;
     if (SWIGLU) {
-      // NR == 2: tile 0 = gate, tile 1 = up of features [16 * blockIdx.x, +16)
-      us4 o;
+      // every 16-row tile holds 8 gate rows (lanes q < 2) and the 8 up rows of the same
+      // features (lanes q >= 2): the up value sits 32 lanes further on
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float g = s[0][e], up = s[NR - 1][e];
-        o[e] = f2bf(g / (1.f + __expf(-g)) * up);
+      for (int i = 0; i < NR; ++i) {
+        us4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = s[i][e], up = __shfl_xor(s[i][e], 32, 64);
+          o[e] = f2bf(g / (1.f + __expf(-g)) * up);
+        }
+        if (q < 2) *reinterpret_cast<us4*>(y + row + ((long long)blockIdx.x * NR + i) * 8 + q * 4) = o;
       }
-      *reinterpret_cast<us4*>(y + row + blockIdx.x * 16 + q * 4) = o;
     } else {
 #pragma unroll
       for (int i = 0; i < NR; ++i) {

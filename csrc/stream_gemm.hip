@@ -17,9 +17,9 @@
 //    across workgroups (grid.y); each split writes an fp32 slab [split][M][N] and the NEXT
 //    kernel (residual-add + RMSNorm, or RoPE) sums the slabs in its prologue — the
 //    launch-boundary reduce: no atomics, no extra kernel, bitwise reproducible.
-//  * SwiGLU epilogue for the gate/up projection: rows are interleaved in groups of 16
-//    (even tiles = gate, odd tiles = up), so wave pairs (0,1) and (2,3) exchange their
-//    accumulators through LDS and write silu(gate) * up in bf16.
+//  * SwiGLU epilogue for the gate/up projection: rows are interleaved in groups of 8, so every
+//    16-row MFMA tile carries 8 gate rows and the 8 up rows of the same features; a wave
+//    finishes silu(gate) * up on its own with one cross-lane read per accumulator register.
 //
 // mfma_f32_16x16x32_bf16 operand maps: A lane l = W[row l&15][k = 8*(l>>4) + j], B lane l =
 // x[token l&15][k = 8*(l>>4) + j]; D lane l reg r = y[token l&15][feature 4*(l>>4) + r].
@@ -107,29 +107,20 @@ __device__ inline void gemm_epilogue(frag_cd (&acc)[MT], unsigned char* lds_raw,
       *reinterpret_cast<us4*>(o + (long long)(j * 16 + r) * ldy + n_base) = v;
     }
   } else {
-    // SwiGLU: odd waves (up tiles) hand their accumulators to the even wave of the pair.
-    __syncthreads();  // all waves are done with the x buffers that alias `ex`
-    float* ex = reinterpret_cast<float*>(lds_raw);  // [2 pairs][MT][4][64]
-    if (wave & 1) {
+    // SwiGLU: a 16-row weight tile holds 8 gate rows and the 8 up rows of the same features, so
+    // lane (q, r) with q < 2 has gate[4q + e] and lane (q + 2, r) the matching up value: one
+    // cross-lane read per register, no LDS round trip, no coupling between waves.
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    const long long i_base = tile * 8 + q * 4;  // intermediate feature index
 #pragma unroll
-      for (int j = 0; j < MT; ++j)
+    for (int j = 0; j < MT; ++j) {
+      us4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ex[(((wave >> 1) * MT + j) * 4 + e) * 64 + lane] = acc[j][e];
-    }
-    __syncthreads();
-    if (!(wave & 1)) {
-      unsigned short* o = reinterpret_cast<unsigned short*>(out);
-      const long long i_base = (tile >> 1) * 16 + q * 4;  // intermediate feature index
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        us4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = acc[j][e], up = ex[(((wave >> 1) * MT + j) * 4 + e) * 64 + lane];
-          v[e] = f2bf(g / (1.f + __expf(-g)) * up);
-        }
-        *reinterpret_cast<us4*>(o + (long long)(j * 16 + r) * ldy + i_base) = v;
+      for (int e = 0; e < 4; ++e) {
+        const float g = acc[j][e], up = __shfl_xor(acc[j][e], 32, 64);
+        v[e] = f2bf(g / (1.f + __expf(-g)) * up);
       }
+      if (q < 2) *reinterpret_cast<us4*>(o + (long long)(j * 16 + r) * ldy + i_base) = v;
     }
   }
 }
@@ -234,14 +225,14 @@ __device__ inline raw16 ldw16(const raw16* p) {
   else return *p;
 }
 
-template <int MT, int KS, int NB, int EPI, bool W8, bool NT>
-__global__ __launch_bounds__(256) void stream_gemm3_kernel(const void* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
+template <int MT, int KS, int NB, int EPI, bool W8, bool NT, int NW>
+__global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
                                                            long long ldx, long long ldy, int groups_per_split, long long slab_stride,
                                                            const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps,
                                                            const float* __restrict__ w_scale) {
   constexpr int AL = W8 ? KS / 2 : KS;
   constexpr int XF = KS * MT;
-  constexpr int XL = (XF + 3) / 4;
+  constexpr int XL = (XF + NW - 1) / NW;  // x fragments of a chunk per wave
   constexpr int PD = NB - 1;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * XF * 1024];
   frag_ab* xs = reinterpret_cast<frag_ab*>(lds_raw);  // [2][XF][64]
@@ -251,13 +242,13 @@ __global__ __launch_bounds__(256) void stream_gemm3_kernel(const void* __restric
   const int ngroups = ksteps / (KS * NB);
   const int g0 = blockIdx.y * groups_per_split;
   const int g1 = g0 + groups_per_split < ngroups ? g0 + groups_per_split : ngroups;
-  const long long tile = (long long)blockIdx.x * 4 + wave;
+  const long long tile = (long long)blockIdx.x * NW + wave;
   const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * (W8 ? ksteps / 2 : ksteps) * 64 + lane;
 
   const __bf16* xsrc[XL];
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
-    const int f = wave + 4 * i;
+    const int f = wave + NW * i;
     const int ks = (f < XF ? f : 0) / MT, j = (f < XF ? f : 0) % MT;
     xsrc[i] = x + (long long)(j * 16 + r) * ldx + ks * 32 + q * 8;
   }
@@ -271,7 +262,7 @@ __global__ __launch_bounds__(256) void stream_gemm3_kernel(const void* __restric
 
 #define KV_ISSUE(slot, chunk)                                                                                   \
   do {                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + 4 * i < XF)                                       \
+    _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + NW * i < XF)                                      \
         xr[slot][i] = *reinterpret_cast<const frag_ab*>(xsrc[i] + (long long)(chunk) * KS * 32);                \
     _Pragma("unroll") for (int u = 0; u < AL; ++u) a[slot][u] = ldw16<NT>(wp + ((long long)(chunk) * AL + u) * 64); \
   } while (0)
@@ -279,8 +270,8 @@ __global__ __launch_bounds__(256) void stream_gemm3_kernel(const void* __restric
 #define KV_CONSUME(slot, chunk)                                                                                 \
   do {                                                                                                          \
     const int buf = (chunk) & 1;                                                                                \
-    _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + 4 * i < XF)                                       \
-        xs[(buf * XF + wave + 4 * i) * 64 + lane] = xr[slot][i];                                                \
+    _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + NW * i < XF)                                      \
+        xs[(buf * XF + wave + NW * i) * 64 + lane] = xr[slot][i];                                               \
     __syncthreads();                                                                                            \
     _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                            \
       frag_ab b[MT];                                                                                            \
@@ -346,38 +337,51 @@ int dispatch_ks(int epi, int ks, bool w8, const Args& a) {
   return ks == 4 ? dispatch_epi<MT, 4, false>(epi, a) : dispatch_epi<MT, 8, false>(epi, a);
 }
 
-template <int MT, int NB, int EPI, bool W8, bool NT>
+template <int MT, int NB, int EPI, bool W8, bool NT, int NW>
 int launch3(const Args& a) {
-  dim3 grid(a.N / 64, a.splits), block(256);
-  hipLaunchKernelGGL((stream_gemm3_kernel<MT, 4, NB, EPI, W8, NT>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
+  dim3 grid(a.N / (16 * NW), a.splits), block(NW * 64);
+  hipLaunchKernelGGL((stream_gemm3_kernel<MT, 4, NB, EPI, W8, NT, NW>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
                      a.slab_stride, a.row_ss, a.ss_parts, 1.f / (float)a.K, a.eps, a.w_scale);
   return (int)hipGetLastError();
 }
 
-template <int MT, int NB, bool W8, bool NT>
+template <int MT, int NB, bool W8, bool NT, int NW>
 int dispatch3_epi(int epi, const Args& a) {
   switch (epi) {
-    case EPI_BF16: return launch3<MT, NB, EPI_BF16, W8, NT>(a);
-    case EPI_SLAB: return launch3<MT, NB, EPI_SLAB, W8, NT>(a);
-    case EPI_SWIGLU: return launch3<MT, NB, EPI_SWIGLU, W8, NT>(a);
+    case EPI_BF16: return launch3<MT, NB, EPI_BF16, W8, NT, NW>(a);
+    case EPI_SLAB: return launch3<MT, NB, EPI_SLAB, W8, NT, NW>(a);
+    case EPI_SWIGLU: return launch3<MT, NB, EPI_SWIGLU, W8, NT, NW>(a);
   }
   return -1;
 }
 
-template <int MT, bool W8>
+template <int MT, bool W8, int NW>
 int dispatch3_nb(int epi, int nb, const Args& a) {
   // weight loads are always non-temporal here: measured 8-12 % faster than the default
   // policy on every decode shape (each weight byte is read once, by one CU)
   switch (nb) {
-    case 2: return dispatch3_epi<MT, 2, W8, true>(epi, a);
-    case 4: return dispatch3_epi<MT, 4, W8, true>(epi, a);
+    case 2: return dispatch3_epi<MT, 2, W8, true, NW>(epi, a);
+    case 4: return dispatch3_epi<MT, 4, W8, true, NW>(epi, a);
+  }
+  return -1;
+}
+
+// nw = waves (16-feature tiles) per workgroup.  4 is the default; 7 makes 1792 tiles (the
+// Llama-3-8B gate/up projection) exactly one workgroup per CU of a 256-CU part; 8 halves the
+// x traffic per weight byte for wide token batches.
+template <int MT, bool W8>
+int dispatch3_nw(int epi, int nb, int nw, const Args& a) {
+  switch (nw) {
+    case 4: return dispatch3_nb<MT, W8, 4>(epi, nb, a);
+    case 7: return dispatch3_nb<MT, W8, 7>(epi, nb, a);
+    case 8: return dispatch3_nb<MT, W8, 8>(epi, nb, a);
   }
   return -1;
 }
 
 template <int MT>
-int dispatch3_w8(int epi, int nb, bool w8, const Args& a) {
-  return w8 ? dispatch3_nb<MT, true>(epi, nb, a) : dispatch3_nb<MT, false>(epi, nb, a);
+int dispatch3_w8(int epi, int nb, int nw, bool w8, const Args& a) {
+  return w8 ? dispatch3_nw<MT, true>(epi, nb, nw, a) : dispatch3_nw<MT, false>(epi, nb, nw, a);
 }
 
 // W[N, K] fp8 bytes (row-major) -> [N/16][K/64][64 lanes][16 bytes]: lane l of a tile holds
@@ -429,7 +433,7 @@ int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chu
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
                    int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream) {
   if (M <= 0 || M > 64 || (M & 15) || (N & 63) || (ks_per_chunk != 4 && ks_per_chunk != 8) || (K % (32 * ks_per_chunk))) return -1;
-  if (epi == EPI_SWIGLU && (N & 127)) return -1;
+  if (epi == EPI_SWIGLU && (N & 15)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
   if (splits < 1 || chunks_per_split < 1 || (long long)splits * chunks_per_split < (K >> 5) / ks_per_chunk) return -1;
   const Args a{Wp, x, out, N, K, ldx, ldy, splits, chunks_per_split, slab_stride, row_ss, ss_parts, eps, w_scale, stream};
@@ -447,11 +451,11 @@ int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K
 // `groups_per_split` groups of `nb` chunks.  Requirements as kv_stream_gemm plus
 // K % (128 * nb) == 0, nb in {2, 4}.  w_scale != nullptr selects FP8 weights.  The plan aims
 // at `target_wgs` workgroups (tiles x splits).
-int kv_stream_gemm3_plan(int N, int K, int nb, int max_splits, int target_wgs, int* groups_per_split) {
-  if (nb < 1 || K % (128 * nb)) return -1;
+int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int target_wgs, int* groups_per_split) {
+  if (nb < 1 || K % (128 * nb) || nw < 1 || N % (16 * nw)) return -1;
   if (target_wgs < 1) target_wgs = 512;
   const int ngroups = K / (128 * nb);
-  const int tiles = N / 64;
+  const int tiles = N / (16 * nw);
   int want = (target_wgs + tiles - 1) / tiles;
   if (want > max_splits) want = max_splits;
   if (want > ngroups) want = ngroups;
@@ -461,20 +465,20 @@ int kv_stream_gemm3_plan(int N, int K, int nb, int max_splits, int target_wgs, i
   return (ngroups + gps - 1) / gps;
 }
 
-int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int splits,
+int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream) {
-  if (M <= 0 || M > 64 || (M & 15) || (N & 63) || (nb != 2 && nb != 4) || (K % (128 * nb))) return -1;
-  if (epi == EPI_SWIGLU && (N & 127)) return -1;
+  if (M <= 0 || M > 64 || (M & 15) || (nw != 4 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4) || (K % (128 * nb))) return -1;
+  if (epi == EPI_SWIGLU && (N & 15)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
   const int ngroups = K / (128 * nb);
   if (splits < 1 || groups_per_split < 1 || (long long)splits * groups_per_split < ngroups || (long long)(splits - 1) * groups_per_split >= ngroups) return -1;
   const Args a{Wp, x, out, N, K, ldx, ldy, splits, groups_per_split, slab_stride, row_ss, ss_parts, eps, w_scale, stream};
   const bool w8 = w_scale != nullptr;
   switch (M >> 4) {
-    case 1: return dispatch3_w8<1>(epi, nb, w8, a);
-    case 2: return dispatch3_w8<2>(epi, nb, w8, a);
-    case 3: return dispatch3_w8<3>(epi, nb, w8, a);
-    case 4: return dispatch3_w8<4>(epi, nb, w8, a);
+    case 1: return dispatch3_w8<1>(epi, nb, nw, w8, a);
+    case 2: return dispatch3_w8<2>(epi, nb, nw, w8, a);
+    case 3: return dispatch3_w8<3>(epi, nb, nw, w8, a);
+    case 4: return dispatch3_w8<4>(epi, nb, nw, w8, a);
   }
   return -1;
 }

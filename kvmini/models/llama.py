@@ -10,9 +10,9 @@ presets and a weight container laid out for the engine's kernels:
 * ``wqkv``   [(n_heads + 2 n_kv) * head_dim, hidden]  — fused Q/K/V projection
 * ``wo``     [hidden, n_heads * head_dim]
 * ``wgu``    [2 * intermediate, hidden] — gate and up rows interleaved in groups
-  of 16 (rows 32j..32j+15 = gate[16j..], rows 32j+16..32j+31 = up[16j..]) so a
-  GEMM wave that owns a 32-row tile holds matching gate/up values and can apply
-  SwiGLU in its epilogue
+  of 8 (rows 16j..16j+7 = gate[8j..], rows 16j+8..16j+15 = up[8j..]) so every
+  16-row MFMA tile of the GEMM holds matching gate/up values and a wave can apply
+  SwiGLU in its epilogue on its own
 * ``wdown``  [hidden, intermediate]
 
 All matrices are ``[out, in]`` row-major (``y = x @ W.T``) in bf16; with tensor
@@ -28,7 +28,7 @@ from typing import Any, Dict, List, Optional
 
 import torch
 
-GU_GROUP = 16  # gate/up interleave granularity (rows)
+GU_GROUP = 8  # gate/up interleave granularity (rows): one 16-row MFMA tile = 8 gate rows + their 8 up rows
 
 
 @dataclass(frozen=True)

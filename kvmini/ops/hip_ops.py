@@ -19,6 +19,8 @@ are processed in 64-row pieces (the weights are re-streamed per piece).
 
 from __future__ import annotations
 
+import functools
+
 from typing import Any, Optional, Tuple, Union
 
 import torch
@@ -151,6 +153,26 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None, keep_full:
     torch.cuda.empty_cache()
 
 
+_NUM_CUS = 256
+
+
+@functools.lru_cache(maxsize=None)
+def _waves_per_workgroup(n_pad: int) -> int:
+    """Waves (16-feature tiles) per workgroup of an unsplit streaming GEMM: the count whose grid
+    fills the CUs most evenly in its last round (28672 features = 1792 tiles = 7 x 256: seven
+    waves give exactly one workgroup per CU where four give 448 workgroups, i.e. 1.75 rounds
+    that cost two); ties go to the larger workgroup (less x traffic per weight byte)."""
+    best, best_eff = 4, -1.0
+    for nw in (4, 7, 8):
+        if n_pad % (16 * nw):
+            continue
+        wgs = n_pad // (16 * nw)
+        eff = wgs / (-(-wgs // _NUM_CUS) * _NUM_CUS)
+        if eff >= best_eff - 1e-9:
+            best, best_eff = nw, max(eff, best_eff)
+    return best
+
+
 def _pad_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     m = x.shape[0]
     mp = (m + 15) // 16 * 16
@@ -172,17 +194,20 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
     ks = w.ks if mp <= 16 else 4
     nchunks = (w.k // 32) // ks
     if mp <= MAX_M and w.k % 256 == 0:
-        # deep-pipeline kernel (v3).  Measured on MI355X: split-K shapes run best with
-        # 2-chunk groups, unsplit ones (gate/up, LM head) with 4-chunk groups up to 32 rows.
+        # deep-pipeline kernel (v3).  Measured on MI355X (scripts/gpu_microbench.py --what nw):
+        # split-K shapes run best as 8-wave workgroups (x is fetched once per 128 features), 2-chunk
+        # groups, ~256 workgroups; unsplit ones (gate/up, LM head) with the waves-per-workgroup
+        # count that fills the 256 CUs most evenly, 4-chunk groups up to 32 rows.
         if allow_slabs and epi == 0 and m == mp and w.n == w.n_pad:
-            splits, gps = C.stream_gemm3_plan(w.n_pad, w.k, 2, MAX_SPLITS, 512)
+            nw, target = (8, 256) if w.n_pad % 128 == 0 else (4, 512)
+            splits, gps = C.stream_gemm3_plan(w.n_pad, w.k, 2, MAX_SPLITS, target, nw)
             if splits > 1:
                 out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
-                C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, 2, splits, gps, None, 0.0, w.wscale)
+                C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, 2, splits, gps, None, 0.0, w.wscale, nw)
                 return Partial(out, ss, eps, w.k)
         nb = 4 if (mp <= 32 and w.k % 512 == 0) else 2
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
-        C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, nb, 1, w.k // (128 * nb), ss, eps, w.wscale)
+        C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, nb, 1, w.k // (128 * nb), ss, eps, w.wscale, _waves_per_workgroup(w.n_pad))
     elif mp <= MAX_M:
         if allow_slabs and epi == 0:
             splits, cps = C.stream_gemm_plan(w.n_pad, w.k, ks, MAX_SPLITS)

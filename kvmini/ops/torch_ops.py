@@ -131,7 +131,7 @@ def paged_attention(
 
 
 def swiglu_interleaved(gu: torch.Tensor) -> torch.Tensor:
-    """``silu(gate) * up`` for the group-of-16 interleaved gate/up layout."""
+    """``silu(gate) * up`` for the interleaved gate/up layout (groups of ``GU_GROUP`` rows)."""
     *lead, n = gu.shape
     x = gu.reshape(*lead, n // (2 * GU_GROUP), 2, GU_GROUP).float()
     return (F.silu(x[..., 0, :]) * x[..., 1, :]).reshape(*lead, n // 2).to(gu.dtype)

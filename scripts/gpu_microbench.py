@@ -138,6 +138,50 @@ def balance_bench(out):
         torch.cuda.empty_cache()
 
 
+def nw_bench(out):
+    """Waves per workgroup of the v3 GEMM (4 / 7 / 8) on the decode shapes at M = 32 and 64."""
+    from kvmini.ops import native
+
+    C = native()
+    dev = torch.device("cuda:0")
+    shapes = {"qkv": (6144, 4096, True), "o": (4096, 4096, True), "gate_up": (28672, 4096, False), "down": (4096, 14336, True), "lm_head": (128256, 4096, False)}
+    for name, (N, K, slabs) in shapes.items():
+        copies = max(3, int(800e6 // (N * K * 2)) + 1)
+        Wps = [C.pack_weight((torch.randn(N, K, device=dev) * 0.02).bfloat16()) for _ in range(copies)]
+        for M in (32, 64):
+            x = torch.randn(M, K, device=dev).bfloat16()
+            y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            st = {"i": 0}
+
+            def mk(nw, nb, target=512):
+                def f():
+                    st["i"] = (st["i"] + 1) % copies
+                    if slabs:
+                        splits, gps = C.stream_gemm3_plan(N, K, nb, 32, target, nw)
+                        o = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
+                        C.stream_gemm3(Wps[st["i"]], N, K, x, o, 1, nb, splits, gps, None, 0.0, None, nw)
+                    else:
+                        C.stream_gemm3(Wps[st["i"]], N, K, x, y, 0, nb, 1, K // (128 * nb), None, 0.0, None, nw)
+                return f
+
+            fns = {}
+            for nw in (4, 7, 8):
+                if N % (16 * nw):
+                    continue
+                for nb in (2, 4):
+                    if slabs:
+                        for target in (256, 512):
+                            fns[f"nw{nw}_nb{nb}_t{target}"] = mk(nw, nb, target)
+                    else:
+                        fns[f"nw{nw}_nb{nb}"] = mk(nw, nb)
+            t = time_fns(fns)
+            row = {"bench": "nw", "shape": name, "N": N, "K": K, "M": M, "us": {k: round(v, 2) for k, v in t.items()}}
+            print(json.dumps(row), flush=True)
+            out.append(row)
+        del Wps
+        torch.cuda.empty_cache()
+
+
 def step_bench(out, model, batch, kernels_list, quantization=None):
     kernels_list = [k for k in kernels_list if k == "hip"]  # the torch ops are not graph-capturable
     from kvmini.engine.engine import EngineConfig, LLMEngine
@@ -268,6 +312,8 @@ def main():
         mall_bench(out)
     if "balance" in a.what:
         balance_bench(out)
+    if "nw" in a.what.split(","):
+        nw_bench(out)
     if "prefill" in a.what:
         prefill_bench(out, a.model)
     if "step" in a.what:

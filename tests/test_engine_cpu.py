@@ -105,7 +105,7 @@ def test_gate_up_interleave_roundtrip():
     gu = interleave_gate_up(g, u)
     g2, u2 = deinterleave_gate_up(gu.T)
     assert torch.equal(g2.T, g) and torch.equal(u2.T, u)
-    assert torch.equal(gu[:16], g[:16]) and torch.equal(gu[16:32], u[:16])
+    assert torch.equal(gu[:8], g[:8]) and torch.equal(gu[8:16], u[:8]) and torch.equal(gu[16:24], g[8:16])
 
 
 def test_native_server_openai_and_tgi_endpoints(tmp_path):

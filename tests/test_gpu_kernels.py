@@ -712,3 +712,22 @@ def test_embed_fed_matches_reference_and_pipelined_engine_matches_sync():
         assert (eng.pipelined_steps > 20) == mode
         assert all(len(s.output_ids) == 24 + 3 * i for i, s in enumerate(seqs))
     assert outs[True] == outs[False]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw", [4, 7, 8])
+@pytest.mark.parametrize("M", [16, 64])
+def test_stream_gemm3_waves_per_workgroup(C, nw, M):
+    torch.manual_seed(nw * 10 + M)
+    N, K = 16 * nw * 6, 1024
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    wp = C.pack_weight(w)
+    ref = x.float() @ w.float().T
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    C.stream_gemm3(wp, N, K, x, y, 0, 2, 1, K // 256, None, 0.0, None, nw)
+    assert torch.allclose(y.float(), ref, atol=0.05, rtol=0.02)
+    splits, gps = C.stream_gemm3_plan(N, K, 2, 8, 64, nw)
+    slabs = torch.empty(splits, M, N, device="cuda", dtype=torch.float32)
+    C.stream_gemm3(wp, N, K, x, slabs, 1, 2, splits, gps, None, 0.0, None, nw)
+    assert splits > 1 and torch.allclose(slabs.sum(0), ref, atol=0.02, rtol=0.01)
