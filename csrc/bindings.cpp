@@ -354,7 +354,7 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
     CHECK_BF16(Wp);
   }
   TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
-  TORCH_CHECK(nw == 4 || nw == 7 || nw == 8, "nw (waves per workgroup) must be 4, 7 or 8");
+  TORCH_CHECK(nw == 4 || nw == 6 || nw == 7 || nw == 8, "nw (waves per workgroup) must be 4, 6, 7 or 8");
   TORCH_CHECK(N % (16 * nw) == 0, "N must be a multiple of 16 * nw");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
   const int64_t M = x.size(0);

@@ -367,12 +367,14 @@ int dispatch3_nb(int epi, int nb, const Args& a) {
 }
 
 // nw = waves (16-feature tiles) per workgroup.  4 is the default; 7 makes 1792 tiles (the
-// Llama-3-8B gate/up projection) exactly one workgroup per CU of a 256-CU part; 8 halves the
-// x traffic per weight byte for wide token batches.
+// Llama-3-8B gate/up projection) exactly one workgroup per CU of a 256-CU part, 6 does the
+// same for 384 tiles x 4 K-splits (its QKV projection); 8 halves the x traffic per weight
+// byte for wide token batches.
 template <int MT, bool W8>
 int dispatch3_nw(int epi, int nb, int nw, const Args& a) {
   switch (nw) {
     case 4: return dispatch3_nb<MT, W8, 4>(epi, nb, a);
+    case 6: return dispatch3_nb<MT, W8, 6>(epi, nb, a);
     case 7: return dispatch3_nb<MT, W8, 7>(epi, nb, a);
     case 8: return dispatch3_nb<MT, W8, 8>(epi, nb, a);
   }
@@ -467,7 +469,7 @@ int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int targe
 
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream) {
-  if (M <= 0 || M > 64 || (M & 15) || (nw != 4 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4) || (K % (128 * nb))) return -1;
+  if (M <= 0 || M > 64 || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4) || (K % (128 * nb))) return -1;
   if (epi == EPI_SWIGLU && (N & 15)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
   const int ngroups = K / (128 * nb);

@@ -173,6 +173,34 @@ def _waves_per_workgroup(n_pad: int) -> int:
     return best
 
 
+@functools.lru_cache(maxsize=None)
+def _plan_slabs(n_pad: int, k: int) -> Tuple[int, int, int]:
+    """(waves per workgroup, K splits, 2-chunk groups per split) of a split-K streaming GEMM,
+    by a three-term cost model fitted to the measured shapes (32 token rows):
+    the weight stream costs 1 / (share of the CU rounds the grid fills) — the kernel's time
+    follows the busiest CU, so feature tiles x splits should be a whole number of rounds over
+    the CUs, all splits equal; every slab is written and read back once (64 x splits / K of the
+    weight bytes, at half price: it stays on chip); x is fetched once per workgroup
+    (1 / waves-per-workgroup, likewise)."""
+    ngroups = k // 256
+    best: Optional[Tuple[float, int, int]] = None
+    for nw in (4, 6, 7, 8):
+        if n_pad % (16 * nw):
+            continue
+        tiles = n_pad // (16 * nw)
+        for splits in range(1, min(MAX_SPLITS, ngroups) + 1):
+            if ngroups % splits:
+                continue
+            wgs = tiles * splits
+            fill = wgs / (-(-wgs // _NUM_CUS) * _NUM_CUS)
+            cost = 1.0 / fill + 64.0 * splits / k + 1.0 / nw
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, nw, splits)
+    if best is None:
+        return 4, 1, ngroups
+    return best[1], best[2], ngroups // best[2]
+
+
 def _pad_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     m = x.shape[0]
     mp = (m + 15) // 16 * 16
@@ -199,8 +227,7 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
         # groups, ~256 workgroups; unsplit ones (gate/up, LM head) with the waves-per-workgroup
         # count that fills the 256 CUs most evenly, 4-chunk groups up to 32 rows.
         if allow_slabs and epi == 0 and m == mp and w.n == w.n_pad:
-            nw, target = (8, 256) if w.n_pad % 128 == 0 else (4, 512)
-            splits, gps = C.stream_gemm3_plan(w.n_pad, w.k, 2, MAX_SPLITS, target, nw)
+            nw, splits, gps = _plan_slabs(w.n_pad, w.k)
             if splits > 1:
                 out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
                 C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, 2, splits, gps, None, 0.0, w.wscale, nw)
