@@ -181,6 +181,9 @@ class LLMEngine:
         self._pending: Optional[Tuple[Batch, Any]] = None  # (batch, runner handle) of the step in flight
         self.pipelined_steps = 0
         self._step_dur: Dict[Tuple[int, bool], float] = {}  # measured device time of a step, by runner key
+        self._probe_ctr: Dict[Tuple[int, bool], int] = {}
+        self._launch_cost = 0.0  # host seconds from the end of the hold to the enqueued step (moving average)
+        self._late_penalty = 0.0
         self._t_collect = 0.0  # when the previous step's ids arrived = when the step in flight started
 
     # ------------------------------------------------------------------
@@ -208,7 +211,8 @@ class LLMEngine:
         if self.ecfg.async_scheduling and self._can_pipeline():
             # launch the next step on top of the one in flight, THEN read that one's tokens:
             # the device never waits for the host between steps
-            self._hold_launch()
+            unheld = self._hold_launch()
+            t_launch = time.perf_counter()
             batch = self.scheduler.schedule()
             handle = None
             if batch.chunks:
@@ -218,7 +222,10 @@ class LLMEngine:
                 launched = True
                 self.pipelined_steps += 1
             had_pending = self._pending is not None
-            events = self._finalize_pending()
+            if handle is not None:
+                handle.timed = unheld and had_pending
+                self._launch_cost = 0.8 * self._launch_cost + 0.2 * (time.perf_counter() - t_launch)
+            events = self._finalize_pending(held=not unheld)
             self._pending = (batch, handle) if handle is not None else None
             if not had_pending:  # nothing was in flight: the new step starts now
                 self._t_collect = time.perf_counter()
@@ -239,22 +246,33 @@ class LLMEngine:
         self._progress = launched or bool(events)
         return events
 
-    def _hold_launch(self) -> None:
+    def _hold_launch(self) -> bool:
         """Just-in-time launch: sleep until shortly before the step in flight should end (its
         duration is known from earlier steps of the same shape), then take in what arrived.  A
         request that arrives during a step thus rides the very next one instead of the one
-        after.  Unknown shapes launch immediately; a late launch only costs idle time, so the
-        margin is generous next to the ~0.2 ms of host work a launch takes."""
+        after.  Unknown shapes launch immediately, and so does every 16th step of a shape: a
+        step enqueued at once behind one in flight runs back to back with it, so the time
+        between the two read-backs IS its device time — the only clock this needs, and one that a
+        late launch cannot inflate.  Returns True when the launch was not held."""
         margin = self.ecfg.launch_margin_ms * 1e-3
-        if self._pending is None or margin <= 0:
-            return
-        dur = self._step_dur.get(self._pending[1].key)
-        if dur is None:
-            return
+        if self._pending is None or margin <= 0 or self.device.type != "cuda":
+            return True
+        # the margin has to cover the host's own launch work (scheduling, staging, the graph
+        # launch call: ~0.2 ms, far more under a profiler or on a crowded host) with room to
+        # spare, plus a penalty that grows while read-backs find the step already finished
+        margin = max(margin, 2.5 * self._launch_cost + 0.2e-3) + self._late_penalty
+        key = self._pending[1].key
+        dur = self._step_dur.get(key)
+        n = self._probe_ctr.get(key, 0)
+        self._probe_ctr[key] = n + 1
+        if dur is None or n % 16 == 0:
+            return True
         wait = self._t_collect + dur - margin - time.perf_counter()
         if wait > 50e-6:
             time.sleep(wait)
             self._drain_inbox()
+            return False
+        return True
 
     def _can_pipeline(self) -> bool:
         """Pipelined stepping needs every token of the next step to be either known or the
@@ -273,18 +291,27 @@ class LLMEngine:
                     return False
         return self.bm.num_free >= len(sch.running) + sch.max_batched_tokens // self.bm.block_size + 2
 
-    def _finalize_pending(self) -> List[TokenEvent]:
-        """Read back the step in flight (if any) and commit its tokens."""
+    def _finalize_pending(self, held: bool = False) -> List[TokenEvent]:
+        """Read back the step in flight (if any) and commit its tokens.  ``held``: the launch
+        that preceded this read-back was delayed on purpose (see :meth:`_hold_launch`)."""
         if self._pending is None:
             return []
         batch, handle = self._pending
         self._pending = None
+        t_wait = time.perf_counter()
         ids, _ = self.runner.collect(handle)
-        d = handle.device_seconds()  # device-side timing: idle time in front of a late launch does not count
-        if d is not None:
+        now = time.perf_counter()
+        if held:
+            if now - t_wait < 50e-6:  # nothing to wait for: the device had run dry, the launch came too late
+                self._late_penalty = min(5e-3, 2.0 * self._late_penalty + 0.2e-3)
+            else:
+                self._late_penalty *= 0.95
+        if handle.timed:  # ran back to back with its predecessor: started when that one was read back
+            d = now - self._t_collect
             old = self._step_dur.get(handle.key)
-            self._step_dur[handle.key] = d if old is None else 0.5 * (old + d)
-        self._t_collect = time.perf_counter()
+            if old is None or d < 1.5 * old:
+                self._step_dur[handle.key] = d if old is None else 0.5 * (old + d)
+        self._t_collect = now
         events: List[TokenEvent] = []
         row = 0
         for ch in batch.chunks:

@@ -75,7 +75,6 @@ class _Stage:
         self.bt_owner: List[Tuple[Any, int]] = [(None, 0)] * smax
         self.out_cpu = torch.zeros(tmax, dtype=torch.int64, pin_memory=pin)
         self.event: Any = None  # recorded behind the step (and the copy of its ids)
-        self.event0: Any = None  # recorded in front of it: the pair times the step on the device
 
 
 @dataclass
@@ -86,12 +85,7 @@ class StepHandle:
     logits: Optional[torch.Tensor]
     stage: _Stage
     key: Tuple[int, bool] = (0, False)  # (token bucket, decode-only): steps of one key take alike
-
-    def device_seconds(self) -> Optional[float]:
-        """Time the step took on the device (after :meth:`ModelRunner.collect`); None on CPU."""
-        if self.stage.event is None:
-            return None
-        return self.stage.event0.elapsed_time(self.stage.event) * 1e-3
+    timed: bool = False  # launched at once on top of a step in flight: its wall time is its device time
 
 
 class ModelRunner:
@@ -472,10 +466,6 @@ class ModelRunner:
         decode_only = all(ch.n_tokens == 1 for ch in batch.chunks)
         o_h = self._off["header"][0]
         st[o_h : o_h + 5] = (t_pad, n_samples, max_ctx, 0, int(decode_only))
-        if self.device.type == "cuda":
-            if sb.event is None:
-                sb.event0, sb.event = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            sb.event0.record(torch.cuda.current_stream(self.device))
         self.stage_dev.copy_(sb.cpu, non_blocking=True)
         if self.tp_size > 1:
             # every rank runs the same step: ship the staged inputs to the followers (see follow())
@@ -484,5 +474,7 @@ class ModelRunner:
         # the ids leave the device right behind the step, before a later launch overwrites them
         sb.out_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
         if self.device.type == "cuda":
+            if sb.event is None:
+                sb.event = torch.cuda.Event()
             sb.event.record(torch.cuda.current_stream(self.device))
         return StepHandle(n_samples, logits, sb, (t_pad, decode_only))
