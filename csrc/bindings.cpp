@@ -31,6 +31,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
                               hipStream_t stream);
 int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
+int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, void* y, int T, int H, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
 int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
                    hipStream_t stream);
@@ -245,6 +246,14 @@ void prefetch(at::Tensor t, int64_t workgroups, at::Tensor sink) {
   check(kv_prefetch(t.data_ptr(), (long long)t.numel() * t.element_size(), (int)workgroups, (unsigned int*)sink.data_ptr(), cur_stream()), "kv_prefetch");
 }
 
+void scale_rows(at::Tensor x, at::Tensor row_ss, double eps, at::Tensor y) {
+  CHECK_DEV(x); CHECK_BF16(x); CHECK_CONTIG(x); CHECK_DEV(y); CHECK_BF16(y); CHECK_CONTIG(y);
+  TORCH_CHECK(x.dim() == 2 && y.sizes() == x.sizes() && x.size(1) % 8 == 0, "x, y must be bf16 [T, H] with H % 8 == 0");
+  int parts = 0;
+  const float* ssp = ss_ptr(row_ss, x.size(0), &parts);
+  check(kv_scale_rows(x.data_ptr(), ssp, parts, (float)eps, y.data_ptr(), (int)x.size(0), (int)x.size(1), cur_stream()), "kv_scale_rows");
+}
+
 void swiglu_interleaved(at::Tensor gu, at::Tensor act) {
   CHECK_DEV(gu); CHECK_BF16(gu); CHECK_BF16(act); CHECK_CONTIG(gu); CHECK_CONTIG(act);
   TORCH_CHECK(gu.dim() == 2 && act.dim() == 2 && gu.size(0) == act.size(0) && gu.size(1) == 2 * act.size(1), "gu [T, 2I], act [T, I]");
@@ -448,6 +457,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("argmax", &argmax);
   m.def("embed_fed", &embed_fed);
   m.def("swiglu_interleaved", &swiglu_interleaved);
+  m.def("scale_rows", &scale_rows);
   m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);
   m.def("stream_gemm_plan", &stream_gemm_plan);

@@ -910,6 +910,25 @@ __global__ __launch_bounds__(256) void embed_fed_kernel(const unsigned short* __
   for (int c = threadIdx.x; c < (H >> 3); c += 256) dst[c] = src[c];
 }
 
+// y[t] = bf16(x[t] / rms(x[t])) from the per-row partial sums of squares of the residual
+// stream (wide token batches: the library GEMM has no row-scale epilogue, so the folded
+// RMSNorm is applied to its input).  One workgroup per row, 16 bytes per thread per trip.
+__global__ __launch_bounds__(256) void scale_rows_kernel(const unsigned short* __restrict__ x, const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
+                                                         unsigned short* __restrict__ y, int H) {
+  const int t = blockIdx.x;
+  float ssum = 0.f;
+  for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)t * ss_parts + p];
+  const float rs = rsqrtf(ssum * inv_h + eps);
+  const bf16x8* src = reinterpret_cast<const bf16x8*>(x + (long long)t * H);
+  bf16x8* dst = reinterpret_cast<bf16x8*>(y + (long long)t * H);
+  for (int c = threadIdx.x; c < (H >> 3); c += 256) {
+    bf16x8 v = src[c], o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(v[j]) * rs);
+    dst[c] = o;
+  }
+}
+
 // silu(gate) * up for the group-of-8 interleaved layout: gu [T, 2I] -> act [T, I]
 __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ act, int I) {
   const int t = blockIdx.y;
@@ -1103,6 +1122,13 @@ int kv_embed_fed(const void* table, const int* tokens, const int* feed, const lo
   if (T <= 0) return 0;
   if (H % 8) return -1;
   hipLaunchKernelGGL(embed_fed_kernel, dim3(T), dim3(256), 0, stream, (const unsigned short*)table, tokens, feed, prev_ids, n_prev, (unsigned short*)out, H, V);
+  return (int)hipGetLastError();
+}
+
+int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, void* y, int T, int H, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (H % 8 || ss_parts < 1) return -1;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(T), dim3(256), 0, stream, (const unsigned short*)x, row_ss, ss_parts, 1.f / (float)H, eps, (unsigned short*)y, H);
   return (int)hipGetLastError();
 }
 

@@ -208,10 +208,15 @@ class LLMEngine:
             return self.spec.step()
         t0 = time.perf_counter()
         launched = False
-        if self.ecfg.async_scheduling and self._can_pipeline():
+        pipelined = self.ecfg.async_scheduling and self._can_pipeline()
+        unheld = True
+        if pipelined:
+            unheld = self._hold_launch()
+            # the hold takes in new requests: one of them may need the synchronous path
+            pipelined = unheld or self._can_pipeline()
+        if pipelined:
             # launch the next step on top of the one in flight, THEN read that one's tokens:
             # the device never waits for the host between steps
-            unheld = self._hold_launch()
             t_launch = time.perf_counter()
             batch = self.scheduler.schedule()
             handle = None

@@ -247,9 +247,12 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
     elif w.w_full is not None:
         # wide token batch (prefill): compute-bound, served by the library GEMM on the
         # row-major copy; the epilogues the streaming kernel fuses run as small kernels here
-        y = F.linear(x[:m], w.w_full[: w.n])
+        xin = x[:m]
         if ss is not None:
-            y = (y.float() * torch.rsqrt(ss[:m].sum(-1, keepdim=True) / w.k + eps)).to(torch.bfloat16)
+            # the folded RMSNorm goes onto the GEMM's input here: one pass over [T, H]
+            xin = torch.empty((m, w.k), dtype=torch.bfloat16, device=x.device)
+            C.scale_rows(x[:m], ss, eps, xin)
+        y = F.linear(xin, w.w_full[: w.n])
         if epi == 2:
             act = torch.empty((m, w.n // 2), dtype=torch.bfloat16, device=x.device)
             C.swiglu_interleaved(y.contiguous(), act)

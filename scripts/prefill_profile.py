@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""A 2048-token prompt through the engine (Llama-3-8B, 1024-token step budget), three times:
+the workload for `rocprofv3 --kernel-trace --stats` of the prefill path.  Prints ms per prompt."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from kvmini.engine.engine import EngineConfig, LLMEngine
+from kvmini.engine.scheduler import SamplingParams
+
+budget = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+eng = LLMEngine(EngineConfig(model="llama-3-8b", device="cuda:0", max_num_seqs=32, max_batched_tokens=budget, max_model_len=4096, kernels="hip", kv_memory_fraction=0.2))
+eng.warmup()
+for rep in range(4):
+    seq = eng.make_sequence([1] + [(7 * i + rep) % 1000 + 10 for i in range(2047)], SamplingParams(max_tokens=1, ignore_eos=True))
+    eng.scheduler.add(seq)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while eng.scheduler.has_work():
+        eng.step()
+    torch.cuda.synchronize()
+    print(f"prompt {rep}: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)

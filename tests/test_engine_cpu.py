@@ -403,3 +403,21 @@ def test_pipelined_stepping_hands_over_to_synchronous_for_sampled_requests():
         eng.step()
     assert eng._pending is None
     assert a.output_ids == dense_greedy(w, PROMPTS[0], 10) and len(b.output_ids) == 5 and -1 not in b.output_ids
+
+
+def test_gemm_workgroup_planner_fills_the_cus_evenly():
+    """Pure-Python part of the streaming-GEMM dispatch: waves per workgroup and K splits are
+    chosen so that the grid is a whole number of rounds over the 256 CUs where the shape allows."""
+    from kvmini.ops.hip_ops import MAX_SPLITS, _plan_slabs, _waves_per_workgroup
+
+    assert _waves_per_workgroup(28672) == 7  # 1792 tiles = 7 x 256
+    assert _waves_per_workgroup(57344) == 7
+    assert _waves_per_workgroup(128256) == 8  # 4 and 8 waves fill alike: the larger workgroup wins
+    assert _waves_per_workgroup(16384) == 4  # 256 workgroups of 4 waves beat 128 of 8
+    for n, k in ((6144, 4096), (4096, 4096), (4096, 14336), (8192, 8192), (8192, 28672), (10240, 8192), (3072, 2048), (2048, 8192), (5120, 13824), (256, 256)):
+        nw, splits, gps = _plan_slabs(n, k)
+        assert nw in (4, 6, 7, 8) and n % (16 * nw) == 0
+        assert 1 <= splits <= MAX_SPLITS and splits * gps == k // 256  # equal splits that cover K exactly
+    for n, k in ((6144, 4096), (4096, 4096), (4096, 14336)):  # the Llama-3-8B projections: one workgroup per CU
+        nw, splits, _ = _plan_slabs(n, k)
+        assert n // (16 * nw) * splits == 256

@@ -731,3 +731,15 @@ def test_stream_gemm3_waves_per_workgroup(C, nw, M):
     slabs = torch.empty(splits, M, N, device="cuda", dtype=torch.float32)
     C.stream_gemm3(wp, N, K, x, slabs, 1, 2, splits, gps, None, 0.0, None, nw)
     assert splits > 1 and torch.allclose(slabs.sum(0), ref, atol=0.02, rtol=0.01)
+
+
+@pytest.mark.gpu
+def test_scale_rows_matches_reference(C):
+    torch.manual_seed(3)
+    T, H = 37, 4096
+    x = torch.randn(T, H, device="cuda").bfloat16()
+    ss = (x.float() ** 2).view(T, 8, 512).sum(-1).contiguous()
+    y = torch.empty_like(x)
+    C.scale_rows(x, ss, 1e-5, y)
+    ref = (x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)).bfloat16()
+    assert torch.allclose(y.float(), ref.float(), atol=1e-2, rtol=1e-2)
