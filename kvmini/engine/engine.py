@@ -100,30 +100,44 @@ def _sample_row(logits: torch.Tensor, p: SamplingParams, gen: Optional[torch.Gen
     return int(torch.multinomial(probs, 1, generator=gen).item())
 
 
-def _sample_rows(logits: torch.Tensor, params: List[SamplingParams]) -> List[int]:
-    """The same sampler for many rows at once (``logits``: ``[R, V]``, one SamplingParams per
-    row, unseeded): one softmax / sort / multinomial over the batch and ONE device
-    synchronisation, instead of R of each — at 20 sampled rows per step the per-row form
-    costs more than the whole forward pass."""
+def _host_to_device(values: List[Any], dtype: torch.dtype, dev: torch.device) -> torch.Tensor:
+    """Small per-step parameter vector to the device without stalling the host: pinned staging
+    and an asynchronous copy (a pageable copy would wait for everything queued on the stream)."""
+    t = torch.tensor(values, dtype=dtype)
+    if dev.type != "cuda":
+        return t
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
+def _sample_rows_device(logits: torch.Tensor, params: List[SamplingParams]) -> torch.Tensor:
+    """Temperature / top-k / top-p sampling of many rows at once (``logits``: ``[R, V]``, one
+    SamplingParams per row, unseeded): one softmax / sort / multinomial over the batch, every
+    op on the device and nothing read back — the ids stay there (int64 ``[R]``)."""
     dev = logits.device
-    temps = torch.tensor([max(p.temperature, 1e-5) for p in params], dtype=torch.float32, device=dev)
+    temps = _host_to_device([max(p.temperature, 1e-5) for p in params], torch.float32, dev)
     x = logits.float() / temps[:, None]
     ks = [min(p.top_k, x.shape[1]) if p.top_k and p.top_k > 0 else 0 for p in params]
     if any(ks):
         vals = torch.topk(x, max(ks), dim=-1).values
-        kidx = torch.tensor([max(k, 1) - 1 for k in ks], device=dev)
+        kidx = _host_to_device([max(k, 1) - 1 for k in ks], torch.int64, dev)
         kth = vals.gather(1, kidx[:, None])
-        use = torch.tensor([k > 0 for k in ks], device=dev)[:, None]
+        use = _host_to_device([k > 0 for k in ks], torch.bool, dev)[:, None]
         x = torch.where(use & (x < kth), torch.full_like(x, float("-inf")), x)
     probs = torch.softmax(x, dim=-1)
     if any(p.top_p < 1.0 for p in params):
-        tp = torch.tensor([p.top_p for p in params], dtype=torch.float32, device=dev)
+        tp = _host_to_device([p.top_p for p in params], torch.float32, dev)
         sp, si = torch.sort(probs, dim=-1, descending=True)
         keep = (torch.cumsum(sp, -1) - sp) < tp[:, None]
         sp = sp * keep
         probs = torch.zeros_like(probs).scatter_(1, si, sp)
         probs = probs / probs.sum(-1, keepdim=True)
-    return torch.multinomial(probs, 1).view(-1).tolist()
+    return torch.multinomial(probs, 1).view(-1)
+
+
+def _sample_rows(logits: torch.Tensor, params: List[SamplingParams]) -> List[int]:
+    """:func:`_sample_rows_device` with ONE device synchronisation at the end, instead of one
+    per row — at 20 sampled rows per step the per-row form costs more than the whole forward pass."""
+    return _sample_rows_device(logits, params).tolist()
 
 
 class LLMEngine:
@@ -222,7 +236,7 @@ class LLMEngine:
             handle = None
             if batch.chunks:
                 with torch.no_grad():
-                    handle = self.runner.launch(batch)
+                    handle = self.runner.launch(batch, self._device_sampler(batch))
                 self.scheduler.launch_commit(batch)
                 launched = True
                 self.pipelined_steps += 1
@@ -279,20 +293,48 @@ class LLMEngine:
             return False
         return True
 
+    def _device_sampler(self, batch: Batch) -> Optional[Callable[[torch.Tensor, torch.Tensor], None]]:
+        """For a step that is launched ahead: the rows with temperature > 0 are sampled by device
+        ops queued right behind the forward pass and written over the argmax ids, so that the
+        next step can take them from there like greedy ones.  None when every row is greedy."""
+        rows: List[int] = []
+        plist: List[SamplingParams] = []
+        r = 0
+        for ch in batch.chunks:
+            if ch.sample:
+                if ch.seq.params.temperature > 0:
+                    rows.append(r)
+                    plist.append(ch.seq.params)
+                r += 1
+        if not rows:
+            return None
+
+        def run(logits: torch.Tensor, out_ids: torch.Tensor) -> None:
+            idx = _host_to_device(rows, torch.int64, logits.device)
+            out_ids.index_copy_(0, idx, _sample_rows_device(logits.index_select(0, idx), plist))
+
+        return run
+
+    @staticmethod
+    def _needs_host_sampling(p: SamplingParams) -> bool:
+        # a per-request seed owns a generator that is advanced on the host; logprobs are read back
+        return bool(p.logprobs) or (p.temperature > 0 and p.seed is not None)
+
     def _can_pipeline(self) -> bool:
-        """Pipelined stepping needs every token of the next step to be either known or the
-        argmax the device already holds (greedy requests only), and no preemption (a preempted
-        sequence is rescheduled from its token list, which may not hold placeholders)."""
+        """Pipelined stepping needs every token of the next step to be either known or already
+        on the device when that step runs (argmax, or unseeded sampling done by device ops), and
+        no preemption (a preempted sequence is rescheduled from its token list, which may not
+        hold placeholders)."""
         r, sch = self.runner, self.scheduler
         if r.tp_active or r.tp_size > 1:
             return False
         for s in sch.running:
-            if s.params.temperature > 0 or s.params.logprobs:
+            if self._needs_host_sampling(s.params):
                 return False
         room = sch.max_num_seqs - len(sch.running)
         if room > 0 and sch.waiting:
             for s in itertools.islice(sch.waiting, room):
-                if s.params.temperature > 0 or s.params.logprobs:
+                if self._needs_host_sampling(s.params):
                     return False
         return self.bm.num_free >= len(sch.running) + sch.max_batched_tokens // self.bm.block_size + 2
 

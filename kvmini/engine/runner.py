@@ -376,11 +376,13 @@ class ModelRunner:
         n = h.n_samples
         return h.stage.out_cpu[:n].tolist(), (h.logits[:n] if h.logits is not None else None)
 
-    def launch(self, batch: Batch) -> StepHandle:
+    def launch(self, batch: Batch, sampler: Any = None) -> StepHandle:
         """Stage and enqueue one step without waiting for it.  A one-token chunk whose token
         is still a placeholder (``PLACEHOLDER``: sampled by the previous step, which the host
         has not read back) is fed on the device from row ``seq.pending_row`` of that step's
-        ids.  At most one launched step may be uncollected when the next one is launched."""
+        ids.  At most one launched step may be uncollected when the next one is launched.
+        ``sampler(logits, out_ids)``, if given, queues device ops behind the forward pass that
+        replace ids in ``out_ids`` (non-greedy rows) before they are copied out."""
         t = batch.num_tokens
         t_pad = self.bucket_for(t)
         sb = self.stages[self._cur]
@@ -471,6 +473,8 @@ class ModelRunner:
             # every rank runs the same step: ship the staged inputs to the followers (see follow())
             torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
         logits = self._run_staged(t_pad, max_ctx, decode_only)
+        if sampler is not None:
+            sampler(logits, self.out_ids)
         # the ids leave the device right behind the step, before a later launch overwrites them
         sb.out_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
         if self.device.type == "cuda":

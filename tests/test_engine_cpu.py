@@ -421,3 +421,23 @@ def test_gemm_workgroup_planner_fills_the_cus_evenly():
     for n, k in ((6144, 4096), (4096, 4096), (4096, 14336)):  # the Llama-3-8B projections: one workgroup per CU
         nw, splits, _ = _plan_slabs(n, k)
         assert n // (16 * nw) * splits == 256
+
+
+def test_unseeded_sampling_rides_the_pipeline():
+    """temperature > 0 without a seed is sampled by device ops behind the forward pass, so the
+    step after it can still be launched ahead.  top_k = 1 makes sampling deterministic: the
+    tokens must equal greedy decoding; a free sample must stay in the vocabulary."""
+    eng, w = _engine(max_num_seqs=4)
+    a = eng.make_sequence(PROMPTS[0], SamplingParams(max_tokens=10, temperature=0.7, top_k=1, ignore_eos=True))
+    b = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=8, ignore_eos=True))
+    c = eng.make_sequence(PROMPTS[2], SamplingParams(max_tokens=9, temperature=1.3, top_p=0.8, ignore_eos=True))
+    for s in (a, b, c):
+        eng.scheduler.add(s)
+    steps = 0
+    while eng.scheduler.has_work():
+        eng.step()
+        steps += 1
+    assert eng.pipelined_steps == steps - 1  # every step but the final read-back launched one
+    assert a.output_ids == dense_greedy(w, PROMPTS[0], 10)
+    assert b.output_ids == dense_greedy(w, PROMPTS[1], 8)
+    assert len(c.output_ids) == 9 and all(0 <= t < w.cfg.vocab_size for t in c.output_ids)
