@@ -19,6 +19,11 @@ __device__ inline unsigned short f2bf(float f) {  // round-to-nearest-even, NaN 
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+// value of lane dpp_ctrl(lane) within the lane's row of 16 (data-parallel primitive: one VALU op)
+template <int CTRL>
+__device__ inline float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ inline float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -503,30 +508,52 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
   // V staging role: key = tid & 31, 16 dims starting at (tid >> 5) * 16
   const int sv_key = tid & 31, sv_d0 = (tid >> 5) << 4;
 
+  // K fragments (B lane = K[key lr][dims 32*ks + 8*lq .. +8]) for the two 16-key blocks of a
+  // step and this thread's share of the V rows, loaded ONE STEP AHEAD: the block-table lookup
+  // and the cache reads of step i+1 are in flight while step i computes (a step is ~100 MFMA
+  // cycles per wave; an unhidden L2 / HBM round trip per step cost 40x that).
+  mfma_ab kf[2][4], kf_n[2][4];
+  bf16x8 v0, v1, v0_n, v1_n;
+  // The block-table entries of a step's two 16-key blocks are fetched one step earlier still,
+  // so the dependent lookup -> address -> cache read chain never stalls the loop.  Keys past
+  // the end clamp to the last key (a valid row; masked in the softmax).
+#define BT_LOAD(KB, B0, B1)                                                   \
+  do {                                                                        \
+    const int k0 = (KB) < last_key ? (KB) : last_key;                         \
+    const int k1 = (KB) + 16 < last_key ? (KB) + 16 : last_key;               \
+    B0 = bt[k0 >> 4];                                                         \
+    B1 = bt[k1 >> 4];                                                         \
+  } while (0)
+#define KV_LOAD_STEP(KB, B0, B1, KF, V0, V1)                                                                            \
+  do {                                                                                                                  \
+    int vkey = (KB) + sv_key;                                                                                           \
+    if (vkey > last_key) vkey = last_key;                                                                               \
+    const unsigned short* vp = v_cache + (((long long)(sv_key < 16 ? B0 : B1) * nkv + g) * BS + (vkey & 15)) * HD + sv_d0; \
+    V0 = *reinterpret_cast<const bf16x8*>(vp);                                                                          \
+    V1 = *reinterpret_cast<const bf16x8*>(vp + 8);                                                                      \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                     \
+      int key = (KB) + b * 16 + lr;                                                                                     \
+      if (key > last_key) key = last_key;                                                                               \
+      const unsigned short* kp = k_cache + (((long long)(b ? B1 : B0) * nkv + g) * BS + (key & 15)) * HD + lq * 8;       \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) KF[b][ks] = *reinterpret_cast<const mfma_ab*>(kp + ks * 32);     \
+    }                                                                                                                   \
+  } while (0)
+  int blk0, blk1;
+  BT_LOAD(0, blk0, blk1);
+  KV_LOAD_STEP(0, blk0, blk1, kf, v0, v1);
+  BT_LOAD(KSTEP, blk0, blk1);
+
   for (int kb = 0; kb <= last_key; kb += KSTEP) {
-    // ---- stage V^T for keys kb .. kb+31 (keys past the end read a valid block and are masked)
-    {
-      int key = kb + sv_key;
-      if (key > last_key) key = last_key;
-      const unsigned short* vp = v_cache + (((long long)bt[key >> 4] * nkv + g) * BS + (key & 15)) * HD + sv_d0;
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vp);
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vp + 8);
-      __syncthreads();  // every wave is done with the previous step's V^T
+    // unconditional (past the end the keys clamp to the last one): a branch around the loads
+    // would leave the in-order load counter unknown at the join and force a full drain there
+    KV_LOAD_STEP(kb + KSTEP, blk0, blk1, kf_n, v0_n, v1_n);
+    BT_LOAD(kb + 2 * KSTEP, blk0, blk1);
+    // ---- stage V^T for keys kb .. kb+31
+    __syncthreads();  // every wave is done with the previous step's V^T
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        vt_lds[(sv_d0 + j) * VT_STRIDE + sv_key] = v0[j];
-        vt_lds[(sv_d0 + 8 + j) * VT_STRIDE + sv_key] = v1[j];
-      }
-    }
-    // ---- K fragments for the two key blocks: B lane = K[key lr][dims 32*ks + 8*lq .. +8]
-    mfma_ab kf[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      int key = kb + b * 16 + lr;
-      if (key > last_key) key = last_key;
-      const unsigned short* kp = k_cache + (((long long)bt[key >> 4] * nkv + g) * BS + (key & 15)) * HD + lq * 8;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = *reinterpret_cast<const mfma_ab*>(kp + ks * 32);
+    for (int j = 0; j < 8; ++j) {
+      vt_lds[(sv_d0 + j) * VT_STRIDE + sv_key] = v0[j];
+      vt_lds[(sv_d0 + 8 + j) * VT_STRIDE + sv_key] = v1[j];
     }
     __syncthreads();  // V^T is staged
 #pragma unroll
@@ -541,30 +568,48 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) sacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[hh][ks], kf[b][ks], sacc[b], 0, 0, 0);
       }
-      // ---- causal mask + online softmax; this lane: queries 4*lq + r, keys kb + 16*b + lr
+      // ---- causal mask + online softmax; this lane: queries 4*lq + r, keys kb + 16*b + lr.
+      // The loop is VALU-bound (16 MFMAs against hundreds of vector ops per step), so: the
+      // mask only on steps that reach the diagonal, row maxima over the 16 key lanes by DPP
+      // (quad swaps + half-row / row mirror: 4 cross-lane ops, no LDS round trip), the row sum
+      // kept per lane and reduced once after the loop, hardware bf16 conversion for P, and
+      // the rescale of O only when some row's maximum moved.
       float p[2][4], corr[4];
+      const bool diag = kb + KSTEP - 1 > pos0;  // some key of the step may be masked for some query
+      bool moved = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qpos = pos0 + 4 * lq + r;
-        float s0 = (kb + lr <= qpos) ? sacc[0][r] * scale_log2e : -1e30f;
-        float s1 = (kb + 16 + lr <= qpos) ? sacc[1][r] * scale_log2e : -1e30f;
+        float s0 = sacc[0][r] * scale_log2e, s1 = sacc[1][r] * scale_log2e;
+        if (diag) {
+          const int qpos = pos0 + 4 * lq + r;
+          s0 = (kb + lr <= qpos) ? s0 : -1e30f;
+          s1 = (kb + 16 + lr <= qpos) ? s1 : -1e30f;
+        }
         float mx = fmaxf(s0, s1);
-        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        mx = fmaxf(mx, dpp_f32<0xB1>(mx));   // quad_perm [1,0,3,2]
+        mx = fmaxf(mx, dpp_f32<0x4E>(mx));   // quad_perm [2,3,0,1]
+        mx = fmaxf(mx, dpp_f32<0x141>(mx));  // row_half_mirror
+        mx = fmaxf(mx, dpp_f32<0x140>(mx));  // row_mirror
         const float m_new = fmaxf(m_run[hh][r], mx);
         p[0][r] = exp2f(s0 - m_new);
         p[1][r] = exp2f(s1 - m_new);
-        float ps = p[0][r] + p[1][r];
-        for (int off = 1; off < 16; off <<= 1) ps += __shfl_xor(ps, off, 64);
+        moved |= m_new != m_run[hh][r];
         corr[r] = exp2f(m_run[hh][r] - m_new);
-        l_run[hh][r] = l_run[hh][r] * corr[r] + ps;
+        l_run[hh][r] = l_run[hh][r] * corr[r] + p[0][r] + p[1][r];  // this lane's keys only
         m_run[hh][r] = m_new;
       }
       // ---- P -> LDS [query][key] (bf16), then back as an A operand
       unsigned short* pw = p_lds[wave][hh];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pw[(4 * lq + r) * KSTEP + lr] = f2bf(p[0][r]);
-        pw[(4 * lq + r) * KSTEP + 16 + lr] = f2bf(p[1][r]);
+        pw[(4 * lq + r) * KSTEP + lr] = __builtin_bit_cast(unsigned short, (__bf16)p[0][r]);
+        pw[(4 * lq + r) * KSTEP + 16 + lr] = __builtin_bit_cast(unsigned short, (__bf16)p[1][r]);
+      }
+      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[hh][nt][r] *= corr[r];
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
       __builtin_amdgcn_wave_barrier();
@@ -572,14 +617,20 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
       // ---- O = O * corr + P V   (B lane = V^T[dim 16*nt + lr][keys 8*lq .. +8])
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[hh][nt][r] *= corr[r];
         const mfma_ab vb = *reinterpret_cast<const mfma_ab*>(vt_lds + (nt * 16 + lr) * VT_STRIDE + lq * 8);
         o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[hh][nt], 0, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();
     }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = kf_n[b][ks];
+    v0 = v0_n;
+    v1 = v1_n;
   }
+#undef KV_LOAD_STEP
+#undef BT_LOAD
   // ---- normalise and store: lane holds O[query 4*lq + r][dim 16*nt + lr]
 #pragma unroll
   for (int hh = 0; hh < HPW; ++hh) {
@@ -588,8 +639,13 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qi = 4 * lq + r;
+      float l = l_run[hh][r];  // per-lane partial sums: fold the 16 key lanes of the row
+      l += dpp_f32<0xB1>(l);
+      l += dpp_f32<0x4E>(l);
+      l += dpp_f32<0x141>(l);
+      l += dpp_f32<0x140>(l);
       if (qi >= n_q) continue;
-      const float inv = l_run[hh][r] > 0.f ? 1.f / l_run[hh][r] : 0.f;
+      const float inv = l > 0.f ? 1.f / l : 0.f;
       unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + lr;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) op[nt * 16] = f2bf(o[hh][nt][r] * inv);

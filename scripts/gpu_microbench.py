@@ -182,6 +182,30 @@ def nw_bench(out):
         torch.cuda.empty_cache()
 
 
+def attn_bench(out):
+    """The tiled prompt-attention kernel alone: one 1024-query chunk of a Llama-3-8B layer
+    (32 q heads / 8 kv heads x 128) at positions 0..1023 and 1024..2047, and a 2048-query chunk."""
+    import math
+
+    from kvmini.ops import hip_ops
+
+    dev = torch.device("cuda:0")
+    nh, nkv, hd, bs = 32, 8, 128, 16
+    nb = 4096 // bs + 8
+    kc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
+    vc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
+    bt = torch.randperm(nb, device=dev)[: 4096 // bs].view(1, -1).int().contiguous()
+    for p0, n in ((0, 1024), (1024, 1024), (0, 2048), (2048, 2048)):
+        q = torch.randn(n, nh, hd, device=dev).bfloat16()
+        o = torch.empty(n, nh * hd, device=dev, dtype=torch.bfloat16)
+        tiles = torch.tensor([(off, 16, p0 + off, 0) for off in range(0, n, 16)], device=dev, dtype=torch.int32).T.contiguous()
+        t = time_fns({"tiled": lambda: hip_ops.prefill_attention(q, kc, vc, bt, tiles, o, 1 / math.sqrt(hd))}, rounds=10, inner=5)["tiled"]
+        flops = 4.0 * hd * nh * sum(p0 + i + 1 for i in range(n))
+        row = {"bench": "prefill_attention", "pos0": p0, "queries": n, "us": round(t, 1), "TFLOPs": round(flops / t / 1e6, 1)}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+
+
 def step_bench(out, model, batch, kernels_list, quantization=None):
     kernels_list = [k for k in kernels_list if k == "hip"]  # the torch ops are not graph-capturable
     from kvmini.engine.engine import EngineConfig, LLMEngine
@@ -312,6 +336,8 @@ def main():
         mall_bench(out)
     if "balance" in a.what:
         balance_bench(out)
+    if "attn" in a.what.split(","):
+        attn_bench(out)
     if "nw" in a.what.split(","):
         nw_bench(out)
     if "prefill" in a.what:
