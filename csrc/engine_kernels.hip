@@ -371,19 +371,27 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
       for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int j = 0; j < 8; ++j) d += qf[h][v * 8 + j] * bf2f(kv[v][j]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
+      d += dpp_f32<0xB1>(d);  // the 4 dim chunks of a key sit in one quad: quad swaps in registers
+      d += dpp_f32<0x4E>(d);
       s[h] = (b * BS + qk_tok < ctx) ? d : -1e30f;
     }
     // ---- online softmax over the block's 16 tokens (token index lives in lane bits 2..5)
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
+      // quads hold equal values: half-row and row mirror fold the 4 quads of a row in
+      // registers, only the two cross-row steps go through the LDS crossbar
       float mx = s[h];
-      for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = fmaxf(mx, dpp_f32<0x141>(mx));
+      mx = fmaxf(mx, dpp_f32<0x140>(mx));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[h], mx);
       const float p = exp2f(s[h] - m_new);
       float ps = p;
-      for (int o = 4; o < 64; o <<= 1) ps += __shfl_xor(ps, o, 64);
+      ps += dpp_f32<0x141>(ps);
+      ps += dpp_f32<0x140>(ps);
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
       const float corr = exp2f(m_run[h] - m_new);
       l_run[h] = l_run[h] * corr + ps;
       m_run[h] = m_new;
@@ -682,7 +690,7 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
   __shared__ float x_lds[REP + 2][HD];
   __shared__ float p_lds[4][REP][BS];
   __shared__ float m_lds[4][REP], l_lds[4][REP];
-  __shared__ float o_lds[4][REP][HD];
+  __shared__ float o_lds[4][4][REP][HD];  // [wave][token group]: partial outputs, summed in the merge
   const int t = blockIdx.x, g = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ctx = ctx_lens[t];
@@ -821,18 +829,26 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
       for (int v = 0; v < 4; ++v)
 #pragma unroll
         for (int j = 0; j < 8; ++j) d += qf[h][v * 8 + j] * bf2f(kv[v][j]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
+      d += dpp_f32<0xB1>(d);  // the 4 dim chunks of a key sit in one quad
+      d += dpp_f32<0x4E>(d);
       s[h] = (b * BS + qk_tok < prev) ? d : -1e30f;
     }
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
+      // all-reduce over the 16 keys: quads hold equal values, so the two mirrors fold the 4
+      // quads of a row in registers; only the two cross-row steps go through the LDS crossbar
       float mx = s[h];
-      for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = fmaxf(mx, dpp_f32<0x141>(mx));
+      mx = fmaxf(mx, dpp_f32<0x140>(mx));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[h], mx);
       const float p = exp2f(s[h] - m_new);
       float ps = p;
-      for (int o = 4; o < 64; o <<= 1) ps += __shfl_xor(ps, o, 64);
+      ps += dpp_f32<0x141>(ps);
+      ps += dpp_f32<0x140>(ps);
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
       const float corr = exp2f(m_run[h] - m_new);
       l_run[h] = l_run[h] * corr + ps;
       m_run[h] = m_new;
@@ -865,8 +881,8 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
       float d = 0.f;
 #pragma unroll
       for (int j = 0; j < 32; ++j) d += qf[h][j] * x_lds[REP][qk_c * 32 + j];
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
+      d += dpp_f32<0xB1>(d);
+      d += dpp_f32<0x4E>(d);
       const float m_new = fmaxf(m_run[h], d);
       const float p = exp2f(d - m_new);
       const float corr = exp2f(m_run[h] - m_new);
@@ -876,20 +892,12 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
       for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * corr + (pv_tg == 0 ? p * x_lds[REP + 1][pv_dv * 8 + j] : 0.f);
     }
   }
+  // every token group leaves its partial output in LDS (the merge adds them up): 16-byte
+  // stores instead of 64 cross-lane exchanges per lane
 #pragma unroll
-  for (int h = 0; h < REP; ++h)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = acc[h][j];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      acc[h][j] = v;
-    }
-  if (pv_tg == 0) {
-#pragma unroll
-    for (int h = 0; h < REP; ++h)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o_lds[wave][h][pv_dv * 8 + j] = acc[h][j];
+  for (int h = 0; h < REP; ++h) {
+    *reinterpret_cast<f32x4*>(&o_lds[wave][pv_tg][h][pv_dv * 8]) = (f32x4){acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
+    *reinterpret_cast<f32x4*>(&o_lds[wave][pv_tg][h][pv_dv * 8 + 4]) = (f32x4){acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
   }
   if (lane == 0) {
 #pragma unroll
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float c = exp2f(m_lds[w][h] - m);
-      num += o_lds[w][h][d] * c;
+      num += (o_lds[w][0][h][d] + o_lds[w][1][h][d] + o_lds[w][2][h][d] + o_lds[w][3][h][d]) * c;
       den += l_lds[w][h] * c;
     }
     orow[i] = f2bf(den > 0.f ? num / den : 0.f);
