@@ -410,8 +410,15 @@ class LLMEngine:
                     gen.manual_seed(p.seed)
                     self._gens[seq.req_id] = gen
                 tok = _sample_row(logits[row], p, gen)
+            lp_entry = None
+            if p.logprobs > 0 and logits is not None:
+                lp = torch.log_softmax(logits[row].float(), -1)
+                tv, ti = torch.topk(lp, min(p.logprobs, lp.numel()))
+                lp_entry = (float(lp[tok]), list(zip(ti.tolist(), tv.tolist())))
             row += 1
             new = self.scheduler.commit(ch, [tok])
+            if lp_entry is not None and new:
+                seq.logprob_log.append(lp_entry)
             self.stats.generation_tokens += len(new)
             done = seq.status == SeqStatus.FINISHED
             if done:

@@ -68,6 +68,8 @@ class Sequence:
     # in-flight sample is known (by length) to be the sequence's last
     pending_row: int = -1
     pending_finish: bool = False
+    # per output token (requests with logprobs > 0): (log-probability of the token, [(id, logprob)] of the top ones)
+    logprob_log: List[Any] = field(default_factory=list)
 
     @property
     def all_ids(self) -> List[int]:

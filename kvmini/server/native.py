@@ -1,7 +1,8 @@
 """OpenAI-compatible HTTP front-end of the native MI355X engine (``kvmini serve``).
 
 Endpoints: ``POST /v1/chat/completions``, ``POST /v1/completions`` (stream and
-non-stream, ``stream_options.include_usage``, ``n`` = 1), ``GET /v1/models``,
+non-stream, ``stream_options.include_usage``, ``n`` choices, ``stop`` strings, ``logprobs`` /
+``top_logprobs``), ``GET /v1/models``,
 ``GET /health``, ``GET /metrics`` (Prometheus text with the ``vllm:*`` names the
 dashboards and the analyzer's cache-hit query use), TGI ``/generate`` and
 ``/generate_stream`` for the A/B harness.
@@ -43,7 +44,7 @@ class NativeServer:
         self.started_at = time.time()
         self.ready_at: Optional[float] = None
         self.loop: Optional[asyncio.AbstractEventLoop] = None
-        self._queues: Dict[int, asyncio.Queue] = {}
+        self._queues: Dict[int, Tuple[asyncio.Queue, int]] = {}  # request id -> (queue, choice index)
         self.requests_total = 0
         self.errors_total = 0
         engine.on_tokens = self._on_tokens
@@ -56,14 +57,19 @@ class NativeServer:
 
     def _deliver(self, events: List[TokenEvent]) -> None:
         for req_id, toks, done, reason, seq in events:
-            q = self._queues.get(req_id)
-            if q is not None:
-                q.put_nowait((toks, done, reason, seq))
+            ent = self._queues.get(req_id)
+            if ent is not None:
+                q, idx = ent
+                q.put_nowait((idx, toks, done, reason, seq))
 
     # helpers --------------------------------------------------------------
-    def _params(self, body: Dict[str, Any]) -> SamplingParams:
+    def _params(self, body: Dict[str, Any], chat: bool = True) -> SamplingParams:
         max_tokens = body.get("max_tokens") or body.get("max_completion_tokens") or 16
         ignore = body.get("ignore_eos")
+        if chat:  # chat: logprobs is a flag, top_logprobs the count; completions: logprobs is the count
+            n_lp = int(body.get("top_logprobs") or 0) or (1 if body.get("logprobs") else 0)
+        else:
+            n_lp = int(body.get("logprobs") or 0)
         return SamplingParams(
             max_tokens=int(max_tokens),
             temperature=float(body.get("temperature") or 0.0),
@@ -71,7 +77,8 @@ class NativeServer:
             top_k=int(body.get("top_k") or 0),
             seed=body.get("seed"),
             ignore_eos=self.ignore_eos if ignore is None else bool(ignore),
-            logprobs=int(body.get("top_logprobs") or (1 if body.get("logprobs") else 0)),
+            logprobs=max(0, min(n_lp, 20)),
+            stop_token_ids=[int(t) for t in (body.get("stop_token_ids") or [])],
         )
 
     def _auth(self, req: Request) -> Optional[Response]:
@@ -79,11 +86,24 @@ class NativeServer:
             return Response.json({"error": {"message": "invalid api key", "type": "authentication_error"}}, 401)
         return None
 
-    async def _run(self, prompt_ids: List[int], params: SamplingParams) -> Tuple[int, asyncio.Queue]:
-        q: asyncio.Queue = asyncio.Queue()
+    async def _run(self, prompt_ids: List[int], params: SamplingParams, q: Optional[asyncio.Queue] = None, idx: int = 0) -> Tuple[int, asyncio.Queue]:
+        """Submit one sequence; its token events arrive on ``q`` tagged with ``idx``."""
+        q = q if q is not None else asyncio.Queue()
         rid = self.engine.submit(prompt_ids, params)
-        self._queues[rid] = q
+        self._queues[rid] = (q, idx)
         return rid, q
+
+    def _logprob_entries(self, seq: Any, first: int, toks: List[int]) -> List[Dict[str, Any]]:
+        """OpenAI chat ``logprobs.content`` entries for output tokens ``first ..`` of a sequence."""
+        out = []
+        for k, t in enumerate(toks):
+            if first + k >= len(seq.logprob_log):
+                break
+            lp, top = seq.logprob_log[first + k]
+            piece = self.tok.decode_token(t) or " "
+            out.append({"token": piece, "logprob": lp, "bytes": list(piece.encode()),
+                        "top_logprobs": [{"token": self.tok.decode_token(i) or " ", "logprob": v, "bytes": list((self.tok.decode_token(i) or " ").encode())} for i, v in top]})
+        return out
 
     # OpenAI ---------------------------------------------------------------
     async def chat(self, req: Request) -> Any:
@@ -112,64 +132,128 @@ class NativeServer:
         if len(prompt_ids) >= self.engine.ecfg.max_model_len:
             self.errors_total += 1
             return Response.json({"error": {"message": f"prompt has {len(prompt_ids)} tokens; max_model_len is {self.engine.ecfg.max_model_len}", "type": "invalid_request_error"}}, 400)
-        params = self._params(body)
+        try:
+            n = max(1, min(int(body.get("n") or 1), 16))
+            params = self._params(body, chat)
+        except (TypeError, ValueError) as e:
+            self.errors_total += 1
+            return Response.json({"error": {"message": f"bad sampling parameter: {e}", "type": "invalid_request_error"}}, 400)
+        stops = body.get("stop") or []
+        stops = [stops] if isinstance(stops, str) else [str(x) for x in stops if x]
         stream = bool(body.get("stream"))
         include_usage = bool((body.get("stream_options") or {}).get("include_usage"))
         model = body.get("model") or self.model_name
         oid = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex[:24]
         created = int(time.time())
-        rid, q = await self._run(prompt_ids, params)
+        want_lp = params.logprobs > 0
+        # n choices = n sequences that share the prompt (its KV blocks through the prefix cache)
+        q: asyncio.Queue = asyncio.Queue()
+        rids: List[int] = []
+        for i in range(n):
+            p_i = params if i == 0 else SamplingParams(**{**vars(params), "stop_token_ids": list(params.stop_token_ids), "seed": None if params.seed is None else params.seed + i})
+            rid, _ = await self._run(prompt_ids, p_i, q, i)
+            rids.append(rid)
         n_prompt = len(prompt_ids)
         obj = "chat.completion" if chat else "text_completion"
+        toks_of: List[List[int]] = [[] for _ in range(n)]
+        text_of = [""] * n
+        reason_of: List[Optional[str]] = [None] * n
+        lp_of: List[List[Dict[str, Any]]] = [[] for _ in range(n)]
+        open_choices = set(range(n))
+
+        def take(idx: int, toks: List[int], done: bool, reason: Optional[str], seq: Any) -> Tuple[str, List[Dict[str, Any]], bool]:
+            """Fold one token event into choice ``idx``.  Returns (new text, logprob entries,
+            finished now) after applying the stop strings (the text is cut in front of the match
+            and the sequence aborted: the engine only knows stop TOKENS)."""
+            if idx not in open_choices:
+                return "", [], False
+            first = len(toks_of[idx])
+            toks_of[idx] += toks
+            piece = "".join(self.tok.decode_token(t) or " " for t in toks) if stream else ""
+            lps = self._logprob_entries(seq, first, toks) if want_lp else []
+            full = text_of[idx] + piece if stream else self.tok.decode(toks_of[idx])
+            hit = min((full.find(sx) for sx in stops if sx in full), default=-1)
+            if hit >= 0:
+                piece = full[len(text_of[idx]) : hit] if stream else ""
+                full = full[:hit]
+                if not done:
+                    self.engine.abort(rids[idx])
+                done, reason = True, "stop"
+            text_of[idx] = full
+            lp_of[idx] += lps
+            if done:
+                reason_of[idx] = reason
+                open_choices.discard(idx)
+            return piece, lps, done
+
+        def cleanup(abort_open: bool) -> None:
+            for i, rid in enumerate(rids):
+                self._queues.pop(rid, None)
+                if abort_open and i in open_choices:
+                    self.engine.abort(rid)
 
         if not stream:
-            out: List[int] = []
-            reason = None
             try:
-                while True:
-                    toks, done, reason, _seq = await q.get()
-                    out += toks
-                    if done:
-                        break
+                while open_choices:
+                    take(*(await q.get()))
             finally:
-                self._queues.pop(rid, None)
-            if reason and reason.startswith("error"):
+                cleanup(abort_open=True)
+            errs = [r for r in reason_of if r and r.startswith("error")]
+            if errs:
                 self.errors_total += 1
-                return Response.json({"error": {"message": reason, "type": "internal_error"}}, 500)
-            text = self.tok.decode(out)
-            usage = {"prompt_tokens": n_prompt, "completion_tokens": len(out), "total_tokens": n_prompt + len(out)}
-            if chat:
-                choice: Dict[str, Any] = {"index": 0, "message": {"role": "assistant", "content": text}, "finish_reason": reason}
-            else:
-                choice = {"index": 0, "text": text, "finish_reason": reason}
-            return Response.json({"id": oid, "object": obj, "created": created, "model": model, "choices": [choice], "usage": usage})
+                return Response.json({"error": {"message": errs[0], "type": "internal_error"}}, 500)
+            n_out = sum(len(t) for t in toks_of)
+            usage = {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
+            choices = []
+            for i in range(n):
+                if chat:
+                    ch: Dict[str, Any] = {"index": i, "message": {"role": "assistant", "content": text_of[i]}, "finish_reason": reason_of[i]}
+                    if want_lp:
+                        ch["logprobs"] = {"content": lp_of[i]}
+                else:
+                    ch = {"index": i, "text": text_of[i], "finish_reason": reason_of[i]}
+                    if want_lp:
+                        ch["logprobs"] = {"tokens": [e["token"] for e in lp_of[i]], "token_logprobs": [e["logprob"] for e in lp_of[i]],
+                                          "top_logprobs": [{t["token"]: t["logprob"] for t in e["top_logprobs"]} for e in lp_of[i]]}
+                choices.append(ch)
+            return Response.json({"id": oid, "object": obj, "created": created, "model": model, "choices": choices, "usage": usage})
 
         async def gen() -> AsyncIterator[bytes]:
             base = {"id": oid, "object": (obj + ".chunk") if chat else obj, "created": created, "model": model}
-            n_out = 0
             finished = False
             try:
                 if chat:
-                    yield sse_event({**base, "choices": [{"index": 0, "delta": {"role": "assistant", "content": ""}, "finish_reason": None}]})
-                while True:
-                    toks, done, reason, _seq = await q.get()
-                    for t in toks:
-                        n_out += 1
-                        piece = self.tok.decode_token(t) or " "
-                        ch = {"index": 0, "delta": {"content": piece}, "finish_reason": None} if chat else {"index": 0, "text": piece, "finish_reason": None}
-                        yield sse_event({**base, "choices": [ch]})
+                    for i in range(n):
+                        yield sse_event({**base, "choices": [{"index": i, "delta": {"role": "assistant", "content": ""}, "finish_reason": None}]})
+                while open_choices:
+                    idx, toks, done, reason, seq = await q.get()
+                    if not stops and not want_lp:
+                        # the common case, one chunk per token
+                        toks_of[idx] += toks
+                        for t in toks:
+                            piece = self.tok.decode_token(t) or " "
+                            ch = {"index": idx, "delta": {"content": piece}, "finish_reason": None} if chat else {"index": idx, "text": piece, "finish_reason": None}
+                            yield sse_event({**base, "choices": [ch]})
+                        if done:
+                            reason_of[idx] = reason
+                            open_choices.discard(idx)
+                    else:
+                        piece, lps, done = take(idx, toks, done, reason, seq)
+                        if piece or lps:
+                            ch = {"index": idx, "delta": {"content": piece}, "finish_reason": None} if chat else {"index": idx, "text": piece, "finish_reason": None}
+                            if want_lp:
+                                ch["logprobs"] = {"content": lps}
+                            yield sse_event({**base, "choices": [ch]})
                     if done:
-                        finished = True
-                        fin = {"index": 0, "delta": {}, "finish_reason": reason} if chat else {"index": 0, "text": "", "finish_reason": reason}
+                        fin = {"index": idx, "delta": {}, "finish_reason": reason_of[idx]} if chat else {"index": idx, "text": "", "finish_reason": reason_of[idx]}
                         yield sse_event({**base, "choices": [fin]})
-                        break
+                finished = True
                 if include_usage:
+                    n_out = sum(len(t) for t in toks_of)
                     yield sse_event({**base, "choices": [], "usage": {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}})
                 yield sse_event("[DONE]")
             finally:
-                self._queues.pop(rid, None)
-                if not finished:
-                    self.engine.abort(rid)  # client went away
+                cleanup(abort_open=not finished)  # client went away: stop generating for it
 
         return StreamingResponse(gen())
 
@@ -192,7 +276,7 @@ class NativeServer:
             out: List[int] = []
             try:
                 while True:
-                    toks, done, reason, _ = await q.get()
+                    _i, toks, done, reason, _ = await q.get()
                     out += toks
                     if done:
                         break
@@ -205,7 +289,7 @@ class NativeServer:
             finished = False
             try:
                 while True:
-                    toks, done, reason, _ = await q.get()
+                    _i, toks, done, reason, _ = await q.get()
                     for i, t in enumerate(toks):
                         out.append(t)
                         ev: Dict[str, Any] = {"index": len(out) - 1, "token": {"id": t, "text": self.tok.decode_token(t) or " ", "logprob": 0.0, "special": False}, "generated_text": None, "details": None}

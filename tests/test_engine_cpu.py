@@ -441,3 +441,56 @@ def test_unseeded_sampling_rides_the_pipeline():
     assert a.output_ids == dense_greedy(w, PROMPTS[0], 10)
     assert b.output_ids == dense_greedy(w, PROMPTS[1], 8)
     assert len(c.output_ids) == 9 and all(0 <= t < w.cfg.vocab_size for t in c.output_ids)
+
+
+def test_native_server_n_choices_stop_strings_and_logprobs():
+    """OpenAI request fields beyond the basics: ``n`` choices (n sequences sharing the prompt),
+    ``stop`` strings (text-level: the engine only knows stop tokens), ``logprobs`` /
+    ``top_logprobs`` in both dialects, streamed and not."""
+    import math
+    import urllib.request
+
+    from kvmini.server.native import start_native_in_thread
+
+    eng, _w = _engine(max_num_seqs=8, max_batched_tokens=32)
+    _ns, url, stop = start_native_in_thread(eng, model_name="tiny")
+
+    def post(path, body):
+        req = urllib.request.Request(url + path, data=json.dumps(body).encode(), headers={"Content-Type": "application/json"})
+        return urllib.request.urlopen(req, timeout=60).read().decode()
+
+    try:
+        msgs = [{"role": "user", "content": "Hello, world!"}]
+        base = json.loads(post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 8}))
+        text = base["choices"][0]["message"]["content"]
+        assert base["usage"]["completion_tokens"] == 8 and base["choices"][0]["finish_reason"] == "length"
+        # n = 3 greedy choices: three identical answers, usage counts all of them
+        r = json.loads(post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 8, "n": 3}))
+        assert [c["index"] for c in r["choices"]] == [0, 1, 2] and all(c["message"]["content"] == text for c in r["choices"])
+        assert r["usage"]["completion_tokens"] == 24
+        # a stop string cuts the text in front of the match
+        words = text.split(" ")
+        cut = next(w for w in words[2:] if w)
+        r = json.loads(post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 8, "stop": [cut]}))
+        assert r["choices"][0]["finish_reason"] == "stop" and r["choices"][0]["message"]["content"] == text[: text.find(cut)]
+        # logprobs: one entry per token, the greedy token is the top one, probabilities are sane
+        r = json.loads(post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 5, "logprobs": True, "top_logprobs": 3}))
+        content = r["choices"][0]["logprobs"]["content"]
+        assert len(content) == 5 and all(len(e["top_logprobs"]) == 3 for e in content)
+        assert all(e["logprob"] <= 0 and abs(e["logprob"] - e["top_logprobs"][0]["logprob"]) < 1e-5 for e in content)
+        assert all(sum(math.exp(t["logprob"]) for t in e["top_logprobs"]) <= 1.0 + 1e-4 for e in content)
+        r = json.loads(post("/v1/completions", {"model": "tiny", "prompt": "abc", "max_tokens": 4, "logprobs": 2}))
+        lp = r["choices"][0]["logprobs"]
+        assert len(lp["tokens"]) == 4 and len(lp["token_logprobs"]) == 4 and all(len(d) <= 2 for d in lp["top_logprobs"])
+        # streamed: n = 2 with logprobs, chunks carry the choice index
+        raw = post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 4, "n": 2, "stream": True, "logprobs": True, "stream_options": {"include_usage": True}})
+        events = [json.loads(ln[6:]) for ln in raw.splitlines() if ln.startswith("data: ") and ln != "data: [DONE]"]
+        per_choice = {0: "", 1: ""}
+        for ev in events:
+            for c in ev["choices"]:
+                per_choice[c["index"]] += (c.get("delta") or {}).get("content") or ""
+        assert per_choice[0] == per_choice[1] != "" and events[-1]["usage"]["completion_tokens"] == 8
+        assert sum(1 for ev in events for c in ev["choices"] if c.get("logprobs")) == 8
+        assert eng.metrics()["running"] == 0
+    finally:
+        stop()
