@@ -316,6 +316,8 @@ def main() -> int:
             "energy_wh_per_1k_tokens": wh_1k,
             "engine_step_ms": round(engine.stats.busy_s / max(1, engine.stats.steps) * 1000.0, 4),
             "engine_steps_timed": engine_steps,
+            "engine_first_token_steps": engine.metrics().get("engine_first_token_steps"),
+            "engine_first_token_ms": engine.metrics().get("engine_first_token_ms"),  # submit -> first sampled token inside the engine (all passes)
             "model_load_s": round(engine.load_s, 2),
             "graph_warmup_s": round(engine.warm_s, 2),
             "vs_baseline_detail": {

@@ -76,6 +76,10 @@ class EngineStats:
     spec_proposed: int = 0
     spec_accepted: int = 0
     step_ms_ewma: float = 0.0
+    # submit -> first sampled token, inside the engine (sum of seconds, count)
+    first_token_s: float = 0.0
+    first_token_n: int = 0
+    first_token_steps: int = 0  # steps launched between submit and the first token (sum)
 
 
 def _resolve_device(name: str) -> torch.device:
@@ -371,9 +375,14 @@ class LLMEngine:
                 row += 1
             if seq.status != SeqStatus.RUNNING:
                 continue
+            first = seq.first_token_time is None
             new = self.scheduler.finalize(ch, tok)
             if not ch.sample:
                 continue
+            if first and seq.first_token_time is not None:
+                self.stats.first_token_s += seq.first_token_time - seq.arrival
+                self.stats.first_token_n += 1
+                self.stats.first_token_steps += self.stats.steps - getattr(seq, "submit_step", self.stats.steps)
             self.stats.generation_tokens += len(new)
             done = seq.status == SeqStatus.FINISHED
             if done:
@@ -416,7 +425,11 @@ class LLMEngine:
                 tv, ti = torch.topk(lp, min(p.logprobs, lp.numel()))
                 lp_entry = (float(lp[tok]), list(zip(ti.tolist(), tv.tolist())))
             row += 1
+            first = seq.first_token_time is None
             new = self.scheduler.commit(ch, [tok])
+            if first and seq.first_token_time is not None:
+                self.stats.first_token_s += seq.first_token_time - seq.arrival
+                self.stats.first_token_n += 1
             if lp_entry is not None and new:
                 seq.logprob_log.append(lp_entry)
             self.stats.generation_tokens += len(new)
@@ -466,6 +479,7 @@ class LLMEngine:
 
     def submit(self, prompt_ids: List[int], params: SamplingParams, user: Any = None) -> int:
         seq = self.make_sequence(prompt_ids, params, user)
+        seq.submit_step = self.stats.steps  # type: ignore[attr-defined]
         self._inbox.put(("add", seq))
         self._wake.set()
         return seq.req_id
@@ -532,6 +546,8 @@ class LLMEngine:
             "spec_accepted": st.spec_accepted,
             "graphs": sorted({b for b, _ in self.runner.graphs}),
             "pipelined_steps": self.pipelined_steps,
+            "engine_first_token_ms": st.first_token_s / st.first_token_n * 1e3 if st.first_token_n else None,
+            "engine_first_token_steps": st.first_token_steps / st.first_token_n if st.first_token_n else None,
             "load_s": self.load_s,
             "warm_s": self.warm_s,
         }
