@@ -11,6 +11,7 @@ asyncio queues with ONE ``call_soon_threadsafe`` per step.
 from __future__ import annotations
 
 import itertools
+import os
 import queue
 import threading
 import time
@@ -56,6 +57,10 @@ class EngineConfig:
     # to end (not right away), so that requests arriving meanwhile still make that launch; 0 =
     # launch immediately
     launch_margin_ms: float = 0.7
+    # let PyTorch's TunableOp pick the rocBLAS / hipBLASLt solution per shape for the library
+    # GEMMs of wide steps (> 64 tokens) during warm-up; timed with a rotating buffer so that the
+    # choice is made for weights that come from HBM, as they do in a real step
+    tune_library_gemm: bool = False
     tp_size: int = 1
     tp_rank: int = 0
     tp_graphs: bool = False
@@ -208,10 +213,22 @@ class LLMEngine:
     def warmup(self) -> float:
         """Capture the HIP graphs (and JIT/allocator warm-up).  Returns seconds."""
         t0 = time.perf_counter()
+        tune = self.ecfg.tune_library_gemm and self.device.type == "cuda"
+        if tune:
+            import tempfile
+
+            tn = torch.cuda.tunable
+            tn.enable(True)
+            tn.tuning_enable(True)
+            tn.set_max_tuning_duration(100)
+            tn.set_rotating_buffer_size(1024)
+            tn.set_filename(os.path.join(tempfile.gettempdir(), f"kvmini_tunableop_{os.getpid()}.csv"))
         with torch.no_grad():
             self.runner.capture_graphs()
             if self.spec is not None:
                 self.spec.warmup()
+        if tune:
+            torch.cuda.tunable.tuning_enable(False)  # keep the choices, stop measuring
         self.warm_s = time.perf_counter() - t0
         return self.warm_s
 
