@@ -381,6 +381,19 @@ int dispatch3_nw(int epi, int nb, int nw, const Args& a) {
   return -1;
 }
 
+// 128 / 256-row steps (prompt chunks): every weight fragment feeds 8 / 16 MFMAs, the x chunk in
+// LDS is 32 / 64 KiB per buffer, one workgroup per CU.
+template <int MT, bool W8>
+int dispatch3_wide(int epi, int nw, const Args& a) {
+  switch (nw) {
+    case 4: return dispatch3_epi<MT, 2, W8, true, 4>(epi, a);
+    case 6: return dispatch3_epi<MT, 2, W8, true, 6>(epi, a);
+    case 7: return dispatch3_epi<MT, 2, W8, true, 7>(epi, a);
+    case 8: return dispatch3_epi<MT, 2, W8, true, 8>(epi, a);
+  }
+  return -1;
+}
+
 template <int MT>
 int dispatch3_w8(int epi, int nb, int nw, bool w8, const Args& a) {
   return w8 ? dispatch3_nw<MT, true>(epi, nb, nw, a) : dispatch3_nw<MT, false>(epi, nb, nw, a);
@@ -469,7 +482,9 @@ int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int targe
 
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream) {
-  if (M <= 0 || M > 64 || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4) || (K % (128 * nb))) return -1;
+  const bool wide = M == 128 || M == 256;  // 8 / 16 row tiles per wave: 2-chunk groups only (registers)
+  if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4) || (K % (128 * nb))) return -1;
+  if (wide && nb != 2) return -1;
   if (epi == EPI_SWIGLU && (N & 15)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
   const int ngroups = K / (128 * nb);
@@ -481,6 +496,8 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
     case 2: return dispatch3_w8<2>(epi, nb, nw, w8, a);
     case 3: return dispatch3_w8<3>(epi, nb, nw, w8, a);
     case 4: return dispatch3_w8<4>(epi, nb, nw, w8, a);
+    case 8: return w8 ? dispatch3_wide<8, true>(epi, nw, a) : dispatch3_wide<8, false>(epi, nw, a);
+    case 16: return w8 ? dispatch3_wide<16, true>(epi, nw, a) : dispatch3_wide<16, false>(epi, nw, a);
   }
   return -1;
 }

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from . import gpu_available, native
 
 MAX_M = 64
+WIDE_M = 256  # token rows the 8 / 16-tile variants of the streaming GEMM cover
 # k-steps (of 32) per pipelined chunk.  Measured on MI355X (Llama-3-8B shapes): 8 (8 KiB of
 # weights in flight per wave) wins by ~2 % for a single 16-row token tile, 4 wins by 3-7 % from
 # 32 rows up (smaller LDS x-tiles, more workgroups resident per CU).
@@ -174,14 +175,14 @@ def _waves_per_workgroup(n_pad: int) -> int:
 
 
 @functools.lru_cache(maxsize=None)
-def _plan_slabs(n_pad: int, k: int) -> Tuple[int, int, int]:
+def _plan_slabs(n_pad: int, k: int, m: int = 32) -> Tuple[int, int, int]:
     """(waves per workgroup, K splits, 2-chunk groups per split) of a split-K streaming GEMM,
     by a three-term cost model fitted to the measured shapes (32 token rows):
     the weight stream costs 1 / (share of the CU rounds the grid fills) — the kernel's time
     follows the busiest CU, so feature tiles x splits should be a whole number of rounds over
-    the CUs, all splits equal; every slab is written and read back once (64 x splits / K of the
-    weight bytes, at half price: it stays on chip); x is fetched once per workgroup
-    (1 / waves-per-workgroup, likewise)."""
+    the CUs, all splits equal; every slab is written and read back once (2 m splits / K of the
+    weight bytes for m token rows, at half price: it stays on chip); x is fetched once per
+    workgroup (m / (32 waves-per-workgroup), likewise)."""
     ngroups = k // 256
     best: Optional[Tuple[float, int, int]] = None
     for nw in (4, 6, 7, 8):
@@ -193,7 +194,7 @@ def _plan_slabs(n_pad: int, k: int) -> Tuple[int, int, int]:
                 continue
             wgs = tiles * splits
             fill = wgs / (-(-wgs // _NUM_CUS) * _NUM_CUS)
-            cost = 1.0 / fill + 64.0 * splits / k + 1.0 / nw
+            cost = 1.0 / fill + 2.0 * m * splits / k + m / (32.0 * nw)
             if best is None or cost < best[0] - 1e-9:
                 best = (cost, nw, splits)
     if best is None:
@@ -244,6 +245,31 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
                 return Partial(out, ss, eps, w.k)
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, ks, 1, nchunks, ss, eps, w.wscale)
+    elif m <= WIDE_M and w.k % 256 == 0 and (m <= 128 or w.w_full is None):
+        # 65..256 tokens (a burst of short prompts next to the running decodes): still one pass
+        # over the weights, 8 / 16 row tiles per wave.  Measured against the library GEMM
+        # (Llama-3-8B shapes, us, library -> streaming): 128 rows: qkv 25.9 -> 17.6, o 26.3 -> 13.8,
+        # gate/up 55.9 -> 54.4, down 77.6 -> 32.9 (a 114-token step: 7.4 -> 5.8 ms); 256 rows: qkv
+        # 39.9 -> 32.9, o 24.9 -> 22.6, down 63.7 -> 52.8 — but gate/up 66.4 -> 97 (every wave
+        # re-reads the whole 64 KiB x chunk from LDS per 4 KiB of weights) and the 256-row slabs
+        # cost their consumers what the GEMMs gain (a 254-token step: 8.2 ms either way).  So: up
+        # to 128 rows stream; 129..256 rows go to the library GEMM when a row-major copy of the
+        # weights is kept, and stream otherwise.
+        mw = 128 if m <= 128 else 256
+        if x.shape[0] != mw:
+            xw = torch.zeros((mw, x.shape[1]), dtype=x.dtype, device=x.device)
+            xw[:m] = x[:m]
+            if ss is not None:
+                ss = torch.cat((ss[:m], torch.ones((mw - m, ss.shape[1]), dtype=ss.dtype, device=ss.device)), 0)
+            x = xw
+        if allow_slabs and epi == 0 and m == mw and w.n == w.n_pad:
+            nw, splits, gps = _plan_slabs(w.n_pad, w.k, mw)
+            if splits > 1:
+                out = torch.empty((splits, mw, w.n_pad), dtype=torch.float32, device=x.device)
+                C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, 2, splits, gps, None, 0.0, w.wscale, nw)
+                return Partial(out, ss, eps, w.k)
+        out = torch.empty((mw, n_out), dtype=torch.bfloat16, device=x.device)
+        C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, 2, 1, w.k // 256, ss, eps, w.wscale, _waves_per_workgroup(w.n_pad))
     elif w.w_full is not None:
         # wide token batch (prefill): compute-bound, served by the library GEMM on the
         # row-major copy; the epilogues the streaming kernel fuses run as small kernels here

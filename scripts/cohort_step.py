@@ -22,7 +22,7 @@ for _ in range(4):
     eng.step()
 ts = []
 for rep in range(6):
-    seqs = [eng.make_sequence([1] + list(range(100 + 20 * rep + i, 113 + 20 * rep + i)), SamplingParams(max_tokens=3, ignore_eos=True)) for i in range(18)]
+    seqs = [eng.make_sequence([1] + list(range(100 + 20 * rep + i, 113 + 20 * rep + i)), SamplingParams(max_tokens=3, ignore_eos=True)) for i in range(int(os.environ.get("COHORT", "18")))]
     for s in seqs:
         eng.scheduler.add(s)
     torch.cuda.synchronize()
@@ -32,4 +32,4 @@ for rep in range(6):
     ts.append((time.perf_counter() - t0) * 1e3)
     for _ in range(4):
         eng.step()
-print("cohort step (18 x 14 prompt tokens + 2 decodes):", " ".join(f"{t:.2f}" for t in ts), "ms")
+print(f"cohort step ({os.environ.get('COHORT', '18')} x 14 prompt tokens + 2 decodes):", " ".join(f"{t:.2f}" for t in ts), "ms")

@@ -138,8 +138,9 @@ def balance_bench(out):
         torch.cuda.empty_cache()
 
 
-def nw_bench(out):
-    """Waves per workgroup of the v3 GEMM (4 / 7 / 8) on the decode shapes at M = 32 and 64."""
+def nw_bench(out, rows=(32, 64)):
+    """Waves per workgroup of the v3 GEMM (4 / 6 / 7 / 8) on the decode shapes at M = 32 and 64
+    (or, ``--what wide``, the 128 / 256-row variants against the library GEMM)."""
     from kvmini.ops import native
 
     C = native()
@@ -148,7 +149,8 @@ def nw_bench(out):
     for name, (N, K, slabs) in shapes.items():
         copies = max(3, int(800e6 // (N * K * 2)) + 1)
         Wps = [C.pack_weight((torch.randn(N, K, device=dev) * 0.02).bfloat16()) for _ in range(copies)]
-        for M in (32, 64):
+        Ws = None
+        for M in rows:
             x = torch.randn(M, K, device=dev).bfloat16()
             y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             st = {"i": 0}
@@ -165,10 +167,19 @@ def nw_bench(out):
                 return f
 
             fns = {}
-            for nw in (4, 7, 8):
+            if M > 64:
+                if Ws is None:
+                    Ws = [(torch.randn(N, K, device=dev) * 0.02).bfloat16() for _ in range(copies)]
+
+                def lib():
+                    st["i"] = (st["i"] + 1) % copies
+                    torch.nn.functional.linear(x, Ws[st["i"]])
+
+                fns["library"] = lib
+            for nw in (4, 6, 7, 8):
                 if N % (16 * nw):
                     continue
-                for nb in (2, 4):
+                for nb in ((2,) if M > 64 else (2, 4)):
                     if slabs:
                         for target in (256, 512):
                             fns[f"nw{nw}_nb{nb}_t{target}"] = mk(nw, nb, target)
@@ -340,6 +351,8 @@ def main():
         attn_bench(out)
     if "nw" in a.what.split(","):
         nw_bench(out)
+    if "wide" in a.what.split(","):
+        nw_bench(out, rows=(128, 256))
     if "prefill" in a.what:
         prefill_bench(out, a.model)
     if "step" in a.what:

@@ -743,3 +743,35 @@ def test_scale_rows_matches_reference(C):
     C.scale_rows(x, ss, 1e-5, y)
     ref = (x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)).bfloat16()
     assert torch.allclose(y.float(), ref.float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [128, 256])
+@pytest.mark.parametrize("nw", [4, 7, 8])
+def test_stream_gemm3_wide_rows(C, M, nw):
+    """128 / 256 token rows in one pass over the weights (8 / 16 row tiles per wave)."""
+    from kvmini.models.llama import interleave_gate_up
+    from kvmini.ops import torch_ops
+
+    torch.manual_seed(M + nw)
+    N, K = 16 * nw * 4, 1024
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    wp = C.pack_weight(w)
+    ref = x.float() @ w.float().T
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    C.stream_gemm3(wp, N, K, x, y, 0, 2, 1, K // 256, None, 0.0, None, nw)
+    assert torch.allclose(y.float(), ref, atol=0.06, rtol=0.02)
+    splits, gps = C.stream_gemm3_plan(N, K, 2, 4, 64, nw)
+    slabs = torch.empty(splits, M, N, device="cuda", dtype=torch.float32)
+    C.stream_gemm3(wp, N, K, x, slabs, 1, 2, splits, gps, None, 0.0, None, nw)
+    assert splits > 1 and torch.allclose(slabs.sum(0), ref, atol=0.02, rtol=0.01)
+    # SwiGLU epilogue + folded row scale
+    wg, wu = w[: N // 2], w[N // 2 :]
+    wgu = interleave_gate_up(wg, wu).contiguous()
+    ss = (x.float() ** 2).view(M, K // 512, 512).sum(-1).contiguous()
+    act = torch.empty(M, N // 2, device="cuda", dtype=torch.bfloat16)
+    C.stream_gemm3(C.pack_weight(wgu), N, K, x, act, 2, 2, 1, K // 256, ss, 1e-5, None, nw)
+    xn = x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)
+    ref_act = torch.nn.functional.silu(xn @ wg.float().T) * (xn @ wu.float().T)
+    assert torch.allclose(act.float(), ref_act, atol=0.08, rtol=0.05)
