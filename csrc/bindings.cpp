@@ -31,6 +31,8 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
                               hipStream_t stream);
 int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
+int kv_sample_rows(const void* logits, long long row_stride, int V, const long long* rows, int R, const float* temperature, const int* top_k,
+                   const float* top_p, const float* uniform, long long* out, hipStream_t stream);
 int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, void* y, int T, int H, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
 int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
@@ -246,6 +248,23 @@ void prefetch(at::Tensor t, int64_t workgroups, at::Tensor sink) {
   check(kv_prefetch(t.data_ptr(), (long long)t.numel() * t.element_size(), (int)workgroups, (unsigned int*)sink.data_ptr(), cur_stream()), "kv_prefetch");
 }
 
+// Temperature / top-k / top-p sampling of rows `rows` of bf16 logits [S, V]; out[rows[r]] = token id.
+void sample_rows(at::Tensor logits, at::Tensor rows, at::Tensor temperature, at::Tensor top_k, at::Tensor top_p, at::Tensor uniform, at::Tensor out) {
+  CHECK_DEV(logits); CHECK_BF16(logits); CHECK_DEV(rows); CHECK_DEV(temperature); CHECK_DEV(top_k); CHECK_DEV(top_p); CHECK_DEV(uniform); CHECK_DEV(out);
+  CHECK_CONTIG(rows); CHECK_CONTIG(temperature); CHECK_CONTIG(top_k); CHECK_CONTIG(top_p); CHECK_CONTIG(uniform); CHECK_CONTIG(out);
+  TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1, "logits must be [S, V] with unit inner stride");
+  const int64_t R = rows.numel();
+  TORCH_CHECK(rows.scalar_type() == at::kLong && out.scalar_type() == at::kLong, "rows / out must be int64");
+  TORCH_CHECK(temperature.scalar_type() == at::kFloat && top_p.scalar_type() == at::kFloat && uniform.scalar_type() == at::kFloat && top_k.scalar_type() == at::kInt,
+              "temperature / top_p / uniform must be fp32, top_k int32");
+  TORCH_CHECK(temperature.numel() == R && top_k.numel() == R && top_p.numel() == R && uniform.numel() == R, "one parameter per sampled row");
+  // rows index both logits and out: the kernel trusts them, so their range is the caller's contract
+  TORCH_CHECK(out.numel() >= logits.size(0), "out must have an entry for every logits row");
+  check(kv_sample_rows(logits.data_ptr(), logits.stride(0), (int)logits.size(1), (const long long*)rows.data_ptr(), (int)R, (const float*)temperature.data_ptr(),
+                       (const int*)top_k.data_ptr(), (const float*)top_p.data_ptr(), (const float*)uniform.data_ptr(), (long long*)out.data_ptr(), cur_stream()),
+        "kv_sample_rows");
+}
+
 void scale_rows(at::Tensor x, at::Tensor row_ss, double eps, at::Tensor y) {
   CHECK_DEV(x); CHECK_BF16(x); CHECK_CONTIG(x); CHECK_DEV(y); CHECK_BF16(y); CHECK_CONTIG(y);
   TORCH_CHECK(x.dim() == 2 && y.sizes() == x.sizes() && x.size(1) % 8 == 0, "x, y must be bf16 [T, H] with H % 8 == 0");
@@ -458,6 +477,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("embed_fed", &embed_fed);
   m.def("swiglu_interleaved", &swiglu_interleaved);
   m.def("scale_rows", &scale_rows);
+  m.def("sample_rows", &sample_rows);
   m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);
   m.def("stream_gemm_plan", &stream_gemm_plan);

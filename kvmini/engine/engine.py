@@ -331,10 +331,23 @@ class LLMEngine:
             return None
 
         def run(logits: torch.Tensor, out_ids: torch.Tensor) -> None:
-            idx = _host_to_device(rows, torch.int64, logits.device)
-            out_ids.index_copy_(0, idx, _sample_rows_device(logits.index_select(0, idx), plist))
+            self._sample_into(logits, rows, plist, out_ids)
 
         return run
+
+    def _sample_into(self, logits: torch.Tensor, rows: List[int], plist: List[SamplingParams], out_ids: torch.Tensor) -> torch.Tensor:
+        """Sample rows ``rows`` of ``logits`` (one SamplingParams each, unseeded) into
+        ``out_ids[rows]`` with device ops only; returns the device index tensor of the rows."""
+        dev = logits.device
+        idx = _host_to_device(rows, torch.int64, dev)
+        kernel = getattr(self.runner.ops, "sample_rows", None)
+        if kernel is not None and logits.dtype == torch.bfloat16 and logits.stride(1) == 1:
+            # one launch, no sort: threshold search on the bf16 logits (csrc/sampling.hip)
+            kernel(logits, idx, _host_to_device([max(p.temperature, 1e-5) for p in plist], torch.float32, dev),
+                   _host_to_device([int(p.top_k or 0) for p in plist], torch.int32, dev), _host_to_device([float(p.top_p) for p in plist], torch.float32, dev), out_ids)
+        else:
+            out_ids.index_copy_(0, idx, _sample_rows_device(logits.index_select(0, idx), plist))
+        return idx
 
     @staticmethod
     def _needs_host_sampling(p: SamplingParams) -> bool:
@@ -415,8 +428,9 @@ class LLMEngine:
             rows_b = [r for r, ch in enumerate(c for c in batch.chunks if c.sample) if ch.seq.params.temperature > 0 and ch.seq.params.seed is None]
             if rows_b:
                 plist = [ch.seq.params for ch in batch.chunks if ch.sample]
-                toks = _sample_rows(logits[torch.tensor(rows_b, device=logits.device)], [plist[r] for r in rows_b])
-                batched = dict(zip(rows_b, toks))
+                tmp = torch.zeros(logits.shape[0], dtype=torch.int64, device=logits.device)
+                idx = self._sample_into(logits, rows_b, [plist[r] for r in rows_b], tmp)
+                batched = dict(zip(rows_b, tmp[idx].tolist()))
         row = 0
         for ch in batch.chunks:
             seq = ch.seq

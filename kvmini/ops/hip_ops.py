@@ -445,6 +445,15 @@ def prefill_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     return out
 
 
+def sample_rows(logits: torch.Tensor, rows: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor, top_p: torch.Tensor, out: torch.Tensor) -> None:
+    """Temperature / top-k / top-p sampling of rows ``rows`` (int64, each < ``logits.shape[0]``)
+    of bf16 ``logits`` ``[S, V]`` without a sort; ``out[rows[r]]`` receives the token id.  One
+    parameter per sampled row (fp32 / int32 / fp32 device tensors); the uniform variates come
+    from the device generator."""
+    u = torch.rand(rows.numel(), dtype=torch.float32, device=logits.device)
+    native().sample_rows(logits, rows, temperature, top_k, top_p, u, out)
+
+
 def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
     out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
     native().argmax(logits, out)

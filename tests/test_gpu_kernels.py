@@ -775,3 +775,48 @@ def test_stream_gemm3_wide_rows(C, M, nw):
     xn = x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)
     ref_act = torch.nn.functional.silu(xn @ wg.float().T) * (xn @ wu.float().T)
     assert torch.allclose(act.float(), ref_act, atol=0.08, rtol=0.05)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("temp,top_k,top_p", [(0.7, 0, 1.0), (1.0, 50, 1.0), (1.3, 0, 0.9), (0.9, 40, 0.8), (1.0, 1, 1.0)])
+def test_sample_rows_kernel_draws_from_the_reference_distribution(C, temp, top_k, top_p):
+    """Inverse-CDF check: with the uniform variates on a regular grid the kernel must hit every
+    token of the nucleus N * p_i times (+-2), and nothing outside it.  Reference: top-k by value
+    threshold, then top-p on the renormalised survivors (ties with the threshold value kept)."""
+    torch.manual_seed(int(temp * 10) + top_k)
+    V, N = 4000, 4000
+    base = (torch.randn(V, device="cuda") * 3).bfloat16()
+    x = base.float() / temp
+    keep = torch.ones(V, dtype=torch.bool, device="cuda")
+    if top_k:
+        keep &= x >= torch.topk(x, top_k).values[-1]
+    probs = torch.softmax(torch.where(keep, x, torch.full_like(x, float("-inf"))), -1)
+    if top_p < 1.0:
+        sp, si = torch.sort(probs, descending=True)
+        n_keep = int(((torch.cumsum(sp, 0) - sp) < top_p).sum())
+        keep &= probs >= sp[n_keep - 1]
+        probs = torch.where(keep, probs, torch.zeros_like(probs))
+        probs = probs / probs.sum()
+    logits = base[None, :].repeat(N, 1).contiguous()
+    rows = torch.arange(N, device="cuda")
+    u = ((torch.arange(N, device="cuda", dtype=torch.float32) + 0.5) / N).contiguous()
+    out = torch.full((N,), -1, dtype=torch.int64, device="cuda")
+    C.sample_rows(logits, rows, torch.full((N,), temp, device="cuda"), torch.full((N,), top_k, dtype=torch.int32, device="cuda"), torch.full((N,), top_p, device="cuda"), u, out)
+    assert int(out.min()) >= 0 and bool(keep[out].all())
+    counts = torch.bincount(out, minlength=V).float()
+    assert float((counts - probs * N).abs().max()) <= 2.5
+
+
+@pytest.mark.gpu
+def test_sample_rows_kernel_full_vocabulary_and_engine_path():
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, kernels="hip", num_blocks=128))
+    eng.warmup()
+    greedy = eng.generate([[1, 5, 9, 11]], SamplingParams(max_tokens=12, ignore_eos=True))[0]
+    steps0 = eng.pipelined_steps
+    a = eng.generate([[1, 5, 9, 11]], SamplingParams(max_tokens=12, temperature=0.8, top_k=1, ignore_eos=True))[0]  # top_k = 1: deterministic
+    b = eng.generate([[1, 5, 9, 11], [1, 7, 7]], SamplingParams(max_tokens=12, temperature=1.1, top_p=0.9, ignore_eos=True))
+    assert a == greedy and eng.pipelined_steps > steps0
+    assert all(len(o) == 12 and all(0 <= t < eng.mcfg.vocab_size for t in o) for o in b)
