@@ -25,6 +25,28 @@ __device__ inline float bf2f(unsigned short b) { return __uint_as_float(((unsign
 // order-preserving key: larger logit <=> larger key (NaNs sort above +inf; never produced by a GEMM of finite inputs)
 __device__ inline unsigned int key16(unsigned short b) { return (b & 0x8000u) ? (unsigned int)(~b & 0xffffu) : (unsigned int)(b | 0x8000u); }
 
+typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+
+// f(raw bf16 bits, index) for every element of the row, each thread in a fixed order of its own:
+// 16-byte loads (8 logits), several in flight — a 2-byte load per trip leaves the loop waiting
+// an L2 round trip for every element.
+template <typename F>
+__device__ inline void for_each_logit(const unsigned short* __restrict__ row, int V, F f) {
+  int done = 0;
+  if ((((uintptr_t)row) & 15) == 0) {
+    const us8* rv = reinterpret_cast<const us8*>(row);
+    const int nv = V >> 3;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < nv; i += TPB) {
+      const us8 a = rv[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f(a[j], i * 8 + j);
+    }
+    done = nv * 8;
+  }
+  for (int i = done + threadIdx.x; i < V; i += TPB) f(row[i], i);
+}
+
 struct Sel {
   float red[TPB / 64];
   float part[TPB / 64][16];
@@ -69,8 +91,7 @@ __device__ inline unsigned int select_threshold(const unsigned short* __restrict
     float acc[15];
 #pragma unroll
     for (int j = 0; j < 15; ++j) acc[j] = 0.f;
-    for (int i = tid; i < V; i += TPB) {
-      const unsigned short raw = row[i];
+    for_each_logit(row, V, [&](unsigned short raw, int) {
       const unsigned int k = key16(raw);
       if (k >= floor_key && k >= lo && k < hi) {
         const float w = BY_WEIGHT ? __expf((bf2f(raw) - m) * inv_t) : 1.f;
@@ -78,7 +99,7 @@ __device__ inline unsigned int select_threshold(const unsigned short* __restrict
 #pragma unroll
         for (int j = 0; j < 15; ++j) acc[j] += (d >= (unsigned int)(j + 1)) ? w : 0.f;
       }
-    }
+    });
 #pragma unroll
     for (int j = 0; j < 15; ++j) {
       float v = acc[j];
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(TPB) void sample_rows_kernel(const unsigned short* 
   const float inv_t = 1.f / fmaxf(temperature[r], 1e-5f);
   // ---- row maximum
   float mx = -INFINITY;
-  for (int i = tid; i < V; i += TPB) mx = fmaxf(mx, bf2f(row[i]));
+  for_each_logit(row, V, [&](unsigned short raw, int) { mx = fmaxf(mx, bf2f(raw)); });
   const float m = block_max(mx, s.red);
   // ---- top-k threshold (by count)
   unsigned int thr = 0;
@@ -129,26 +150,23 @@ __global__ __launch_bounds__(TPB) void sample_rows_kernel(const unsigned short* 
   if (k > 0 && k < V) thr = select_threshold<false>(row, V, m, inv_t, 0u, (float)k, s);
   // ---- total weight of the survivors, then the top-p threshold (by weight) among them
   float z = 0.f;
-  for (int i = tid; i < V; i += TPB) {
-    const unsigned short raw = row[i];
+  for_each_logit(row, V, [&](unsigned short raw, int) {
     if (key16(raw) >= thr) z += __expf((bf2f(raw) - m) * inv_t);
-  }
+  });
   float kept = block_sum(z, s.red);
   const float p = top_p[r];
   if (p < 1.f) {
     const unsigned int thr_p = select_threshold<true>(row, V, m, inv_t, thr, p * kept, s);
     if (thr_p > thr) thr = thr_p;
   }
-  // ---- draw: invert the running sum of kept weights (index order) at u * W_kept.  Thread t owns
-  // the contiguous segment [t * seg, (t + 1) * seg).
-  const int seg = (V + TPB - 1) / TPB;
-  const int i0 = tid * seg, i1 = min(V, i0 + seg);
+  // ---- draw: invert the running sum of the kept weights at u * W_kept.  Any fixed order of the
+  // tokens gives the right distribution; the order here is thread-major (all of thread 0's
+  // elements in its own traversal order, then thread 1's, ...): a block scan over the per-thread
+  // sums finds the thread, which then walks its elements again.
   float mine = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    const unsigned short raw = row[i];
+  for_each_logit(row, V, [&](unsigned short raw, int) {
     if (key16(raw) >= thr) mine += __expf((bf2f(raw) - m) * inv_t);
-  }
-  // inclusive block scan of the segment sums
+  });
   float inc = mine;
   const int lane = tid & 63, wave = tid >> 6;
   for (int o = 1; o < 64; o <<= 1) {
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(TPB) void sample_rows_kernel(const unsigned short* 
   inc += base;
   const float exc = inc - mine;
   const float target = fminf(uniform[r], 0.99999994f) * total;
-  // exactly one thread's half-open interval [exc, inc) holds the target (inc is monotone, the last one = total > target)
+  // one thread's half-open interval [exc, inc) holds the target (inc is monotone, the last one = total > target)
   if (mine > 0.f && exc <= target && target < inc) winner = tid;
   __syncthreads();
   if (winner < 0) {  // rounding at an interval edge: fall back to the last thread that kept anything
@@ -175,14 +193,13 @@ __global__ __launch_bounds__(TPB) void sample_rows_kernel(const unsigned short* 
   if (tid == winner) {
     float acc = exc;
     long long pick = -1, last_kept = -1;
-    for (int i = i0; i < i1; ++i) {
-      const unsigned short raw = row[i];
-      if (key16(raw) >= thr) {
+    for_each_logit(row, V, [&](unsigned short raw, int i) {
+      if (pick < 0 && key16(raw) >= thr) {
         acc += __expf((bf2f(raw) - m) * inv_t);
         last_kept = i;
-        if (acc > target) { pick = i; break; }
+        if (acc > target) pick = i;
       }
-    }
+    });
     out[row_id] = pick >= 0 ? pick : (last_kept >= 0 ? last_kept : 0);
   }
 }

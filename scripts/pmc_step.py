@@ -14,7 +14,9 @@ from kvmini.engine.scheduler import SamplingParams
 model = sys.argv[1] if len(sys.argv) > 1 else "llama-3-8b"
 eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=64, max_model_len=512, kernels="hip", kv_memory_fraction=0.1, use_graphs=False))
 prompts = [[1] + list(range(100 + i, 113 + i)) for i in range(20)]
-seqs = [eng.make_sequence(p, SamplingParams(max_tokens=8, ignore_eos=True)) for p in prompts]
+seqs = [eng.make_sequence(p, SamplingParams(max_tokens=8, ignore_eos=True)) for p in prompts[:18]]
+# two sampled requests: the threshold-search sampling kernel shows up in the counters too
+seqs += [eng.make_sequence(p, SamplingParams(max_tokens=8, temperature=0.8, top_p=0.9, top_k=50, ignore_eos=True)) for p in prompts[18:]]
 for s in seqs:
     eng.scheduler.add(s)
 n = 0
