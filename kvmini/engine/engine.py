@@ -61,6 +61,11 @@ class EngineConfig:
     # GEMMs of wide steps (> 64 tokens) during warm-up; timed with a rotating buffer so that the
     # choice is made for weights that come from HBM, as they do in a real step
     tune_library_gemm: bool = False
+    # prompt backlogs up to this many tokens ride along with the running decodes in steps of at
+    # most 64 (128) tokens instead of one wide step (see Scheduler.ride_along_limit); 0 = off.
+    # Measured on the headline mix (18 prompts arriving together): first token 11.0 -> 9.4 ms, but
+    # inter-token p95 3.6 -> 4.2 ms and 0.8 % fewer requests/s, hence off by default
+    ride_along_limit: int = 0
     tp_size: int = 1
     tp_rank: int = 0
     tp_graphs: bool = False
@@ -185,7 +190,7 @@ class LLMEngine:
         )
         self.runner = ModelRunner(weights, rcfg, tp_group)
         self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)
-        self.scheduler = Scheduler(self.bm, ecfg.max_num_seqs, ecfg.max_batched_tokens, ecfg.max_model_len, self.mcfg.eos_token_id)
+        self.scheduler = Scheduler(self.bm, ecfg.max_num_seqs, ecfg.max_batched_tokens, ecfg.max_model_len, self.mcfg.eos_token_id, ecfg.ride_along_limit)
         self.spec = None
         if ecfg.draft_model and ecfg.num_speculative_tokens > 0:
             from .speculative import SpeculativeDecoder

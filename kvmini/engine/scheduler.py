@@ -114,12 +114,20 @@ class Scheduler:
         max_batched_tokens: int = 256,
         max_model_len: int = 8192,
         eos_token_id: int = 2,
+        ride_along_limit: int = 0,
     ):
         self.bm = block_manager
         self.max_num_seqs = max_num_seqs
         self.max_batched_tokens = max_batched_tokens
         self.max_model_len = max_model_len
         self.eos_token_id = eos_token_id
+        # While sequences are decoding, a SMALL backlog of prompt tokens (<= this many; 0 = off)
+        # is fed to them in steps that stay within the weight-streaming GEMM's row limits (64
+        # tokens, or 128 next to more than 48 decodes) instead of one wide step: the prompts ride
+        # along almost for free (the weights are streamed for the decodes anyway), the running
+        # requests see no long step, and a burst of arrivals is spread over consecutive steps
+        # rather than kept in lock-step.  Larger backlogs (long prompts) take the full budget.
+        self.ride_along_limit = ride_along_limit
         self.waiting: Deque[Sequence] = deque()
         self.running: List[Sequence] = []
         self._free_slots: List[int] = list(range(max_num_seqs - 1, -1, -1))
@@ -173,10 +181,30 @@ class Scheduler:
             return True
         return False
 
+    def _step_budget(self) -> int:
+        """Token budget of the next step (see ``ride_along_limit``)."""
+        budget = self.max_batched_tokens
+        if self.ride_along_limit <= 0:
+            return budget
+        n_decode = sum(1 for s in self.running if not s.is_prefilling and not s.pending_finish)
+        if n_decode == 0 or n_decode > 112:
+            return budget
+        backlog = 0
+        for s in self.running:
+            if s.is_prefilling:
+                backlog += len(s.prompt_ids) - s.num_computed
+        for s in self.waiting:
+            backlog += s.num_tokens - s.num_computed
+            if backlog > self.ride_along_limit:
+                return budget
+        if backlog == 0 or backlog > self.ride_along_limit:
+            return budget
+        return min(budget, 64 if n_decode <= 48 else 128)
+
     def schedule(self, spec_tokens: int = 0) -> Batch:
         """Pick the chunks for the next step.  ``spec_tokens`` > 0 lets a decoding
         sequence carry that many draft tokens to verify in the same pass."""
-        budget = self.max_batched_tokens
+        budget = self._step_budget()
         chunks: List[ScheduledChunk] = []
         scheduled = set()
 

@@ -494,3 +494,32 @@ def test_native_server_n_choices_stop_strings_and_logprobs():
         assert eng.metrics()["running"] == 0
     finally:
         stop()
+
+
+def test_ride_along_budget_keeps_bursts_in_streaming_sized_steps():
+    """With ``ride_along_limit`` a small prompt backlog is fed to the running decodes in steps of
+    at most 64 tokens; a long prompt still gets the full budget; outputs are unchanged."""
+    eng, w = _engine(max_num_seqs=16, max_batched_tokens=256, max_model_len=512, num_blocks=400, ride_along_limit=128)
+    sch = eng.scheduler
+    first = [eng.make_sequence([1, 2 + i, 3, 4], SamplingParams(max_tokens=30, ignore_eos=True)) for i in range(3)]
+    for s in first:
+        sch.add(s)
+    eng.step(); eng.step(); eng.step()
+    burst = [eng.make_sequence([1] + list(range(10 + i, 40 + i)), SamplingParams(max_tokens=4, ignore_eos=True)) for i in range(4)]  # 4 x 31 = 124 tokens
+    for s in burst:
+        sch.add(s)
+    assert sch._step_budget() == 64
+    sizes = []
+    while any(s.is_prefilling for s in burst):
+        b = sch._step_budget()
+        eng.step()
+        sizes.append(b)
+    assert sizes and max(sizes) == 64 and len(sizes) >= 2
+    long = eng.make_sequence([1] + [(7 * i) % 200 + 5 for i in range(300)], SamplingParams(max_tokens=2, ignore_eos=True))
+    sch.add(long)
+    assert sch._step_budget() == 256  # backlog above the limit: full budget
+    while sch.has_work():
+        eng.step()
+    for s in burst:
+        assert s.output_ids == dense_greedy(w, s.prompt_ids, 4)
+    assert long.output_ids == dense_greedy(w, long.prompt_ids, 2)
