@@ -431,3 +431,47 @@ def test_spec_delta_report_with_self_speculation_on_cpu(in_tmp):
     assert {"time_to_first_token_ms", "itl_p50_ms", "p95_ms", "tokens_per_sec"} <= keys
     page = open("spec/spec_delta.html").read()
     assert "acceptance rate" in page.lower() and "self:1" in page
+
+
+def test_router_fails_over_when_a_replica_goes_away():
+    """Router over two running servers: requests spread over both; after one stops, its next
+    request comes back 503 once, the replica is marked down, and traffic continues on the other;
+    /health stays 200 while one replica is left."""
+    import asyncio
+    import json as _json
+    import urllib.error
+    import urllib.request
+
+    from kvmini.server.httpd import run_server_in_thread
+    from kvmini.server.mock import start_mock_in_thread
+    from kvmini.server.router import Router
+
+    _m1, u1, stop1 = start_mock_in_thread()
+    _m2, u2, stop2 = start_mock_in_thread()
+    router = Router([u1, u2])
+    _srv, port, stop_router = run_server_in_thread(router.build_server)
+    url = f"http://127.0.0.1:{port}"
+
+    def chat():
+        req = urllib.request.Request(url + "/v1/chat/completions", data=_json.dumps({"model": "mock-llm", "messages": [{"role": "user", "content": "hi"}], "max_tokens": 4}).encode(),
+                                     headers={"Content-Type": "application/json"})
+        try:
+            with urllib.request.urlopen(req, timeout=10) as r:
+                return r.status, r.headers.get("X-Kvmini-Replica")
+        except urllib.error.HTTPError as e:
+            return e.code, None
+
+    try:
+        seen = {chat()[1] for _ in range(6)}
+        assert seen == {"0", "1"}
+        stop2()
+        codes = [chat() for _ in range(6)]
+        assert sum(1 for c, _ in codes if c == 503) <= 1  # at most the one request that found it dead
+        assert all(rep == "0" for c, rep in codes if c == 200) and sum(1 for c, _ in codes if c == 200) >= 5
+        assert router.replicas[1].healthy is False and router.replicas[1].errors >= 1
+        assert urllib.request.urlopen(url + "/health", timeout=5).status == 200
+        metrics = urllib.request.urlopen(url + "/metrics", timeout=5).read().decode()
+        assert 'kvmini_router_replica_healthy{replica="1"} 0' in metrics
+    finally:
+        stop_router()
+        stop1()
