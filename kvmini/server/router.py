@@ -60,18 +60,27 @@ class Router:
         return cands[next(self._rr) % len(cands)]
 
     async def forward(self, req: Request) -> Any:
-        rep = self.pick()
-        if rep is None:
-            return Response.json({"error": {"message": "no replica available", "type": "service_unavailable"}}, 503)
-        rep.inflight += 1
-        headers = {k: v for k, v in req.headers.items() if k in ("content-type", "authorization", "traceparent", "accept")}
-        try:
-            up = await self.client.request(req.method, rep.url + req.path, body=req.body or None, headers={k.title(): v for k, v in headers.items()}, timeout=self.timeout_s)
-        except Exception as e:
-            rep.inflight -= 1
-            rep.errors += 1
-            rep.healthy = False  # the health loop brings it back
-            return Response.json({"error": {"message": f"replica {rep.index} unreachable: {e}", "type": "bad_gateway"}}, 503)
+        headers = {k.title(): v for k, v in req.headers.items() if k in ("content-type", "authorization", "traceparent", "accept")}
+        up = rep = None
+        last_err: Optional[Exception] = None
+        # a replica that cannot be reached has not seen the request: try the next one
+        for _ in range(max(1, len(self.replicas))):
+            rep = self.pick()
+            if rep is None:
+                break
+            rep.inflight += 1
+            try:
+                up = await self.client.request(req.method, rep.url + req.path, body=req.body or None, headers=headers, timeout=self.timeout_s)
+                break
+            except Exception as e:
+                rep.inflight -= 1
+                rep.errors += 1
+                rep.healthy = False  # the health loop brings it back
+                last_err = e
+                if not any(r.healthy for r in self.replicas):
+                    break
+        if up is None or rep is None:
+            return Response.json({"error": {"message": f"no replica available: {last_err}", "type": "service_unavailable"}}, 503)
         ctype = up.headers.get("content-type", "application/json")
         if "text/event-stream" in ctype or "chunked" in up.headers.get("transfer-encoding", "").lower():
 

@@ -434,9 +434,9 @@ def test_spec_delta_report_with_self_speculation_on_cpu(in_tmp):
 
 
 def test_router_fails_over_when_a_replica_goes_away():
-    """Router over two running servers: requests spread over both; after one stops, its next
-    request comes back 503 once, the replica is marked down, and traffic continues on the other;
-    /health stays 200 while one replica is left."""
+    """Router over two running servers: requests spread over both; after one stops, the request
+    that finds it dead is retried on the other (no error reaches the client), the replica is
+    marked down, and /health stays 200 while one replica is left."""
     import asyncio
     import json as _json
     import urllib.error
@@ -466,8 +466,7 @@ def test_router_fails_over_when_a_replica_goes_away():
         assert seen == {"0", "1"}
         stop2()
         codes = [chat() for _ in range(6)]
-        assert sum(1 for c, _ in codes if c == 503) <= 1  # at most the one request that found it dead
-        assert all(rep == "0" for c, rep in codes if c == 200) and sum(1 for c, _ in codes if c == 200) >= 5
+        assert all(c == 200 and rep == "0" for c, rep in codes), codes
         assert router.replicas[1].healthy is False and router.replicas[1].errors >= 1
         assert urllib.request.urlopen(url + "/health", timeout=5).status == 200
         metrics = urllib.request.urlopen(url + "/metrics", timeout=5).read().decode()
