@@ -1,7 +1,7 @@
 #!/bin/bash
 # The benchmark configurations of BASELINE.json on ONE MI355X box, through the harness CLI
 # (native server + load generator + analyzer + cost + reports).  Artifacts: gpurun_out/configs/.
-# Usage: scripts/gpu_configs.sh [headline] [grid] [quant] [70b] [ab] [spec]   (default: all)
+# Usage: scripts/gpu_configs.sh [headline] [grid] [quant] [70b] [ab] [spec] [probes]   (default: all but probes)
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
@@ -69,5 +69,13 @@ spec)      # config 3: speculative decoding TTFT / inter-token delta report
   timeout -k 10 600 python -m kvmini spec-delta --model "$MODEL" --profile speculative-decoding --port 8109 --output-dir "$OUT/spec_llama1b" \
     > "$OUT/spec_llama1b.log" 2>&1 || { tail -30 "$OUT/spec_llama1b.log"; exit 1; }
   tail -14 "$OUT/spec_llama1b.log" ;;
+probes)    # prefix-cache probe, OpenAI parity matrix and the fairness guard against the native engine
+  start_server probes 8108 --model "$MODEL" --max-num-seqs 32 || exit 1
+  timeout -k 10 300 python -m kvmini cache-probe --url http://127.0.0.1:8108 --model "$MODEL" --base-requests 100 --concurrency 8 --max-tokens 16 --pad-tokens 512 --settle-sec 1 \
+    --cluster-backend local --service probes --namespace local --run-dir "$OUT/cache_probe" > "$OUT/cache_probe.log" 2>&1 || { tail -30 "$OUT/cache_probe.log"; exit 1; }
+  tail -8 "$OUT/cache_probe.log"
+  timeout -k 10 120 python -m kvmini parity --url http://127.0.0.1:8108 --model "$MODEL" --out "$OUT/parity/capability_matrix.json" --html "$OUT/parity/capability_matrix.html" > "$OUT/parity.log" 2>&1
+  tail -8 "$OUT/parity.log"
+  stop_server ;;
 esac
 done
