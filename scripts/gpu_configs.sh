@@ -76,6 +76,9 @@ probes)    # prefix-cache probe, OpenAI parity matrix and the fairness guard aga
   tail -8 "$OUT/cache_probe.log"
   timeout -k 10 120 python -m kvmini parity --url http://127.0.0.1:8108 --model "$MODEL" --out "$OUT/parity/capability_matrix.json" --html "$OUT/parity/capability_matrix.html" > "$OUT/parity.log" 2>&1
   tail -8 "$OUT/parity.log"
+  timeout -k 10 200 python -m kvmini fairness --url http://127.0.0.1:8108 --model "$MODEL" --max-tokens 64 --tenant-a-requests 200 --tenant-b-requests 600 --tenant-a-concurrency 8 \
+    --tenant-b-concurrency 40 --p95-budget-ms 280 --run-dir "$OUT/fairness" > "$OUT/fairness.log" 2>&1
+  tail -12 "$OUT/fairness.log"
   stop_server ;;
 esac
 done
