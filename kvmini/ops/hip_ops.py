@@ -180,26 +180,31 @@ def _plan_slabs(n_pad: int, k: int, m: int = 32) -> Tuple[int, int, int]:
     by a three-term cost model fitted to the measured shapes (32 token rows):
     the weight stream costs 1 / (share of the CU rounds the grid fills) — the kernel's time
     follows the busiest CU, so feature tiles x splits should be a whole number of rounds over
-    the CUs, all splits equal; every slab is written and read back once (2 m splits / K of the
+    the CUs, splits as equal as K allows; every slab is written and read back once (2 m splits / K of the
     weight bytes for m token rows, at half price: it stays on chip); x is fetched once per
     workgroup (m / (32 waves-per-workgroup), likewise)."""
     ngroups = k // 256
-    best: Optional[Tuple[float, int, int]] = None
+    best: Optional[Tuple[float, int, int, int]] = None
     for nw in (4, 6, 7, 8):
         if n_pad % (16 * nw):
             continue
         tiles = n_pad // (16 * nw)
-        for splits in range(1, min(MAX_SPLITS, ngroups) + 1):
-            if ngroups % splits:
+        seen = set()
+        for want in range(1, min(MAX_SPLITS, ngroups) + 1):
+            gps = -(-ngroups // want)
+            splits = -(-ngroups // gps)  # the last split may be shorter (K = 11008: 43 groups)
+            if (splits, gps) in seen:
                 continue
+            seen.add((splits, gps))
             wgs = tiles * splits
             fill = wgs / (-(-wgs // _NUM_CUS) * _NUM_CUS)
-            cost = 1.0 / fill + 2.0 * m * splits / k + m / (32.0 * nw)
+            even = ngroups / (splits * gps)  # the longest split sets the time
+            cost = 1.0 / (fill * even) + 2.0 * m * splits / k + m / (32.0 * nw)
             if best is None or cost < best[0] - 1e-9:
-                best = (cost, nw, splits)
+                best = (cost, nw, splits, gps)
     if best is None:
         return 4, 1, ngroups
-    return best[1], best[2], ngroups // best[2]
+    return best[1], best[2], best[3]
 
 
 def _pad_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:

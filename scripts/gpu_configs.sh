@@ -1,7 +1,7 @@
 #!/bin/bash
 # The benchmark configurations of BASELINE.json on ONE MI355X box, through the harness CLI
 # (native server + load generator + analyzer + cost + reports).  Artifacts: gpurun_out/configs/.
-# Usage: scripts/gpu_configs.sh [headline] [grid] [quant] [70b] [ab] [spec] [probes]   (default: all but probes)
+# Usage: scripts/gpu_configs.sh [headline] [grid] [quant] [70b] [ab] [spec] [probes] [build]   (default: all but probes and build)
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
@@ -80,5 +80,11 @@ probes)    # prefix-cache probe, OpenAI parity matrix and the fairness guard aga
     --tenant-b-concurrency 40 --p95-budget-ms 280 --run-dir "$OUT/fairness" > "$OUT/fairness.log" 2>&1
   tail -12 "$OUT/fairness.log"
   stop_server ;;
+build)     # engine "build" (start -> healthy: weight re-ordering, KV sizing, graph capture) vs served performance, per engine profile
+  for prof in profiles/engine/*.yaml; do
+    timeout -k 10 400 python -m kvmini build-vs-perf --profile "$prof" --mode local --port 8109 --requests 200 --concurrency 10 --max-tokens 64 --streaming \
+      --output "$OUT/build_vs_perf.csv" >> "$OUT/build_vs_perf.log" 2>&1 || { tail -30 "$OUT/build_vs_perf.log"; exit 1; }
+  done
+  cat "$OUT/build_vs_perf.csv" ;;
 esac
 done

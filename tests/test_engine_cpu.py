@@ -414,10 +414,10 @@ def test_gemm_workgroup_planner_fills_the_cus_evenly():
     assert _waves_per_workgroup(57344) == 7
     assert _waves_per_workgroup(128256) == 8  # 4 and 8 waves fill alike: the larger workgroup wins
     assert _waves_per_workgroup(16384) == 4  # 256 workgroups of 4 waves beat 128 of 8
-    for n, k in ((6144, 4096), (4096, 4096), (4096, 14336), (8192, 8192), (8192, 28672), (10240, 8192), (3072, 2048), (2048, 8192), (5120, 13824), (256, 256)):
+    for n, k in ((6144, 4096), (4096, 4096), (4096, 14336), (8192, 8192), (8192, 28672), (10240, 8192), (3072, 2048), (2048, 8192), (5120, 13824), (256, 256), (4096, 11008)):
         nw, splits, gps = _plan_slabs(n, k)
         assert nw in (4, 6, 7, 8) and n % (16 * nw) == 0
-        assert 1 <= splits <= MAX_SPLITS and splits * gps == k // 256  # equal splits that cover K exactly
+        assert 1 <= splits <= MAX_SPLITS and splits * gps >= k // 256 > (splits - 1) * gps  # the splits cover K, the last one may be shorter
     for n, k in ((6144, 4096), (4096, 4096), (4096, 14336)):  # the Llama-3-8B projections: one workgroup per CU
         nw, splits, _ = _plan_slabs(n, k)
         assert n // (16 * nw) * splits == 256
