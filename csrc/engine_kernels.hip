@@ -1115,7 +1115,10 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
   switch (rep) {                  \
     case 1: KV_LAUNCH(1, D); break; \
     case 2: KV_LAUNCH(2, D); break; \
+    case 3: KV_LAUNCH(3, D); break; \
     case 4: KV_LAUNCH(4, D); break; \
+    case 6: KV_LAUNCH(6, D); break; \
+    case 7: KV_LAUNCH(7, D); break; \
     case 8: KV_LAUNCH(8, D); break; \
     default: return -1;           \
   }
@@ -1141,7 +1144,10 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   switch (rep) {
     case 1: KV_LAUNCH(1); break;
     case 2: KV_LAUNCH(2); break;
+    case 3: KV_LAUNCH(3); break;
     case 4: KV_LAUNCH(4); break;
+    case 6: KV_LAUNCH(6); break;
+    case 7: KV_LAUNCH(7); break;
     case 8: KV_LAUNCH(8); break;
     default: return -1;
   }
@@ -1168,7 +1174,10 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
   switch (rep) {
     case 1: KV_LAUNCH(1); break;
     case 2: KV_LAUNCH(2); break;
+    case 3: KV_LAUNCH(3); break;
     case 4: KV_LAUNCH(4); break;
+    case 6: KV_LAUNCH(6); break;
+    case 7: KV_LAUNCH(7); break;
     case 8: KV_LAUNCH(8); break;
     default: return -1;
   }

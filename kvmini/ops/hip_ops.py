@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from . import gpu_available, native
 
 MAX_M = 64
+GQA_RATIOS = (1, 2, 3, 4, 6, 7, 8)  # query heads per kv head the attention kernels are instantiated for
 WIDE_M = 256  # token rows the 8 / 16-tile variants of the streaming GEMM cover
 # k-steps (of 32) per pipelined chunk.  Measured on MI355X (Llama-3-8B shapes): 8 (8 KiB of
 # weights in flight per wave) wins by ~2 % for a single 16-row token tile, 4 wins by 3-7 % from
@@ -396,7 +397,7 @@ def paged_attention(
     max_blocks: Optional[int] = None,
 ) -> torch.Tensor:
     t, nh, hd = q.shape
-    if hd not in (64, 128) or k_cache.shape[2] != 16 or nh // k_cache.shape[1] not in (1, 2, 4, 8):
+    if hd not in (64, 128) or k_cache.shape[2] != 16 or nh // k_cache.shape[1] not in GQA_RATIOS:
         # shapes outside the kernel's specialisation (test-sized models): reference path
         from . import torch_ops
 
@@ -409,7 +410,7 @@ def paged_attention(
 def supports_fused_decode_attention(qkv: Any, n_heads: int, k_cache: torch.Tensor) -> bool:
     """Shapes the one-launch RoPE + KV write + attention kernel covers."""
     nkv, bs, hd = k_cache.shape[1], k_cache.shape[2], k_cache.shape[3]
-    return isinstance(qkv, Partial) and hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in (1, 2, 4, 8)
+    return isinstance(qkv, Partial) and hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in GQA_RATIOS
 
 
 def rope_attention_fused(
@@ -438,7 +439,7 @@ def rope_attention_fused(
 
 def supports_prefill_attention(n_heads: int, k_cache: torch.Tensor) -> bool:
     nkv, bs, hd = k_cache.shape[1], k_cache.shape[2], k_cache.shape[3]
-    return hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in (1, 2, 4, 8)
+    return hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in GQA_RATIOS
 
 
 def prefill_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor, tiles: torch.Tensor, out: torch.Tensor, scale: float) -> torch.Tensor:

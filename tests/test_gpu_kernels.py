@@ -105,7 +105,7 @@ def test_rope_kv_write(C):
     assert torch.equal(vc, vc_ref)
 
 
-@pytest.mark.parametrize("rep", [1, 4, 8])
+@pytest.mark.parametrize("rep", [1, 3, 4, 7, 8])
 @pytest.mark.parametrize("hd", [128, 64])
 def test_paged_attention(C, rep, hd):
     from kvmini.ops import torch_ops
@@ -552,7 +552,7 @@ def test_sampler_loaded_before_torch_keeps_one_hip_runtime():
     assert "WH 1.0" in r.stdout and "NHIP 1" in r.stdout, r.stdout
 
 
-@pytest.mark.parametrize("rep", [1, 4, 8])
+@pytest.mark.parametrize("rep", [1, 3, 4, 6, 8])
 def test_fused_decode_attention_matches_two_kernel_path(rep):
     """RoPE + KV write + attention in one launch == rope_kv_write_slabs followed by
     paged_attention, for a decode-only step (one new token per sequence, padding rows included)."""
@@ -631,7 +631,7 @@ def _tp_one_rank_body(graphs):
     assert eng.generate(prompts, params) == want
 
 
-@pytest.mark.parametrize("rep", [1, 2, 4, 8])
+@pytest.mark.parametrize("rep", [1, 2, 3, 4, 7, 8])
 def test_prefill_attention_tiles_match_reference(rep):
     """The tiled MFMA prompt-attention kernel against the per-token reference: chunks that
     start at position 0, mid-block continuations of an earlier chunk, short chunks, and rows
