@@ -208,6 +208,17 @@ def _plan_slabs(n_pad: int, k: int, m: int = 32) -> Tuple[int, int, int]:
     return best[1], best[2], best[3]
 
 
+_warned: set = set()
+
+
+def _warn_once(msg: str) -> None:
+    if msg not in _warned:
+        _warned.add(msg)
+        import warnings
+
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def _pad_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     m = x.shape[0]
     mp = (m + 15) // 16 * 16
@@ -400,6 +411,9 @@ def paged_attention(
     if hd not in (64, 128) or k_cache.shape[2] != 16 or nh // k_cache.shape[1] not in GQA_RATIOS:
         # shapes outside the kernel's specialisation (test-sized models): reference path
         from . import torch_ops
+
+        _warn_once(f"paged attention: head_dim {hd}, block {k_cache.shape[2]}, {nh // k_cache.shape[1]} query heads per kv head is outside the HIP kernels' "
+                   f"specialisation (head_dim 64 / 128, block 16, ratios {GQA_RATIOS}): using the PyTorch reference path, which is far slower")
 
         return torch_ops.paged_attention(q, k_cache, v_cache, block_tables, tok_seq, ctx_lens, scale, max_blocks)
     out = torch.empty((t, nh * hd), dtype=q.dtype, device=q.device)
