@@ -29,7 +29,7 @@ import os
 import subprocess
 import sys
 import time
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -25,7 +25,7 @@ import signal
 import subprocess
 import sys
 import time
-from typing import Any, AsyncIterator, Dict, List, Optional
+from typing import Any, AsyncIterator, List, Optional
 
 from kvmini.loadgen.httpclient import HttpClient
 from kvmini.server.httpd import HttpServer, Request, Response, StreamingResponse
