@@ -820,3 +820,21 @@ def test_sample_rows_kernel_full_vocabulary_and_engine_path():
     b = eng.generate([[1, 5, 9, 11], [1, 7, 7]], SamplingParams(max_tokens=12, temperature=1.1, top_p=0.9, ignore_eos=True))
     assert a == greedy and eng.pipelined_steps > steps0
     assert all(len(o) == 12 and all(0 <= t < eng.mcfg.vocab_size for t in o) for o in b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(4096, 11008), (6144, 4096), (2560, 10240)])
+def test_split_k_linear_with_uneven_splits_matches_reference(n, k):
+    """hip_ops.linear with split-K slabs on shapes whose K does not divide evenly into the
+    planned splits (11008 = 43 groups of 256): the last split is shorter, the sum is exact."""
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(n + k)
+    w = (torch.randn(n, k, device="cuda") * 0.02).bfloat16()
+    x = torch.randn(32, k, device="cuda").bfloat16()
+    nw, splits, gps = hip_ops._plan_slabs(n, k)
+    assert splits * gps >= k // 256 > (splits - 1) * gps
+    y = hip_ops.linear(x, hip_ops.PackedLinear(w), allow_slabs=True)
+    assert isinstance(y, hip_ops.Partial) and y.slabs.shape[0] == splits
+    ref = x.float() @ w.float().T
+    assert torch.allclose(y.reduce().float(), ref, atol=0.06, rtol=0.02)
