@@ -28,7 +28,7 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              hipStream_t stream);
+                              int waves, hipStream_t stream);
 int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
 int kv_sample_rows(const void* logits, long long row_stride, int V, const long long* rows, int R, const float* temperature, const int* top_k,
@@ -199,7 +199,8 @@ const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* 
 // RoPE + KV write + paged attention in one launch (decode-only steps; see engine_kernels.hip)
 void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
                             at::Tensor slot_mapping, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor out, int64_t nh,
-                            c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale) {
+                            c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale, int64_t waves) {
+  TORCH_CHECK(waves == 4 || waves == 8, "waves per workgroup must be 4 or 8");
   CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_I32(positions); CHECK_I32(slot_mapping); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
   CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_BF16(out); CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(out); CHECK_CONTIG(block_tables);
   CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping); CHECK_CONTIG(tok_seq); CHECK_CONTIG(ctx_lens); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t);
@@ -218,7 +219,7 @@ void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor c
                                   (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(),
                                   (const int*)block_tables.data_ptr(), (int)block_tables.size(1), (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(),
                                   out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps, (float)scale,
-                                  cur_stream()),
+                                  (int)waves, cur_stream()),
         "kv_decode_attention_fused");
 }
 
@@ -472,7 +473,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rope_kv_write", &rope_kv_write);
   m.def("paged_attention", &paged_attention);
   m.def("prefill_attention", &prefill_attention);
-  m.def("decode_attention_fused", &decode_attention_fused);
+  m.def("decode_attention_fused", &decode_attention_fused, py::arg("slabs"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
+        py::arg("v_cache"), py::arg("slot_mapping"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"), py::arg("out"), py::arg("nh"),
+        py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4);
   m.def("argmax", &argmax);
   m.def("embed_fed", &embed_fed);
   m.def("swiglu_interleaved", &swiglu_interleaved);

@@ -290,6 +290,10 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
   }
 }
 
+// packed bf16 pairs, the operand type of v_dot2_f32_bf16
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+struct bf16x2x4 { bf16x2 p[4]; };
+
 // ---------------------------------------------------------------------------------
 // Ragged paged attention.  One workgroup per (token, kv head); the REP = nh/nkv query
 // heads of the group share every K/V load.  Each of the 4 waves walks KV blocks
@@ -301,46 +305,61 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
 //       against the REP query heads; two xor-shuffles finish the 128-dim dot.
 //   PV: lane = 16*tg + dv; it owns 1/16 of the output dims and tokens {tg, tg+4, tg+8,
 //       tg+12} of the block; the 4 token groups are summed once at the end.
-template <int REP, int HD>
-__global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
+template <int REP, int HD, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
                                                               const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
                                                               const int* __restrict__ block_tables, int max_blocks_per_seq,
                                                               const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
                                                               unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
-  constexpr int BS = 16;
+  constexpr int BS = 16, NT = 64 * NWAVE;
   constexpr int DQ = HD / 4;   // dims of the QK dot owned by a lane
   constexpr int NV = DQ / 8;   // 16-byte K loads per lane
   constexpr int DP = HD / 16;  // output dims owned by a lane in PV
   static_assert(HD == 64 || HD == 128, "head_dim 64 or 128");
-  __shared__ float p_lds[4][REP][BS];        // per-wave probabilities of the current block
-  __shared__ float m_lds[4][REP], l_lds[4][REP];
-  __shared__ float o_lds[4][REP][HD];
+  __shared__ float p_lds[NWAVE][REP][BS];    // per-wave probabilities of the current block
+  __shared__ float m_lds[NWAVE][REP], l_lds[NWAVE][REP];
+  __shared__ float o_lds[NWAVE][REP][HD];
   const int t = blockIdx.x, g = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ctx = ctx_lens[t];
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
   if (ctx <= 0) {  // padding token
-    for (int i = tid; i < REP * HD; i += 256) orow[i] = 0;
+    for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
     return;
   }
   const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
   const int n_blocks = (ctx + BS - 1) / BS;
 
-  // this lane's DQ-dim slice of the REP query heads, pre-scaled by scale*log2(e)
+  // each wave keeps one K/V block in flight beyond the one it computes on: the first loads go
+  // out before anything else
   const int qk_tok = lane >> 2, qk_c = lane & 3;
-  float qf[REP][DQ];
+  const int pv_tg = lane >> 4, pv_dv = lane & 15;
+  typedef __attribute__((ext_vector_type(DP))) unsigned short vrow_t;  // 16 B (HD 128) or 8 B (HD 64)
+  bf16x8 kv[NV];
+  vrow_t vv[4];
+  if (wave < n_blocks) {
+    const long long base = ((long long)bt[wave] * nkv + g) * BS * HD;
+    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * DQ;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+    const unsigned short* vp = v_cache + base + pv_dv * DP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
+  }
+  // this lane's DQ-dim slice of the REP query heads, kept as packed bf16 pairs for
+  // v_dot2_f32_bf16 (half the registers and multiplies of an fp32 copy, no unpacking of K)
+  bf16x2 qp[REP][DQ / 2];
   {
     const unsigned short* qrow = q + (long long)t * q_row_stride + (long long)g * REP * HD + qk_c * DQ;
 #pragma unroll
     for (int h = 0; h < REP; ++h)
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        bf16x8 a = *reinterpret_cast<const bf16x8*>(qrow + h * HD + v * 8);
+        const bf16x2x4 a = __builtin_bit_cast(bf16x2x4, *reinterpret_cast<const bf16x8*>(qrow + h * HD + v * 8));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[h][v * 8 + j] = bf2f(a[j]) * scale_log2e;
+        for (int j = 0; j < 4; ++j) qp[h][v * 4 + j] = a.p[j];
       }
   }
-  const int pv_tg = lane >> 4, pv_dv = lane & 15;
   float acc[REP][DP];
   float m_run[REP], l_run[REP];
 #pragma unroll
@@ -350,30 +369,33 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
     for (int j = 0; j < DP; ++j) acc[h][j] = 0.f;
   }
 
-  for (int b = wave; b < n_blocks; b += 4) {
-    const long long base = ((long long)bt[b] * nkv + g) * BS * HD;
+  for (int b = wave; b < n_blocks; b += NWAVE) {
+    // this block's K / V are in registers; start the next block's loads before computing
+    bf16x8 kn[NV];
+    vrow_t vn[4];
+    if (b + NWAVE < n_blocks) {
+      const long long nbase = ((long long)bt[b + NWAVE] * nkv + g) * BS * HD;
+      const unsigned short* kp = k_cache + nbase + qk_tok * HD + qk_c * DQ;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+      const unsigned short* vp = v_cache + nbase + pv_dv * DP;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
+    }
     // ---- QK^T
-    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * DQ;
-    bf16x8 kv[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-    // V loads issued early: they do not depend on the softmax
-    typedef __attribute__((ext_vector_type(DP))) unsigned short vrow_t;  // 16 B (HD 128) or 8 B (HD 64)
-    vrow_t vv[4];
-    const unsigned short* vp = v_cache + base + pv_dv * DP;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
     float s[REP];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
       float d = 0.f;
 #pragma unroll
-      for (int v = 0; v < NV; ++v)
+      for (int v = 0; v < NV; ++v) {
+        const bf16x2x4 kw = __builtin_bit_cast(bf16x2x4, kv[v]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d += qf[h][v * 8 + j] * bf2f(kv[v][j]);
+        for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_fdot2_f32_bf16(qp[h][v * 4 + j], kw.p[j], d, false);
+      }
       d += dpp_f32<0xB1>(d);  // the 4 dim chunks of a key sit in one quad: quad swaps in registers
       d += dpp_f32<0x4E>(d);
-      s[h] = (b * BS + qk_tok < ctx) ? d : -1e30f;
+      s[h] = (b * BS + qk_tok < ctx) ? d * scale_log2e : -1e30f;
     }
     // ---- online softmax over the block's 16 tokens (token index lives in lane bits 2..5)
 #pragma unroll
@@ -413,6 +435,12 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (b + NWAVE < n_blocks) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) kv[v] = kn[v];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vv[i] = vn[i];
+    }
   }
   // ---- sum the 4 token groups inside the wave (lanes l, l^16, l^32, ...)
 #pragma unroll
@@ -435,13 +463,15 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const unsigned sho
     for (int h = 0; h < REP; ++h) { m_lds[wave][h] = m_run[h]; l_lds[wave][h] = l_run[h]; }
   }
   __syncthreads();
-  // ---- merge the 4 waves; thread i handles output element i (REP*128 elements)
-  for (int i = tid; i < REP * HD; i += 256) {
+  // ---- merge the waves; thread i handles output element i (REP*HD elements)
+  for (int i = tid; i < REP * HD; i += NT) {
     const int h = i / HD, d = i % HD;
-    float m = fmaxf(fmaxf(m_lds[0][h], m_lds[1][h]), fmaxf(m_lds[2][h], m_lds[3][h]));
+    float m = m_lds[0][h];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) m = fmaxf(m, m_lds[w][h]);
     float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NWAVE; ++w) {
       const float c = exp2f(m_lds[w][h] - m);
       num += o_lds[w][h][d] * c;
       den += l_lds[w][h] * c;
@@ -674,8 +704,8 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
 //            same lane roles as paged_attention_kernel) and wave 0 folds in the token's own
 //            key / value from LDS — nothing written in phase A is read back from memory.
 // Saves one kernel boundary and one slab -> q round trip per layer.  head_dim 128, block 16.
-template <int REP>
-__global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+template <int REP, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                                      const int* __restrict__ positions, const float* __restrict__ cos_t,
                                                                      const float* __restrict__ sin_t, unsigned short* __restrict__ k_cache,
                                                                      unsigned short* __restrict__ v_cache, const int* __restrict__ slot_mapping,
@@ -684,19 +714,20 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
                                                                      unsigned short* __restrict__ out, int nh, int nkv,
                                                                      const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
                                                                      float scale_log2e) {
-  constexpr int HD = 128, BS = 16, HALF = 64;
-  // rows 0..REP-1: q (after A.2: RoPE'd, bf16-rounded, times scale*log2(e)); row REP: this
-  // token's key (RoPE'd); row REP+1: its value — all bf16-rounded like the cache contents
+  constexpr int HD = 128, BS = 16, HALF = 64, NT = 64 * NWAVE;
+  // rows 0..REP-1: q; row REP: this token's key; row REP+1: its value — the projection output,
+  // bf16-rounded like the cache contents.  A.2 leaves q and the key, RoPE'd, as bf16 in xb_lds.
   __shared__ float x_lds[REP + 2][HD];
-  __shared__ float p_lds[4][REP][BS];
-  __shared__ float m_lds[4][REP], l_lds[4][REP];
-  __shared__ float o_lds[4][4][REP][HD];  // [wave][token group]: partial outputs, summed in the merge
+  __shared__ __attribute__((aligned(16))) unsigned short xb_lds[REP + 1][HD];
+  __shared__ float p_lds[NWAVE][REP][BS];
+  __shared__ float m_lds[NWAVE][REP], l_lds[NWAVE][REP];
+  __shared__ float o_lds[NWAVE][4][REP][HD];  // [wave][token group]: partial outputs, summed in the merge
   const int t = blockIdx.x, g = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ctx = ctx_lens[t];
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
   if (ctx <= 0) {  // padding token: no KV write (slot -1), zero output
-    for (int i = tid; i < REP * HD; i += 256) orow[i] = 0;
+    for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
     return;
   }
   // The keys / values of earlier positions do not depend on phase A: each wave loads its
@@ -741,7 +772,7 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
     const float* row0 = slabs + (long long)t * width;
     constexpr int PIECES = (REP + 2) * (HD / 4);  // q heads, then k, then v; 32 pieces per row
     constexpr int MAX_S = 16;
-    for (int pc = tid; pc < PIECES; pc += 256) {
+    for (int pc = tid; pc < PIECES; pc += NT) {
       const int r = pc >> 5, c4 = (pc & 31) << 2;
       const int col = (r < REP ? (g * REP + r) * HD : r == REP ? (nh + g) * HD : (nh + nkv + g) * HD) + c4;
       f32x4 v[MAX_S];
@@ -766,20 +797,15 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
       if (task < ROT) {
         const int hsel = task >> 3, d0 = (task & 7) << 3;
         bf16x8 oa, ob;
-        float fa[8], fb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float c = csr[j >> 2][j & 3], sv = snr[j >> 2][j & 3];
           const float x1 = x_lds[hsel][d0 + j], x2 = x_lds[hsel][HALF + d0 + j];
           oa[j] = f2bf(x1 * c - x2 * sv);
           ob[j] = f2bf(x2 * c + x1 * sv);
-          fa[j] = bf2f(oa[j]);
-          fb[j] = bf2f(ob[j]);
         }
-        // in-place is safe: this task owns dims d0..d0+7 and HALF+d0.. of row hsel
-        const float sc = hsel < REP ? scale_log2e : 1.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { x_lds[hsel][d0 + j] = fa[j] * sc; x_lds[hsel][HALF + d0 + j] = fb[j] * sc; }
+        *reinterpret_cast<bf16x8*>(&xb_lds[hsel][d0]) = oa;
+        *reinterpret_cast<bf16x8*>(&xb_lds[hsel][HALF + d0]) = ob;
         if (hsel == REP && cache_row >= 0) {
           *reinterpret_cast<bf16x8*>(k_cache + cache_row + d0) = oa;
           *reinterpret_cast<bf16x8*>(k_cache + cache_row + HALF + d0) = ob;
@@ -795,11 +821,18 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
   }
   __syncthreads();
   // ---- phase B: earlier positions from the cache
-  float qf[REP][32];
+  // q stays packed as bf16 pairs (16 registers per head instead of 32) and meets the keys in
+  // v_dot2_f32_bf16: half the multiply instructions, no bf16 -> fp32 unpacking of K, and a
+  // register footprint that lets 8 waves per workgroup (2 per SIMD) run without spilling
+  bf16x2 qp[REP][16];
 #pragma unroll
   for (int h = 0; h < REP; ++h)
 #pragma unroll
-    for (int j = 0; j < 32; ++j) qf[h][j] = x_lds[h][qk_c * 32 + j];
+    for (int v = 0; v < 4; ++v) {
+      const bf16x2x4 qw = __builtin_bit_cast(bf16x2x4, *reinterpret_cast<const bf16x8*>(&xb_lds[h][qk_c * 32 + v * 8]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qp[h][v * 4 + j] = qw.p[j];
+    }
   float acc[REP][8];
   float m_run[REP], l_run[REP];
 #pragma unroll
@@ -808,12 +841,12 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
   }
-  for (int b = wave; b < n_blocks; b += 4) {
+  for (int b = wave; b < n_blocks; b += NWAVE) {
     // this block's K / V are in registers (loaded before phase A, or by the previous
     // iteration); start the next block's loads before computing on this one
     bf16x8 kn[4], vn[4];
-    if (b + 4 < n_blocks) {
-      const long long nbase = ((long long)bt[b + 4] * nkv + g) * BS * HD;
+    if (b + NWAVE < n_blocks) {
+      const long long nbase = ((long long)bt[b + NWAVE] * nkv + g) * BS * HD;
       const unsigned short* kp = k_cache + nbase + qk_tok * HD + qk_c * 32;
 #pragma unroll
       for (int v = 0; v < 4; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
@@ -826,12 +859,14 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
     for (int h = 0; h < REP; ++h) {
       float d = 0.f;
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
+      for (int v = 0; v < 4; ++v) {
+        const bf16x2x4 kw = __builtin_bit_cast(bf16x2x4, kv[v]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d += qf[h][v * 8 + j] * bf2f(kv[v][j]);
+        for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_fdot2_f32_bf16(qp[h][v * 4 + j], kw.p[j], d, false);
+      }
       d += dpp_f32<0xB1>(d);  // the 4 dim chunks of a key sit in one quad
       d += dpp_f32<0x4E>(d);
-      s[h] = (b * BS + qk_tok < prev) ? d : -1e30f;
+      s[h] = (b * BS + qk_tok < prev) ? d * scale_log2e : -1e30f;
     }
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
@@ -869,20 +904,28 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (b + 4 < n_blocks) {
+    if (b + NWAVE < n_blocks) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) { kv[v] = kn[v]; vv[v] = vn[v]; }
     }
   }
   // ---- the token's own key / value (wave 0; one token group adds the value)
   if (wave == 0) {
+    bf16x2 kp2[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bf16x2x4 kw = __builtin_bit_cast(bf16x2x4, *reinterpret_cast<const bf16x8*>(&xb_lds[REP][qk_c * 32 + v * 8]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kp2[v * 4 + j] = kw.p[j];
+    }
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
       float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) d += qf[h][j] * x_lds[REP][qk_c * 32 + j];
+      for (int j = 0; j < 16; ++j) d = __builtin_amdgcn_fdot2_f32_bf16(qp[h][j], kp2[j], d, false);
       d += dpp_f32<0xB1>(d);
       d += dpp_f32<0x4E>(d);
+      d *= scale_log2e;
       const float m_new = fmaxf(m_run[h], d);
       const float p = exp2f(d - m_new);
       const float corr = exp2f(m_run[h] - m_new);
@@ -904,12 +947,14 @@ __global__ __launch_bounds__(256) void decode_attention_fused_kernel(const float
     for (int h = 0; h < REP; ++h) { m_lds[wave][h] = m_run[h]; l_lds[wave][h] = l_run[h]; }
   }
   __syncthreads();
-  for (int i = tid; i < REP * HD; i += 256) {
+  for (int i = tid; i < REP * HD; i += NT) {
     const int h = i / HD, d = i % HD;
-    float m = fmaxf(fmaxf(m_lds[0][h], m_lds[1][h]), fmaxf(m_lds[2][h], m_lds[3][h]));
+    float m = m_lds[0][h];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) m = fmaxf(m, m_lds[w][h]);
     float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NWAVE; ++w) {
       const float c = exp2f(m_lds[w][h] - m);
       num += (o_lds[w][0][h][d] + o_lds[w][1][h][d] + o_lds[w][2][h][d] + o_lds[w][3][h][d]) * c;
       den += l_lds[w][h] * c;
@@ -1107,10 +1152,13 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
   if ((hd != 128 && hd != 64) || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
-  dim3 grid(T, nkv), block(256);
-#define KV_LAUNCH(R, D)                                                                                                                          \
-  hipLaunchKernelGGL((paged_attention_kernel<R, D>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
+  // 8 waves per workgroup (twice the K/V blocks in flight) wherever the head group's registers
+  // fit 2 waves per SIMD
+  dim3 grid(T, nkv), block(rep <= 4 ? 512 : 256);
+#define KV_LAUNCH_W(R, D, W)                                                                                                                        \
+  hipLaunchKernelGGL((paged_attention_kernel<R, D, W>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
                      (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, sl)
+#define KV_LAUNCH(R, D) KV_LAUNCH_W(R, D, ((R) <= 4 ? 8 : 4))
 #define KV_BY_REP(D)              \
   switch (rep) {                  \
     case 1: KV_LAUNCH(1, D); break; \
@@ -1125,6 +1173,7 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
   if (hd == 128) { KV_BY_REP(128) } else { KV_BY_REP(64) }
 #undef KV_BY_REP
 #undef KV_LAUNCH
+#undef KV_LAUNCH_W
   return (int)hipGetLastError();
 }
 
@@ -1160,17 +1209,24 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              hipStream_t stream) {
+                              int waves, hipStream_t stream) {
   if (T <= 0) return 0;
-  if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1 || n_slabs > 16) return -1;
+  if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1 || n_slabs > 16 || (waves != 4 && waves != 8)) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
   const float inv_h = h_in > 0 ? 1.f / (float)h_in : 0.f;
-  dim3 grid(T, nkv), block(256);
-#define KV_LAUNCH(R)                                                                                                                                   \
-  hipLaunchKernelGGL(decode_attention_fused_kernel<R>, grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t,                   \
+  if (rep > 4) waves = 4;  // 8 waves of the wider head groups do not fit the 256 registers per lane that 2 waves per SIMD leave
+  dim3 grid(T, nkv), block(64 * waves);
+#define KV_LAUNCH_W(R, W)                                                                                                                              \
+  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t,                   \
                      (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens,            \
                      (unsigned short*)out, nh, nkv, row_ss, ss_parts, inv_h, eps, sl)
+#define KV_LAUNCH(R)      \
+  if (waves == 8) {       \
+    KV_LAUNCH_W(R, 8);    \
+  } else {                \
+    KV_LAUNCH_W(R, 4);    \
+  }
   switch (rep) {
     case 1: KV_LAUNCH(1); break;
     case 2: KV_LAUNCH(2); break;
@@ -1182,6 +1238,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
     default: return -1;
   }
 #undef KV_LAUNCH
+#undef KV_LAUNCH_W
   return (int)hipGetLastError();
 }
 

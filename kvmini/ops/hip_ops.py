@@ -20,6 +20,7 @@ are processed in 64-row pieces (the weights are re-streamed per piece).
 from __future__ import annotations
 
 import functools
+import os
 
 from typing import Any, Optional, Tuple, Union
 
@@ -427,6 +428,11 @@ def supports_fused_decode_attention(qkv: Any, n_heads: int, k_cache: torch.Tenso
     return isinstance(qkv, Partial) and hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in GQA_RATIOS
 
 
+# Waves per workgroup of the fused decode attention kernel: every wave keeps one 16-token K/V
+# block in flight, so a long context streams at (workgroups x waves x 8 KB) / latency.
+DECODE_ATTENTION_WAVES = int(os.environ.get("KVMINI_DECODE_WAVES", "8"))
+
+
 def rope_attention_fused(
     qkv: Partial,
     positions: torch.Tensor,
@@ -447,7 +453,7 @@ def rope_attention_fused(
     t = qkv.slabs.shape[1]
     hd = k_cache.shape[3]
     out = torch.empty((t, n_heads * hd), dtype=torch.bfloat16, device=qkv.slabs.device)
-    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale)
+    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale, DECODE_ATTENTION_WAVES)
     return out
 
 

@@ -217,6 +217,33 @@ def attn_bench(out):
         out.append(row)
 
 
+def decode_attn_bench(out):
+    """The paged decode-attention kernel alone: 20 single-token queries of a Llama-3-8B layer
+    (32 q heads / 8 kv heads x 128), one per sequence, against contexts of 128 .. 8000 tokens;
+    the K/V bytes read per call over the time."""
+    import math
+
+    from kvmini.ops import hip_ops
+
+    dev = torch.device("cuda:0")
+    nh, nkv, hd, bs, nseq = 32, 8, 128, 16, 20
+    for ctx in (128, 1024, 4096, 8000):
+        per = (ctx + bs - 1) // bs
+        nb = nseq * per
+        kc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
+        vc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
+        bt = torch.randperm(nb, device=dev).view(nseq, per).int().contiguous()
+        q = torch.randn(nseq, nh, hd, device=dev).bfloat16()
+        tok_seq = torch.arange(nseq, device=dev, dtype=torch.int32)
+        ctx_lens = torch.full((nseq,), ctx, device=dev, dtype=torch.int32)
+        t = time_fns({"paged": lambda: hip_ops.paged_attention(q, kc, vc, bt, tok_seq, ctx_lens, 1 / math.sqrt(hd))}, rounds=10, inner=5)["paged"]
+        gb = 2.0 * nseq * ctx * nkv * hd * 2 / 1e9
+        row = {"bench": "paged_decode_attention", "seqs": nseq, "ctx": ctx, "us": round(t, 1), "kv_GB": round(gb, 3), "TBps": round(gb / t * 1e3, 2)}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+        del kc, vc
+
+
 def step_bench(out, model, batch, kernels_list, quantization=None):
     kernels_list = [k for k in kernels_list if k == "hip"]  # the torch ops are not graph-capturable
     from kvmini.engine.engine import EngineConfig, LLMEngine
@@ -349,6 +376,8 @@ def main():
         balance_bench(out)
     if "attn" in a.what.split(","):
         attn_bench(out)
+    if "decode_attn" in a.what.split(","):
+        decode_attn_bench(out)
     if "nw" in a.what.split(","):
         nw_bench(out)
     if "wide" in a.what.split(","):
