@@ -320,7 +320,9 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   __shared__ float m_lds[NWAVE][REP], l_lds[NWAVE][REP];
   __shared__ float o_lds[NWAVE][REP][HD];
   const int t = blockIdx.x, g = blockIdx.y;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // wave index in a scalar register: the block-table reads below become scalar loads, which do
+  // not queue behind (and so do not drain) the K/V loads in flight
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ctx = ctx_lens[t];
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
   if (ctx <= 0) {  // padding token
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
   const int n_blocks = (ctx + BS - 1) / BS;
 
-  // each wave keeps one K/V block in flight beyond the one it computes on: the first loads go
+  // each wave keeps two K/V blocks in flight beyond the one it computes on: the first loads go
   // out before anything else
   const int qk_tok = lane >> 2, qk_c = lane & 3;
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
@@ -345,6 +347,17 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
     const unsigned short* vp = v_cache + base + pv_dv * DP;
 #pragma unroll
     for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
+  }
+  bf16x8 kn[NV];
+  vrow_t vn[4];
+  if (wave + NWAVE < n_blocks) {
+    const long long base = ((long long)bt[wave + NWAVE] * nkv + g) * BS * HD;
+    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * DQ;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+    const unsigned short* vp = v_cache + base + pv_dv * DP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
   }
   // this lane's DQ-dim slice of the REP query heads, kept as packed bf16 pairs for
   // v_dot2_f32_bf16 (half the registers and multiplies of an fp32 copy, no unpacking of K)
@@ -370,17 +383,18 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   }
 
   for (int b = wave; b < n_blocks; b += NWAVE) {
-    // this block's K / V are in registers; start the next block's loads before computing
-    bf16x8 kn[NV];
-    vrow_t vn[4];
-    if (b + NWAVE < n_blocks) {
-      const long long nbase = ((long long)bt[b + NWAVE] * nkv + g) * BS * HD;
+    // this block's K / V and the next one's are in registers or on their way; start the loads
+    // of the block after those before computing
+    bf16x8 kf[NV];
+    vrow_t vf[4];
+    if (b + 2 * NWAVE < n_blocks) {
+      const long long nbase = ((long long)bt[b + 2 * NWAVE] * nkv + g) * BS * HD;
       const unsigned short* kp = k_cache + nbase + qk_tok * HD + qk_c * DQ;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+      for (int v = 0; v < NV; ++v) kf[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
       const unsigned short* vp = v_cache + nbase + pv_dv * DP;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
+      for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
     }
     // ---- QK^T
     float s[REP];
@@ -435,12 +449,11 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (b + NWAVE < n_blocks) {
+    __builtin_amdgcn_sched_barrier(0);  // the rotation waits for the newest loads: keep it behind the PV math
 #pragma unroll
-      for (int v = 0; v < NV; ++v) kv[v] = kn[v];
+    for (int v = 0; v < NV; ++v) { kv[v] = kn[v]; kn[v] = kf[v]; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vv[i] = vn[i];
-    }
+    for (int i = 0; i < 4; ++i) { vv[i] = vn[i]; vn[i] = vf[i]; }
   }
   // ---- sum the 4 token groups inside the wave (lanes l, l^16, l^32, ...)
 #pragma unroll
@@ -723,7 +736,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   __shared__ float m_lds[NWAVE][REP], l_lds[NWAVE][REP];
   __shared__ float o_lds[NWAVE][4][REP][HD];  // [wave][token group]: partial outputs, summed in the merge
   const int t = blockIdx.x, g = blockIdx.y;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // wave index in a scalar register: block-table reads become scalar loads (see paged_attention_kernel)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ctx = ctx_lens[t];
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
   if (ctx <= 0) {  // padding token: no KV write (slot -1), zero output
@@ -746,6 +760,16 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     const unsigned short* vp = v_cache + base + pv_dv * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+  }
+  bf16x8 kn[4], vn[4];  // the block after that: two blocks (16 KB) per wave in flight at any time
+  if (wave + NWAVE < n_blocks) {
+    const long long base = ((long long)bt[wave + NWAVE] * nkv + g) * BS * HD;
+    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+    const unsigned short* vp = v_cache + base + pv_dv * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
   }
   // likewise the RoPE table row of this token (needed in A.2)
   constexpr int ROT = (REP + 1) * 8;  // (q heads + k) x 8 pieces of 8 dims and their partners
@@ -842,17 +866,17 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
   }
   for (int b = wave; b < n_blocks; b += NWAVE) {
-    // this block's K / V are in registers (loaded before phase A, or by the previous
-    // iteration); start the next block's loads before computing on this one
-    bf16x8 kn[4], vn[4];
-    if (b + NWAVE < n_blocks) {
-      const long long nbase = ((long long)bt[b + NWAVE] * nkv + g) * BS * HD;
+    // this block's K / V and the next one's are in registers or on their way (loaded before
+    // phase A, or by earlier iterations); start the loads of the block after those
+    bf16x8 kf[4], vf[4];
+    if (b + 2 * NWAVE < n_blocks) {
+      const long long nbase = ((long long)bt[b + 2 * NWAVE] * nkv + g) * BS * HD;
       const unsigned short* kp = k_cache + nbase + qk_tok * HD + qk_c * 32;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
+      for (int v = 0; v < 4; ++v) kf[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
       const unsigned short* vp = v_cache + nbase + pv_dv * 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+      for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
     }
     float s[REP];
 #pragma unroll
@@ -904,10 +928,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (b + NWAVE < n_blocks) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) { kv[v] = kn[v]; vv[v] = vn[v]; }
-    }
+    for (int v = 0; v < 4; ++v) { kv[v] = kn[v]; vv[v] = vn[v]; kn[v] = kf[v]; vn[v] = vf[v]; }
   }
   // ---- the token's own key / value (wave 0; one token group adds the value)
   if (wave == 0) {

@@ -232,15 +232,18 @@ def decode_attn_bench(out):
         nb = nseq * per
         kc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
         vc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
-        bt = torch.randperm(nb, device=dev).view(nseq, per).int().contiguous()
         q = torch.randn(nseq, nh, hd, device=dev).bfloat16()
         tok_seq = torch.arange(nseq, device=dev, dtype=torch.int32)
         ctx_lens = torch.full((nseq,), ctx, device=dev, dtype=torch.int32)
-        t = time_fns({"paged": lambda: hip_ops.paged_attention(q, kc, vc, bt, tok_seq, ctx_lens, 1 / math.sqrt(hd))}, rounds=10, inner=5)["paged"]
         gb = 2.0 * nseq * ctx * nkv * hd * 2 / 1e9
-        row = {"bench": "paged_decode_attention", "seqs": nseq, "ctx": ctx, "us": round(t, 1), "kv_GB": round(gb, 3), "TBps": round(gb / t * 1e3, 2)}
-        print(json.dumps(row), flush=True)
-        out.append(row)
+        # block order: as a fresh engine hands blocks out (consecutive per sequence) and as a
+        # long-running one does (any free block)
+        for order, bt in (("sequential", torch.arange(nb, device=dev)), ("shuffled", torch.randperm(nb, device=dev))):
+            bt = bt.view(nseq, per).int().contiguous()
+            t = time_fns({"paged": lambda: hip_ops.paged_attention(q, kc, vc, bt, tok_seq, ctx_lens, 1 / math.sqrt(hd))}, rounds=30, inner=20)["paged"]
+            row = {"bench": "paged_decode_attention", "seqs": nseq, "ctx": ctx, "blocks": order, "us": round(t, 1), "kv_GB": round(gb, 3), "TBps": round(gb / t * 1e3, 2)}
+            print(json.dumps(row), flush=True)
+            out.append(row)
         del kc, vc
 
 
