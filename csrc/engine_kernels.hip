@@ -512,57 +512,66 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_ab;
 typedef __attribute__((ext_vector_type(4))) float mfma_cd;
 
-template <int REP>
-__global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
-                                                                const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
-                                                                const int* __restrict__ block_tables, int max_blocks_per_seq,
-                                                                const int* __restrict__ tile_row0, const int* __restrict__ tile_n,
-                                                                const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq,
-                                                                unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
+// One pass over the keys for QT consecutive 16-query tiles (rows row0 .., positions pos0 ..,
+// n_q valid queries in all) of one sequence: with QT = 2 every K fragment, every staged V^T
+// row and every workgroup barrier serves twice the MFMA work.
+//
+// Everything is computed TRANSPOSED, so that P never leaves the registers:
+//   S^T = K Q^T   A = K rows (lane: key lr, dims 32*ks + 8*lq ..), B = Q (lane: query lr, same
+//                 dims) -> accumulator lane (lr, lq), reg r = score(key 4*lq + r, query lr):
+//                 a lane owns ONE query and 8 of a step's 32 keys;
+//   softmax       the row maximum is 7 in-lane max + 2 cross-lane exchanges (the 4 lanes of a
+//                 query), one running maximum / sum / rescale factor per lane;
+//   O^T += V^T P^T  the exponentiated accumulators, packed to bf16, ARE the B operand
+//                 (lane: query lr, k-slots 8*lq ..+8) once the k dimension is read as the
+//                 permutation slot(8*q + 4*b + j) = key 16*b + 4*q + j; V^T is staged into LDS
+//                 with its columns in that slot order and read as the A operand.
+// The output accumulator lane holds O[query lr][dims 16*nt + 4*lq .. +4]: 8-byte stores.
+template <int REP, int QT>
+__device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __restrict__ q, long long q_row_stride, const unsigned short* __restrict__ k_cache,
+                                                        const unsigned short* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
+                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, unsigned short* vt_lds) {
   constexpr int HD = 128, BS = 16, KSTEP = 32, VT_STRIDE = 40;  // 80-byte rows: 16-byte aligned fragments
   constexpr int HPW = (REP + 3) / 4;                           // query heads per wave
-  __shared__ __attribute__((aligned(16))) unsigned short vt_lds[HD * VT_STRIDE];        // V^T [dim][key]
-  __shared__ __attribute__((aligned(16))) unsigned short p_lds[4][HPW][16 * KSTEP];     // P [query][key] per wave and head
-  // grid = (kv heads, tiles): consecutive workgroup ids differ in the kv head, so with the
-  // round-robin placement of workgroups on the 8 XCDs every tile of kv head g (when nkv is a
-  // multiple of 8) runs on XCD g % 8 and that head's K/V stay in ONE XCD's L2
-  const int g = blockIdx.x, tile = blockIdx.y;
-  const int n_q = tile_n[tile];
-  if (n_q <= 0) return;
-  const int row0 = tile_row0[tile], pos0 = tile_pos0[tile];
-  const int* bt = block_tables + (long long)tile_seq[tile] * max_blocks_per_seq;
+  const int g = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
   const int last_key = pos0 + n_q - 1;  // highest key index any query of the tile may see
 
-  // Q fragments: A lane = Q[query lr][dims 32*ks + 8*lq .. +8]
-  mfma_ab qa[HPW][4];
-  const int qrow = row0 + (lr < n_q ? lr : n_q - 1);
+  // Q fragments: lane = Q[query lr][dims 32*ks + 8*lq .. +8]
+  mfma_ab qa[QT][HPW][4];
 #pragma unroll
-  for (int hh = 0; hh < HPW; ++hh) {
-    const int h = wave + 4 * hh;
-    if (h < REP) {
-      const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + h) * HD + lq * 8;
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = 16 * qt + lr;
+    const int qrow = row0 + (qi < n_q ? qi : n_q - 1);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qa[hh][ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 32);
+    for (int hh = 0; hh < HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h < REP) {
+        const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + h) * HD + lq * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qa[qt][hh][ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 32);
+      }
     }
   }
-  mfma_cd o[HPW][8];
-  float m_run[HPW][4], l_run[HPW][4];
+  mfma_cd o[QT][HPW][8];
+  float m_run[QT][HPW], l_run[QT][HPW];
 #pragma unroll
-  for (int hh = 0; hh < HPW; ++hh) {
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { m_run[hh][r] = -1e30f; l_run[hh][r] = 0.f; }
+    for (int hh = 0; hh < HPW; ++hh) {
+      m_run[qt][hh] = -1e30f;
+      l_run[qt][hh] = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) o[hh][nt] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
-  }
-  // V staging role: key = tid & 31, 16 dims starting at (tid >> 5) * 16
+      for (int nt = 0; nt < 8; ++nt) o[qt][hh][nt] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
+    }
+  // V staging role: key = tid & 31 (column = its k-slot), 16 dims starting at (tid >> 5) * 16
   const int sv_key = tid & 31, sv_d0 = (tid >> 5) << 4;
+  const int sv_col = ((sv_key & 15) >> 2) * 8 + (sv_key >> 4) * 4 + (sv_key & 3);
 
-  // K fragments (B lane = K[key lr][dims 32*ks + 8*lq .. +8]) for the two 16-key blocks of a
+  // K fragments (lane = K[key lr][dims 32*ks + 8*lq .. +8]) for the two 16-key blocks of a
   // step and this thread's share of the V rows, loaded ONE STEP AHEAD: the block-table lookup
-  // and the cache reads of step i+1 are in flight while step i computes (a step is ~100 MFMA
-  // cycles per wave; an unhidden L2 / HBM round trip per step cost 40x that).
+  // and the cache reads of step i+1 are in flight while step i computes.
   mfma_ab kf[2][4], kf_n[2][4];
   bf16x8 v0, v1, v0_n, v1_n;
   // The block-table entries of a step's two 16-key blocks are fetched one step earlier still,
@@ -599,79 +608,74 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
     // would leave the in-order load counter unknown at the join and force a full drain there
     KV_LOAD_STEP(kb + KSTEP, blk0, blk1, kf_n, v0_n, v1_n);
     BT_LOAD(kb + 2 * KSTEP, blk0, blk1);
-    // ---- stage V^T for keys kb .. kb+31
+    // ---- stage V^T for keys kb .. kb+31, columns in k-slot order
     __syncthreads();  // every wave is done with the previous step's V^T
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      vt_lds[(sv_d0 + j) * VT_STRIDE + sv_key] = v0[j];
-      vt_lds[(sv_d0 + 8 + j) * VT_STRIDE + sv_key] = v1[j];
+      vt_lds[(sv_d0 + j) * VT_STRIDE + sv_col] = v0[j];
+      vt_lds[(sv_d0 + 8 + j) * VT_STRIDE + sv_col] = v1[j];
     }
     __syncthreads();  // V^T is staged
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh) {
       const int h = wave + 4 * hh;
       if (h >= REP) continue;
-      // ---- S = Q K^T for 2 x 16 keys
-      mfma_cd sacc[2];
+      mfma_ab pb[QT];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        sacc[b] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < QT; ++qt) {
+        // ---- S^T = K Q^T for 2 x 16 keys: st[b][r] = score(key kb + 16*b + 4*lq + r, query 16*qt + lr)
+        mfma_cd st[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) sacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[hh][ks], kf[b][ks], sacc[b], 0, 0, 0);
-      }
-      // ---- causal mask + online softmax; this lane: queries 4*lq + r, keys kb + 16*b + lr.
-      // The loop is VALU-bound (16 MFMAs against hundreds of vector ops per step), so: the
-      // mask only on steps that reach the diagonal, row maxima over the 16 key lanes by DPP
-      // (quad swaps + half-row / row mirror: 4 cross-lane ops, no LDS round trip), the row sum
-      // kept per lane and reduced once after the loop, hardware bf16 conversion for P, and
-      // the rescale of O only when some row's maximum moved.
-      float p[2][4], corr[4];
-      const bool diag = kb + KSTEP - 1 > pos0;  // some key of the step may be masked for some query
-      bool moved = false;
+        for (int b = 0; b < 2; ++b) {
+          st[b] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s0 = sacc[0][r] * scale_log2e, s1 = sacc[1][r] * scale_log2e;
-        if (diag) {
-          const int qpos = pos0 + 4 * lq + r;
-          s0 = (kb + lr <= qpos) ? s0 : -1e30f;
-          s1 = (kb + 16 + lr <= qpos) ? s1 : -1e30f;
+          for (int ks = 0; ks < 4; ++ks) st[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[b][ks], qa[qt][hh][ks], st[b], 0, 0, 0);
         }
-        float mx = fmaxf(s0, s1);
-        mx = fmaxf(mx, dpp_f32<0xB1>(mx));   // quad_perm [1,0,3,2]
-        mx = fmaxf(mx, dpp_f32<0x4E>(mx));   // quad_perm [2,3,0,1]
-        mx = fmaxf(mx, dpp_f32<0x141>(mx));  // row_half_mirror
-        mx = fmaxf(mx, dpp_f32<0x140>(mx));  // row_mirror
-        const float m_new = fmaxf(m_run[hh][r], mx);
-        p[0][r] = exp2f(s0 - m_new);
-        p[1][r] = exp2f(s1 - m_new);
-        moved |= m_new != m_run[hh][r];
-        corr[r] = exp2f(m_run[hh][r] - m_new);
-        l_run[hh][r] = l_run[hh][r] * corr[r] + p[0][r] + p[1][r];  // this lane's keys only
-        m_run[hh][r] = m_new;
-      }
-      // ---- P -> LDS [query][key] (bf16), then back as an A operand
-      unsigned short* pw = p_lds[wave][hh];
+        // ---- causal mask (only on steps that reach the diagonal) + online softmax
+        float sc[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pw[(4 * lq + r) * KSTEP + lr] = __builtin_bit_cast(unsigned short, (__bf16)p[0][r]);
-        pw[(4 * lq + r) * KSTEP + 16 + lr] = __builtin_bit_cast(unsigned short, (__bf16)p[1][r]);
-      }
-      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
+          for (int r = 0; r < 4; ++r) sc[4 * b + r] = st[b][r] * scale_log2e;
+        if (kb + KSTEP - 1 > pos0 + 16 * qt) {
+          const int lim = pos0 + 16 * qt + lr - kb - 4 * lq;  // key offset 16*b + r is visible iff <= lim
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[hh][nt][r] *= corr[r];
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[4 * b + r] = (16 * b + r <= lim) ? sc[4 * b + r] : -1e30f;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));  // the 4 lanes of a query
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_old = m_run[qt][hh];
+        const float m_new = fmaxf(m_old, mx);
+        float pr[8], psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pr[j] = exp2f(sc[j] - m_new);
+          psum += pr[j];
+        }
+        const float corr = exp2f(m_old - m_new);
+        l_run[qt][hh] = l_run[qt][hh] * corr + psum;  // this lane's keys only; folded after the loop
+        m_run[qt][hh] = m_new;
+        // ---- P^T as the B operand, straight from the accumulator layout (hardware bf16 conversion)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[qt][j] = (__bf16)pr[j];
+        if (__builtin_amdgcn_ballot_w64(m_new != m_old) != 0) {  // rescale O only when some query's maximum moved
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[qt][hh][nt][r] *= corr;
+        }
       }
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
-      __builtin_amdgcn_wave_barrier();
-      const mfma_ab pa = *reinterpret_cast<const mfma_ab*>(pw + lr * KSTEP + lq * 8);
-      // ---- O = O * corr + P V   (B lane = V^T[dim 16*nt + lr][keys 8*lq .. +8])
+      // ---- O^T += V^T P^T   (A lane = V^T[dim 16*nt + lr][k-slots 8*lq .. +8]): one V^T
+      // fragment read serves every query tile
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-        const mfma_ab vb = *reinterpret_cast<const mfma_ab*>(vt_lds + (nt * 16 + lr) * VT_STRIDE + lq * 8);
-        o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[hh][nt], 0, 0, 0);
+        const mfma_ab va = *reinterpret_cast<const mfma_ab*>(vt_lds + (nt * 16 + lr) * VT_STRIDE + lq * 8);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qt], o[qt][hh][nt], 0, 0, 0);
       }
-      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -682,25 +686,68 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const unsigned s
   }
 #undef KV_LOAD_STEP
 #undef BT_LOAD
-  // ---- normalise and store: lane holds O[query 4*lq + r][dim 16*nt + lr]
+  // ---- normalise and store: lane holds O[query 16*qt + lr][dims 16*nt + 4*lq + r]
 #pragma unroll
-  for (int hh = 0; hh < HPW; ++hh) {
-    const int h = wave + 4 * hh;
-    if (h >= REP) continue;
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qi = 4 * lq + r;
-      float l = l_run[hh][r];  // per-lane partial sums: fold the 16 key lanes of the row
-      l += dpp_f32<0xB1>(l);
-      l += dpp_f32<0x4E>(l);
-      l += dpp_f32<0x141>(l);
-      l += dpp_f32<0x140>(l);
+    for (int hh = 0; hh < HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h >= REP) continue;
+      float l = l_run[qt][hh];  // per-lane partial sums: fold the 4 lanes of the query
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const int qi = 16 * qt + lr;
       if (qi >= n_q) continue;
       const float inv = l > 0.f ? 1.f / l : 0.f;
-      unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + lr;
+      unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + 4 * lq;
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) op[nt * 16] = f2bf(o[hh][nt][r] * inv);
+      for (int nt = 0; nt < 8; ++nt) {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+        us4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = f2bf(o[qt][hh][nt][r] * inv);
+        *reinterpret_cast<us4*>(op + nt * 16) = w;
+      }
     }
+}
+
+// grid = (kv heads, tile groups): consecutive workgroup ids differ in the kv head, so with the
+// round-robin placement of workgroups on the 8 XCDs every tile of kv head g (when nkv is a
+// multiple of 8) runs on XCD g % 8 and that head's K/V stay in ONE XCD's L2.  A workgroup owns
+// QT consecutive entries of the tile arrays: when they are consecutive tiles of one chunk
+// (the usual case: the host lists a chunk's tiles in order) they share one pass over the keys,
+// otherwise each gets a pass of its own.
+template <int REP, int QT>
+__global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
+                                                                const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
+                                                                const int* __restrict__ block_tables, int max_blocks_per_seq,
+                                                                const int* __restrict__ tile_row0, const int* __restrict__ tile_n,
+                                                                const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq, int n_tiles,
+                                                                unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
+  constexpr int HD = 128, VT_STRIDE = 40;
+  __shared__ __attribute__((aligned(16))) unsigned short vt_lds[HD * VT_STRIDE];  // V^T [dim][k-slot]
+  const int t0 = blockIdx.y * QT;
+  if constexpr (QT == 2) {
+    const int t1 = t0 + 1;
+    const int n0 = tile_n[t0], n1 = t1 < n_tiles ? tile_n[t1] : 0;
+    if (n0 == 16 && n1 > 0 && tile_seq[t1] == tile_seq[t0] && tile_pos0[t1] == tile_pos0[t0] + 16 && tile_row0[t1] == tile_row0[t0] + 16) {
+      prefill_attention_tiles<REP, 2>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
+                                      16 + n1, out, nh, nkv, scale_log2e, vt_lds);
+      return;
+    }
+    if (n0 > 0)
+      prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
+                                      out, nh, nkv, scale_log2e, vt_lds);
+    if (n1 > 0) {
+      __syncthreads();  // the first pass is done with the LDS tiles
+      prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t1] * max_blocks_per_seq, tile_row0[t1], tile_pos0[t1], n1,
+                                      out, nh, nkv, scale_log2e, vt_lds);
+    }
+  } else {
+    const int n0 = tile_n[t0];
+    if (n0 > 0)
+      prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
+                                      out, nh, nkv, scale_log2e, vt_lds);
   }
 }
 
@@ -1208,10 +1255,20 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   if (hd != 128 || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
-  dim3 grid(nkv, n_tiles), block(256);
-#define KV_LAUNCH(R)                                                                                                                              \
-  hipLaunchKernelGGL(prefill_attention_kernel<R>, grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
-                     (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, (unsigned short*)out, nh, nkv, sl)
+  // two tiles per workgroup where one wave owns one query head (its registers hold both tiles)
+  // and the halved grid still fills the chip several times over
+  const int qt = (rep <= 4 && (long long)nkv * n_tiles >= 512) ? 2 : 1;
+  dim3 grid(nkv, (n_tiles + qt - 1) / qt), block(256);
+#define KV_LAUNCH_Q(R, Q)                                                                                                                                  \
+  hipLaunchKernelGGL((prefill_attention_kernel<R, Q>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache,      \
+                     (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, n_tiles, (unsigned short*)out, \
+                     nh, nkv, sl)
+#define KV_LAUNCH(R)                          \
+  if (qt == 2) {                              \
+    KV_LAUNCH_Q(R, ((R) <= 4 ? 2 : 1));       \
+  } else {                                    \
+    KV_LAUNCH_Q(R, 1);                        \
+  }
   switch (rep) {
     case 1: KV_LAUNCH(1); break;
     case 2: KV_LAUNCH(2); break;
@@ -1223,6 +1280,7 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
     default: return -1;
   }
 #undef KV_LAUNCH
+#undef KV_LAUNCH_Q
   return (int)hipGetLastError();
 }
 
