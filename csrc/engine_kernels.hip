@@ -497,15 +497,12 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
 // Tiled (flash-style) causal attention for prompt chunks on the paged cache, on MFMA.
 // paged_attention_kernel gives every query token its own workgroup and re-reads the whole
 // prefix per token: fine for decode, quadratic L2 traffic for a prompt.  Here one workgroup
-// serves a tile of 16 consecutive query tokens of ONE chunk for one kv head (all REP query
-// heads of the group: wave w owns heads w, w+4, ...), walking the keys 32 at a time:
-//   S = Q K^T   mfma_f32_16x16x32_bf16, A = Q rows (registers, loaded once), B = K rows read
-//               straight from the paged cache (a lane's 8 dims of one key are 16 contiguous
-//               bytes: no staging needed);
-//   softmax     online, in the accumulator layout (lane l, reg r = query 4*(l>>4)+r, key l&15);
-//   O += P V    P goes through a per-wave LDS tile to become an A operand; V^T is the B
-//               operand, so the workgroup stages the 32 value rows once per step into LDS
-//               TRANSPOSED ([dim][key]), shared by all heads of the group.
+// serves one or two tiles of 16 consecutive query tokens of ONE chunk for one kv head (all REP
+// query heads of the group: wave w owns heads w, w+4, ...), walking the keys 32 at a time with
+// mfma_f32_16x16x32_bf16; K rows are read straight from the paged cache (a lane's 8 dims of
+// one key are 16 contiguous bytes: no staging needed), the 32 value rows of a step are staged
+// once per workgroup into LDS TRANSPOSED ([dim][key slot]) and shared by all heads.  The
+// operand roles are described at prefill_attention_tiles.
 // Tiles are described by host-staged arrays (first token row, valid queries, first position,
 // block-table row); tile_n == 0 marks an unused tile.  K/V of the chunk's own tokens must be
 // in the cache already (rope_kv_write runs first).  head_dim 128, block_size 16.
@@ -530,8 +527,10 @@ typedef __attribute__((ext_vector_type(4))) float mfma_cd;
 template <int REP, int QT>
 __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __restrict__ q, long long q_row_stride, const unsigned short* __restrict__ k_cache,
                                                         const unsigned short* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
-                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, unsigned short* vt_lds) {
+                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, unsigned short* vt_lds,
+                                                        unsigned short* k_lds) {
   constexpr int HD = 128, BS = 16, KSTEP = 32, VT_STRIDE = 40;  // 80-byte rows: 16-byte aligned fragments
+  constexpr int K_STRIDE = HD + 8;                             // 272-byte key rows: the 16 key lanes of a fragment read spread over the banks
   constexpr int HPW = (REP + 3) / 4;                           // query heads per wave
   const int g = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -565,57 +564,59 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) o[qt][hh][nt] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
     }
-  // V staging role: key = tid & 31 (column = its k-slot), 16 dims starting at (tid >> 5) * 16
+  // Staging role, the same for K and V: key = tid & 31, 16 dims starting at (tid >> 5) * 16.
+  // The 32 key rows and 32 value rows of a step are read from the cache ONCE per workgroup
+  // (32 bytes of each per thread), one step ahead, and staged into LDS: K row-major (the four
+  // waves read their MFMA fragments from there instead of each fetching the tile from L2),
+  // V transposed with its columns in k-slot order.
   const int sv_key = tid & 31, sv_d0 = (tid >> 5) << 4;
   const int sv_col = ((sv_key & 15) >> 2) * 8 + (sv_key >> 4) * 4 + (sv_key & 3);
-
-  // K fragments (lane = K[key lr][dims 32*ks + 8*lq .. +8]) for the two 16-key blocks of a
-  // step and this thread's share of the V rows, loaded ONE STEP AHEAD: the block-table lookup
-  // and the cache reads of step i+1 are in flight while step i computes.
-  mfma_ab kf[2][4], kf_n[2][4];
-  bf16x8 v0, v1, v0_n, v1_n;
-  // The block-table entries of a step's two 16-key blocks are fetched one step earlier still,
-  // so the dependent lookup -> address -> cache read chain never stalls the loop.  Keys past
-  // the end clamp to the last key (a valid row; masked in the softmax).
-#define BT_LOAD(KB, B0, B1)                                                   \
-  do {                                                                        \
-    const int k0 = (KB) < last_key ? (KB) : last_key;                         \
-    const int k1 = (KB) + 16 < last_key ? (KB) + 16 : last_key;               \
-    B0 = bt[k0 >> 4];                                                         \
-    B1 = bt[k1 >> 4];                                                         \
+  bf16x8 k0, k1, v0, v1, k0_n, k1_n, v0_n, v1_n;
+  // The block-table entry of a step's key is fetched one step earlier still, so the dependent
+  // lookup -> address -> cache read chain never stalls the loop.  Keys past the end clamp to
+  // the last key (a valid row; masked in the softmax).
+#define BT_LOAD(KB, B)                                 \
+  do {                                                 \
+    int key = (KB) + sv_key;                           \
+    if (key > last_key) key = last_key;                \
+    B = bt[key >> 4];                                  \
   } while (0)
-#define KV_LOAD_STEP(KB, B0, B1, KF, V0, V1)                                                                            \
-  do {                                                                                                                  \
-    int vkey = (KB) + sv_key;                                                                                           \
-    if (vkey > last_key) vkey = last_key;                                                                               \
-    const unsigned short* vp = v_cache + (((long long)(sv_key < 16 ? B0 : B1) * nkv + g) * BS + (vkey & 15)) * HD + sv_d0; \
-    V0 = *reinterpret_cast<const bf16x8*>(vp);                                                                          \
-    V1 = *reinterpret_cast<const bf16x8*>(vp + 8);                                                                      \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                     \
-      int key = (KB) + b * 16 + lr;                                                                                     \
-      if (key > last_key) key = last_key;                                                                               \
-      const unsigned short* kp = k_cache + (((long long)(b ? B1 : B0) * nkv + g) * BS + (key & 15)) * HD + lq * 8;       \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) KF[b][ks] = *reinterpret_cast<const mfma_ab*>(kp + ks * 32);     \
-    }                                                                                                                   \
+#define KV_LOAD_STEP(KB, B, K0, K1, V0, V1)                                                   \
+  do {                                                                                        \
+    int key = (KB) + sv_key;                                                                  \
+    if (key > last_key) key = last_key;                                                       \
+    const long long off = (((long long)(B) * nkv + g) * BS + (key & 15)) * HD + sv_d0;        \
+    K0 = *reinterpret_cast<const bf16x8*>(k_cache + off);                                     \
+    K1 = *reinterpret_cast<const bf16x8*>(k_cache + off + 8);                                 \
+    V0 = *reinterpret_cast<const bf16x8*>(v_cache + off);                                     \
+    V1 = *reinterpret_cast<const bf16x8*>(v_cache + off + 8);                                 \
   } while (0)
-  int blk0, blk1;
-  BT_LOAD(0, blk0, blk1);
-  KV_LOAD_STEP(0, blk0, blk1, kf, v0, v1);
-  BT_LOAD(KSTEP, blk0, blk1);
+  int blk;
+  BT_LOAD(0, blk);
+  KV_LOAD_STEP(0, blk, k0, k1, v0, v1);
+  BT_LOAD(KSTEP, blk);
 
   for (int kb = 0; kb <= last_key; kb += KSTEP) {
     // unconditional (past the end the keys clamp to the last one): a branch around the loads
     // would leave the in-order load counter unknown at the join and force a full drain there
-    KV_LOAD_STEP(kb + KSTEP, blk0, blk1, kf_n, v0_n, v1_n);
-    BT_LOAD(kb + 2 * KSTEP, blk0, blk1);
-    // ---- stage V^T for keys kb .. kb+31, columns in k-slot order
-    __syncthreads();  // every wave is done with the previous step's V^T
+    KV_LOAD_STEP(kb + KSTEP, blk, k0_n, k1_n, v0_n, v1_n);
+    BT_LOAD(kb + 2 * KSTEP, blk);
+    // ---- stage K and V^T for keys kb .. kb+31
+    __syncthreads();  // every wave is done with the previous step's tiles
+    *reinterpret_cast<bf16x8*>(k_lds + sv_key * K_STRIDE + sv_d0) = k0;
+    *reinterpret_cast<bf16x8*>(k_lds + sv_key * K_STRIDE + sv_d0 + 8) = k1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       vt_lds[(sv_d0 + j) * VT_STRIDE + sv_col] = v0[j];
       vt_lds[(sv_d0 + 8 + j) * VT_STRIDE + sv_col] = v1[j];
     }
-    __syncthreads();  // V^T is staged
+    __syncthreads();  // the tiles are staged
+    // K fragments: lane = K[key 16*b + lr][dims 32*ks + 8*lq .. +8]
+    mfma_ab kf[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = *reinterpret_cast<const mfma_ab*>(k_lds + (16 * b + lr) * K_STRIDE + ks * 32 + lq * 8);
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh) {
       const int h = wave + 4 * hh;
@@ -677,10 +678,8 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
         for (int qt = 0; qt < QT; ++qt) o[qt][hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qt], o[qt][hh][nt], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = kf_n[b][ks];
+    k0 = k0_n;
+    k1 = k1_n;
     v0 = v0_n;
     v1 = v1_n;
   }
@@ -726,28 +725,30 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
                                                                 unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
   constexpr int HD = 128, VT_STRIDE = 40;
   __shared__ __attribute__((aligned(16))) unsigned short vt_lds[HD * VT_STRIDE];  // V^T [dim][k-slot]
-  const int t0 = blockIdx.y * QT;
+  __shared__ __attribute__((aligned(16))) unsigned short k_lds[32 * (HD + 8)];    // K [key][dim], padded rows
+  // later tiles of a chunk see more keys: hand them out first, so the longest passes do not start last
+  const int t0 = (gridDim.y - 1 - blockIdx.y) * QT;
   if constexpr (QT == 2) {
     const int t1 = t0 + 1;
     const int n0 = tile_n[t0], n1 = t1 < n_tiles ? tile_n[t1] : 0;
     if (n0 == 16 && n1 > 0 && tile_seq[t1] == tile_seq[t0] && tile_pos0[t1] == tile_pos0[t0] + 16 && tile_row0[t1] == tile_row0[t0] + 16) {
       prefill_attention_tiles<REP, 2>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
-                                      16 + n1, out, nh, nkv, scale_log2e, vt_lds);
+                                      16 + n1, out, nh, nkv, scale_log2e, vt_lds, k_lds);
       return;
     }
     if (n0 > 0)
       prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
-                                      out, nh, nkv, scale_log2e, vt_lds);
+                                      out, nh, nkv, scale_log2e, vt_lds, k_lds);
     if (n1 > 0) {
       __syncthreads();  // the first pass is done with the LDS tiles
       prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t1] * max_blocks_per_seq, tile_row0[t1], tile_pos0[t1], n1,
-                                      out, nh, nkv, scale_log2e, vt_lds);
+                                      out, nh, nkv, scale_log2e, vt_lds, k_lds);
     }
   } else {
     const int n0 = tile_n[t0];
     if (n0 > 0)
       prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
-                                      out, nh, nkv, scale_log2e, vt_lds);
+                                      out, nh, nkv, scale_log2e, vt_lds, k_lds);
   }
 }
 
