@@ -290,6 +290,25 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
   }
 }
 
+// All-reduce over the 4 lanes {l, l^16, l^32, l^48} in the VALU: v_permlane16_swap exchanges the
+// odd 16-lane rows of one register with the even rows of another, v_permlane32_swap the upper
+// half of one with the lower half of the other; fed the same value twice they leave a pair
+// (x[l], x[l^16]) resp. (x[l], x[l^32]) in every lane — no LDS crossbar round trip.
+__device__ inline float quad_rows_max(float x) {
+  unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ inline float quad_rows_sum(float x) {
+  unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // packed bf16 pairs, the operand type of v_dot2_f32_bf16
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 struct bf16x2x4 { bf16x2 p[4]; };
@@ -591,32 +610,46 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
     V0 = *reinterpret_cast<const bf16x8*>(v_cache + off);                                     \
     V1 = *reinterpret_cast<const bf16x8*>(v_cache + off + 8);                                 \
   } while (0)
+  // Two LDS buffers: the tiles of step i+1 are written while step i computes, so a step needs
+  // ONE workgroup barrier (tiles of i+1 staged, everyone done with those of i).
+  constexpr int VT_TILE = HD * VT_STRIDE, K_TILE = KSTEP * K_STRIDE;
+#define STAGE_TILES(BUF)                                                                         \
+  do {                                                                                           \
+    unsigned short* kd = k_lds + (BUF) * K_TILE + sv_key * K_STRIDE + sv_d0;                      \
+    *reinterpret_cast<bf16x8*>(kd) = k0;                                                         \
+    *reinterpret_cast<bf16x8*>(kd + 8) = k1;                                                     \
+    unsigned short* vd = vt_lds + (BUF) * VT_TILE + sv_d0 * VT_STRIDE + sv_col;                   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                              \
+      vd[j * VT_STRIDE] = v0[j];                                                                 \
+      vd[(8 + j) * VT_STRIDE] = v1[j];                                                           \
+    }                                                                                            \
+  } while (0)
   int blk;
   BT_LOAD(0, blk);
   KV_LOAD_STEP(0, blk, k0, k1, v0, v1);
   BT_LOAD(KSTEP, blk);
+  STAGE_TILES(0);
+  KV_LOAD_STEP(KSTEP, blk, k0, k1, v0, v1);
+  BT_LOAD(2 * KSTEP, blk);
+  __syncthreads();
 
-  for (int kb = 0; kb <= last_key; kb += KSTEP) {
+  int buf = 0;
+  for (int kb = 0; kb <= last_key; kb += KSTEP, buf ^= 1) {
     // unconditional (past the end the keys clamp to the last one): a branch around the loads
     // would leave the in-order load counter unknown at the join and force a full drain there
-    KV_LOAD_STEP(kb + KSTEP, blk, k0_n, k1_n, v0_n, v1_n);
-    BT_LOAD(kb + 2 * KSTEP, blk);
-    // ---- stage K and V^T for keys kb .. kb+31
-    __syncthreads();  // every wave is done with the previous step's tiles
-    *reinterpret_cast<bf16x8*>(k_lds + sv_key * K_STRIDE + sv_d0) = k0;
-    *reinterpret_cast<bf16x8*>(k_lds + sv_key * K_STRIDE + sv_d0 + 8) = k1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      vt_lds[(sv_d0 + j) * VT_STRIDE + sv_col] = v0[j];
-      vt_lds[(sv_d0 + 8 + j) * VT_STRIDE + sv_col] = v1[j];
-    }
-    __syncthreads();  // the tiles are staged
+    // registers hold the rows of step kb + KSTEP (loaded a step ago): into the other buffer,
+    // then start the loads of the step after that
+    STAGE_TILES(buf ^ 1);
+    KV_LOAD_STEP(kb + 2 * KSTEP, blk, k0_n, k1_n, v0_n, v1_n);
+    BT_LOAD(kb + 3 * KSTEP, blk);
+    const unsigned short* kt = k_lds + buf * K_TILE;
+    const unsigned short* vt = vt_lds + buf * VT_TILE;
     // K fragments: lane = K[key 16*b + lr][dims 32*ks + 8*lq .. +8]
     mfma_ab kf[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = *reinterpret_cast<const mfma_ab*>(k_lds + (16 * b + lr) * K_STRIDE + ks * 32 + lq * 8);
+      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = *reinterpret_cast<const mfma_ab*>(kt + (16 * b + lr) * K_STRIDE + ks * 32 + lq * 8);
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh) {
       const int h = wave + 4 * hh;
@@ -633,11 +666,13 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
           for (int ks = 0; ks < 4; ++ks) st[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[b][ks], qa[qt][hh][ks], st[b], 0, 0, 0);
         }
         // ---- causal mask (only on steps that reach the diagonal) + online softmax
+        // scores stay unscaled: scale * log2(e) > 0 commutes with the maximum and folds into
+        // the exponent's fma
         float sc[8];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[4 * b + r] = st[b][r] * scale_log2e;
+          for (int r = 0; r < 4; ++r) sc[4 * b + r] = st[b][r];
         if (kb + KSTEP - 1 > pos0 + 16 * qt) {
           const int lim = pos0 + 16 * qt + lr - kb - 4 * lq;  // key offset 16*b + r is visible iff <= lim
 #pragma unroll
@@ -646,17 +681,19 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
             for (int r = 0; r < 4; ++r) sc[4 * b + r] = (16 * b + r <= lim) ? sc[4 * b + r] : -1e30f;
         }
         float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));  // the 4 lanes of a query
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad_rows_max(mx);  // the 4 lanes of a query
         const float m_old = m_run[qt][hh];
         const float m_new = fmaxf(m_old, mx);
+        // v_exp_f32 as is (arguments <= 0; a result below the normal range flushes to 0, which
+        // is what a softmax weight of 2^-126 is worth)
+        const float m_scaled = m_new * scale_log2e;
         float pr[8], psum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          pr[j] = exp2f(sc[j] - m_new);
+          pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], scale_log2e, -m_scaled));
           psum += pr[j];
         }
-        const float corr = exp2f(m_old - m_new);
+        const float corr = __builtin_amdgcn_exp2f((m_old - m_new) * scale_log2e);
         l_run[qt][hh] = l_run[qt][hh] * corr + psum;  // this lane's keys only; folded after the loop
         m_run[qt][hh] = m_new;
         // ---- P^T as the B operand, straight from the accumulator layout (hardware bf16 conversion)
@@ -673,7 +710,7 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
       // fragment read serves every query tile
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-        const mfma_ab va = *reinterpret_cast<const mfma_ab*>(vt_lds + (nt * 16 + lr) * VT_STRIDE + lq * 8);
+        const mfma_ab va = *reinterpret_cast<const mfma_ab*>(vt + (nt * 16 + lr) * VT_STRIDE + lq * 8);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qt], o[qt][hh][nt], 0, 0, 0);
       }
@@ -682,7 +719,9 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
     k1 = k1_n;
     v0 = v0_n;
     v1 = v1_n;
+    __syncthreads();  // the next step's tiles are staged, and every wave is done with this step's
   }
+#undef STAGE_TILES
 #undef KV_LOAD_STEP
 #undef BT_LOAD
   // ---- normalise and store: lane holds O[query 16*qt + lr][dims 16*nt + 4*lq + r]
@@ -693,8 +732,7 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
       const int h = wave + 4 * hh;
       if (h >= REP) continue;
       float l = l_run[qt][hh];  // per-lane partial sums: fold the 4 lanes of the query
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      l = quad_rows_sum(l);
       const int qi = 16 * qt + lr;
       if (qi >= n_q) continue;
       const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -724,8 +762,8 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
                                                                 const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq, int n_tiles,
                                                                 unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
   constexpr int HD = 128, VT_STRIDE = 40;
-  __shared__ __attribute__((aligned(16))) unsigned short vt_lds[HD * VT_STRIDE];  // V^T [dim][k-slot]
-  __shared__ __attribute__((aligned(16))) unsigned short k_lds[32 * (HD + 8)];    // K [key][dim], padded rows
+  __shared__ __attribute__((aligned(16))) unsigned short vt_lds[2 * HD * VT_STRIDE];  // V^T [buffer][dim][k-slot]
+  __shared__ __attribute__((aligned(16))) unsigned short k_lds[2 * 32 * (HD + 8)];    // K [buffer][key][dim], padded rows
   // later tiles of a chunk see more keys: hand them out first, so the longest passes do not start last
   const int t0 = (gridDim.y - 1 - blockIdx.y) * QT;
   if constexpr (QT == 2) {
