@@ -438,16 +438,14 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
       float mx = s[h];
       mx = fmaxf(mx, dpp_f32<0x141>(mx));
       mx = fmaxf(mx, dpp_f32<0x140>(mx));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = quad_rows_max(mx);
       const float m_new = fmaxf(m_run[h], mx);
-      const float p = exp2f(s[h] - m_new);
+      const float p = __builtin_amdgcn_exp2f(s[h] - m_new);
       float ps = p;
       ps += dpp_f32<0x141>(ps);
       ps += dpp_f32<0x140>(ps);
-      ps += __shfl_xor(ps, 16, 64);
-      ps += __shfl_xor(ps, 32, 64);
-      const float corr = exp2f(m_run[h] - m_new);
+      ps = quad_rows_sum(ps);
+      const float corr = __builtin_amdgcn_exp2f(m_run[h] - m_new);
       l_run[h] = l_run[h] * corr + ps;
       m_run[h] = m_new;
 #pragma unroll
@@ -504,7 +502,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
     float num = 0.f, den = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) {
-      const float c = exp2f(m_lds[w][h] - m);
+      const float c = __builtin_amdgcn_exp2f(m_lds[w][h] - m);
       num += o_lds[w][h][d] * c;
       den += l_lds[w][h] * c;
     }
@@ -985,16 +983,14 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       float mx = s[h];
       mx = fmaxf(mx, dpp_f32<0x141>(mx));
       mx = fmaxf(mx, dpp_f32<0x140>(mx));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = quad_rows_max(mx);
       const float m_new = fmaxf(m_run[h], mx);
-      const float p = exp2f(s[h] - m_new);
+      const float p = __builtin_amdgcn_exp2f(s[h] - m_new);
       float ps = p;
       ps += dpp_f32<0x141>(ps);
       ps += dpp_f32<0x140>(ps);
-      ps += __shfl_xor(ps, 16, 64);
-      ps += __shfl_xor(ps, 32, 64);
-      const float corr = exp2f(m_run[h] - m_new);
+      ps = quad_rows_sum(ps);
+      const float corr = __builtin_amdgcn_exp2f(m_run[h] - m_new);
       l_run[h] = l_run[h] * corr + ps;
       m_run[h] = m_new;
 #pragma unroll
@@ -1035,8 +1031,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       d += dpp_f32<0x4E>(d);
       d *= scale_log2e;
       const float m_new = fmaxf(m_run[h], d);
-      const float p = exp2f(d - m_new);
-      const float corr = exp2f(m_run[h] - m_new);
+      const float p = __builtin_amdgcn_exp2f(d - m_new);
+      const float corr = __builtin_amdgcn_exp2f(m_run[h] - m_new);
       l_run[h] = l_run[h] * corr + p;
       m_run[h] = m_new;
 #pragma unroll
@@ -1063,7 +1059,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     float num = 0.f, den = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) {
-      const float c = exp2f(m_lds[w][h] - m);
+      const float c = __builtin_amdgcn_exp2f(m_lds[w][h] - m);
       num += (o_lds[w][0][h][d] + o_lds[w][1][h][d] + o_lds[w][2][h][d] + o_lds[w][3][h][d]) * c;
       den += l_lds[w][h] * c;
     }
