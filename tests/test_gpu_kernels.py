@@ -631,21 +631,23 @@ def _tp_one_rank_body(graphs):
     assert eng.generate(prompts, params) == want
 
 
-@pytest.mark.parametrize("rep", [1, 2, 3, 4, 7, 8])
-def test_prefill_attention_tiles_match_reference(rep):
+@pytest.mark.parametrize("rep,nkv,chunks", [(r, 2, [(0, 0, 40), (1, 37, 23), (2, 0, 5), (3, 300, 33)]) for r in (1, 2, 3, 4, 7, 8)]
+                         + [(r, 8, [(0, 0, 600), (1, 37, 250), (2, 0, 5), (3, 300, 200)]) for r in (1, 4, 8)])
+def test_prefill_attention_tiles_match_reference(rep, nkv, chunks):
     """The tiled MFMA prompt-attention kernel against the per-token reference: chunks that
     start at position 0, mid-block continuations of an earlier chunk, short chunks, and rows
-    that belong to no tile (left untouched)."""
+    that belong to no tile (left untouched).  The larger case (8 kv heads, 68 tiles) reaches
+    the two-tiles-per-workgroup path, with pairs that straddle chunk boundaries, a partial
+    second tile and an odd tile count."""
     from kvmini.ops import hip_ops, torch_ops
 
     torch.manual_seed(11)
-    nkv, hd, bs, nb = 2, 128, 16, 200
+    hd, bs, nb = 128, 16, 200
     nh = nkv * rep
-    n_seqs, max_blocks = 4, 24
+    n_seqs, max_blocks = 4, 40
     kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
     bt = torch.randperm(nb, device=_dev())[: n_seqs * max_blocks].view(n_seqs, max_blocks).int()
-    # (block-table row, first position, tokens): flat rows in this order, one decode row between
-    chunks = [(0, 0, 40), (1, 37, 23), (2, 0, 5), (3, 300, 33)]
+    # chunks: (block-table row, first position, tokens): flat rows in this order, one decode row between
     rows, tok_seq, ctx, tiles = 0, [], [], []
     for k, (seq, p0, n) in enumerate(chunks):
         if k == 2:  # a row owned by nobody: must keep its sentinel value
