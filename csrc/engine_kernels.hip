@@ -1256,13 +1256,19 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
   if ((hd != 128 && hd != 64) || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
-  // 8 waves per workgroup (twice the K/V blocks in flight) wherever the head group's registers
-  // fit 2 waves per SIMD
-  dim3 grid(T, nkv), block(rep <= 4 ? 512 : 256);
+  // 8 waves per workgroup (twice the K/V blocks in flight) where the head group's registers fit
+  // 2 waves per SIMD and the grid does not fill the 256 CUs on its own
+  const bool wide = rep <= 4 && (long long)T * nkv <= 256;
+  dim3 grid(T, nkv), block(wide ? 512 : 256);
 #define KV_LAUNCH_W(R, D, W)                                                                                                                        \
   hipLaunchKernelGGL((paged_attention_kernel<R, D, W>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
                      (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, sl)
-#define KV_LAUNCH(R, D) KV_LAUNCH_W(R, D, ((R) <= 4 ? 8 : 4))
+#define KV_LAUNCH(R, D)                       \
+  if (wide) {                                 \
+    KV_LAUNCH_W(R, D, ((R) <= 4 ? 8 : 4));    \
+  } else {                                    \
+    KV_LAUNCH_W(R, D, 4);                     \
+  }
 #define KV_BY_REP(D)              \
   switch (rep) {                  \
     case 1: KV_LAUNCH(1, D); break; \

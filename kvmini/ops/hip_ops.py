@@ -428,9 +428,19 @@ def supports_fused_decode_attention(qkv: Any, n_heads: int, k_cache: torch.Tenso
     return isinstance(qkv, Partial) and hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in GQA_RATIOS
 
 
-# Waves per workgroup of the fused decode attention kernel: every wave keeps one 16-token K/V
-# block in flight, so a long context streams at (workgroups x waves x 8 KB) / latency.
-DECODE_ATTENTION_WAVES = int(os.environ.get("KVMINI_DECODE_WAVES", "8"))
+# Waves per workgroup of the fused decode attention kernel: every wave keeps two 16-token K/V
+# blocks in flight, so a long context streams at (workgroups x waves x 16 KB) / latency.  Eight
+# waves when the (tokens x kv heads) grid does not fill the 256 CUs on its own (Llama-3-8B at
+# batch 20: 160 workgroups); with more workgroups than that, two 4-wave workgroups per CU keep
+# as much in flight without the wider merge (Llama-2-7B at batch 10, 320 workgroups: 3.00 vs
+# 3.13 ms per step).  KVMINI_DECODE_WAVES=4|8 pins it.
+DECODE_ATTENTION_WAVES = int(os.environ.get("KVMINI_DECODE_WAVES", "0"))
+
+
+def _decode_attention_waves(tokens: int, n_kv_heads: int) -> int:
+    if DECODE_ATTENTION_WAVES in (4, 8):
+        return DECODE_ATTENTION_WAVES
+    return 8 if tokens * n_kv_heads <= _NUM_CUS else 4
 
 
 def rope_attention_fused(
@@ -453,7 +463,7 @@ def rope_attention_fused(
     t = qkv.slabs.shape[1]
     hd = k_cache.shape[3]
     out = torch.empty((t, n_heads * hd), dtype=torch.bfloat16, device=qkv.slabs.device)
-    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale, DECODE_ATTENTION_WAVES)
+    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale, _decode_attention_waves(t, k_cache.shape[1]))
     return out
 
 

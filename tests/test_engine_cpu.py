@@ -421,6 +421,11 @@ def test_gemm_workgroup_planner_fills_the_cus_evenly():
     for n, k in ((6144, 4096), (4096, 4096), (4096, 14336)):  # the Llama-3-8B projections: one workgroup per CU
         nw, splits, _ = _plan_slabs(n, k)
         assert n // (16 * nw) * splits == 256
+    # decode attention: 8 waves per workgroup only while (tokens x kv heads) leaves CUs idle
+    from kvmini.ops.hip_ops import _decode_attention_waves
+
+    assert _decode_attention_waves(20, 8) == 8 and _decode_attention_waves(32, 8) == 8
+    assert _decode_attention_waves(10, 32) == 4 and _decode_attention_waves(64, 8) == 4
 
 
 def test_unseeded_sampling_rides_the_pipeline():
