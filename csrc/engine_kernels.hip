@@ -6,6 +6,7 @@
 // (8 bf16), math is fp32, wavefronts are 64 lanes, workgroups are 256 threads.
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 namespace {
@@ -1297,8 +1298,12 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
   // two tiles per workgroup where one wave owns one query head (its registers hold both tiles)
-  // and the halved grid still fills the chip several times over
-  const int qt = (rep <= 4 && (long long)nkv * n_tiles >= 512) ? 2 : 1;
+  // and the halved grid still fills the chip several times over.  Head groups of 6-8 already
+  // share every K / V^T fragment between the two heads of a wave; two tiles on top of that need
+  // one wave per SIMD and lose (8 heads per group, 2048 queries x 4096 keys: 691 vs 496 TFLOP/s)
+  // (KVMINI_PREFILL_TILES=1|2 pins the choice, for measurements)
+  static const int pinned = [] { const char* e = getenv("KVMINI_PREFILL_TILES"); return e ? atoi(e) : 0; }();
+  const int qt = rep > 4 ? 1 : (pinned == 1 || pinned == 2 ? pinned : ((long long)nkv * n_tiles >= 512 ? 2 : 1));
   dim3 grid(nkv, (n_tiles + qt - 1) / qt), block(256);
 #define KV_LAUNCH_Q(R, Q)                                                                                                                                  \
   hipLaunchKernelGGL((prefill_attention_kernel<R, Q>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache,      \

@@ -201,7 +201,7 @@ def attn_bench(out):
     from kvmini.ops import hip_ops
 
     dev = torch.device("cuda:0")
-    nh, nkv, hd, bs = 32, 8, 128, 16
+    nh, nkv, hd, bs = int(os.environ.get("ATTN_HEADS", "32")), 8, 128, 16
     nb = 4096 // bs + 8
     kc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
     vc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
@@ -212,7 +212,7 @@ def attn_bench(out):
         tiles = torch.tensor([(off, 16, p0 + off, 0) for off in range(0, n, 16)], device=dev, dtype=torch.int32).T.contiguous()
         t = time_fns({"tiled": lambda: hip_ops.prefill_attention(q, kc, vc, bt, tiles, o, 1 / math.sqrt(hd))}, rounds=10, inner=5)["tiled"]
         flops = 4.0 * hd * nh * sum(p0 + i + 1 for i in range(n))
-        row = {"bench": "prefill_attention", "pos0": p0, "queries": n, "us": round(t, 1), "TFLOPs": round(flops / t / 1e6, 1)}
+        row = {"bench": "prefill_attention", "heads": nh, "pos0": p0, "queries": n, "us": round(t, 1), "TFLOPs": round(flops / t / 1e6, 1)}
         print(json.dumps(row), flush=True)
         out.append(row)
 
