@@ -100,6 +100,8 @@ def main() -> int:
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = rehearsal of the multi-rank flow over gloo with the reference ops (not a benchmark)")
     args = ap.parse_args()
 
+    # the host driver offers dmabuf IPC only: RCCL's peer-memory exchange between the ranks' processes needs this
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -477,6 +477,7 @@ def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
 def init_tensor_parallel(a: argparse.Namespace) -> Any:
     """One process per GPU (torchrun): join the RCCL world, pin this rank to its GPU and
     return the TP process group.  ``--device cpu`` uses gloo (tests)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL's peer-memory exchange needs on hosts without the legacy mode
     import torch
     import torch.distributed as dist
 
