@@ -1349,7 +1349,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
                      (unsigned short*)out, nh, nkv, row_ss, ss_parts, inv_h, eps, sl)
 #define KV_LAUNCH(R)      \
   if (waves == 8) {       \
-    KV_LAUNCH_W(R, 8);    \
+    KV_LAUNCH_W(R, ((R) <= 4 ? 8 : 4)); /* wider head groups exist with 4 waves only */ \
   } else {                \
     KV_LAUNCH_W(R, 4);    \
   }
