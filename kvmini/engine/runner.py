@@ -16,7 +16,6 @@ the partial O-proj / down-proj outputs are summed with an all-reduce
 
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -112,7 +111,7 @@ class ModelRunner:
         self.nh = cfg.num_heads // self.tp_size
         self.nkv = cfg.num_kv_heads // self.tp_size
         self.hd = cfg.head_dim
-        self.scale = 1.0 / math.sqrt(cfg.head_dim)
+        self.scale = cfg.softmax_scale
         self.block_size = rcfg.block_size
         self.max_blocks_per_seq = (rcfg.max_model_len + rcfg.block_size - 1) // rcfg.block_size
         self.cos, self.sin = rope_tables(cfg, rcfg.max_model_len, self.device)

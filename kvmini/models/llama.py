@@ -46,6 +46,13 @@ class LlamaConfig:
     max_position: int = 8192
     bos_token_id: int = 1
     eos_token_id: int = 2
+    # set by pad_head_dim(): the softmax scale and the rotary width of the un-padded heads
+    attn_scale: Optional[float] = None
+    rope_dim: Optional[int] = None
+
+    @property
+    def softmax_scale(self) -> float:
+        return self.attn_scale if self.attn_scale is not None else 1.0 / math.sqrt(self.head_dim)
 
     @property
     def q_size(self) -> int:
@@ -277,9 +284,41 @@ def rope_tables(cfg: LlamaConfig, max_pos: int, device: torch.device | str) -> "
     """cos/sin tables [max_pos, head_dim/2] in fp32 (rotate-half / NeoX pairing:
     element i pairs with i + head_dim/2, as in HF Llama)."""
     half = cfg.head_dim // 2
-    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, half, dtype=torch.float64) / half))
+    real = (cfg.rope_dim or cfg.head_dim) // 2  # padded heads: pairs beyond the real width are (0, 0) and do not turn
+    inv = torch.zeros(half, dtype=torch.float64)
+    inv[:real] = 1.0 / (cfg.rope_theta ** (torch.arange(0, real, dtype=torch.float64) / real))
     ang = torch.arange(max_pos, dtype=torch.float64)[:, None] * inv[None, :]
     return ang.cos().float().to(device), ang.sin().float().to(device)
+
+
+def pad_head_dim(weights: "LlamaWeights", to: int = 128) -> "LlamaWeights":
+    """The same model with every attention head widened to ``to`` dims by zero rows of the
+    Q/K/V projections and zero columns of the output projection — head widths such as 80 or 96
+    then run on the kernels specialised for 128.  The rotate-half halves of a head move to
+    ``[0, hd/2)`` and ``[to/2, to/2 + hd/2)`` so that the pairing ``i <-> i + to/2`` is the
+    original ``i <-> i + hd/2``; scores, softmax scale (``attn_scale``) and outputs are
+    unchanged, the KV cache grows by ``to / hd``."""
+    cfg = weights.cfg
+    hd = cfg.head_dim
+    if hd == to:
+        return weights
+    assert hd < to and hd % 2 == 0 and to % 2 == 0
+    h2, t2 = hd // 2, to // 2
+
+    def widen_rows(w: torch.Tensor) -> torch.Tensor:  # [heads * hd, H] -> [heads * to, H]
+        heads = w.shape[0] // hd
+        src = w.view(heads, hd, w.shape[1])
+        out = torch.zeros((heads, to, w.shape[1]), dtype=w.dtype, device=w.device)
+        out[:, :h2] = src[:, :h2]
+        out[:, t2 : t2 + h2] = src[:, h2:]
+        return out.view(heads * to, w.shape[1])
+
+    layers = []
+    for lw in weights.layers:
+        assert not lw.fp8, "pad before quantising"
+        layers.append(replace(lw, wqkv=widen_rows(lw.wqkv).contiguous(), wo=widen_rows(lw.wo.T.contiguous()).T.contiguous()))
+    new_cfg = replace(cfg, head_dim=to, attn_scale=cfg.softmax_scale, rope_dim=cfg.rope_dim or hd)
+    return replace(weights, cfg=new_cfg, layers=layers)
 
 
 def quantize_fp8_rows(w: torch.Tensor) -> "tuple[torch.Tensor, torch.Tensor]":

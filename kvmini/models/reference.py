@@ -7,7 +7,6 @@ can be checked token-for-token against it.
 
 from __future__ import annotations
 
-import math
 from typing import List
 
 import torch
@@ -49,7 +48,7 @@ def dense_logits(w: LlamaWeights, token_ids: List[int]) -> torch.Tensor:
         rep = nh // nkv
         k = k.repeat_interleave(rep, 1)
         v = v.repeat_interleave(rep, 1)
-        sc = torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(hd)
+        sc = torch.einsum("qhd,khd->hqk", q, k) * cfg.softmax_scale
         sc = sc.masked_fill(~mask[None], float("-inf"))
         a = torch.einsum("hqk,khd->qhd", sc.softmax(-1), v).reshape(t, nh * hd)
         x = x + a @ lw.wo.float().T

@@ -29,6 +29,23 @@ def _engine(**kw):
 PROMPTS = [[1, 5, 9, 33, 47, 100, 21], [1] + list(range(60, 82)), [1, 5, 9, 33, 47, 100, 21, 99, 98]]
 
 
+def test_padded_heads_are_the_same_model():
+    """pad_head_dim: heads widened with zero rows / columns (rotate-half halves moved to the
+    halves of the wider head, softmax scale and rotary width kept) give the same logits, in
+    the dense oracle and through the engine's paged path."""
+    from kvmini.models.llama import pad_head_dim
+    from kvmini.models.reference import dense_logits
+
+    w = random_weights(get_config("tiny"), "cpu", torch.float32, seed=3)  # head_dim 32
+    wp = pad_head_dim(w, 48)
+    assert wp.cfg.head_dim == 48 and wp.cfg.rope_dim == 32 and abs(wp.cfg.softmax_scale - 32 ** -0.5) < 1e-9
+    assert wp.layers[0].wqkv.shape[0] == (4 + 2 * 2) * 48 and wp.layers[0].wo.shape == (128, 4 * 48)
+    a, b = dense_logits(w, PROMPTS[1]), dense_logits(wp, PROMPTS[1])
+    assert (a - b).abs().max().item() < 1e-4
+    eng = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=16, max_model_len=128, num_blocks=64, block_size=4), weights=wp)
+    assert eng.generate([PROMPTS[0]], SamplingParams(max_tokens=8, ignore_eos=True))[0] == dense_greedy(w, PROMPTS[0], 8)
+
+
 def test_engine_matches_dense_reference_with_chunked_prefill_and_prefix_cache():
     eng, w = _engine()
     outs = eng.generate(PROMPTS, SamplingParams(max_tokens=10, ignore_eos=True))

@@ -673,6 +673,32 @@ def test_prefill_attention_tiles_match_reference(rep, nkv, chunks):
     assert (out[~owned] == 7.0).all()
 
 
+def test_engine_pads_unsupported_head_widths_to_128():
+    """A model with 80-dim heads runs on the 128-dim attention kernels (zero-padded heads)
+    and still follows the dense oracle built from the un-padded weights."""
+    from dataclasses import replace
+
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.models.reference import dense_logits
+
+    cfg = replace(get_config("small-hd128"), name="small-hd80", head_dim=80)
+    w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=5)
+    oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=5)
+    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip"), weights=w)
+    assert eng.mcfg.head_dim == 128 and eng.mcfg.rope_dim == 80
+    eng.warmup()
+    prompt = [1] + [(11 * i) % 900 + 20 for i in range(40)]
+    out = eng.generate([prompt, [1, 2, 3]], SamplingParams(max_tokens=6, ignore_eos=True))[0]
+    ids = list(prompt)
+    for tok in out:
+        lg = dense_logits(oracle, ids)[-1]
+        top = lg.max().item()
+        assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05
+        ids.append(tok)
+
+
 @pytest.mark.gpu
 def test_embed_fed_matches_reference_and_pipelined_engine_matches_sync():
     from kvmini.ops import hip_ops, torch_ops
