@@ -173,13 +173,6 @@ class LLMEngine:
                 if ecfg.tail_damping > 0 and ecfg.draft_model and ecfg.draft_model.startswith("self:"):
                     damp = (int(ecfg.draft_model.split(":", 1)[1]), float(ecfg.tail_damping))
                 weights = random_weights(self.mcfg, self.device, dtype, ecfg.seed, ecfg.tp_rank, ecfg.tp_size, tail_damping=damp)
-        if self.device.type == "cuda" and ecfg.kernels != "torch" and weights.cfg.head_dim not in (64, 128) and weights.cfg.head_dim < 128:
-            # head widths the attention kernels are not specialised for (80, 96, ...): zero-pad every
-            # head to 128 instead of dropping to the reference attention path
-            from kvmini.models.llama import pad_head_dim
-
-            weights = pad_head_dim(weights, 128)
-            self.mcfg = weights.cfg
         self.weights = weights
         rcfg = RunnerConfig(
             max_num_seqs=ecfg.max_num_seqs,
@@ -196,6 +189,7 @@ class LLMEngine:
             tp_force_collectives=ecfg.tp_force_collectives,
         )
         self.runner = ModelRunner(weights, rcfg, tp_group)
+        self.weights, self.mcfg = self.runner.w, self.runner.cfg  # the runner may have re-shaped the model (padded heads)
         self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)
         self.scheduler = Scheduler(self.bm, ecfg.max_num_seqs, ecfg.max_batched_tokens, ecfg.max_model_len, self.mcfg.eos_token_id, ecfg.ride_along_limit)
         self.spec = None

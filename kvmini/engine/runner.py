@@ -99,6 +99,13 @@ class ModelRunner:
         # (tests: the RCCL all-reduce and its capture into HIP graphs on a single GPU)
         self.tp_active = tp_group is not None and (weights.tp_size > 1 or rcfg.tp_force_collectives)
         self.ops = select_ops(rcfg.kernels, self.device)
+        if hasattr(self.ops, "prepare_weights") and self.cfg.head_dim not in (64, 128) and self.cfg.head_dim < 128 and not hasattr(weights, "_hip_prepared"):
+            # head widths the attention kernels are not specialised for (80, 96, ...): zero-pad every
+            # head to 128 instead of dropping to the reference attention path
+            from kvmini.models.llama import pad_head_dim
+
+            weights = pad_head_dim(weights, 128)
+            self.w, self.cfg = weights, weights.cfg
         if hasattr(self.ops, "prepare_weights"):
             # one-time re-order of every linear weight into MFMA fragment order
             self.ops.prepare_weights(weights, rcfg.quantization, keep_full=rcfg.prefill_gemm == "library" and rcfg.max_batched_tokens > 64)
