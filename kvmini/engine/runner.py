@@ -106,6 +106,18 @@ class ModelRunner:
 
             weights = pad_head_dim(weights, 128)
             self.w, self.cfg = weights, weights.cfg
+        if hasattr(self.ops, "prepare_weights") and not hasattr(weights, "_hip_prepared"):
+            # query heads per kv head outside the kernels' set (5, 16, ...): store each K/V head
+            # several times, so that the ratio becomes one of the set
+            from kvmini.ops.hip_ops import GQA_RATIOS
+
+            ratio = self.cfg.num_heads // self.cfg.num_kv_heads
+            if ratio not in GQA_RATIOS:
+                from kvmini.models.llama import replicate_kv_heads
+
+                factor = min(f for f in range(2, ratio + 1) if ratio % f == 0 and ratio // f in GQA_RATIOS)
+                weights = replicate_kv_heads(weights, factor)
+                self.w, self.cfg = weights, weights.cfg
         if hasattr(self.ops, "prepare_weights"):
             # one-time re-order of every linear weight into MFMA fragment order
             self.ops.prepare_weights(weights, rcfg.quantization, keep_full=rcfg.prefill_gemm == "library" and rcfg.max_batched_tokens > 64)

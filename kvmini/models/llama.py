@@ -342,3 +342,23 @@ def fake_quantize_fp8(weights: "LlamaWeights") -> None:
             q, scale = quantize_fp8_rows(w)
             setattr(lw, name, (q.float() * scale[:, None]).to(w.dtype))
     weights.quantization = "fp8"
+
+
+def replicate_kv_heads(weights: "LlamaWeights", factor: int) -> "LlamaWeights":
+    """The same model with every K/V head stored ``factor`` times (rows of the K and V
+    projections duplicated), i.e. ``factor`` times fewer query heads per kv head — a grouping
+    ratio the attention kernels are not specialised for (5, 16, ...) becomes one they are, at
+    the price of a ``factor`` times larger KV cache."""
+    cfg = weights.cfg
+    if factor == 1:
+        return weights
+    nh_l, nkv_l, hd = cfg.num_heads // weights.tp_size, cfg.num_kv_heads // weights.tp_size, cfg.head_dim
+    assert (nh_l // nkv_l) % factor == 0
+    layers = []
+    for lw in weights.layers:
+        assert not lw.fp8, "replicate before quantising"
+        q, k, v = lw.wqkv.split((nh_l * hd, nkv_l * hd, nkv_l * hd), 0)
+        k = k.view(nkv_l, 1, hd, -1).expand(nkv_l, factor, hd, k.shape[1]).reshape(nkv_l * factor * hd, -1)
+        v = v.view(nkv_l, 1, hd, -1).expand(nkv_l, factor, hd, v.shape[1]).reshape(nkv_l * factor * hd, -1)
+        layers.append(replace(lw, wqkv=torch.cat((q, k, v), 0).contiguous()))
+    return replace(weights, cfg=replace(cfg, num_kv_heads=cfg.num_kv_heads * factor), layers=layers)

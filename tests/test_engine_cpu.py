@@ -46,6 +46,20 @@ def test_padded_heads_are_the_same_model():
     assert eng.generate([PROMPTS[0]], SamplingParams(max_tokens=8, ignore_eos=True))[0] == dense_greedy(w, PROMPTS[0], 8)
 
 
+def test_replicated_kv_heads_are_the_same_model():
+    """replicate_kv_heads: K/V heads stored twice (2 query heads per kv head become 1) give the
+    same logits and the same greedy continuation through the engine."""
+    from kvmini.models.llama import replicate_kv_heads
+    from kvmini.models.reference import dense_logits
+
+    w = random_weights(get_config("tiny"), "cpu", torch.float32, seed=4)  # 4 query heads, 2 kv heads
+    wr = replicate_kv_heads(w, 2)
+    assert wr.cfg.num_kv_heads == 4 and wr.layers[0].wqkv.shape[0] == (4 + 2 * 4) * 32
+    assert (dense_logits(w, PROMPTS[1]) - dense_logits(wr, PROMPTS[1])).abs().max().item() < 1e-4
+    eng = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=16, max_model_len=128, num_blocks=64, block_size=4), weights=wr)
+    assert eng.generate([PROMPTS[2]], SamplingParams(max_tokens=8, ignore_eos=True))[0] == dense_greedy(w, PROMPTS[2], 8)
+
+
 def test_engine_matches_dense_reference_with_chunked_prefill_and_prefix_cache():
     eng, w = _engine()
     outs = eng.generate(PROMPTS, SamplingParams(max_tokens=10, ignore_eos=True))

@@ -699,6 +699,32 @@ def test_engine_pads_unsupported_head_widths_to_128():
         ids.append(tok)
 
 
+def test_engine_replicates_kv_heads_for_unsupported_grouping():
+    """5 query heads per kv head is outside the attention kernels' set: the runner stores every
+    K/V head 5 times (ratio 1) and the engine still follows the oracle of the original model."""
+    from dataclasses import replace
+
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.models.reference import dense_logits
+
+    cfg = replace(get_config("small-hd128"), name="small-gqa5", num_heads=10, num_kv_heads=2)
+    w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=6)
+    oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=6)
+    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip"), weights=w)
+    assert eng.mcfg.num_kv_heads == 10
+    eng.warmup()
+    prompt = [1] + [(7 * i) % 900 + 20 for i in range(40)]
+    out = eng.generate([prompt, [1, 2, 3]], SamplingParams(max_tokens=6, ignore_eos=True))[0]
+    ids = list(prompt)
+    for tok in out:
+        lg = dense_logits(oracle, ids)[-1]
+        top = lg.max().item()
+        assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05
+        ids.append(tok)
+
+
 @pytest.mark.gpu
 def test_embed_fed_matches_reference_and_pipelined_engine_matches_sync():
     from kvmini.ops import hip_ops, torch_ops
