@@ -19,6 +19,14 @@ which caps measured throughput below its own published 47.2 RPS; the default her
 is ``--target-rps 0`` = saturating arrivals (all requests due immediately, 20 in
 flight at all times), i.e. the same mix at the highest load concurrency 20 allows.
 ``--target-rps 40`` reproduces the reference pacing.
+
+Launching: ``python bench.py --gpus N`` starts the N rank processes itself (a parent
+that never imports torch or touches HIP spawns N fresh children, each with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, relays rank 0's JSON line and
+fails if any child fails); under ``python -m torch.distributed.run ... bench.py --gpus N``
+the ranks already exist and the script runs as one of them.  Either way a rank whose world
+size differs from ``--gpus`` exits 2, and ``rccl_ranks`` in the JSON line is the sum of a
+``1`` per rank over a real all-reduce (RCCL on GPUs, gloo in the CPU rehearsal).
 """
 
 from __future__ import annotations
@@ -72,6 +80,55 @@ class LoadChild:
             self.p.kill()
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
+def self_launch(n: int, argv: List[str], isolate: bool) -> int:
+    """Run ``n`` ranks of this script as fresh child processes (no torch, no HIP in this
+    parent).  Children see every GPU and pick ``LOCAL_RANK`` (what torchrun does: RCCL's
+    peer-to-peer transport over xGMI needs the peers' devices visible); ``isolate`` gives
+    each child only its own GPU through HIP_VISIBLE_DEVICES instead."""
+    port = _free_port()
+    procs: List[subprocess.Popen] = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        if isolate:
+            env["HIP_VISIBLE_DEVICES"] = str(r)
+            env["LOCAL_RANK"] = "0"
+        else:
+            env["LOCAL_RANK"] = str(r)
+        # rank 0 owns stdout (the ONE JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        deadline = None
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
+                    rc = rc or code
+                    deadline = deadline or time.time() + 30.0  # the others cannot finish a collective without it
+            if deadline is not None and time.time() > deadline:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +155,13 @@ def main() -> int:
     ap.add_argument("--out-dir", default=None, help="write run artifacts (requests.csv, power.json, results.json) here")
     ap.add_argument("--gpu-hourly", type=float, default=None, help="$/GPU-hour (default: cost.yaml MI355X entry)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = rehearsal of the multi-rank flow over gloo with the reference ops (not a benchmark)")
+    ap.add_argument("--isolate-devices", action="store_true", help="self-launch only: give every rank just its own GPU (HIP_VISIBLE_DEVICES=<rank>) instead of all GPUs + LOCAL_RANK")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus, sys.argv[1:], args.isolate_devices)
 
     # the host driver offers dmabuf IPC only: RCCL's peer-memory exchange between the ranks' processes needs this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -109,6 +172,9 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {args.gpus} (or plain `python bench.py --gpus {args.gpus}`)", file=sys.stderr)
+        return 2
     on_gpu = args.device == "cuda"
     if on_gpu and not torch.cuda.is_available():
         print("bench.py needs a ROCm GPU (use --device cpu only to rehearse the multi-rank flow)", file=sys.stderr)
@@ -205,33 +271,60 @@ def main() -> int:
     local = {k: cat(k) for k in ("latency_ms", "ttfb_ms", "ttft_ms", "status", "completion_tokens", "total_tokens")}
     itl = cat("itl_ms")
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    one = torch.ones(1, dtype=torch.int32, device=device)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(one)  # every rank contributes a 1: the sum is the number of ranks that took part in a real collective
     elapsed_max = float(el.item())
+    collective_ranks = int(one.item())
 
     n_local = local["latency_ms"].size
     mat = torch.from_numpy(np.stack([local[k] for k in ("latency_ms", "ttfb_ms", "ttft_ms", "status", "completion_tokens", "total_tokens")])).to(device)
-    itl_fixed = np.full(args.steps * args.requests * max(1, args.max_tokens), np.nan)
-    itl_fixed[: min(itl.size, itl_fixed.size)] = itl[: itl_fixed.size]
-    itl_t = torch.from_numpy(itl_fixed).to(device)
     if world > 1:
         g = torch.empty((world,) + tuple(mat.shape), dtype=mat.dtype, device=device)
         dist.all_gather_into_tensor(g.view(-1), mat.reshape(-1))
         mat_all = g.permute(1, 0, 2).reshape(mat.shape[0], world * n_local)
-        gi = torch.empty((world, itl_t.numel()), dtype=itl_t.dtype, device=device)
-        dist.all_gather_into_tensor(gi.view(-1), itl_t)
-        itl_all = gi.reshape(1, -1)
     else:
-        mat_all, itl_all = mat, itl_t.reshape(1, -1)
+        mat_all = mat
 
-    # lock-step telemetry table over RCCL
+    # inter-token gaps: one rank keeps its samples (exact quantiles); several ranks bin theirs
+    # into the 2048-bin log-spaced streaming histogram (the kernel of the live view) and merge
+    # the bins with ONE 8 KiB all-reduce instead of all-gathering every sample
+    from kvmini.ops.hist_quantile import StreamingHistogram
+
+    itl_hist = None
+    if world > 1:
+        itl_hist = StreamingHistogram(1, device=device)
+        if itl.size:
+            itl_hist.update(itl.astype(np.float32))
+        itl_hist.all_reduce(dist)
+
+    # lock-step telemetry table: C++ ncclAllGather on its own communicator and stream when the
+    # ranks are GPU processes, the torch.distributed path over gloo in the CPU rehearsal
     from kvmini.parallel.telemetry_gather import TelemetryGather, table_to_power_json
 
     tw = torch.tensor([t0_wall, t1_wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.broadcast(tw, 0)
-    tg = TelemetryGather(device=device)
+    tg = TelemetryGather(device=device, native=on_gpu and world > 1, device_index=local_rank)
     table = tg.gather_table(samples, float(tw[0]), float(tw[1]), 0.1)
+
+    # resource-seconds of this replica through the same record `kvmini cost` reads
+    import tempfile
+
+    from kvmini.cluster.backends import LocalBackend
+    from kvmini.cost.estimator import sum_resource_seconds
+    from kvmini.cost.pricing import load_pricing
+
+    pricing = load_pricing(os.path.join(ROOT, "cost.yaml"))
+    with tempfile.TemporaryDirectory() as td:
+        lb = LocalBackend(os.path.join(args.out_dir or td, f"local_cluster_rank{rank}.json"))
+        lb.register_server("bench", url, os.getpid(), proc_start, gpus=1)
+        rsecs = sum_resource_seconds(lb.get_pods("local", "bench"), float(tw[0]), float(tw[0]) + elapsed_max, pricing)
+    rs_t = torch.tensor([rsecs["gpu_seconds"], rsecs["cpu_core_seconds"], rsecs["mem_gib_seconds"]], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(rs_t)
+    gpu_s, cpu_s, mem_s = (float(v) for v in rs_t.tolist())
 
     rc = 0
     if rank == 0:
@@ -244,28 +337,32 @@ def main() -> int:
         ttft = torch.where(ok, mat_all[2], torch.full_like(mat_all[2], float("nan")))
         if on_gpu:
             q, stats = hq.batched_quantiles(torch.stack([lat, ttfb, ttft]), (0.5, 0.95, 0.99), return_stats=True)
-            qi, _ = hq.batched_quantiles(itl_all, (0.5, 0.95, 0.99), return_stats=True)
         else:  # rehearsal: the same reduction on the host
             m3 = torch.stack([lat, ttfb, ttft]).numpy()
             q = np.nanquantile(m3, (0.5, 0.95, 0.99), axis=1).T
             stats = [{"mean": float(np.nanmean(r))} for r in m3]
-            qi = np.nanquantile(itl_all.numpy(), (0.5, 0.95, 0.99), axis=1).T
+        if itl_hist is not None:
+            snap = itl_hist.snapshot((0.5, 0.95, 0.99))[0]["quantiles"]
+            qi = [[snap.get(p, float("nan")) for p in (0.5, 0.95, 0.99)]]
+            itl_engine = ("hip:stream_hist" if on_gpu else "numpy histogram") + " + all-reduce of 2048 bins"
+        elif on_gpu and itl.size:
+            qi, _ = hq.batched_quantiles(torch.from_numpy(itl).to(device).reshape(1, -1), (0.5, 0.95, 0.99), return_stats=True)
+            itl_engine = "hip:kv_radix_select"
+        else:
+            qi = [np.nanquantile(itl, (0.5, 0.95, 0.99)).tolist()] if itl.size else [[float("nan")] * 3]
+            itl_engine = "numpy"
         n_ok = int(ok.sum().item())
         n_total = int(status.numel())
         completion = float(mat_all[4][ok].sum().item())
         total_tokens = float(mat_all[5][ok].sum().item())
         rps = n_ok / elapsed_max
 
-        # cost: resource-seconds model of cost_estimator (GPU + CPU + memory share, +overhead)
-        from kvmini.cost.pricing import load_pricing
-
-        pricing = load_pricing(os.path.join(ROOT, "cost.yaml"))
+        # cost: the resource-seconds model of `kvmini cost` (GPU + CPU + memory share of every replica's record, + overhead)
         gpu_hourly = args.gpu_hourly if args.gpu_hourly is not None else pricing.gpu_hourly("AMD_Instinct_MI355X")
-        cpu_cores, mem_gib = 8.0, 64.0
-        dollars = world * elapsed_max / 3600.0 * (gpu_hourly + cpu_cores * pricing.cpu_hourly_per_core + mem_gib * pricing.mem_hourly_per_gib) * (1.0 + pricing.overhead_fraction)
+        dollars = (gpu_s * gpu_hourly + cpu_s * pricing.cpu_hourly_per_core + mem_s * pricing.mem_hourly_per_gib) / 3600.0 * (1.0 + pricing.overhead_fraction)
         cost_1k = dollars / total_tokens * 1000.0 if total_tokens else None
 
-        pj = table_to_power_json(table, 0.1)
+        pj = table_to_power_json(table, 0.1, source=tg.source)
         watts = [s["watts"] for s in pj["samples"] if s["watts"] is not None]
         wh = None
         if len(watts) >= 2:
@@ -281,6 +378,7 @@ def main() -> int:
             "value": round(rps, 3),
             "unit": "requests/s",
             "n_gpus": world,
+            "rccl_ranks": collective_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1000.0, 3),
@@ -336,7 +434,10 @@ def main() -> int:
                 "wh_per_1k_tokens": round(wh_1k / BASELINE["wh_per_1k_tokens"], 5) if wh_1k else None,
             },
             "quantile_engine": "hip:kv_radix_select" if on_gpu else "numpy (cpu rehearsal)",
+            "itl_quantile_engine": itl_engine,
+            "collective_backend": (dist.get_backend() if world > 1 else None),
             "telemetry": pj["source"] if watts else "unavailable",
+            "resource_seconds": {"gpu": gpu_s, "cpu_core": cpu_s, "mem_gib": mem_s},
         }
         if n_ok == 0:
             out["error"] = passes[-1].get("errors")

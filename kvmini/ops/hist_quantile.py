@@ -159,24 +159,64 @@ def equal_width_histogram(data: Iterable[float], num_bins: int = 20) -> Dict[str
     }
 
 
+def log_bins_numpy(x: np.ndarray) -> np.ndarray:
+    """Bin index of every sample, the formula of ``log_bin`` in ``csrc/hist_quantile.hip``
+    (float32 ``log2``, truncation, clamped to ``[0, BINS)``; non-positive values -> bin 0)."""
+    v = np.asarray(x, dtype=np.float32)
+    inv_step = np.float32(BINS / (HI_LOG2 - LO_LOG2))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f = (np.log2(v, dtype=np.float32) - np.float32(LO_LOG2)) * inv_step
+    f = np.where(v > 0, f, np.float32(0.0))
+    return np.clip(f.astype(np.int64), 0, BINS - 1)
+
+
 class StreamingHistogram:
-    """Persistent device histogram for live inter-token-latency statistics.
+    """Persistent histogram for live inter-token-latency statistics.
 
     ``update()`` bins a new slice of samples (ms) into 2048 log-spaced bins per
     metric and keeps count/sum/min/max; nothing is ever re-read.  ``snapshot()``
     returns approximate quantiles (log-interpolated inside the bin, ~1 % bin
     width) — the live view; the exact offline numbers come from
-    :func:`batched_quantiles` over the stored events."""
+    :func:`batched_quantiles` over the stored events.
+
+    On a GPU the bins live on the device and ``update`` is one launch of
+    ``stream_hist_kernel``; with ``device='cpu'`` (no GPU in the load generator's
+    host, CI) the same bins are kept in numpy with the same binning formula.
+    Histograms of several ranks merge by adding bins: :meth:`all_reduce`."""
 
     def __init__(self, n_metrics: int = 1, device: Any = "cuda"):
         torch = _torch()
         self.m = n_metrics
         self.device = torch.device(device)
-        self.state, self.hist = _new_stream_state(n_metrics, self.device)
+        self.on_gpu = self.device.type == "cuda"
         self.is_double = False
+        if self.on_gpu:
+            self.state, self.hist = _new_stream_state(n_metrics, self.device)
+        else:
+            self.hist = torch.zeros((n_metrics, BINS), dtype=torch.int32)
+            self._count = np.zeros(n_metrics, dtype=np.int64)
+            self._sum = np.zeros(n_metrics, dtype=np.float64)
+            self._min = np.full(n_metrics, np.inf)
+            self._max = np.full(n_metrics, -np.inf)
 
     def update(self, samples: Any) -> None:
         torch = _torch()
+        if not self.on_gpu:
+            x = np.asarray(samples.cpu().numpy() if hasattr(samples, "cpu") else samples)
+            if x.ndim == 1:
+                x = x.reshape(1, -1)
+            assert x.shape[0] == self.m
+            h = self.hist.numpy()
+            for i in range(self.m):
+                row = x[i][~np.isnan(x[i])]
+                if not row.size:
+                    continue
+                h[i] += np.bincount(log_bins_numpy(row), minlength=BINS).astype(np.int32)
+                self._count[i] += row.size
+                self._sum[i] += float(row.astype(np.float64).sum())
+                self._min[i] = min(self._min[i], float(row.min()))
+                self._max[i] = max(self._max[i], float(row.max()))
+            return
         x = torch.as_tensor(samples)
         if x.dtype not in (torch.float32, torch.float64):
             x = x.float()
@@ -185,15 +225,48 @@ class StreamingHistogram:
         if x.dim() == 1:
             x = x.unsqueeze(0)
         assert x.shape[0] == self.m
-        native().stream_hist(x, x.shape[1], self.hist, self.state, LO_LOG2, HI_LOG2)
+        if x.shape[1]:
+            native().stream_hist(x, x.shape[1], self.hist, self.state, LO_LOG2, HI_LOG2)
+
+    def stats(self) -> List[Dict[str, Any]]:
+        if self.on_gpu:
+            return _decode_stream_state(self.state.cpu().numpy(), self.m, self.is_double)
+        out = []
+        for i in range(self.m):
+            d: Dict[str, Any] = {"count": int(self._count[i]), "sum": float(self._sum[i])}
+            if d["count"]:
+                d.update(min=float(self._min[i]), max=float(self._max[i]), mean=d["sum"] / d["count"])
+            out.append(d)
+        return out
 
     def merge_counts(self, other_hist: Any) -> None:
         """Add another rank's bin counts (after an all-reduce/all-gather)."""
         self.hist += other_hist.to(self.hist.device)
 
+    def all_reduce(self, dist: Any, group: Any = None) -> None:
+        """Merge the histograms of every rank of a ``torch.distributed`` group in place: one
+        sum all-reduce of the ``[n_metrics, 2048]`` int32 bins (8 KiB per metric; RCCL's
+        ``ncclAllReduce`` on GPUs) plus a 4-scalar exchange for count / sum / min / max."""
+        torch = _torch()
+        st = self.stats()
+        sc = torch.tensor([[s["count"], s["sum"]] for s in st], dtype=torch.float64, device=self.device)
+        mn = torch.tensor([s.get("min", float("inf")) for s in st], dtype=torch.float64, device=self.device)
+        mx = torch.tensor([s.get("max", float("-inf")) for s in st], dtype=torch.float64, device=self.device)
+        dist.all_reduce(self.hist, group=group)
+        dist.all_reduce(sc, group=group)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        self._merged = [{"count": int(sc[i, 0].item()), "sum": float(sc[i, 1].item()), "min": float(mn[i].item()), "max": float(mx[i].item())} for i in range(self.m)]
+        for d in self._merged:
+            if d["count"]:
+                d["mean"] = d["sum"] / d["count"]
+            else:
+                d.pop("min"), d.pop("max")
+
     def snapshot(self, ps: Sequence[float] = (0.5, 0.95, 0.99)) -> List[Dict[str, Any]]:
         hist = self.hist.cpu().numpy().astype(np.int64)
-        stats = _decode_stream_state(self.state.cpu().numpy(), self.m, self.is_double)
+        stats = getattr(self, "_merged", None) or self.stats()
+        stats = [dict(s) for s in stats]
         step = (HI_LOG2 - LO_LOG2) / BINS
         for i, st in enumerate(stats):
             n = int(hist[i].sum())

@@ -52,9 +52,35 @@ def snapshot_vector(rank: int, seq: int, sample: Optional[Dict[str, Any]]) -> np
     return v
 
 
+def samples_to_matrix(samples: Sequence[Dict[str, Any]]) -> np.ndarray:
+    """``[n, 16]`` snapshot rows (rank / seq columns left at 0) of a list of sampler readings,
+    built column by column (no per-sample Python objects beyond the one pass that reads the dicts)."""
+    n = len(samples)
+    out = np.full((n, SNAPSHOT_F64), np.nan, dtype=np.float64)
+    if not n:
+        return out
+    out[:, 0] = out[:, 1] = 0.0
+
+    def col(key: str) -> np.ndarray:
+        return np.array([np.nan if s.get(key) is None else s[key] for s in samples], dtype=np.float64)
+
+    out[:, 2] = col("ts_s")
+    for i, key in ((3, "watts"), (4, "gfx_util"), (5, "vram_used"), (7, "temp_c"), (8, "sclk_mhz")):
+        out[:, i] = col(key)
+    firsts = [(s.get("per_gpu") or [{}])[0] for s in samples]
+    out[:, 6] = np.array([np.nan if g.get("vram_total") is None else g["vram_total"] for g in firsts], dtype=np.float64)
+    out[:, 9] = np.array([np.nan if g.get("energy_uj") is None else g["energy_uj"] for g in firsts], dtype=np.float64)
+    return out
+
+
 class TelemetryGather:
-    def __init__(self, group: Optional[Any] = None, device: Optional[torch.device] = None):
+    def __init__(self, group: Optional[Any] = None, device: Optional[torch.device] = None, native: bool = False, device_index: int = 0, impl: str = "rccl"):
+        """``native=True`` routes the exchange through ``libkvmini_gather.so`` (C++: its own
+        RCCL communicator and HIP stream; ``impl`` = ``rccl`` for ``ncclAllGather`` or ``p2p`` for
+        the one-shot peer-store kernel) instead of ``torch.distributed``."""
         self.group = group
+        self.native = None
+        self.impl = impl
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if device is None:
@@ -64,6 +90,20 @@ class TelemetryGather:
         self.stream = torch.cuda.Stream(device, priority=0) if device.type == "cuda" else None
         self.seq = 0
         self.dropped_ticks = 0
+        if native and self.world > 1:
+            from kvmini.telemetry.native_rt import NativeGather
+
+            self.native = NativeGather(device_index, impl=impl)
+
+    @property
+    def source(self) -> str:
+        """What actually moved the snapshots (goes into power.json)."""
+        if self.world == 1:
+            return "amd-smi"
+        if self.native is not None:
+            return "amd-smi+" + ("xgmi-p2p-allgather" if self.impl == "p2p" else "rccl-allgather(ncclAllGather)")
+        backend = dist.get_backend(self.group) if dist.is_initialized() else "none"
+        return "amd-smi+" + ("rccl-allgather" if backend == "nccl" else f"{backend}-allgather")
 
     @classmethod
     def with_own_group(cls, device: Optional[torch.device] = None) -> "TelemetryGather":
@@ -76,6 +116,8 @@ class TelemetryGather:
     def _all_gather(self, local: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return local.unsqueeze(0)
+        if self.native is not None:
+            return torch.from_numpy(self.native.gather(local.cpu().numpy().reshape(-1, SNAPSHOT_F64))).reshape((self.world,) + tuple(local.shape))
         out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -110,15 +152,14 @@ class TelemetryGather:
             ts = np.array([s["ts_s"] for s in samples], dtype=np.float64)
             # nearest earlier-or-equal sample for each tick (sample-and-hold)
             idx = np.clip(np.searchsorted(ts, local[:, 2], side="right") - 1, 0, len(samples) - 1)
-            for k in range(n_ticks):
-                sv = snapshot_vector(self.rank, k, samples[idx[k]])
-                local[k, 3:] = sv[3:]
-        table = self._all_gather(torch.from_numpy(local).to(self.device)).cpu().numpy()
+            local[:, 3:] = samples_to_matrix(samples)[idx, 3:]
+        src = torch.from_numpy(local)
+        table = self._all_gather(src if self.native is not None else src.to(self.device)).cpu().numpy()
         assert np.all(table[:, :, 1] == np.arange(n_ticks)[None, :]), "telemetry table out of lock-step"
         return table
 
 
-def table_to_power_json(table: np.ndarray, dt: float) -> Dict[str, Any]:
+def table_to_power_json(table: np.ndarray, dt: float, source: Optional[str] = None) -> Dict[str, Any]:
     """Node-level power.json from a gathered table: per tick, watts summed over
     ranks (NaN-aware) and per-GPU detail."""
     world, n_ticks, _ = table.shape
@@ -132,4 +173,6 @@ def table_to_power_json(table: np.ndarray, dt: float) -> Dict[str, Any]:
         u = [p["gfx_util"] for p in per if p["gfx_util"] is not None]
         m = [p["vram_used"] for p in per if p["vram_used"] is not None]
         samples.append({"ts_s": float(table[0, k, 2]), "watts": sum(w) if w else None, "gfx_util": sum(u) / len(u) if u else None, "vram_used": sum(m) if m else None, "per_gpu": per})
-    return {"samples": samples, "interval_s": dt, "source": "amd-smi+rccl-allgather", "world_size": int(world)}
+    if source is None:
+        source = "amd-smi" if world == 1 else "amd-smi+rccl-allgather"
+    return {"samples": samples, "interval_s": dt, "source": source, "world_size": int(world)}

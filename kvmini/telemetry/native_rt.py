@@ -214,14 +214,17 @@ class NativeGather:
     """``ncclAllGather`` of telemetry snapshots through the native runtime.  The
     unique id travels over the already-initialised ``torch.distributed`` group."""
 
-    def __init__(self, device_index: int):
+    def __init__(self, device_index: int, impl: str = "rccl"):
         import torch
         import torch.distributed as dist
 
         lib = load_gather()
         if lib is None:
             raise RuntimeError("libkvmini_gather.so not available")
+        if impl not in ("rccl", "p2p"):
+            raise ValueError(f"gather impl {impl!r}: rccl or p2p")
         self._lib = lib
+        self.impl = impl
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         nbytes = int(lib.kvt_unique_id_bytes())

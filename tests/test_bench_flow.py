@@ -33,3 +33,27 @@ def test_bench_two_ranks_gloo_one_json_line():
     assert abs(out["value"] - 2 * 2 * 24 / (out["ms_per_step"] * 2 / 1000.0)) / out["value"] < 1e-3
     assert out["tokens_per_sec"] > 0 and out["p95_ms"] >= out["p50_ms"] > 0
     assert out["ttft_mean_ms"] <= out["first_content_token_mean_ms"]
+
+
+def test_bench_self_launches_ranks_without_torchrun():
+    """``python bench.py --gpus 2`` (no torchrun): the parent spawns two fresh rank processes,
+    relays rank 0's one JSON line, and the line proves both ranks took part in a collective."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--device", "cpu", "--model", "tiny", "--requests", "16",
+           "--concurrency", "4", "--max-tokens", "6", "--max-model-len", "128"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    assert out["config"]["parallelism"] == "dp2"
+    assert out["itl_quantile_engine"].endswith("all-reduce of 2048 bins") and out["itl_p50_ms"] > 0
+    assert out["resource_seconds"]["gpu"] > 0
+
+
+def test_bench_rejects_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu", "--model", "tiny"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
