@@ -186,7 +186,12 @@ __global__ __launch_bounds__(TPB) void sample_rows_kernel(const unsigned short* 
   // one thread's half-open interval [exc, inc) holds the target (inc is monotone, the last one = total > target)
   if (mine > 0.f && exc <= target && target < inc) winner = tid;
   __syncthreads();
-  if (winner < 0) {  // rounding at an interval edge: fall back to the last thread that kept anything
+  // rounding at an interval edge can leave no winner: fall back to the last thread that kept
+  // anything.  The decision is taken on a snapshot that every thread reads between the same two
+  // barriers, so all waves take the same side of the branch (the barrier inside it is uniform).
+  const int w0 = winner;
+  __syncthreads();
+  if (w0 < 0) {
     if (mine > 0.f) atomicMax(&winner, tid);
     __syncthreads();
   }

@@ -206,6 +206,7 @@ class LLMEngine:
         self._thread: Optional[threading.Thread] = None
         self.on_tokens: Optional[Callable[[List[TokenEvent]], None]] = None
         self._gens: Dict[int, torch.Generator] = {}
+        self._rejected: List[Sequence] = []
         self.warm_s = 0.0
         self._pending: Optional[Tuple[Batch, Any]] = None  # (batch, runner handle) of the step in flight
         self.pipelined_steps = 0
@@ -481,10 +482,14 @@ class LLMEngine:
         """Offline batch generation (blocking)."""
         seqs = [self.make_sequence(p, params and SamplingParams(**vars(params))) for p in prompts]
         for s in seqs:
-            self.scheduler.add(s)
+            why = self.scheduler.add(s)
+            if why is not None:
+                raise ValueError(why)
         while self.scheduler.has_work():
             if not self.step() and self._pending is None and not self.scheduler.running and self.scheduler.waiting:
                 raise RuntimeError("scheduler cannot make progress (KV cache too small for the prompt?)")
+            if self.scheduler.failed:
+                raise RuntimeError(self.scheduler.failed.pop().finish_reason)
         return [s.output_ids for s in seqs]
 
     # --- asynchronous API (server) ----------------------------------------
@@ -532,9 +537,19 @@ class LLMEngine:
             except queue.Empty:
                 return
             if kind == "add":
-                self.scheduler.add(item)
+                if self.scheduler.add(item) is not None:
+                    self._rejected.append(item)
             elif kind == "abort":
                 self.scheduler.abort(item)
+
+    def _failure_events(self) -> List[TokenEvent]:
+        """Requests that ended without a step of their own: rejected at intake, or given up by
+        the scheduler.  Each fails alone; running requests are not touched."""
+        out: List[TokenEvent] = [(s.req_id, [], True, s.finish_reason, s) for s in self._rejected]
+        out += [(s.req_id, [], True, s.finish_reason, s) for s in self.scheduler.failed]
+        self._rejected.clear()
+        self.scheduler.failed.clear()
+        return out
 
     def _loop(self) -> None:
         if self.device.type == "cuda":
@@ -542,11 +557,16 @@ class LLMEngine:
         while not self._stop:
             self._drain_inbox()
             if not self.scheduler.has_work():
+                fails = self._failure_events()
+                if fails and self.on_tokens is not None:
+                    self.on_tokens(fails)
+                    continue
                 self._wake.wait(0.05)
                 self._wake.clear()
                 continue
             try:
                 events = self.step()
+                events += self._failure_events()  # also what the hold inside step() took in
             except Exception as e:  # fail the in-flight requests, keep serving
                 import traceback
 

@@ -136,6 +136,12 @@ class ModelRunner:
         self.cos, self.sin = rope_tables(cfg, rcfg.max_model_len, self.device)
 
         self.num_blocks = rcfg.num_blocks or self._auto_num_blocks()
+        if tp_group is not None and self.tp_size > 1:
+            # only the scheduling rank hands out block ids, so every rank's cache must hold the
+            # same number of blocks: take the smallest (the rank with the least free memory)
+            nb = torch.tensor([self.num_blocks], dtype=torch.int64, device=self.device if self.device.type == "cuda" else "cpu")
+            torch.distributed.all_reduce(nb, op=torch.distributed.ReduceOp.MIN, group=tp_group)
+            self.num_blocks = int(nb.item())
         dt = weights.embed.dtype
         # [layer, k/v, block, kv_head, slot_in_block, head_dim]
         self.kv_cache = torch.zeros((cfg.num_layers, 2, self.num_blocks, self.nkv, self.block_size, self.hd), dtype=dt, device=self.device)

@@ -132,12 +132,47 @@ class Scheduler:
         self.running: List[Sequence] = []
         self._free_slots: List[int] = list(range(max_num_seqs - 1, -1, -1))
         self.num_preemptions = 0
+        # sequences the scheduler gave up on by itself (finish reason "error: ..."); the engine
+        # drains this list into token events
+        self.failed: List[Sequence] = []
 
     # ------------------------------------------------------------------
-    def add(self, seq: Sequence) -> None:
+    def validate(self, seq: Sequence) -> Optional[str]:
+        """Why this request can never be served (None = it can).  Checked at intake so that a
+        malformed request fails alone instead of raising inside a step that carries others."""
+        import math
+
+        p = seq.params
+        if not seq.prompt_ids:
+            return "empty prompt"
+        if len(seq.prompt_ids) >= self.max_model_len:
+            return f"prompt has {len(seq.prompt_ids)} tokens; max_model_len is {self.max_model_len}"
+        if p.seed is not None and (isinstance(p.seed, bool) or not isinstance(p.seed, int)):
+            return f"seed must be an integer, got {p.seed!r}"
+        for name in ("temperature", "top_p"):
+            v = getattr(p, name)
+            if not isinstance(v, (int, float)) or isinstance(v, bool) or not math.isfinite(v) or v < 0:
+                return f"{name} must be a finite non-negative number, got {v!r}"
+        if not isinstance(p.max_tokens, int) or p.max_tokens < 1:
+            return f"max_tokens must be a positive integer, got {p.max_tokens!r}"
+        bs = self.bm.block_size
+        n_max = min(len(seq.prompt_ids) + p.max_tokens, self.max_model_len)
+        if (n_max + bs - 1) // bs > self.bm.num_blocks - 1:
+            return f"request needs {(n_max + bs - 1) // bs} KV blocks of {bs} tokens; the cache has {self.bm.num_blocks - 1}"
+        return None
+
+    def add(self, seq: Sequence) -> Optional[str]:
+        """Queue a request.  Returns the rejection reason (and does not queue) when the
+        request can never run."""
+        why = self.validate(seq)
+        if why is not None:
+            seq.status = SeqStatus.FINISHED
+            seq.finish_reason = f"error: {why}"
+            return why
         if len(seq.prompt_ids) + seq.params.max_tokens > self.max_model_len:
             seq.params.max_tokens = max(1, self.max_model_len - len(seq.prompt_ids))
         self.waiting.append(seq)
+        return None
 
     def has_work(self) -> bool:
         return bool(self.waiting or self.running)
@@ -229,6 +264,10 @@ class Scheduler:
             if need:
                 got = self.bm.allocate(need)
                 if got is None:
+                    if len(self.running) == 1 and not chunks:
+                        # alone, nothing left to preempt and still no room: it never will be
+                        self._finish(seq, f"error: KV cache exhausted ({self.bm.num_blocks} blocks) at {seq.num_computed} tokens")
+                        self.failed.append(seq)
                     continue  # cannot run this step
                 seq.blocks += got
             chunks.append(ScheduledChunk(seq, seq.num_computed, n, seq.num_computed + n == known))

@@ -78,6 +78,9 @@ def _latest_symlink(run_dir: str) -> None:
         pass
 
 
+EXIT_NO_SUCCESS = 4  # every request of the load test failed
+
+
 def main(argv: Optional[List[str]] = None) -> int:
     a = build_arg_parser().parse_args(argv)
     if a.list_profiles:
@@ -265,7 +268,7 @@ def main(argv: Optional[List[str]] = None) -> int:
 
         generate_single_report(os.path.join(run_dir, "results.json"), os.path.join(run_dir, "report.html"))
 
-    print("\n=== DONE ===")
+    print("\n=== DONE ===" if n_ok else "\n=== FAILED: no request succeeded ===")
     print(f"Results: {run_dir}/results.json")
     res = load_json(os.path.join(run_dir, "results.json"))
     brief = {k: res.get(k) for k in ("p50_ms", "p95_ms", "p99_ms", "throughput_rps", "tokens_per_sec", "error_rate", "time_to_first_token_ms", "cold_start_count", "cost_per_1k_tokens", "energy_wh_per_1k_tokens")}
@@ -283,6 +286,12 @@ def main(argv: Optional[List[str]] = None) -> int:
         rc = gate.main(["--results", os.path.join(run_dir, "results.json"), "--slo", a.slo] + (["--energy", os.path.join(run_dir, "energy.json")] if os.path.exists(os.path.join(run_dir, "energy.json")) else []))
     if a.serve and server_proc:
         backend.delete_isvc(a.namespace, a.service)
+    if n_ok == 0:
+        # every request failed: the artifacts are written (they show the errors) but the run is
+        # not a measurement; callers (sweeps, CI) must not read it as one
+        errs = sorted({str(r.error) for r in results if r.error})[:3]
+        print(f"ERROR: 0 of {len(results)} requests succeeded" + (f" ({'; '.join(errs)})" if errs else ""), file=sys.stderr)
+        return rc or EXIT_NO_SUCCESS
     return rc
 
 

@@ -101,23 +101,27 @@ def main_grid(argv: Optional[List[str]] = None) -> int:
     ptoks = _ints(a.prompt_tokens) or [0]
     cells = list(itertools.product(concs, toks, pats, ptoks))
     print(f"=== Grid sweep: {len(cells)} runs -> {out} ===")
-    new_file = not (a.resume and os.path.exists(out))
-    with open(out, "w" if new_file else "a", newline="") as f:
+    skipped = 0
+    with open(out, "w", newline="") as f:  # rows of resumed cells are rebuilt from their results.json
         w = csv.writer(f)
-        if new_file:
-            w.writerow(GRID_HEADER)
+        w.writerow(GRID_HEADER)
         for i, (c, t, p, pt) in enumerate(cells, 1):
             tag = f"c{c}_t{t}_{p}" + (f"_p{pt}" if pt else "")
             run_dir = os.path.join(a.runs_root, f"grid_{ts if not a.resume else 'resume'}_{tag}")
             print(f"[{i}/{len(cells)}] concurrency={c} max_tokens={t} pattern={p}" + (f" prompt_tokens={pt}" if pt else ""))
             res_path = os.path.join(run_dir, "results.json")
-            if not (a.resume and os.path.exists(res_path)):
+            if a.resume and os.path.exists(res_path):
+                skipped += 1
+                print("  resume: results.json exists, not re-run")
+            else:
                 cell = argparse.Namespace(**vars(a))
                 if pt:
                     cell.loadtest_args = (a.loadtest_args + f" --prompt-tokens {pt}").strip()
                 args = _common_bench_args(cell) + ["--requests", str(a.requests), "--concurrency", str(c), "--max-tokens", str(t), "--pattern", p, "--run-dir", run_dir]
                 rc = _bench(args)
                 if rc != 0:
+                    if os.path.exists(res_path):
+                        os.replace(res_path, res_path + ".failed")  # a failed cell must not look finished to --resume
                     w.writerow([c, t, p] + ["ERROR"] * 11 + [run_dir])
                     f.flush()
                     continue
@@ -140,7 +144,7 @@ def main_grid(argv: Optional[List[str]] = None) -> int:
         from kvmini.report.generator import generate_grid_report
 
         print("Report:", generate_grid_report(out, os.path.splitext(out)[0] + "_report.html"))
-    print(f"\nSweep results: {out}")
+    print(f"\nSweep results: {out}" + (f" ({skipped} cells resumed)" if skipped else ""))
     return 0
 
 
@@ -177,6 +181,15 @@ def autoscale_summary(csv_path: str) -> Dict[str, Any]:
     }
 
 
+def _autoscale_row(cc: int, init: int, grace: str, stable: str, panic: str, r: Dict[str, Any], run_dir: str, deploy_s: Any) -> List[Any]:
+    c95, w95 = r.get("cold_p95_ms"), r.get("warm_p95_ms")
+    mult = c95 / w95 if c95 and w95 else ""
+    g = lambda k: "" if r.get(k) is None else r.get(k)  # noqa: E731
+    return [cc, init, grace, stable, panic, g("p50_ms"), g("p95_ms"), g("p99_ms"), g("warm_p50_ms"), g("warm_p95_ms"), g("cold_p50_ms"), g("cold_p95_ms"), g("cold_start_count"), mult,
+            g("throughput_rps"), g("tokens_per_sec"), g("error_rate"), g("cost_per_request"), g("cost_per_1k_tokens"), g("cold_cost_per_request"), g("warm_cost_per_request"),
+            g("cold_cost_per_1k_tokens"), g("warm_cost_per_1k_tokens"), g("energy_wh_per_1k_tokens"), g("gpu_util_avg"), run_dir, deploy_s, "success"]
+
+
 def main_autoscale(argv: Optional[List[str]] = None) -> int:
     ap = argparse.ArgumentParser(prog="kvmini autoscale-sweep", description="Knative autoscaling parameter sweep")
     _add_common(ap)
@@ -207,8 +220,14 @@ def main_autoscale(argv: Optional[List[str]] = None) -> int:
         w.writerow(AUTOSCALE_HEADER)
         for i, (cc, init, grace, stable, panic) in enumerate(grid, 1):
             svc = dns1123_label(f"{a.service}-as{i}")
-            run_dir = os.path.join(a.runs_root, f"autoscale_{ts}_cc{cc}_is{init}_g{grace}_s{stable}_p{panic}")
+            run_dir = os.path.join(a.runs_root, f"autoscale_{ts if not a.resume else 'resume'}_cc{cc}_is{init}_g{grace}_s{stable}_p{panic}")
             print(f"[{i}/{len(grid)}] target={cc} initialScale={init} grace={grace} stable={stable} panic={panic}")
+            res_path = os.path.join(run_dir, "results.json")
+            if a.resume and os.path.exists(res_path):
+                print("  resume: results.json exists, not re-deployed")
+                w.writerow(_autoscale_row(cc, init, grace, stable, panic, load_json(res_path), run_dir, load_json(res_path).get("deploy_time_sec", "")))
+                f.flush()
+                continue
             builder = mf.BUILDERS[a.backend]
             isvc = builder(svc, a.namespace, a.model_uri) if a.backend.startswith("vllm") else builder(svc, a.namespace)
             # panic window is a percentage of the stable window in Knative
@@ -239,16 +258,14 @@ def main_autoscale(argv: Optional[List[str]] = None) -> int:
             if a.cluster_backend:
                 args += ["--cluster-backend", a.cluster_backend]
             rc = _bench(args)
-            res_path = os.path.join(run_dir, "results.json")
             if rc == 0 and os.path.exists(res_path):
-                r = load_json(res_path)
-                c95, w95 = r.get("cold_p95_ms"), r.get("warm_p95_ms")
-                mult = c95 / w95 if c95 and w95 else ""
-                g = lambda k: "" if r.get(k) is None else r.get(k)  # noqa: E731
-                w.writerow([cc, init, grace, stable, panic, g("p50_ms"), g("p95_ms"), g("p99_ms"), g("warm_p50_ms"), g("warm_p95_ms"), g("cold_p50_ms"), g("cold_p95_ms"), g("cold_start_count"), mult,
-                            g("throughput_rps"), g("tokens_per_sec"), g("error_rate"), g("cost_per_request"), g("cost_per_1k_tokens"), g("cold_cost_per_request"), g("warm_cost_per_request"),
-                            g("cold_cost_per_1k_tokens"), g("warm_cost_per_1k_tokens"), g("energy_wh_per_1k_tokens"), g("gpu_util_avg"), run_dir, f"{deploy_s:.1f}", "success"])
+                from kvmini.utils import merge_json_file
+
+                merge_json_file(res_path, {"deploy_time_sec": round(deploy_s, 1)})  # a resumed sweep reads it back
+                w.writerow(_autoscale_row(cc, init, grace, stable, panic, load_json(res_path), run_dir, f"{deploy_s:.1f}"))
             else:
+                if os.path.exists(res_path):
+                    os.replace(res_path, res_path + ".failed")  # a failed cell must not look finished to --resume
                 w.writerow([cc, init, grace, stable, panic] + [""] * 20 + [run_dir, f"{deploy_s:.1f}", "benchmark_failed"])
             f.flush()
             if not a.no_cleanup:
@@ -291,8 +308,15 @@ def main_partition(argv: Optional[List[str]] = None) -> int:
             builder = mf.BUILDERS[a.backend]
             isvc = builder(svc, a.namespace, a.model_uri) if a.backend.startswith("vllm") else builder(svc, a.namespace)
             isvc = mf.apply_partition_profile(isvc, prof)
-            run_dir = os.path.join(a.runs_root, f"partition_{ts}_{pname}")
+            run_dir = os.path.join(a.runs_root, f"partition_{ts if not a.resume else 'resume'}_{pname}")
             print(f"=== partition profile {pname} ===")
+            res_path = os.path.join(run_dir, "results.json")
+            if a.resume and os.path.exists(res_path):
+                print("  resume: results.json exists, not re-deployed")
+                r = load_json(res_path)
+                w.writerow([pname, r.get("p50_ms"), r.get("p95_ms"), r.get("throughput_rps"), r.get("energy_wh_per_1k_tokens"), r.get("cost_per_1k_tokens"), r.get("error_rate")])
+                f.flush()
+                continue
             try:
                 backend.apply(isvc)
                 backend.wait_ready(a.namespace, svc, 600)
@@ -307,12 +331,13 @@ def main_partition(argv: Optional[List[str]] = None) -> int:
             if a.cluster_backend:
                 args += ["--cluster-backend", a.cluster_backend]
             rc = _bench(args)
-            res_path = os.path.join(run_dir, "results.json")
+            if rc != 0 and os.path.exists(res_path):
+                os.replace(res_path, res_path + ".failed")
             if rc == 0 and os.path.exists(res_path):
                 r = load_json(res_path)
                 w.writerow([pname, r.get("p50_ms"), r.get("p95_ms"), r.get("throughput_rps"), r.get("energy_wh_per_1k_tokens"), r.get("cost_per_1k_tokens"), r.get("error_rate")])
             else:
-                w.writerow([pname] + ["NO_RESULTS"] * 6)
+                w.writerow([pname] + ["ERROR" if rc != 0 else "NO_RESULTS"] * 6)
             f.flush()
             try:
                 backend.delete_isvc(a.namespace, svc)

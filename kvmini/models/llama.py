@@ -49,6 +49,10 @@ class LlamaConfig:
     # set by pad_head_dim(): the softmax scale and the rotary width of the un-padded heads
     attn_scale: Optional[float] = None
     rope_dim: Optional[int] = None
+    # Llama-3.1 / 3.2 "llama3" rotary scaling: (factor, low_freq_factor, high_freq_factor,
+    # original_max_position); None = plain rotary frequencies
+    rope_scaling: Optional["tuple[float, float, float, int]"] = None
+    tie_word_embeddings: bool = False
 
     @property
     def softmax_scale(self) -> float:
@@ -80,8 +84,11 @@ PRESETS: Dict[str, LlamaConfig] = {
     # Llama 3
     "llama-3-8b": LlamaConfig("llama-3-8b", 128256, 4096, 14336, 32, 32, 8, 128, 500000.0, 1e-5, 8192, 128000, 128001),
     "llama-3-70b": LlamaConfig("llama-3-70b", 128256, 8192, 28672, 80, 64, 8, 128, 500000.0, 1e-5, 8192, 128000, 128001),
-    "llama-3.2-1b": LlamaConfig("llama-3.2-1b", 128256, 2048, 8192, 16, 32, 8, 64, 500000.0, 1e-5, 131072, 128000, 128001),
-    "llama-3.2-3b": LlamaConfig("llama-3.2-3b", 128256, 3072, 8192, 28, 24, 8, 128, 500000.0, 1e-5, 131072, 128000, 128001),
+    # Llama 3.1 / 3.2: same layers, 128 k positions through the "llama3" rotary scaling
+    "llama-3.1-8b": LlamaConfig("llama-3.1-8b", 128256, 4096, 14336, 32, 32, 8, 128, 500000.0, 1e-5, 131072, 128000, 128001, rope_scaling=(8.0, 1.0, 4.0, 8192)),
+    "llama-3.1-70b": LlamaConfig("llama-3.1-70b", 128256, 8192, 28672, 80, 64, 8, 128, 500000.0, 1e-5, 131072, 128000, 128001, rope_scaling=(8.0, 1.0, 4.0, 8192)),
+    "llama-3.2-1b": LlamaConfig("llama-3.2-1b", 128256, 2048, 8192, 16, 32, 8, 64, 500000.0, 1e-5, 131072, 128000, 128001, rope_scaling=(32.0, 1.0, 4.0, 8192), tie_word_embeddings=True),
+    "llama-3.2-3b": LlamaConfig("llama-3.2-3b", 128256, 3072, 8192, 28, 24, 8, 128, 500000.0, 1e-5, 131072, 128000, 128001, rope_scaling=(32.0, 1.0, 4.0, 8192), tie_word_embeddings=True),
     # Llama 2 / CodeLlama / Mistral (names used by the reference's matrices and engine profiles)
     "llama-2-7b": LlamaConfig("llama-2-7b", 32000, 4096, 11008, 32, 32, 32, 128, 10000.0, 1e-5, 4096, 1, 2),
     "llama-2-13b": LlamaConfig("llama-2-13b", 32000, 5120, 13824, 40, 40, 40, 128, 10000.0, 1e-5, 4096, 1, 2),
@@ -92,11 +99,11 @@ PRESETS: Dict[str, LlamaConfig] = {
 }
 
 _ALIASES = {
-    "llama-3.1-8b": "llama-3-8b",
-    "meta-llama/llama-3.1-8b-instruct": "llama-3-8b",
+    "meta-llama/llama-3.1-8b-instruct": "llama-3.1-8b",
+    "meta-llama/llama-3.1-8b": "llama-3.1-8b",
+    "meta-llama/llama-3.1-70b-instruct": "llama-3.1-70b",
     "meta-llama/meta-llama-3-8b-instruct": "llama-3-8b",
     "llama3-8b": "llama-3-8b",
-    "llama-3.1-70b": "llama-3-70b",
     "llama3-70b": "llama-3-70b",
     "llama2-7b": "llama-2-7b",
     "llama-7b": "llama-2-7b",
@@ -242,6 +249,9 @@ def load_hf_safetensors(path: str, cfg: LlamaConfig, device: torch.device | str 
     files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
     if not files:
         raise FileNotFoundError(f"no .safetensors files under {path}")
+    if cfg.num_heads % tp_size or cfg.num_kv_heads % tp_size or cfg.intermediate_size % (tp_size * GU_GROUP):
+        raise ValueError(f"{cfg.name}: {cfg.num_heads} heads / {cfg.num_kv_heads} kv heads / intermediate {cfg.intermediate_size} do not split over {tp_size} tensor-parallel ranks")
+    check_hf_config(os.path.join(path, "config.json"), cfg)
     for fpath in files:
         with safe_open(fpath, framework="pt", device="cpu") as f:
             for k in f.keys():
@@ -280,6 +290,42 @@ def load_hf_safetensors(path: str, cfg: LlamaConfig, device: torch.device | str 
     return LlamaWeights(cfg, embed, layers, get("model.norm.weight").to(dev), lm_head, tp_rank, tp_size)
 
 
+def check_hf_config(config_json: str, cfg: LlamaConfig) -> None:
+    """Compare a checkpoint's ``config.json`` (when present) with the architecture preset the
+    engine was started with; a mismatch would load without an error and produce wrong logits."""
+    import json
+    import os
+
+    if not os.path.exists(config_json):
+        return
+    with open(config_json) as f:
+        hf = json.load(f)
+    nh = hf.get("num_attention_heads")
+    want = {
+        "hidden_size": cfg.hidden_size, "intermediate_size": cfg.intermediate_size, "num_hidden_layers": cfg.num_layers, "num_attention_heads": cfg.num_heads,
+        "num_key_value_heads": cfg.num_kv_heads, "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta,
+    }
+    bad = [f"{k}: checkpoint {hf[k]!r}, preset {v!r}" for k, v in want.items() if k in hf and (abs(float(hf[k]) - float(v)) > 1e-9 * max(1.0, abs(float(v))))]
+    if "head_dim" in hf or (nh and "hidden_size" in hf):
+        hd = hf.get("head_dim") or hf["hidden_size"] // nh
+        if hd != (cfg.rope_dim or cfg.head_dim):
+            bad.append(f"head_dim: checkpoint {hd}, preset {cfg.rope_dim or cfg.head_dim}")
+    if "tie_word_embeddings" in hf and bool(hf["tie_word_embeddings"]) != cfg.tie_word_embeddings:
+        bad.append(f"tie_word_embeddings: checkpoint {hf['tie_word_embeddings']}, preset {cfg.tie_word_embeddings}")
+    rs = hf.get("rope_scaling")
+    if rs and (rs.get("rope_type") or rs.get("type")) not in (None, "default"):
+        kind = rs.get("rope_type") or rs.get("type")
+        got = (float(rs.get("factor", 1.0)), float(rs.get("low_freq_factor", 1.0)), float(rs.get("high_freq_factor", 4.0)), int(rs.get("original_max_position_embeddings", 8192)))
+        if kind != "llama3":
+            bad.append(f"rope_scaling type {kind!r} is not supported (llama3 only)")
+        elif cfg.rope_scaling is None or any(abs(a - b) > 1e-9 for a, b in zip(got, cfg.rope_scaling)):
+            bad.append(f"rope_scaling: checkpoint {got}, preset {cfg.rope_scaling}")
+    elif cfg.rope_scaling is not None and "rope_scaling" in hf:
+        bad.append(f"rope_scaling: checkpoint has none, preset {cfg.rope_scaling}")
+    if bad:
+        raise ValueError(f"checkpoint config.json does not match preset {cfg.name!r}: " + "; ".join(bad))
+
+
 def rope_tables(cfg: LlamaConfig, max_pos: int, device: torch.device | str) -> "tuple[torch.Tensor, torch.Tensor]":
     """cos/sin tables [max_pos, head_dim/2] in fp32 (rotate-half / NeoX pairing:
     element i pairs with i + head_dim/2, as in HF Llama)."""
@@ -287,6 +333,16 @@ def rope_tables(cfg: LlamaConfig, max_pos: int, device: torch.device | str) -> "
     real = (cfg.rope_dim or cfg.head_dim) // 2  # padded heads: pairs beyond the real width are (0, 0) and do not turn
     inv = torch.zeros(half, dtype=torch.float64)
     inv[:real] = 1.0 / (cfg.rope_theta ** (torch.arange(0, real, dtype=torch.float64) / real))
+    if cfg.rope_scaling is not None:
+        # "llama3" scaling: wavelengths beyond the original context are slowed by `factor`,
+        # short ones are kept, the band in between is blended — it changes the low-frequency
+        # components at EVERY position, so checkpoints trained with it need it from position 0
+        factor, low_f, high_f, orig = cfg.rope_scaling
+        wavelen = 2.0 * math.pi / inv[:real]
+        smooth = ((orig / wavelen) - low_f) / (high_f - low_f)
+        blended = (1.0 - smooth) * inv[:real] / factor + smooth * inv[:real]
+        scaled = torch.where(wavelen > orig / low_f, inv[:real] / factor, torch.where(wavelen < orig / high_f, inv[:real], blended))
+        inv[:real] = scaled
     ang = torch.arange(max_pos, dtype=torch.float64)[:, None] * inv[None, :]
     return ang.cos().float().to(device), ang.sin().float().to(device)
 

@@ -75,11 +75,33 @@ class NativeServer:
             temperature=float(body.get("temperature") or 0.0),
             top_p=float(body.get("top_p") or 1.0),
             top_k=int(body.get("top_k") or 0),
-            seed=body.get("seed"),
+            seed=self._seed(body.get("seed")),
             ignore_eos=self.ignore_eos if ignore is None else bool(ignore),
             logprobs=max(0, min(n_lp, 20)),
             stop_token_ids=[int(t) for t in (body.get("stop_token_ids") or [])],
         )
+
+    @staticmethod
+    def _seed(v: Any) -> Optional[int]:
+        """A request's seed as an int (or None); anything else is the client's error."""
+        if v is None:
+            return None
+        if isinstance(v, bool) or not isinstance(v, (int, float, str)):
+            raise ValueError(f"seed must be an integer, got {v!r}")
+        if isinstance(v, float) and v != int(v):
+            raise ValueError(f"seed must be an integer, got {v!r}")
+        return int(v)
+
+    def _reject(self, prompt_ids: List[int], params: SamplingParams) -> Optional[Response]:
+        """400 for a request the engine could never serve (too long for the model or the KV
+        cache, non-finite sampling parameters): checked here, before anything is queued."""
+        from kvmini.engine.scheduler import Sequence
+
+        why = self.engine.scheduler.validate(Sequence(0, prompt_ids, params))
+        if why is None:
+            return None
+        self.errors_total += 1
+        return Response.json({"error": {"message": why, "type": "invalid_request_error"}}, 400)
 
     def _auth(self, req: Request) -> Optional[Response]:
         if self.api_key and req.headers.get("authorization", "") != f"Bearer {self.api_key}":
@@ -129,15 +151,15 @@ class NativeServer:
             if isinstance(prompt, list):
                 prompt = prompt[0] if prompt else ""
             prompt_ids = self.tok.encode(str(prompt), add_bos=True)
-        if len(prompt_ids) >= self.engine.ecfg.max_model_len:
-            self.errors_total += 1
-            return Response.json({"error": {"message": f"prompt has {len(prompt_ids)} tokens; max_model_len is {self.engine.ecfg.max_model_len}", "type": "invalid_request_error"}}, 400)
         try:
             n = max(1, min(int(body.get("n") or 1), 16))
             params = self._params(body, chat)
         except (TypeError, ValueError) as e:
             self.errors_total += 1
             return Response.json({"error": {"message": f"bad sampling parameter: {e}", "type": "invalid_request_error"}}, 400)
+        bad = self._reject(prompt_ids, params)
+        if bad:
+            return bad
         stops = body.get("stop") or []
         stops = [stops] if isinstance(stops, str) else [str(x) for x in stops if x]
         stream = bool(body.get("stream"))
@@ -259,18 +281,28 @@ class NativeServer:
 
     # TGI ------------------------------------------------------------------
     async def tgi(self, req: Request) -> Any:
+        bad = self._auth(req)
+        if bad:
+            return bad
         body = req.json() or {}
         self.requests_total += 1
         prm = body.get("parameters") or {}
-        params = SamplingParams(
-            max_tokens=int(prm.get("max_new_tokens") or 20),
-            temperature=float(prm.get("temperature") or 0.0) if prm.get("do_sample") else 0.0,
-            top_p=float(prm.get("top_p") or 1.0),
-            top_k=int(prm.get("top_k") or 0),
-            seed=prm.get("seed"),
-            ignore_eos=self.ignore_eos,
-        )
+        try:
+            params = SamplingParams(
+                max_tokens=int(prm.get("max_new_tokens") or 20),
+                temperature=float(prm.get("temperature") or 0.0) if prm.get("do_sample") else 0.0,
+                top_p=float(prm.get("top_p") or 1.0),
+                top_k=int(prm.get("top_k") or 0),
+                seed=self._seed(prm.get("seed")),
+                ignore_eos=self.ignore_eos,
+            )
+        except (TypeError, ValueError) as e:
+            self.errors_total += 1
+            return Response.json({"error": f"bad parameter: {e}", "error_type": "validation"}, 422)
         prompt_ids = self.tok.encode(str(body.get("inputs", "")), add_bos=True)
+        bad = self._reject(prompt_ids, params)
+        if bad:
+            return bad
         rid, q = await self._run(prompt_ids, params)
         if not req.path.endswith("_stream"):
             out: List[int] = []

@@ -559,3 +559,82 @@ def test_ride_along_budget_keeps_bursts_in_streaming_sized_steps():
     for s in burst:
         assert s.output_ids == dense_greedy(w, s.prompt_ids, 4)
     assert long.output_ids == dense_greedy(w, long.prompt_ids, 2)
+
+
+def test_malformed_requests_fail_alone_and_early():
+    """A request the engine can never serve is refused at intake (HTTP 400 / 422 / 401) and the
+    requests running next to it finish normally: bad seed, non-finite temperature, a prompt at
+    the model length, a request larger than the whole KV cache — on the OpenAI and TGI routes,
+    which also both check the API key."""
+    import threading
+    import urllib.error
+    import urllib.request
+
+    from kvmini.server.native import start_native_in_thread
+
+    eng, _w = _engine(max_num_seqs=4, max_batched_tokens=32, max_model_len=64, num_blocks=12, block_size=4)
+    _ns, url, stop = start_native_in_thread(eng, model_name="tiny", api_key="k")
+
+    def post(path, body, key="k"):
+        req = urllib.request.Request(url + path, data=json.dumps(body).encode(), headers={"Content-Type": "application/json", "Authorization": f"Bearer {key}"})
+        try:
+            with urllib.request.urlopen(req, timeout=60) as r:
+                return r.status, json.loads(r.read().decode())
+        except urllib.error.HTTPError as e:
+            return e.code, json.loads(e.read().decode() or "{}")
+
+    try:
+        msgs = [{"role": "user", "content": "hi"}]
+        good: dict = {}
+        th = threading.Thread(target=lambda: good.update(r=post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 24})))
+        th.start()
+        assert post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 4, "temperature": 0.7, "seed": "abc"})[0] == 400
+        assert post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 4, "temperature": 0.7, "seed": 1.5})[0] == 400
+        assert post("/v1/chat/completions", {"model": "tiny", "messages": msgs, "max_tokens": 4, "temperature": float("inf")})[0] == 400
+        long_text = "word " * 200
+        st, body = post("/v1/chat/completions", {"model": "tiny", "messages": [{"role": "user", "content": long_text}], "max_tokens": 4})
+        assert st == 400 and "max_model_len" in body["error"]["message"]
+        # fits the model length but not the 11 usable KV blocks of 4 tokens
+        st, body = post("/v1/completions", {"model": "tiny", "prompt": "a b c", "max_tokens": 60})
+        assert st == 400 and "KV blocks" in body["error"]["message"]
+        # TGI routes: key checked, same limits
+        assert post("/generate", {"inputs": "hello", "parameters": {"max_new_tokens": 4}}, key="wrong")[0] == 401
+        assert post("/generate", {"inputs": long_text, "parameters": {"max_new_tokens": 4}})[0] == 400
+        assert post("/generate", {"inputs": "hello", "parameters": {"max_new_tokens": 4, "do_sample": True, "temperature": 0.5, "seed": "x"}})[0] == 422
+        st, body = post("/generate", {"inputs": "hello", "parameters": {"max_new_tokens": 4}})
+        assert st == 200 and body["details"]["generated_tokens"] == 4
+        th.join(60)
+        assert good["r"][0] == 200 and good["r"][1]["usage"]["completion_tokens"] == 24
+        assert eng.metrics()["running"] == 0 and eng.metrics()["waiting"] == 0
+    finally:
+        stop()
+    # the engine's own intake refuses too (a front-end that skipped the check)
+    with pytest.raises(ValueError):
+        eng.generate([[1] * 64], SamplingParams(max_tokens=4))
+
+
+def test_llama3_rope_scaling_tables_and_checkpoint_config_check(tmp_path):
+    """The 3.1 / 3.2 presets carry the 'llama3' rotary scaling: high-frequency pairs are those of
+    the plain table, low-frequency pairs turn `factor` times slower; a checkpoint whose
+    config.json disagrees with the preset is refused."""
+    from kvmini.models.llama import check_hf_config, rope_tables
+
+    c31, c3 = get_config("llama-3.1-8b"), get_config("llama-3-8b")
+    cos31, sin31 = rope_tables(c31, 64, "cpu")
+    cos3, sin3 = rope_tables(c3, 64, "cpu")
+    assert torch.equal(cos31[:, :16], cos3[:, :16])  # wavelengths far below the original context: untouched
+    ang3 = torch.atan2(sin3[1, -1].double(), cos3[1, -1].double())
+    ang31 = torch.atan2(sin31[1, -1].double(), cos31[1, -1].double())
+    assert abs(float(ang3 / ang31) - 8.0) < 1e-3  # the slowest pair: 8x slower
+    assert get_config("meta-llama/Llama-3.1-8B-Instruct").rope_scaling == (8.0, 1.0, 4.0, 8192)
+    good = {"hidden_size": 4096, "intermediate_size": 14336, "num_hidden_layers": 32, "num_attention_heads": 32, "num_key_value_heads": 8, "vocab_size": 128256,
+            "rms_norm_eps": 1e-5, "rope_theta": 500000.0, "tie_word_embeddings": False,
+            "rope_scaling": {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}}
+    p = tmp_path / "config.json"
+    p.write_text(json.dumps(good))
+    check_hf_config(str(p), c31)
+    with pytest.raises(ValueError, match="rope_scaling"):
+        check_hf_config(str(p), c3)
+    p.write_text(json.dumps({**good, "num_key_value_heads": 4}))
+    with pytest.raises(ValueError, match="num_key_value_heads"):
+        check_hf_config(str(p), c31)
