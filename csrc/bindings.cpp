@@ -41,6 +41,10 @@ int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
                    int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
+int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant);
+int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int bm, int bn, int variant, int splits,
+                 int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int m_fastest,
+                 hipStream_t stream, unsigned long long* dbg);
 int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int target_wgs, int* groups_per_split);
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
@@ -405,6 +409,48 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
         "kv_stream_gemm3");
 }
 
+// ---- tiled MFMA GEMM for wide token batches (csrc/wide_gemm.hip); same packed weights as the streaming kernels
+int64_t wide_gemm_stage_ksteps(int64_t bm, int64_t bn, int64_t variant) { return kv_wide_gemm_stage_ksteps((int)bm, (int)bn, (int)variant); }
+
+void wide_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t bm, int64_t bn, int64_t variant, int64_t splits,
+               int64_t stages_per_split, c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale, bool m_fastest, c10::optional<at::Tensor> dbg) {
+  CHECK_DEV(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
+  const float* wsp = nullptr;
+  if (w_scale.has_value()) {
+    const at::Tensor& ws = *w_scale;
+    TORCH_CHECK(Wp.scalar_type() == at::kByte, "FP8 weights are passed as uint8 bytes");
+    TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kFloat && ws.is_contiguous() && ws.numel() == N, "w_scale must be contiguous fp32 [N]");
+    wsp = (const float*)ws.data_ptr();
+  } else {
+    CHECK_BF16(Wp);
+  }
+  unsigned long long* dbgp = nullptr;
+  if (dbg.has_value()) {  // diagnostic builds: 8 x int64 per wave of the grid
+    TORCH_CHECK(dbg->is_cuda() && dbg->scalar_type() == at::kLong && dbg->is_contiguous() && dbg->numel() >= ((x.size(0) + bm - 1) / bm) * (N / bn) * splits * 8 * 8, "dbg too small");
+    dbgp = (unsigned long long*)dbg->data_ptr();
+  }
+  TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
+  TORCH_CHECK(K % 64 == 0 && N % bn == 0, "wide_gemm: K must be a multiple of 64 and N of the feature tile");
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
+  const int64_t M = x.size(0);
+  int parts = 0;
+  const float* ssp = ss_ptr(row_ss, M, &parts);
+  long long ldy = 0, slab_stride = 0;
+  if (epi == 1) {
+    TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && out.dim() == 3 && out.size(0) == splits && out.size(1) == M && out.size(2) == N,
+                "slab output must be contiguous fp32 [splits, M, N]");
+    ldy = N; slab_stride = M * N;
+  } else {
+    CHECK_BF16(out);
+    TORCH_CHECK(out.dim() == 2 && out.size(0) == M && out.size(1) == (epi == 2 ? N / 2 : N) && out.stride(1) == 1 && out.stride(0) % 4 == 0, "bad output shape");
+    TORCH_CHECK(splits == 1, "bf16 / SwiGLU epilogues need a single split");
+    ldy = out.stride(0);
+  }
+  check(kv_wide_gemm(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)bm, (int)bn, (int)variant, (int)splits,
+                     (int)stages_per_split, slab_stride, ssp, parts, (float)eps, wsp, m_fastest ? 1 : 0, cur_stream(), dbgp),
+        "kv_wide_gemm");
+}
+
 void add_rmsnorm_slabs(at::Tensor slabs, at::Tensor residual, at::Tensor w, at::Tensor y, double eps) {
   CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_BF16(residual); CHECK_BF16(w); CHECK_BF16(y); CHECK_CONTIG(residual); CHECK_CONTIG(w); CHECK_CONTIG(y);
   TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3, "slabs must be fp32 [S, T, H]");
@@ -490,6 +536,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_gemm3_plan", &stream_gemm3_plan, py::arg("N"), py::arg("K"), py::arg("nb"), py::arg("max_splits"), py::arg("target_wgs") = 512, py::arg("nw") = 4);
   m.def("stream_gemm3", &stream_gemm3, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("nb"), py::arg("splits"),
         py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4);
+  m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
+  m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
+        py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true, py::arg("dbg") = py::none());
   m.def("prefetch", &prefetch);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs);

@@ -30,5 +30,5 @@ for k, cs in acc.items():
     if row.get("SQ_LDS_IDX_ACTIVE"):
         row["lds_bank_conflict_rate"] = row.get("SQ_LDS_BANK_CONFLICT", 0.0) / row["SQ_LDS_IDX_ACTIVE"]
     out[k] = row
-keep = {k: v for k, v in out.items() if any(t in k for t in ("stream_gemm", "attention", "residual_reduce", "rope_kv", "argmax", "radix", "stream_hist", "equal_hist", "trapz", "sample_rows", "embed_fed", "scale_rows"))}
+keep = {k: v for k, v in out.items() if any(t in k for t in ("stream_gemm", "attention", "residual_reduce", "rope_kv", "argmax", "radix", "stream_hist", "equal_hist", "trapz", "sample_rows", "embed_fed", "scale_rows", "wide_gemm", "Cijk", "allreduce", "logits_mask"))}
 print(json.dumps(keep, indent=1))
