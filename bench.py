@@ -151,7 +151,7 @@ def main() -> int:
     ap.add_argument("--no-async-scheduling", action="store_true", help="one step at a time: read the sampled ids back before launching the next step")
     ap.add_argument("--launch-margin-ms", type=float, default=None, help="pipelined stepping: launch this long before the step in flight should end (engine default when omitted; 0 = at once)")
     ap.add_argument("--ride-along-limit", type=int, default=None, help="prompt backlog (tokens) up to which prompts ride along with running decodes in <= 64-token steps (engine default when omitted; 0 = off)")
-    ap.add_argument("--tune-gemm", action="store_true", help="TunableOp for the library GEMMs of wide steps (off in the headline configuration)")
+    ap.add_argument("--tune-gemm", action="store_true", help=argparse.SUPPRESS)  # accepted for old command lines: no library GEMM is left to tune
     ap.add_argument("--out-dir", default=None, help="write run artifacts (requests.csv, power.json, results.json) here")
     ap.add_argument("--gpu-hourly", type=float, default=None, help="$/GPU-hour (default: cost.yaml MI355X entry)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = rehearsal of the multi-rank flow over gloo with the reference ops (not a benchmark)")
@@ -213,7 +213,6 @@ def main() -> int:
             kernels=args.kernels,
             kv_memory_fraction=0.3,
             async_scheduling=not args.no_async_scheduling,
-            tune_library_gemm=args.tune_gemm,
             **({} if args.ride_along_limit is None else {"ride_along_limit": args.ride_along_limit}),
             **({} if args.launch_margin_ms is None else {"launch_margin_ms": args.launch_margin_ms}),
         )

@@ -44,7 +44,7 @@ int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K
 int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant);
 int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int bm, int bn, int variant, int splits,
                  int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int m_fastest,
-                 hipStream_t stream, unsigned long long* dbg);
+                 hipStream_t stream);
 int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int target_wgs, int* groups_per_split);
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
@@ -413,7 +413,7 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
 int64_t wide_gemm_stage_ksteps(int64_t bm, int64_t bn, int64_t variant) { return kv_wide_gemm_stage_ksteps((int)bm, (int)bn, (int)variant); }
 
 void wide_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t bm, int64_t bn, int64_t variant, int64_t splits,
-               int64_t stages_per_split, c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale, bool m_fastest, c10::optional<at::Tensor> dbg) {
+               int64_t stages_per_split, c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale, bool m_fastest) {
   CHECK_DEV(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
   const float* wsp = nullptr;
   if (w_scale.has_value()) {
@@ -423,11 +423,6 @@ void wide_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out
     wsp = (const float*)ws.data_ptr();
   } else {
     CHECK_BF16(Wp);
-  }
-  unsigned long long* dbgp = nullptr;
-  if (dbg.has_value()) {  // diagnostic builds: 8 x int64 per wave of the grid
-    TORCH_CHECK(dbg->is_cuda() && dbg->scalar_type() == at::kLong && dbg->is_contiguous() && dbg->numel() >= ((x.size(0) + bm - 1) / bm) * (N / bn) * splits * 8 * 8, "dbg too small");
-    dbgp = (unsigned long long*)dbg->data_ptr();
   }
   TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
   TORCH_CHECK(K % 64 == 0 && N % bn == 0, "wide_gemm: K must be a multiple of 64 and N of the feature tile");
@@ -447,7 +442,7 @@ void wide_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out
     ldy = out.stride(0);
   }
   check(kv_wide_gemm(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)bm, (int)bn, (int)variant, (int)splits,
-                     (int)stages_per_split, slab_stride, ssp, parts, (float)eps, wsp, m_fastest ? 1 : 0, cur_stream(), dbgp),
+                     (int)stages_per_split, slab_stride, ssp, parts, (float)eps, wsp, m_fastest ? 1 : 0, cur_stream()),
         "kv_wide_gemm");
 }
 
@@ -538,7 +533,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4);
   m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
-        py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true, py::arg("dbg") = py::none());
+        py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);
   m.def("prefetch", &prefetch);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs);

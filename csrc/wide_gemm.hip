@@ -11,12 +11,11 @@
 //    (BM/WM) x (BN/WN) outputs = FB x FA tiles of mfma_f32_16x16x32_bf16 (W is the A operand,
 //    x the B operand: an accumulator register holds 4 consecutive features of one token).
 //  * Both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
-//    instruction, no VGPR round trip) into a ring of NS stages; NS - 1 stages of loads stay in
-//    flight ACROSS the barriers (counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per
-//    stage): with 32 workgroups of an XCD marching through K in lock-step every stage's
-//    first touch misses the L2, and one stage of lookahead does not cover that round trip.
-//    Optionally each wave also touches the lines of a stage further ahead with 4-byte LDS-DMAs
-//    into a scratch area (an L2 prefetch that needs no registers and no LDS stage).
+//    instruction, no VGPR round trip) into a ring of NS stages whose loads stay in flight
+//    ACROSS the barriers (counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per stage).
+//  * Software pipeline in registers: while the MFMAs of stage i run from one register set, the
+//    fragments of stage i+1 are read from LDS into the other set and the DMA of stage i+NS is
+//    issued, all interleaved between the MFMAs (see the kernel's header comment).
 //  * Weights: a (16-feature tile, k-step) fragment is 1 KiB contiguous in memory AND in LDS;
 //    a wave's ds_read_b128 of it is lane-linear, hence bank-conflict-free with no swizzle.
 //  * x is row-major, so it is staged in full 128-byte lines (8 rows x 128 B per LDS-DMA piece)
@@ -78,29 +77,29 @@ struct Params {
   int stages_per_split, splits; long long slab_stride;
   const float* row_ss; int ss_parts; float inv_k, eps; const float* w_scale;
   int n_mtiles, n_ntiles, m_fastest;
-  unsigned long long* dbg;  // diagnostic builds only: per-wave cycle sums of the loop's segments
 };
 
-// KS  = k-steps (of 32) per LDS stage: 2 -> 128-byte x rows (full cache lines), 1 -> 64-byte rows
-// NS  = LDS stages in the ring; NS - 1 stages of loads are in flight while one is computed on
-// PFD = L2 prefetch distance in stages beyond the LDS ring (0 = off): one 4-byte LDS-DMA per
-//       cache line of a future stage into a scratch area, so that the real loads of that stage
-//       find their lines in the XCD's L2 instead of waiting ~2 us for the Infinity Cache / HBM
-// One s_memtime stamp (diagnostic builds): its own wait keeps it ordered against LDS reads.
-__device__ inline unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-
-template <int BM, int BN, int WM, int WN, int KS, int NS, int PFD, int EPI, bool W8, bool STAMP = false>
+// KS = k-steps (of 32) per LDS stage: 2 -> 128-byte x rows (full cache lines), 1 -> 64-byte rows
+// NS = LDS stages in the ring
+//
+// Software pipeline (one barrier per stage, every wave's stage is the same mix of work):
+//   top of step i:  s_waitcnt vmcnt((NS - 2) G)   this wave's pieces of stage i+1 have landed
+//                   s_barrier                     ... and everybody's; all reads of stage i are done
+//                   LDS-DMA of stage i+NS   -> buffer i % NS (free: stage i sits in registers)
+//                   fragment reads of stage i+1 -> register set (i+1) & 1   } interleaved
+//                   MFMAs on register set i & 1 (stage i)                   }
+// so neither the DMA issue (~10 cycles of the CU's vector-memory path per KiB), nor LDS read
+// latency, nor the wait for a stage stands between two MFMAs of a wave: measured on the first
+// version of this kernel (all DMAs, then all reads, then all MFMAs per stage) those took 23 %,
+// 13 % and 22 % (barrier skew) of a step next to 38 % for the MFMAs.
+// Stages past the end of the K range are re-reads of the last one (the counts stay exact).
+template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, bool W8>
 __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tokens x features
   constexpr int FB = TM / 16, FA = TN / 16;  // B (x) and A (W) fragment tiles per wave and k-step
   static_assert(!W8 || KS == 2, "FP8 weights are packed two k-steps per 16-byte unit");
+  static_assert(NS >= 2, "ring of at least two stages");
   constexpr int A_TILE = W8 ? 1024 : KS * 1024;  // bytes of one 16-feature tile per stage
   constexpr int A_BYTES = (BN / 16) * A_TILE;
   constexpr int XROW = KS * 64;                  // bytes of an x row per stage
@@ -109,11 +108,12 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
   constexpr int PA = A_BYTES / 1024, PX = X_BYTES / 1024;  // 1 KiB LDS-DMA pieces per stage
   static_assert(PA % NW == 0 && PX % NW == 0, "every wave issues the same number of LDS-DMA pieces (exact vmcnt counts)");
   constexpr int PA_W = PA / NW, PX_W = PX / NW;
-  constexpr int G = PA_W + PX_W;                 // LDS-DMA instructions per wave and stage
-  constexpr int A_LINES = A_BYTES / 128;         // cache lines of a stage: W, then one per x row
-  constexpr int PF_OPS = PFD > 0 ? (A_LINES + BM + NW * 64 - 1) / (NW * 64) : 0;
-  constexpr int OPS = G + PF_OPS;                // vector-memory operations per wave and step
-  constexpr int SCRATCH = NS * STAGE;            // [NW][256] landing area of the prefetch DMAs
+  constexpr int G = PA_W + PX_W;         // LDS-DMA instructions per wave and stage
+  constexpr int AR = W8 ? FA : KS * FA;  // 16-byte LDS reads of W per wave and stage
+  constexpr int NREAD = AR + KS * FB;    // LDS reads per wave and stage
+  constexpr int NGRP = KS * FA;          // MFMA groups (FB MFMAs each) per stage
+  constexpr int MEM = NREAD + G;         // mem ops to spread over the groups
+  constexpr int PER = (MEM + NGRP - 1) / NGRP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -170,38 +170,6 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
     row = row < p.M ? row : p.M - 1;  // rows past the end read the last row; their outputs are not stored
     xsrc[i] = reinterpret_cast<const unsigned char*>(p.x + (long long)row * p.ldx + (long long)s0 * (32 * KS)) + chunk * 16;
   }
-  // L2 prefetch: lane slot g of a stage = cache line g of its weights, or x row g - A_LINES
-  const unsigned char* pfsrc[PF_OPS > 0 ? PF_OPS : 1];
-  long long pfstep[PF_OPS > 0 ? PF_OPS : 1];
-#pragma unroll
-  for (int i = 0; i < PF_OPS; ++i) {
-    int g = (i * NW + wave) * 64 + lane;
-    g = g < A_LINES + BM ? g : A_LINES + BM - 1;
-    if (g < A_LINES) {
-      const int ti = g / (A_TILE / 128), ln = g % (A_TILE / 128);
-      pfsrc[i] = p.Wp + (((long long)(n0 >> 4) + ti) * nst + s0) * A_TILE + ln * 128;
-      pfstep[i] = A_TILE;
-    } else {
-      int row = m0 + g - A_LINES;
-      row = row < p.M ? row : p.M - 1;
-      pfsrc[i] = reinterpret_cast<const unsigned char*>(p.x + (long long)row * p.ldx + (long long)s0 * (32 * KS));
-      pfstep[i] = XROW;
-    }
-  }
-
-  auto stage = [&](int buf, int st) {  // st = stage index relative to s0
-    unsigned char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < PA_W; ++i) dma16(asrc[i] + (long long)st * A_TILE, base + (wave + NW * i) * 1024);
-#pragma unroll
-    for (int i = 0; i < PX_W; ++i) dma16(xsrc[i] + (long long)st * XROW, base + A_BYTES + (wave + NW * i) * 1024);
-  };
-  auto prefetch = [&](int st) {
-    const int stc = st < n ? st : n - 1;  // past the end of this split: touch its last stage again (same count of operations)
-#pragma unroll
-    for (int i = 0; i < PF_OPS; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(pfsrc[i] + stc * pfstep[i]), (lds_void*)(smem + SCRATCH + wave * 256), 4, 0, 0);
-  };
 
   frag_cd acc[FA][FB];
 #pragma unroll
@@ -219,72 +187,71 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
     x_off[0] = A_BYTES + (wm * TM + r) * 64 + ((q ^ ((4 - (r >> 2)) & 3)) << 4);
   }
 
-  // ---- prologue: NS - 1 stages in flight (stages past the end are re-reads of the last one
-  // into their own buffers: the operation count per step stays exact)
+  // two register sets of fragments: W as read (bf16: one k-step per read, laid out [tile][k-step];
+  // FP8: both k-steps of a tile in one read), x per k-step and token tile
+  raw16 ra[2][AR];
+  frag_ab fb[2][KS][FB];
+
+  // mem op m of a step: m < G -> LDS-DMA piece m of stage `st` into `dst`; else fragment read m - G
+  // of the stage at `src` into register set SET
+#define WG_MEMOP(m, SET, dst, src, st)                                                                                                   \
+  do {                                                                                                                                  \
+    if ((m) < PA_W) dma16(asrc[(m) < PA_W ? (m) : 0] + (long long)(st) * A_TILE, (dst) + (wave + NW * (m)) * 1024);                     \
+    else if ((m) < G) dma16(xsrc[(m) >= PA_W && (m) < G ? (m) - PA_W : 0] + (long long)(st) * XROW, (dst) + A_BYTES + (wave + NW * ((m) - PA_W)) * 1024); \
+    else if ((m) - G < AR) ra[SET][(m) >= G && (m) - G < AR ? (m) - G : 0] = *reinterpret_cast<const raw16*>((src) + a_off + ((m) - G) * 1024); \
+    else {                                                                                                                              \
+      const int kk_ = (m) - G - AR;                                                                                                     \
+      const int ss_ = kk_ >= 0 && kk_ < KS * FB ? kk_ / FB : 0, jj_ = kk_ >= 0 ? kk_ % FB : 0;                                          \
+      fb[SET][ss_][jj_] = *reinterpret_cast<const frag_ab*>((src) + x_off[ss_] + jj_ * (16 * XROW));                                    \
+    }                                                                                                                                   \
+  } while (0)
+
+  // ---- prologue: the whole ring in flight, then stage 0 into register set 0
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) {
-    stage(s, s < n ? s : n - 1);
-    prefetch(s + NS - 1 + PFD);
+  for (int s = 0; s < NS; ++s) {
+    unsigned char* dst = smem + s * STAGE;
+    const int st = s < n ? s : n - 1;
+#pragma unroll
+    for (int m = 0; m < G; ++m) WG_MEMOP(m, 0, dst, smem, st);
   }
-  unsigned long long seg[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
-  for (int i = 0; i < n; ++i) {
-    const int buf = i % NS;
-    if constexpr (STAMP) t0 = stamp();
-    // Stage i has landed once all but the (NS - 2) younger steps' operations of this wave are
-    // done; the barrier then orders every wave's pieces before anybody's reads, and says that
-    // every wave has finished reading the buffer that is re-filled next.
-    if constexpr ((NS - 2) * OPS == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
-    if constexpr (STAMP) { t1 = stamp(); seg[0] += t1 - t0; t0 = t1; }
-    __builtin_amdgcn_s_barrier();
-    if constexpr (STAMP) { t1 = stamp(); seg[1] += t1 - t0; t0 = t1; }
-    {
-      const int st = i + NS - 1;
-      stage(st % NS, st < n ? st : n - 1);
-      prefetch(st + PFD);
-    }
-    if constexpr (STAMP) { t1 = stamp(); seg[2] += t1 - t0; t0 = t1; }
-    const unsigned char* sb = smem + buf * STAGE;
-    // all fragment reads of the stage are issued up front (registers permitting), so that the
-    // MFMAs wait for LDS latency once per stage, not once per group of four
-    frag_ab a[KS][FA], b[KS][FB];
+  if constexpr ((NS - 1) * G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * G) : "memory");
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if constexpr (W8) {
-        if (s == 0) {
-#pragma unroll
-          for (int ii = 0; ii < FA; ++ii) {
-            const raw16 v = *reinterpret_cast<const raw16*>(sb + a_off + ii * 1024);
-            a[0][ii] = fp8x8_to_bf16(v[0], v[1]);
-            a[KS - 1][ii] = fp8x8_to_bf16(v[2], v[3]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int ii = 0; ii < FA; ++ii) a[s][ii] = *reinterpret_cast<const frag_ab*>(sb + a_off + (ii * KS + s) * 1024);
-      }
-#pragma unroll
-      for (int j = 0; j < FB; ++j) b[s][j] = *reinterpret_cast<const frag_ab*>(sb + x_off[s] + j * (16 * XROW));
-    }
-    if constexpr (STAMP) { t1 = stamp(); seg[3] += t1 - t0; t0 = t1; }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ii = 0; ii < FA; ++ii)
-#pragma unroll
-        for (int j = 0; j < FB; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][ii], b[s][j], acc[ii][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    if constexpr (STAMP) { t1 = stamp(); seg[4] += t1 - t0; }
+  for (int m = G; m < MEM; ++m) WG_MEMOP(m, 0, smem, smem, 0);
+
+  // one step: MFMAs on register set CUR; the DMA of stage I + NS and the reads of stage I + 1
+  // (into set NXT) are spread between the MFMA groups
+#define WG_STEP(CUR, NXT, I)                                                                                                 \
+  do {                                                                                                                      \
+    const int i_ = (I);                                                                                                     \
+    if constexpr ((NS - 2) * G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");                                                \
+    __builtin_amdgcn_s_barrier();                                                                                           \
+    unsigned char* dst_ = smem + (i_ % NS) * STAGE;                                                                         \
+    const unsigned char* src_ = smem + ((i_ + 1) % NS) * STAGE;                                                             \
+    const int st_ = i_ + NS < n ? i_ + NS : n - 1;                                                                          \
+    _Pragma("unroll") for (int g = 0; g < NGRP; ++g) {                                                                      \
+      const int s = g / FA, ii = g % FA;                                                                                    \
+      frag_ab af;                                                                                                           \
+      if constexpr (W8) af = s == 0 ? fp8x8_to_bf16(ra[CUR][ii][0], ra[CUR][ii][1]) : fp8x8_to_bf16(ra[CUR][ii][2], ra[CUR][ii][3]); \
+      else af = __builtin_bit_cast(frag_ab, ra[CUR][(ii * KS + s) < AR ? ii * KS + s : 0]);                                  \
+      _Pragma("unroll") for (int j = 0; j < FB; ++j)                                                                        \
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, fb[CUR][s][j], acc[ii][j], 0, 0, 0);                      \
+      _Pragma("unroll") for (int m = g * PER; m < (g + 1) * PER; ++m)                                                       \
+          if (m < MEM) WG_MEMOP(m, NXT, dst_, src_, st_);                                                                   \
+      __builtin_amdgcn_sched_barrier(0); /* keep the hand-placed interleave: the scheduler would sink the reads to their use */ \
+    }                                                                                                                       \
+  } while (0)
+
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    WG_STEP(0, 1, i);
+    WG_STEP(1, 0, i + 1);
   }
-  if constexpr (STAMP) {
-    if (lane == 0 && p.dbg != nullptr) {
-      unsigned long long* d = p.dbg + ((long long)blockIdx.x * NW + wave) * 8;
-      for (int k = 0; k < 5; ++k) d[k] = seg[k];
-      d[5] = n;
-    }
-  }
+  if (i < n) WG_STEP(0, 1, i);
+#undef WG_STEP
+#undef WG_MEMOP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-read stages of the tail
 
   // ---- epilogue: acc[i][j][e] = y[token m0 + wm TM + 16 j + r][feature n0 + wn TN + 16 i + 4 q + e]
@@ -302,14 +269,14 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
     }
   }
 #pragma unroll
-  for (int i = 0; i < FA; ++i) {
-    const int f = feat0 + 16 * i;
+  for (int ii = 0; ii < FA; ++ii) {
+    const int f = feat0 + 16 * ii;
     frag_cd ws = (frag_cd){1.f, 1.f, 1.f, 1.f};
     if constexpr (W8) ws = *reinterpret_cast<const frag_cd*>(p.w_scale + f);
 #pragma unroll
     for (int j = 0; j < FB; ++j) {
       const int t = tok0 + 16 * j;
-      frag_cd v = acc[i][j];
+      frag_cd v = acc[ii][j];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= ws[e] * rs[j];
       if constexpr (EPI == EPI_SLAB) {
@@ -328,19 +295,19 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
           const float g = v[e], up = __shfl_xor(v[e], 32, 64);
           o[e] = f2bf(g / (1.f + __expf(-g)) * up);
         }
-        const int fi = ((n0 + wn * TN + 16 * i) >> 1) + 4 * q;
+        const int fi = ((n0 + wn * TN + 16 * ii) >> 1) + 4 * q;
         if (q < 2 && t < p.M) *reinterpret_cast<us4*>(reinterpret_cast<unsigned short*>(p.out) + (long long)t * p.ldy + fi) = o;
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NS, int PFD, int EPI, bool W8, bool STAMP = false>
+template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, bool W8>
 int launch(const Params& p, hipStream_t stream) {
   constexpr int A_BYTES = (BN / 16) * (W8 ? 1024 : KS * 1024);
-  constexpr int LDS = NS * (A_BYTES + BM * KS * 64) + (PFD > 0 ? WM * WN * 256 : 0);
+  constexpr int LDS = NS * (A_BYTES + BM * KS * 64);
   static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
-  auto kern = wide_gemm_kernel<BM, BN, WM, WN, KS, NS, PFD, EPI, W8, STAMP>;
+  auto kern = wide_gemm_kernel<BM, BN, WM, WN, KS, NS, EPI, W8>;
   static bool attr_set = false;  // per instantiation; LDS above the 64 KiB default has to be requested once
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
@@ -351,59 +318,43 @@ int launch(const Params& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NS, int PFD, bool W8>
+template <int BM, int BN, int WM, int WN, int KS, int NS, bool W8>
 int dispatch_epi(int epi, const Params& p, hipStream_t s) {
   switch (epi) {
-    case EPI_BF16: return launch<BM, BN, WM, WN, KS, NS, PFD, EPI_BF16, W8>(p, s);
-    case EPI_SLAB: return launch<BM, BN, WM, WN, KS, NS, PFD, EPI_SLAB, W8>(p, s);
-    case EPI_SWIGLU: return launch<BM, BN, WM, WN, KS, NS, PFD, EPI_SWIGLU, W8>(p, s);
+    case EPI_BF16: return launch<BM, BN, WM, WN, KS, NS, EPI_BF16, W8>(p, s);
+    case EPI_SLAB: return launch<BM, BN, WM, WN, KS, NS, EPI_SLAB, W8>(p, s);
+    case EPI_SWIGLU: return launch<BM, BN, WM, WN, KS, NS, EPI_SWIGLU, W8>(p, s);
   }
   return -1;
 }
 
-// variant = pipeline shape of a tile: 0 = two 64-wide stages, 1 = the same + L2 prefetch,
-// 2 = deep ring (as many stages as the LDS holds), 3 = deep ring + L2 prefetch
+// variant = pipeline shape of a tile: 0 = 64-wide stages in the deepest ring the LDS holds,
+// 1 / 3 = 32-wide stages (bf16 weights only), 2 = 64-wide stages in a two-stage ring
 template <bool W8>
 int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStream_t s) {
   const int key = bm * 1000 + bn;
   switch (key * 10 + variant) {
     // 256 x 256, 8 waves (wave: 64 tokens x 128 features)
-    case 2562560: return dispatch_epi<256, 256, 4, 2, 2, 2, 0, W8>(epi, p, s);
-    case 2562561: return dispatch_epi<256, 256, 4, 2, 2, 2, 3, W8>(epi, p, s);
-    case 2562565: return dispatch_epi<256, 256, 2, 2, 2, 2, 0, W8>(epi, p, s);  // 4 waves (wave: 128 x 128, one per SIMD)
+    case 2562560: return dispatch_epi<256, 256, 4, 2, 2, 2, W8>(epi, p, s);
     // 256 x 128, 8 waves (wave: 64 x 64)
-    case 2561280: return dispatch_epi<256, 128, 4, 2, 2, 2, 0, W8>(epi, p, s);
-    case 2561281: return dispatch_epi<256, 128, 4, 2, 2, 2, 3, W8>(epi, p, s);
-    case 2561282: return dispatch_epi<256, 128, 4, 2, 2, 3, 0, W8>(epi, p, s);
-    case 2561283: return dispatch_epi<256, 128, 4, 2, 2, 3, 2, W8>(epi, p, s);
+    case 2561280: return dispatch_epi<256, 128, 4, 2, 2, 3, W8>(epi, p, s);
+    case 2561282: return dispatch_epi<256, 128, 4, 2, 2, 2, W8>(epi, p, s);
     // 128 x 256, 8 waves (wave: 64 x 64)
-    case 1282560: return dispatch_epi<128, 256, 2, 4, 2, 2, 0, W8>(epi, p, s);
-    case 1282562: return dispatch_epi<128, 256, 2, 4, 2, 3, 0, W8>(epi, p, s);
-    case 1282563: return dispatch_epi<128, 256, 2, 4, 2, 3, 2, W8>(epi, p, s);
+    case 1282560: return dispatch_epi<128, 256, 2, 4, 2, 3, W8>(epi, p, s);
+    case 1282562: return dispatch_epi<128, 256, 2, 4, 2, 2, W8>(epi, p, s);
     // 128 x 128, 4 waves (wave: 64 x 64); two workgroups per CU with two stages
-    case 1281280: return dispatch_epi<128, 128, 2, 2, 2, 2, 0, W8>(epi, p, s);
-    case 1281282: return dispatch_epi<128, 128, 2, 2, 2, 4, 0, W8>(epi, p, s);
-    case 1281283: return dispatch_epi<128, 128, 2, 2, 2, 4, 2, W8>(epi, p, s);
+    case 1281280: return dispatch_epi<128, 128, 2, 2, 2, 4, W8>(epi, p, s);
+    case 1281282: return dispatch_epi<128, 128, 2, 2, 2, 2, W8>(epi, p, s);
   }
   if constexpr (!W8) {
-    // diagnostic builds (segment stamps, p.dbg): variants 90 + v of the 256 x 256 tile, bf16 output
-    if (key == 256256 && epi == EPI_BF16 && p.dbg != nullptr) {
-      if (variant == 90) return launch<256, 256, 4, 2, 2, 2, 0, EPI_BF16, false, true>(p, s);
-      if (variant == 92) return launch<256, 256, 4, 2, 1, 4, 0, EPI_BF16, false, true>(p, s);
-      if (variant == 95) return launch<256, 256, 2, 2, 2, 2, 0, EPI_BF16, false, true>(p, s);
-    }
-  }
-  if constexpr (!W8) {  // bf16 weights only: 256 x 64 (an FP8 stage of it is 4 pieces for 8 waves) and the 32-wide stages
     switch (key * 10 + variant) {
-      // 256 x 64, 8 waves (wave: 32 x 64)
-      case 2560640: return dispatch_epi<256, 64, 8, 1, 2, 2, 0, false>(epi, p, s);
-      case 2560642: return dispatch_epi<256, 64, 8, 1, 2, 3, 0, false>(epi, p, s);
-      case 2560643: return dispatch_epi<256, 64, 8, 1, 2, 3, 2, false>(epi, p, s);
-      // 256 x 256 with a 4 / 5-deep ring of 32-wide stages
-      case 2562562: return dispatch_epi<256, 256, 4, 2, 1, 4, 0, false>(epi, p, s);
-      case 2562563: return dispatch_epi<256, 256, 4, 2, 1, 4, 4, false>(epi, p, s);
-      case 2562564: return dispatch_epi<256, 256, 4, 2, 1, 5, 0, false>(epi, p, s);
-      case 2562566: return dispatch_epi<256, 256, 2, 2, 1, 4, 0, false>(epi, p, s);  // 4 waves, 4-deep ring
+      // 32-wide stages: deeper rings in the same LDS
+      case 2562561: return dispatch_epi<256, 256, 4, 2, 1, 4, false>(epi, p, s);
+      case 2562563: return dispatch_epi<256, 256, 4, 2, 1, 5, false>(epi, p, s);
+      case 2561281: return dispatch_epi<256, 128, 4, 2, 1, 6, false>(epi, p, s);
+      // 256 x 64, 8 waves (wave: 32 x 64); an FP8 stage of it would be 4 pieces for 8 waves
+      case 2560640: return dispatch_epi<256, 64, 8, 1, 2, 3, false>(epi, p, s);
+      case 2560642: return dispatch_epi<256, 64, 8, 1, 2, 2, false>(epi, p, s);
     }
   }
   return -1;
@@ -414,10 +365,7 @@ int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStre
 extern "C" {
 
 // k-steps (of 32) per pipeline stage of a (tile, variant): K splits are handed out in stages
-int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant) {
-  variant %= 90;
-  return (bm == 256 && bn == 256 && (variant == 2 || variant == 3 || variant == 4 || variant == 6)) ? 1 : 2;
-}
+int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant) { (void)bm; (void)bn; return (variant == 1 || variant == 3) ? 1 : 2; }
 
 // epi: 0 = bf16 y[M, N], 1 = fp32 slabs out[splits][M][N], 2 = SwiGLU bf16 y[M, N/2].
 // (bm, bn): workgroup tile, one of (256,256) (256,128) (256,64) (128,128) (128,256); variant: see
@@ -426,7 +374,7 @@ int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant) {
 // w_scale != nullptr: Wp holds e4m3 bytes packed by kv_pack_weight_fp8, w_scale[N] the row scales.
 int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int bm, int bn, int variant, int splits,
                  int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int m_fastest,
-                 hipStream_t stream, unsigned long long* dbg) {
+                 hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K & 63) || bn <= 0 || (N % bn)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
   const int nst = K / (32 * kv_wide_gemm_stage_ksteps(bm, bn, variant));
@@ -437,7 +385,7 @@ int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, 
   p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
   p.stages_per_split = stages_per_split; p.splits = splits; p.slab_stride = slab_stride;
   p.row_ss = row_ss; p.ss_parts = ss_parts; p.inv_k = 1.f / (float)K; p.eps = eps; p.w_scale = w_scale;
-  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest; p.dbg = dbg;
+  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest;
   return w_scale ? dispatch_tile<true>(bm, bn, variant, epi, p, stream) : dispatch_tile<false>(bm, bn, variant, epi, p, stream);
 }
 

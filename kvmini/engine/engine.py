@@ -44,7 +44,6 @@ class EngineConfig:
     enable_prefix_caching: bool = True
     weights_path: Optional[str] = None
     quantization: Optional[str] = None  # None | fp8
-    prefill_gemm: str = "library"  # library | stream (see RunnerConfig)
     # speculative decoding
     draft_model: Optional[str] = None  # preset name, or "self:<K>" = early exit after K layers of the target
     num_speculative_tokens: int = 0
@@ -57,10 +56,6 @@ class EngineConfig:
     # to end (not right away), so that requests arriving meanwhile still make that launch; 0 =
     # launch immediately
     launch_margin_ms: float = 0.7
-    # let PyTorch's TunableOp pick the rocBLAS / hipBLASLt solution per shape for the library
-    # GEMMs of wide steps (> 64 tokens) during warm-up; timed with a rotating buffer so that the
-    # choice is made for weights that come from HBM, as they do in a real step
-    tune_library_gemm: bool = False
     # prompt backlogs up to this many tokens ride along with the running decodes in steps of at
     # most 64 (128) tokens instead of one wide step (see Scheduler.ride_along_limit); 0 = off.
     # Measured on the headline mix (18 prompts arriving together): first token 11.0 -> 9.4 ms, but
@@ -184,7 +179,6 @@ class LLMEngine:
             use_graphs=ecfg.use_graphs,
             kernels=ecfg.kernels,
             quantization=ecfg.quantization,
-            prefill_gemm=ecfg.prefill_gemm,
             tp_graphs=ecfg.tp_graphs,
             tp_force_collectives=ecfg.tp_force_collectives,
         )
@@ -220,22 +214,10 @@ class LLMEngine:
     def warmup(self) -> float:
         """Capture the HIP graphs (and JIT/allocator warm-up).  Returns seconds."""
         t0 = time.perf_counter()
-        tune = self.ecfg.tune_library_gemm and self.device.type == "cuda"
-        if tune:
-            import tempfile
-
-            tn = torch.cuda.tunable
-            tn.enable(True)
-            tn.tuning_enable(True)
-            tn.set_max_tuning_duration(100)
-            tn.set_rotating_buffer_size(1024)
-            tn.set_filename(os.path.join(tempfile.gettempdir(), f"kvmini_tunableop_{os.getpid()}.csv"))
         with torch.no_grad():
             self.runner.capture_graphs()
             if self.spec is not None:
                 self.spec.warmup()
-        if tune:
-            torch.cuda.tunable.tuning_enable(False)  # keep the choices, stop measuring
         self.warm_s = time.perf_counter() - t0
         return self.warm_s
 

@@ -41,10 +41,6 @@ class RunnerConfig:
     kernels: str = "auto"  # auto | hip | torch
     return_logits: bool = False
     quantization: Optional[str] = None  # None | fp8 (weight-only, HIP kernels)
-    # GEMM for token batches wider than 64: "library" keeps a row-major weight copy for
-    # hipBLASLt (2x weight memory, fast prefill), "stream" re-streams the packed weights
-    # once per 64 tokens (no extra memory)
-    prefill_gemm: str = "library"
     tp_graphs: bool = False  # capture HIP graphs (with the RCCL all-reduces inside) under tensor parallelism
     tp_force_collectives: bool = False  # run the TP collectives even for a group of one rank (tests)
 
@@ -120,7 +116,7 @@ class ModelRunner:
                 self.w, self.cfg = weights, weights.cfg
         if hasattr(self.ops, "prepare_weights"):
             # one-time re-order of every linear weight into MFMA fragment order
-            self.ops.prepare_weights(weights, rcfg.quantization, keep_full=rcfg.prefill_gemm == "library" and rcfg.max_batched_tokens > 64)
+            self.ops.prepare_weights(weights, rcfg.quantization)
         elif rcfg.quantization == "fp8":
             # reference ops: emulate weight-only FP8 by a quantise/dequantise round trip
             from kvmini.models.llama import fake_quantize_fp8

@@ -8,13 +8,16 @@ residual, and the ``1/rms`` row scale is applied in the projection's epilogue
 (or by the consumer of its split-K slabs).  :class:`Normed` and :class:`Partial`
 carry that bookkeeping between ops.
 
-Linear layers run on the weight-streaming MFMA kernel (``csrc/stream_gemm.hip``)
-with weights re-ordered once, at load time, into MFMA fragment order
-(:class:`PackedLinear`).  For narrow outputs the kernel splits K across
-workgroups and returns fp32 partial-sum *slabs* ``[splits, T, N]``; the next op
+Linear layers run on two hand-written MFMA kernels that read the SAME weights,
+re-ordered once, at load time, into MFMA fragment order (:class:`PackedLinear`):
+the weight-streaming kernel (``csrc/stream_gemm.hip``) up to 128 token rows, where
+the op is bound by reading W once, and the tiled kernel (``csrc/wide_gemm.hip``:
+both operands staged through LDS by LDS-DMA, software-pipelined MFMA loop) above,
+where it is compute-bound.  No vendor GEMM is called and no second (row-major)
+copy of the weights exists.  For narrow outputs both kernels can split K across
+workgroups and return fp32 partial-sum *slabs* ``[splits, T, N]``; the next op
 (:func:`add_rmsnorm` or :func:`rope_kv_write`) accepts slabs and sums them in its
-prologue, so the reduction costs no extra launch.  Batches above 64 token rows
-are processed in 64-row pieces (the weights are re-streamed per piece).
+prologue, so the reduction costs no extra launch.
 """
 
 from __future__ import annotations
@@ -32,6 +35,7 @@ from . import gpu_available, native
 MAX_M = 64
 GQA_RATIOS = (1, 2, 3, 4, 6, 7, 8)  # query heads per kv head the attention kernels are instantiated for
 WIDE_M = 256  # token rows the 8 / 16-tile variants of the streaming GEMM cover
+STREAM_MAX_M = 128  # above this many token rows the tiled (compute-bound) GEMM takes over
 # k-steps (of 32) per pipelined chunk.  Measured on MI355X (Llama-3-8B shapes): 8 (8 KiB of
 # weights in flight per wave) wins by ~2 % for a single 16-row token tile, 4 wins by 3-7 % from
 # 32 rows up (smaller LDS x-tiles, more workgroups resident per CU).
@@ -50,9 +54,9 @@ class PackedLinear:
     """A bf16 ``[N, K]`` weight re-ordered into MFMA fragment order
     ``[N/16][K/32][64][8]`` (N zero-padded to a multiple of 64)."""
 
-    __slots__ = ("wp", "n", "k", "n_pad", "ks", "wscale", "w_full")
+    __slots__ = ("wp", "n", "k", "n_pad", "ks", "wscale")
 
-    def __init__(self, w: torch.Tensor, fp8: bool = False, keep_full: bool = False):
+    def __init__(self, w: torch.Tensor, fp8: bool = False):
         """``fp8=True`` stores the weight as OCP e4m3 bytes with one fp32 scale per
         output row (weight-only quantisation: activations and accumulation stay
         bf16 / fp32), halving the bytes the decode GEMM streams from HBM."""
@@ -66,22 +70,14 @@ class PackedLinear:
         if n_pad != n:
             w = torch.cat((w, torch.zeros(n_pad - n, k, dtype=w.dtype, device=w.device)), 0)
         self.wscale: Optional[torch.Tensor] = None
-        # row-major copy for the library GEMM that serves token batches wider than the
-        # streaming kernel's 64-token tile (prefill chunks); FP8 keeps the dequantised values
-        # so both paths compute with the same weights
-        self.w_full: Optional[torch.Tensor] = None
         if fp8:
             from kvmini.models.llama import quantize_fp8_rows
 
             q, scale = quantize_fp8_rows(w)
             self.wp = native().pack_weight_fp8(q.view(torch.uint8).contiguous())
             self.wscale = scale.contiguous()
-            if keep_full:
-                self.w_full = (q.float() * scale[:, None]).to(torch.bfloat16)
         else:
             self.wp = native().pack_weight(w.contiguous())
-            if keep_full:
-                self.w_full = w.contiguous()
         self.n, self.k, self.n_pad, self.ks = n, k, n_pad, ks
 
     @property
@@ -126,7 +122,7 @@ class Partial:
         return y.to(torch.bfloat16)
 
 
-def prepare_weights(weights: Any, quantization: Optional[str] = None, keep_full: bool = False) -> None:
+def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
     """Fold every RMSNorm gain into the projection that consumes it and pack every
     linear weight of a ``LlamaWeights`` into MFMA fragment order, in place.
     ``quantization='fp8'`` stores the layer projections as e4m3 (the LM head stays
@@ -137,10 +133,10 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None, keep_full:
         raise ValueError(f"unsupported quantization {quantization!r} (native engine: fp8)")
     fp8 = quantization == "fp8"
 
-    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor], q: bool = fp8, full: bool = keep_full) -> PackedLinear:
+    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor], q: bool = fp8) -> PackedLinear:
         if gain is not None:
             w = (w.float() * gain.float()[None, :]).to(torch.bfloat16)
-        return PackedLinear(w, fp8=q and w.shape[1] % 64 == 0, keep_full=full)
+        return PackedLinear(w, fp8=q and w.shape[1] % 64 == 0)
 
     for lw in weights.layers:
         lw.wqkv = fold_pack(lw.wqkv, lw.attn_norm)
@@ -149,7 +145,7 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None, keep_full:
         lw.wdown = fold_pack(lw.wdown, None)
         lw.attn_norm = torch.ones_like(lw.attn_norm)
         lw.mlp_norm = torch.ones_like(lw.mlp_norm)
-    weights.lm_head = fold_pack(weights.lm_head, weights.final_norm, False, False)  # a tied embedding stays untouched: fold_pack copies
+    weights.lm_head = fold_pack(weights.lm_head, weights.final_norm, False)  # a tied embedding stays untouched: fold_pack copies
     weights.final_norm = torch.ones_like(weights.final_norm)
     weights._hip_prepared = True
     weights.quantization = "fp8" if fp8 else None
@@ -209,6 +205,65 @@ def _plan_slabs(n_pad: int, k: int, m: int = 32) -> Tuple[int, int, int]:
     return best[1], best[2], best[3]
 
 
+# Tiled (wide) GEMM: (token tile, feature tile, pipeline variant) -> measured microseconds per
+# 64-wide K step of one workgroup with every CU busy (Llama-3-8B shapes, 1 x MI355X).  Per FLOP
+# 256 x 256 and 256 x 128 are alike (~1.28 PFLOP/s with every CU busy); the smaller tiles trade
+# efficiency for more workgroups.
+_WIDE_TILES_BF16 = (((256, 256, 1), 1.66), ((256, 128, 0), 0.845), ((128, 256, 0), 0.87), ((128, 128, 0), 0.62), ((256, 64, 0), 0.65))
+_WIDE_TILES_FP8 = (((256, 256, 0), 1.9), ((256, 128, 0), 0.845), ((128, 256, 0), 0.87), ((128, 128, 0), 0.62))
+_WIDE_STAGE_KSTEPS = {1: 1, 3: 1}  # pipeline variants with 32-wide stages (kv_wide_gemm_stage_ksteps)
+
+
+@functools.lru_cache(maxsize=None)
+def _plan_wide(m: int, n_pad: int, k: int, fp8: bool, may_split: bool) -> Tuple[int, int, int, int, int]:
+    """(token tile, feature tile, variant, K splits, pipeline stages per split) of the tiled GEMM
+    for a shape: the candidate with the lowest modelled time = rounds over the 256 CUs x K steps
+    x measured step time of the tile, plus, for split K, the slab bytes written and read back by
+    the consumer (2 x splits x m x n x 4 bytes at ~2.5 TB/s: slabs stay in the Infinity Cache)."""
+    best: Optional[Tuple[float, Tuple[int, int, int, int, int]]] = None
+    for (bm, bn, variant), step_us in (_WIDE_TILES_FP8 if fp8 else _WIDE_TILES_BF16):
+        if n_pad % bn:
+            continue
+        tiles = -(-m // bm) * (n_pad // bn)
+        per_stage = 32 * _WIDE_STAGE_KSTEPS.get(variant, 2)
+        nst = k // per_stage
+        for splits in ((1, 2, 4, 8) if may_split else (1,)):
+            if splits > 1 and (tiles * splits > 512 or nst < 4 * splits):
+                continue
+            sps = -(-nst // splits)
+            if (splits - 1) * sps >= nst:
+                continue
+            rounds = -(-tiles * splits // _NUM_CUS)
+            t = rounds * (sps * per_stage / 64.0) * step_us + (2.0 * splits * m * n_pad * 4 / 2.5e6 if splits > 1 else 0.0)
+            # token rows of the last tile that are padding still cost MFMAs
+            if best is None or t < best[0] - 1e-9:
+                best = (t, (bm, bn, variant, splits, sps))
+    if best is None:
+        raise ValueError(f"no tiled-GEMM configuration for N={n_pad}, K={k}")
+    return best[1]
+
+
+def _wide(w: PackedLinear, h: Union[torch.Tensor, "Normed"], epi: int, allow_slabs: bool) -> Union[torch.Tensor, "Partial"]:
+    """More than 128 token rows: the tiled MFMA kernel on the packed weights."""
+    C = native()
+    ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
+    x = h.x if isinstance(h, Normed) else h
+    if x.stride(1) != 1 or x.stride(0) % 8:
+        x = x.contiguous()
+    m = x.shape[0]
+    may_split = allow_slabs and epi == 0 and w.n == w.n_pad
+    bm, bn, variant, splits, sps = _plan_wide(m, w.n_pad, w.k, w.wscale is not None, may_split)
+    if splits > 1:
+        out = torch.empty((splits, m, w.n_pad), dtype=torch.float32, device=x.device)
+        C.wide_gemm(w.wp, w.n_pad, w.k, x, out, 1, bm, bn, variant, splits, sps, None, 0.0, w.wscale, True)
+        return Partial(out, ss, eps, w.k)
+    n_out = w.n_pad // 2 if epi == 2 else w.n_pad
+    out = torch.empty((m, n_out), dtype=torch.bfloat16, device=x.device)
+    C.wide_gemm(w.wp, w.n_pad, w.k, x, out, epi, bm, bn, variant, 1, sps, ss, eps, w.wscale, True)
+    n_true = w.n // 2 if epi == 2 else w.n
+    return out if n_true == n_out else out[:, :n_true]
+
+
 _warned: set = set()
 
 
@@ -231,6 +286,8 @@ def _pad_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
 
 
 def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_slabs: bool) -> Union[torch.Tensor, Partial]:
+    if (h.x if isinstance(h, Normed) else h).shape[0] > STREAM_MAX_M and w.k % 64 == 0:
+        return _wide(w, h, epi, allow_slabs)
     C = native()
     ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
     x, m = _pad_rows(h.x if isinstance(h, Normed) else h)
@@ -263,16 +320,10 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
                 return Partial(out, ss, eps, w.k)
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         C.stream_gemm(w.wp, w.n_pad, w.k, x, out, epi, ks, 1, nchunks, ss, eps, w.wscale)
-    elif m <= WIDE_M and w.k % 256 == 0 and (m <= 128 or w.w_full is None):
-        # 65..256 tokens (a burst of short prompts next to the running decodes): still one pass
-        # over the weights, 8 / 16 row tiles per wave.  Measured against the library GEMM
-        # (Llama-3-8B shapes, us, library -> streaming): 128 rows: qkv 25.9 -> 17.6, o 26.3 -> 13.8,
-        # gate/up 55.9 -> 54.4, down 77.6 -> 32.9 (a 114-token step: 7.4 -> 5.8 ms); 256 rows: qkv
-        # 39.9 -> 32.9, o 24.9 -> 22.6, down 63.7 -> 52.8 — but gate/up 66.4 -> 97 (every wave
-        # re-reads the whole 64 KiB x chunk from LDS per 4 KiB of weights) and the 256-row slabs
-        # cost their consumers what the GEMMs gain (a 254-token step: 8.2 ms either way).  So: up
-        # to 128 rows stream; 129..256 rows go to the library GEMM when a row-major copy of the
-        # weights is kept, and stream otherwise.
+    elif m <= WIDE_M and w.k % 256 == 0:
+        # 65..128 tokens (a handful of short prompts next to the running decodes): still one pass
+        # over the weights, 8 row tiles per wave.  (The 16-tile / 256-row variant remains for
+        # K that is not a multiple of 64, which the tiled kernel does not take.)
         mw = 128 if m <= 128 else 256
         if x.shape[0] != mw:
             xw = torch.zeros((mw, x.shape[1]), dtype=x.dtype, device=x.device)
@@ -288,20 +339,6 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
                 return Partial(out, ss, eps, w.k)
         out = torch.empty((mw, n_out), dtype=torch.bfloat16, device=x.device)
         C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, 2, 1, w.k // 256, ss, eps, w.wscale, _waves_per_workgroup(w.n_pad))
-    elif w.w_full is not None:
-        # wide token batch (prefill): compute-bound, served by the library GEMM on the
-        # row-major copy; the epilogues the streaming kernel fuses run as small kernels here
-        xin = x[:m]
-        if ss is not None:
-            # the folded RMSNorm goes onto the GEMM's input here: one pass over [T, H]
-            xin = torch.empty((m, w.k), dtype=torch.bfloat16, device=x.device)
-            C.scale_rows(x[:m], ss, eps, xin)
-        y = F.linear(xin, w.w_full[: w.n])
-        if epi == 2:
-            act = torch.empty((m, w.n // 2), dtype=torch.bfloat16, device=x.device)
-            C.swiglu_interleaved(y.contiguous(), act)
-            return act
-        return y
     else:
         out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
         for r0 in range(0, mp, MAX_M):

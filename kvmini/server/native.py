@@ -471,7 +471,7 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--no-async-scheduling", action="store_true", help="read every step's tokens back before launching the next one (default: launch ahead; greedy requests only)")
     ap.add_argument("--launch-margin-ms", type=float, default=0.7, help="launch-ahead stepping: enqueue the next step this long before the one in flight should end, so late arrivals still make it (0 = at once)")
     ap.add_argument("--ride-along-limit", type=int, default=0, help="prompt backlogs up to this many tokens are fed to the running decodes in steps of <= 64 tokens instead of one wide step (better first-token time under bursts, slightly lower throughput; 0 = off)")
-    ap.add_argument("--tune-gemm", action="store_true", help="pick the rocBLAS / hipBLASLt kernel per shape for wide steps during warm-up (PyTorch TunableOp; adds seconds to the start)")
+    ap.add_argument("--tune-gemm", action="store_true", help=argparse.SUPPRESS)  # accepted for old command lines: no library GEMM is left to tune
     ap.add_argument("--tp-graphs", action="store_true", help="capture HIP graphs under tensor parallelism (the RCCL all-reduces are recorded inside them)")
     ap.add_argument("--honor-eos", action="store_true", help="stop at EOS (default: ignore EOS with random-init weights)")
 
@@ -501,7 +501,6 @@ def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
         tp_graphs=getattr(a, "tp_graphs", False),
         async_scheduling=not getattr(a, "no_async_scheduling", False),
         launch_margin_ms=getattr(a, "launch_margin_ms", 0.7),
-        tune_library_gemm=getattr(a, "tune_gemm", False),
         ride_along_limit=getattr(a, "ride_along_limit", 0),
     )
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The step the closed-loop headline workload produces once per cycle: 18 prompts of 14 tokens
-admitted together next to 2 decoding sequences (254 tokens, library-GEMM path).  Prints its
+admitted together next to 2 decoding sequences (254 tokens: tiled-GEMM path).  Prints its
 time, for rocprofv3 --kernel-trace --stats.  GPU box."""
 import os
 import sys

@@ -333,16 +333,16 @@ def mall_bench(out):
 
 
 def prefill_bench(out, model):
-    """One engine step that prefills 256 prompt tokens, with the library GEMM vs the
-    re-streamed packed weights, plus a 2048-token prompt end to end."""
+    """One engine step that prefills 256 prompt tokens (254 for the headline's cycle) and a
+    2048-token prompt end to end, per step token budget, bf16 and FP8 weights."""
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
 
-    for mode, budget in (("library", 256), ("library", 1024), ("library", 2048), ("stream", 256)):
-        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=budget, max_model_len=4096, kernels="hip", kv_memory_fraction=0.2, prefill_gemm=mode))
+    for mode, budget in ((None, 256), (None, 1024), (None, 2048), ("fp8", 1024), ("fp8", 2048)):
+        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=budget, max_model_len=4096, kernels="hip", kv_memory_fraction=0.2, quantization=mode))
         eng.warmup()
         res = {}
-        for plen in (256, 2048):
+        for plen in (254, 256, 2048):
             ts = []
             for rep in range(3):
                 seq = eng.make_sequence([1] + [(7 * i + rep) % 1000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=1, ignore_eos=True))
@@ -354,7 +354,7 @@ def prefill_bench(out, model):
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
             res[plen] = min(ts) * 1e3
-        row = {"bench": "prefill", "model": model, "prefill_gemm": mode, "max_batched_tokens": budget, "ms_256_tokens": res[256], "ms_2048_tokens": res[2048], "tok_per_s_2048": 2048 / res[2048] * 1e3, "mem_GB": torch.cuda.memory_allocated() / 1e9}
+        row = {"bench": "prefill", "model": model, "quantization": mode, "max_batched_tokens": budget, "ms_254_tokens": res[254], "ms_256_tokens": res[256], "ms_2048_tokens": res[2048], "tok_per_s_2048": 2048 / res[2048] * 1e3, "mem_GB": torch.cuda.memory_allocated() / 1e9}
         print(json.dumps(row), flush=True)
         out.append(row)
         del eng

@@ -437,11 +437,17 @@ def test_engine_fp8_matches_fake_quantised_oracle():
     oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=4)
     bytes_bf16 = oracle.nbytes()
     fake_quantize_fp8(oracle)
-    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", quantization="fp8"), weights=w)
+    proj_bf16 = sum(t.numel() * 2 for lw in oracle.layers for t in (lw.wqkv, lw.wo, lw.wgu, lw.wdown))
+    # a 1024-token step budget: wide steps run on the tiled kernel, which reads the same packed
+    # e4m3 bytes (widened in registers) — no dequantised or row-major copy is kept for them
+    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=1024, max_model_len=2048, num_blocks=256, kernels="hip", quantization="fp8"), weights=w)
     eng.warmup()
     assert eng.weights.quantization == "fp8" and eng.weights.layers[0].wqkv.wscale is not None
-    assert eng.weights.nbytes() < 0.8 * bytes_bf16  # layer projections are half the bytes
-    prompts = [[1, 50, 60, 70, 80], list(range(1, 30))]
+    proj_fp8 = sum(t.wp.numel() * t.wp.element_size() + t.wscale.numel() * 4 for lw in eng.weights.layers for t in (lw.wqkv, lw.wo, lw.wgu, lw.wdown))
+    assert proj_fp8 <= 0.55 * proj_bf16, (proj_fp8, proj_bf16)
+    assert not any(hasattr(t, "w_full") for lw in eng.weights.layers for t in (lw.wqkv, lw.wo, lw.wgu, lw.wdown))
+    assert eng.weights.nbytes() < 0.8 * bytes_bf16  # embedding and LM head stay bf16
+    prompts = [[1, 50, 60, 70, 80], list(range(1, 30)), [1] + [(7 * i) % 900 + 20 for i in range(299)]]
     outs = eng.generate(prompts, SamplingParams(max_tokens=8, ignore_eos=True))
     for p, o in zip(prompts, outs):
         ids = list(p)
@@ -474,10 +480,10 @@ def test_speculative_decoding_on_gpu_matches_plain_greedy():
     assert spec.stats.spec_proposed > 0
 
 
-@pytest.mark.parametrize("mode", ["library", "stream"])
-def test_engine_wide_prefill_paths_match_oracle(mode):
-    """A 200-token prompt is prefilled in chunks wider than the streaming GEMM's
-    64-token tile: both wide-batch paths must agree with the dense oracle."""
+@pytest.mark.parametrize("budget", [256, 1024])
+def test_engine_wide_prefill_paths_match_oracle(budget):
+    """A 200-token prompt is prefilled in one chunk wider than the streaming GEMM's rows: the
+    tiled MFMA kernel (on the same packed weights, no second copy) must agree with the dense oracle."""
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
     from kvmini.models.llama import get_config, random_weights
@@ -486,9 +492,9 @@ def test_engine_wide_prefill_paths_match_oracle(mode):
     cfg = get_config("small-hd128")
     w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
     oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
-    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=256, max_model_len=512, num_blocks=256, kernels="hip", prefill_gemm=mode), weights=w)
+    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=budget, max_model_len=512, num_blocks=256, kernels="hip"), weights=w)
     eng.warmup()
-    assert (eng.weights.layers[0].wqkv.w_full is not None) == (mode == "library")
+    assert not hasattr(eng.weights.layers[0].wqkv, "w_full")
     prompt = [1] + [(13 * i) % 900 + 20 for i in range(199)]
     out = eng.generate([prompt, [1, 2, 3]], SamplingParams(max_tokens=4, ignore_eos=True))[0]
     ids = list(prompt)
@@ -892,3 +898,69 @@ def test_split_k_linear_with_uneven_splits_matches_reference(n, k):
     assert isinstance(y, hip_ops.Partial) and y.slabs.shape[0] == splits
     ref = x.float() @ w.float().T
     assert torch.allclose(y.reduce().float(), ref, atol=0.06, rtol=0.02)
+
+
+@pytest.mark.parametrize("M", [129, 254, 512, 1024, 2048])
+def test_tiled_gemm_through_the_op_layer_matches_fp32(M):
+    """More than 128 token rows go to the tiled MFMA kernel (csrc/wide_gemm.hip) on the packed
+    weights — bf16 output with the folded-norm row scale, split-K slabs for the narrow
+    projections, SwiGLU on the interleaved gate/up rows — against an fp32 matmul."""
+    import torch.nn.functional as F
+
+    from kvmini.ops import hip_ops as ops
+
+    dev = _dev()
+    torch.manual_seed(M)
+    K, N = 1024, 2048
+    x = torch.randn(M, K, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    pw = ops.PackedLinear(W)
+    ref = x.float() @ W.float().T
+    # plain
+    y = ops.linear(x, pw)
+    assert y.shape == (M, N) and (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    # folded norm: row scale in the epilogue, or carried by the slabs
+    ss = (x.float() ** 2).sum(-1, keepdim=True).contiguous()
+    rs = torch.rsqrt(ss / K + 1e-5)
+    y = ops.linear(ops.Normed(x, ss, 1e-5), pw)
+    assert (y.float() - ref * rs).abs().max().item() <= 1e-2 * (ref * rs).abs().max().item()
+    part = ops.linear(ops.Normed(x, ss, 1e-5), pw, allow_slabs=True)
+    got = part.reduce().float() if isinstance(part, ops.Partial) else part.float()
+    assert (got - ref * rs).abs().max().item() <= 1e-2 * (ref * rs).abs().max().item()
+    # SwiGLU
+    act = ops.linear_swiglu(x, pw)
+    g = ref.view(M, N // 16, 2, 8)
+    want = (F.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)
+    assert act.shape == (M, N // 2) and (act.float() - want).abs().max().item() <= 1.5e-2 * want.abs().max().item() + 1e-3
+    # FP8 weights: same kernel, bytes widened in registers, per-feature scale in the epilogue
+    from kvmini.models.llama import quantize_fp8_rows
+
+    q, scale = quantize_fp8_rows(W)
+    ref8 = x.float() @ (q.float() * scale[:, None]).T
+    y8 = ops.linear(x, ops.PackedLinear(W, fp8=True))
+    assert (y8.float() - ref8).abs().max().item() <= 1e-2 * ref8.abs().max().item()
+
+
+@pytest.mark.parametrize("tile,variant", [((256, 256), 0), ((256, 256), 1), ((256, 256), 3), ((256, 128), 0), ((256, 128), 1), ((256, 128), 2), ((128, 256), 0), ((128, 256), 2),
+                                          ((256, 64), 0), ((256, 64), 2), ((128, 128), 0), ((128, 128), 2)])
+def test_tiled_gemm_every_tile_and_pipeline_shape(C, tile, variant):
+    """Every compiled (workgroup tile, ring depth) of the tiled kernel: M not a multiple of the
+    tile, three uneven K splits, token-tile-fastest and feature-tile-fastest block orders."""
+    dev = _dev()
+    torch.manual_seed(3)
+    bm, bn = tile
+    M, N, K = 300, 512, 448  # 7 x 64: odd stage counts exercise the pipeline's tail
+    x = torch.randn(M, K, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    wp = C.pack_weight(W)
+    ref = x.float() @ W.float().T
+    nst = K // (32 * C.wide_gemm_stage_ksteps(bm, bn, variant))
+    for mf in (True, False):
+        y = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        C.wide_gemm(wp, N, K, x, y, 0, bm, bn, variant, 1, nst, None, 0.0, None, mf)
+        assert (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    sps = (nst + 2) // 3
+    nsp = -(-nst // sps)
+    sl = torch.full((nsp, M, N), float("nan"), device=dev, dtype=torch.float32)
+    C.wide_gemm(wp, N, K, x, sl, 1, bm, bn, variant, nsp, sps, None, 0.0, None, True)
+    assert (sl.sum(0) - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
