@@ -41,6 +41,21 @@ int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
                    int chunks_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream);
+int kvx_max_wg();
+void* kvx_create(int world, int rank, long long slot_bytes);
+int kvx_handle_bytes();
+int kvx_get_handle(void* h, void* out);
+int kvx_open_peer(void* h, int r, const void* handle);
+int kvx_ready(void* h);
+long long kvx_slot_bytes(void* h);
+long long kvx_calls(void* h);
+int kvx_parity(void* h);
+int kvx_errors(void* h);
+int kvx_allgather(void* h, const void* x, void* out, long long nbytes, hipStream_t stream);
+int kvx_allreduce(void* h, const void* x, void* out, long long n, int two_shot, hipStream_t stream);
+int kvx_residual_allreduce(void* h, const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T,
+                           int H, hipStream_t stream);
+int kvx_destroy(void* h);
 int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant);
 int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int bm, int bn, int variant, int splits,
                  int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int m_fastest,
@@ -500,6 +515,61 @@ at::Tensor residual_reduce(at::Tensor x, at::Tensor residual, bool has_residual)
   return ss;
 }
 
+// ---- xGMI peer-memory collectives (csrc/xgmi_collectives.hip); the communicator is an opaque integer handle
+int64_t xgmi_create(int64_t world, int64_t rank, int64_t slot_bytes) {
+  void* h = kvx_create((int)world, (int)rank, slot_bytes);
+  TORCH_CHECK(h != nullptr, "xgmi_create failed (world 1..8, slot bytes a multiple of 4096, uncached device memory available)");
+  return (int64_t)(uintptr_t)h;
+}
+py::bytes xgmi_handle(int64_t h) {
+  std::string buf((size_t)kvx_handle_bytes(), '\0');
+  TORCH_CHECK(kvx_get_handle((void*)(uintptr_t)h, buf.data()) == 0, "hipIpcGetMemHandle failed");
+  return py::bytes(buf);
+}
+void xgmi_open_peer(int64_t h, int64_t r, const std::string& handle) {
+  TORCH_CHECK((int)handle.size() == kvx_handle_bytes(), "bad IPC handle size");
+  const int rc = kvx_open_peer((void*)(uintptr_t)h, (int)r, handle.data());
+  TORCH_CHECK(rc == 0, "hipIpcOpenMemHandle failed for peer ", r, " (rc ", rc, ")");
+}
+bool xgmi_ready(int64_t h) { return kvx_ready((void*)(uintptr_t)h) != 0; }
+int64_t xgmi_errors(int64_t h) { return kvx_errors((void*)(uintptr_t)h); }
+int64_t xgmi_calls(int64_t h) { return kvx_calls((void*)(uintptr_t)h); }
+int64_t xgmi_slot_bytes(int64_t h) { return kvx_slot_bytes((void*)(uintptr_t)h); }
+int64_t xgmi_max_wg() { return kvx_max_wg(); }
+void xgmi_destroy(int64_t h) { kvx_destroy((void*)(uintptr_t)h); }
+
+void xgmi_allgather(int64_t h, at::Tensor x, at::Tensor out) {
+  CHECK_DEV(x); CHECK_DEV(out); CHECK_CONTIG(x); CHECK_CONTIG(out);
+  const int64_t nbytes = x.numel() * x.element_size();
+  TORCH_CHECK(nbytes % 16 == 0 && out.numel() * out.element_size() % nbytes == 0, "all-gather payload must be a multiple of 16 bytes, out = world x payload");
+  check(kvx_allgather((void*)(uintptr_t)h, x.data_ptr(), out.data_ptr(), nbytes, cur_stream()), "kvx_allgather");
+}
+void xgmi_allreduce(int64_t h, at::Tensor x, at::Tensor out, bool two_shot) {
+  CHECK_BF16(x); CHECK_BF16(out); CHECK_CONTIG(x); CHECK_CONTIG(out);
+  TORCH_CHECK(x.numel() == out.numel(), "shape mismatch");
+  check(kvx_allreduce((void*)(uintptr_t)h, x.data_ptr(), out.data_ptr(), x.numel(), two_shot ? 1 : 0, cur_stream()), "kvx_allreduce");
+}
+// residual' = residual + all-reduce(x) (x: bf16 [T, H] or fp32 slabs [S, T, H]); returns the partial sums of squares [T, ceil(H/512)]
+at::Tensor xgmi_residual_allreduce(int64_t h, at::Tensor x, at::Tensor residual, bool has_residual) {
+  CHECK_DEV(x); CHECK_CONTIG(x); CHECK_BF16(residual); CHECK_CONTIG(residual);
+  TORCH_CHECK(residual.dim() == 2, "residual must be [T, H]");
+  const int64_t T = residual.size(0), H = residual.size(1);
+  auto ss = at::empty({T, (H + 511) / 512}, residual.options().dtype(at::kFloat));
+  if (x.dim() == 3) {
+    TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(1) == T && x.size(2) == H, "slabs must be fp32 [S, T, H]");
+    check(kvx_residual_allreduce((void*)(uintptr_t)h, (const float*)x.data_ptr(), (int)x.size(0), T * H, nullptr, residual.data_ptr(), has_residual ? 1 : 0,
+                                 (float*)ss.data_ptr(), (int)T, (int)H, cur_stream()),
+          "kvx_residual_allreduce");
+  } else {
+    CHECK_BF16(x);
+    TORCH_CHECK(x.dim() == 2 && x.size(0) == T && x.size(1) == H, "x must be bf16 [T, H]");
+    check(kvx_residual_allreduce((void*)(uintptr_t)h, nullptr, 0, 0, x.data_ptr(), residual.data_ptr(), has_residual ? 1 : 0, (float*)ss.data_ptr(), (int)T, (int)H,
+                                 cur_stream()),
+          "kvx_residual_allreduce");
+  }
+  return ss;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -534,6 +604,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);
+  m.def("xgmi_create", &xgmi_create);
+  m.def("xgmi_handle", &xgmi_handle);
+  m.def("xgmi_open_peer", &xgmi_open_peer);
+  m.def("xgmi_ready", &xgmi_ready);
+  m.def("xgmi_errors", &xgmi_errors);
+  m.def("xgmi_calls", &xgmi_calls);
+  m.def("xgmi_slot_bytes", &xgmi_slot_bytes);
+  m.def("xgmi_max_wg", &xgmi_max_wg);
+  m.def("xgmi_destroy", &xgmi_destroy);
+  m.def("xgmi_allgather", &xgmi_allgather);
+  m.def("xgmi_allreduce", &xgmi_allreduce);
+  m.def("xgmi_residual_allreduce", &xgmi_residual_allreduce);
   m.def("prefetch", &prefetch);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs);

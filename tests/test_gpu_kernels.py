@@ -964,3 +964,45 @@ def test_tiled_gemm_every_tile_and_pipeline_shape(C, tile, variant):
     sl = torch.full((nsp, M, N), float("nan"), device=dev, dtype=torch.float32)
     C.wide_gemm(wp, N, K, x, sl, 1, bm, bn, variant, nsp, sps, None, 0.0, None, True)
     assert (sl.sum(0) - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_xgmi_collectives_single_rank_is_its_own_peer(C):
+    """The peer-memory collectives with a group of one rank (the rank's buffer is its own peer):
+    all-gather, one-shot and two-shot all-reduce are identities, and the fused TP epilogue equals
+    the single-GPU residual_reduce kernel bit for bit — the same kernels that W ranks run."""
+    from kvmini.parallel.xgmi import XgmiComm
+
+    dev = _dev()
+    comm = XgmiComm(device=dev, world=1, rank=0)
+    torch.manual_seed(0)
+    tab = torch.randn(24, 16, device=dev, dtype=torch.float64)
+    assert torch.equal(comm.all_gather(tab)[0], tab)
+    for n, two in ((8 * 1237, False), (8 * 40000, True), (8 * 40000, None)):
+        x = torch.randn(n, device=dev).bfloat16()
+        y = x.clone()
+        comm.all_reduce(y, two_shot=two)
+        assert torch.equal(x, y)
+    for T, H, S in ((20, 4096, 4), (3, 8192, 8), (64, 4096, 0)):
+        res = torch.randn(T, H, device=dev).bfloat16()
+        x = torch.randn(S, T, H, device=dev) if S else torch.randn(T, H, device=dev).bfloat16()
+        r1, r2 = res.clone(), res.clone()
+        ss1 = C.residual_reduce(x, r1, True)
+        ss2 = comm.residual_allreduce(x, r2, True)
+        assert torch.equal(r1, r2) and torch.allclose(ss1, ss2, rtol=1e-6)
+    assert comm.errors() == 0 and comm.calls == 7
+    comm.close()
+
+
+def test_xgmi_collectives_two_rank_processes_share_one_gpu():
+    """Two rank processes on this one GPU: buffers exported / mapped through HIP IPC, each
+    rank's kernels spin on flags the other rank's kernels store — the protocol of the 8-GPU
+    node minus the links.  Every result is checked against sums formed over gloo."""
+    import json
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "xgmi_selftest.py"), "--world", "2", "--same-gpu", "--iters", "30"], capture_output=True, text=True,
+                       timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ok"] and all(g["timeouts"] == 0 for g in out["ranks"])
