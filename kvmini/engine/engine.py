@@ -63,7 +63,9 @@ class EngineConfig:
     ride_along_limit: int = 0
     tp_size: int = 1
     tp_rank: int = 0
-    tp_graphs: bool = False
+    tp_graphs: bool = True  # HIP graphs under tensor parallelism (peer-memory all-reduce inside)
+    tp_rccl_graphs: bool = False  # also capture the buckets whose all-reduce is RCCL's
+    tp_custom_allreduce: bool = True
     tp_force_collectives: bool = False
 
 
@@ -180,6 +182,8 @@ class LLMEngine:
             kernels=ecfg.kernels,
             quantization=ecfg.quantization,
             tp_graphs=ecfg.tp_graphs,
+            tp_rccl_graphs=ecfg.tp_rccl_graphs,
+            tp_custom_allreduce=ecfg.tp_custom_allreduce,
             tp_force_collectives=ecfg.tp_force_collectives,
         )
         self.runner = ModelRunner(weights, rcfg, tp_group)
@@ -219,7 +223,16 @@ class LLMEngine:
             if self.spec is not None:
                 self.spec.warmup()
         self.warm_s = time.perf_counter() - t0
+        self.check_collectives()
         return self.warm_s
+
+    def check_collectives(self) -> None:
+        """Raise if a peer-memory collective timed out waiting for a peer (its results are garbage)."""
+        x = self.runner.xgmi
+        if x is not None:
+            n = x.errors()
+            if n:
+                raise RuntimeError(f"{n} xGMI collective wait(s) timed out: a tensor-parallel rank did not take part in a step")
 
     # --- synchronous API (tests, offline generation) ---------------------
     def make_sequence(self, prompt_ids: List[int], params: Optional[SamplingParams] = None, user: Any = None) -> Sequence:
@@ -349,15 +362,17 @@ class LLMEngine:
         no preemption (a preempted sequence is rescheduled from its token list, which may not
         hold placeholders)."""
         r, sch = self.runner, self.scheduler
-        if r.tp_active or r.tp_size > 1:
-            return False
+        # tensor parallelism: the followers run the forward pass and the argmax only, so a token
+        # that is fed on the device must be the argmax on every rank — greedy requests pipeline,
+        # sampled ones are stepped synchronously (their ids reach the followers staged by the host)
+        greedy_only = r.tp_size > 1
         for s in sch.running:
-            if self._needs_host_sampling(s.params):
+            if self._needs_host_sampling(s.params) or (greedy_only and s.params.temperature > 0):
                 return False
         room = sch.max_num_seqs - len(sch.running)
         if room > 0 and sch.waiting:
             for s in itertools.islice(sch.waiting, room):
-                if self._needs_host_sampling(s.params):
+                if self._needs_host_sampling(s.params) or (greedy_only and s.params.temperature > 0):
                     return False
         return self.bm.num_free >= len(sch.running) + sch.max_batched_tokens // self.bm.block_size + 2
 
@@ -589,4 +604,5 @@ class LLMEngine:
             "engine_first_token_steps": st.first_token_steps / st.first_token_n if st.first_token_n else None,
             "load_s": self.load_s,
             "warm_s": self.warm_s,
+            "tp_allreduce": ("xgmi-peer-memory" if self.runner.xgmi is not None else ("rccl" if self.runner.tp_active else None)),
         }

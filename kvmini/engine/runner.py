@@ -9,9 +9,15 @@ records hipGraph nodes on ROCm) and replayed per step, so a decode step costs on
 graph launch instead of ~300 kernel launches.  Per-step inputs are packed into
 one pinned int32 staging buffer and moved with a single async H2D copy.
 
-With tensor parallelism each rank holds a shard of the heads / MLP columns and
-the partial O-proj / down-proj outputs are summed with an all-reduce
-(``torch.distributed`` -> RCCL over xGMI; captured inside the graph).
+With tensor parallelism each rank holds a shard of the heads / MLP columns and the
+partial O-proj / down-proj outputs are summed over the ranks.  On GPUs that sum runs
+in the hand-written xGMI peer-memory kernels (``kvmini/parallel/xgmi.py``): for
+messages up to the slot size ONE launch does split-K slab sum -> one-shot all-reduce
+-> residual add -> sums of squares, captured inside the HIP graph like any other
+kernel; larger messages (wide prefill steps) take the two-shot kernel or RCCL.  The
+scheduling rank hands every step's staged inputs to the other ranks through a
+shared-memory ring on the host (``kvmini/parallel/step_channel.py``), so followers
+never wait for their GPU to learn what to run next and steps can be launched ahead.
 """
 
 from __future__ import annotations
@@ -41,8 +47,14 @@ class RunnerConfig:
     kernels: str = "auto"  # auto | hip | torch
     return_logits: bool = False
     quantization: Optional[str] = None  # None | fp8 (weight-only, HIP kernels)
-    tp_graphs: bool = False  # capture HIP graphs (with the RCCL all-reduces inside) under tensor parallelism
+    tp_graphs: bool = True  # capture HIP graphs under tensor parallelism (buckets whose all-reduce runs in the peer-memory kernels)
+    tp_rccl_graphs: bool = False  # also capture buckets whose all-reduce is RCCL's (every rank must capture in step)
+    tp_custom_allreduce: bool = True  # hand-written xGMI peer-memory kernels for the TP all-reduce (HIP ops on GPUs)
     tp_force_collectives: bool = False  # run the TP collectives even for a group of one rank (tests)
+
+
+def cfg_hidden(cfg: LlamaConfig) -> int:
+    return cfg.hidden_size
 
 
 def select_ops(kernels: str, device: torch.device) -> Any:
@@ -131,11 +143,19 @@ class ModelRunner:
         self.max_blocks_per_seq = (rcfg.max_model_len + rcfg.block_size - 1) // rcfg.block_size
         self.cos, self.sin = rope_tables(cfg, rcfg.max_model_len, self.device)
 
+        self.xgmi = None
+        if self.tp_active and self.device.type == "cuda" and rcfg.tp_custom_allreduce and hasattr(self.ops, "prepare_weights"):
+            from kvmini.parallel.xgmi import XgmiComm
+
+            # slots sized for the widest step the fused epilogue should serve: 256 rows of the residual stream
+            slot = max(4 << 20, 256 * cfg_hidden(self.cfg) * 2)
+            self.xgmi = XgmiComm(group=tp_group, device=self.device, slot_bytes=slot) if self.tp_size > 1 else XgmiComm(device=self.device, slot_bytes=slot, world=1, rank=0)
         self.num_blocks = rcfg.num_blocks or self._auto_num_blocks()
         if tp_group is not None and self.tp_size > 1:
             # only the scheduling rank hands out block ids, so every rank's cache must hold the
             # same number of blocks: take the smallest (the rank with the least free memory)
-            nb = torch.tensor([self.num_blocks], dtype=torch.int64, device=self.device if self.device.type == "cuda" else "cpu")
+            on_dev = self.device.type == "cuda" and torch.distributed.get_backend(tp_group) == "nccl"
+            nb = torch.tensor([self.num_blocks], dtype=torch.int64, device=self.device if on_dev else "cpu")
             torch.distributed.all_reduce(nb, op=torch.distributed.ReduceOp.MIN, group=tp_group)
             self.num_blocks = int(nb.item())
         dt = weights.embed.dtype
@@ -185,6 +205,23 @@ class ModelRunner:
         self.graphs: Dict[Tuple[int, bool], Any] = {}  # (token bucket, decode-only variant) -> (graph, logits)
         self._graph_pool = None
         self.steps = 0
+        # tensor parallelism: the scheduling rank publishes every step's staged image to the
+        # followers through host shared memory (no device broadcast, no follower read-back)
+        self.channel = None
+        if tp_group is not None and self.tp_size > 1:
+            from kvmini.parallel.step_channel import StepChannel
+
+            me = torch.distributed.get_rank(tp_group)
+            box = [None]
+            if me == 0:
+                import os as _os
+
+                self.channel = StepChannel(f"kvmini_tp_{_os.getpid()}_{id(self) & 0xffff:x}", off, ring=4, create=True, n_readers=self.tp_size - 1)
+                box[0] = self.channel.name
+            torch.distributed.broadcast_object_list(box, src=self._tp_src(), group=tp_group)
+            if me != 0:
+                self.channel = StepChannel(box[0], off, ring=4, reader=me - 1)
+            torch.distributed.barrier(group=tp_group)  # everybody is attached before the first image
 
     def set_spec_width(self, width: int) -> None:
         self.spec_width = width
@@ -234,8 +271,9 @@ class ModelRunner:
 
         x = ops.embed_tokens(w.embed, tokens, self._dev("feed", t_pad), self.out_ids)
         residual = None  # the first residual add is a copy
+        pending_reduce = False  # x is a row-parallel projection's partial output that still has to be summed over the TP ranks
         for li, lw in enumerate(w.layers):
-            h, residual = ops.add_rmsnorm(x, residual, lw.attn_norm, cfg.rms_eps)
+            h, residual = self._add_rmsnorm(x, residual, lw.attn_norm, pending_reduce)
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             if decode_only and self._fused_ok(qkv, kc):
@@ -249,18 +287,34 @@ class ModelRunner:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
             x = ops.linear(a, lw.wo, allow_slabs=True)
-            if self.tp_active:
-                x = self._tp_all_reduce(x)
-            h, residual = ops.add_rmsnorm(x, residual, lw.mlp_norm, cfg.rms_eps)
+            h, residual = self._add_rmsnorm(x, residual, lw.mlp_norm, True)
             act = ops.linear_swiglu(h, lw.wgu)
             x = ops.linear(act, lw.wdown, allow_slabs=True)
-            if self.tp_active:
-                x = self._tp_all_reduce(x)
-        h, residual = ops.add_rmsnorm(x, residual, w.final_norm, cfg.rms_eps)
+            pending_reduce = True
+        h, residual = self._add_rmsnorm(x, residual, w.final_norm, pending_reduce)
         hs = ops.select_rows(h, sample_idx[: self.sample_rows(t_pad)])
         logits = ops.linear(hs, w.lm_head)
         self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
         return logits
+
+    def _add_rmsnorm(self, x: Any, residual: Optional[torch.Tensor], norm_w: torch.Tensor, partial: bool) -> Tuple[Any, torch.Tensor]:
+        """Residual update + norm in front of a projection.  ``partial``: ``x`` is this rank's
+        share of a row-parallel projection and is summed over the TP ranks on the way — in the
+        fused peer-memory kernel (slab sum -> all-reduce -> residual add -> sums of squares, one
+        launch) when the message fits its slots, else all-reduced first."""
+        ops, eps = self.ops, self.cfg.rms_eps
+        if not (partial and self.tp_active):
+            return ops.add_rmsnorm(x, residual, norm_w, eps)
+        if self.xgmi is not None:
+            src = x.slabs if hasattr(x, "slabs") else (x if x.is_contiguous() else x.contiguous())
+            t, hdim = (src.shape[1], src.shape[2]) if src.dim() == 3 else src.shape
+            if self.xgmi.fits_residual(t, hdim):
+                has_res = residual is not None
+                if residual is None:
+                    residual = torch.empty((t, hdim), dtype=torch.bfloat16, device=src.device)
+                ss = self.xgmi.residual_allreduce(src, residual, has_res)
+                return ops.Normed(residual, ss, eps), residual
+        return ops.add_rmsnorm(self._tp_all_reduce(x), residual, norm_w, eps)
 
     def _tp_all_reduce(self, x: Any) -> torch.Tensor:
         """Sum a row-parallel projection's partial output over the TP ranks.  Split-K slabs are
@@ -270,7 +324,16 @@ class ModelRunner:
         if hasattr(x, "reduce"):  # hip_ops.Partial
             x = x.reduce()
         x = x.contiguous()
-        torch.distributed.all_reduce(x, group=self.tp_group)
+        if self.xgmi is not None and x.dtype == torch.bfloat16 and self.xgmi.fits(x.numel() * 2) and x.numel() % (8 * self.xgmi.world) == 0:
+            return self.xgmi.all_reduce(x, two_shot=True)  # wide steps: reduce-scatter + all-gather through peer memory
+        if self.tp_size > 1:
+            if x.is_cuda and torch.distributed.get_backend(self.tp_group) != "nccl":
+                # a host-side group (tests: several ranks sharing one GPU): sum through the host
+                xc = x.float().cpu()
+                torch.distributed.all_reduce(xc, group=self.tp_group)
+                x.copy_(xc.to(x.dtype))
+            else:
+                torch.distributed.all_reduce(x, group=self.tp_group)
         return x
 
     def _tiled_ok(self, k_cache: torch.Tensor) -> bool:
@@ -288,7 +351,7 @@ class ModelRunner:
         if self.device.type != "cuda" or not self.rcfg.use_graphs:
             return
         if self.tp_active and not self.rcfg.tp_graphs:
-            return  # collectives inside captured graphs are opt-in (every rank must capture in step)
+            return
         self._stage_dummy()
         # Nothing may free device memory while a stream is capturing: a garbage-collection pass
         # that drops an older engine's graphs (and their private memory pool) in the middle of a
@@ -314,6 +377,8 @@ class ModelRunner:
             key = (b, dec)
             if key in self.graphs:
                 continue
+            if self.tp_active and self.tp_size > 1 and not self.rcfg.tp_rccl_graphs and not (self.xgmi is not None and self.xgmi.fits(b * self.cfg.hidden_size * 2)):
+                continue  # this bucket's all-reduce would be RCCL's: left eager unless asked for (every rank must capture in step)
             # warm-up on a side stream (allocator + lazy init), then capture
             s = torch.cuda.Stream(self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
@@ -348,29 +413,42 @@ class ModelRunner:
         return 0 if g is None else torch.distributed.get_global_rank(g, 0)
 
     def follow(self) -> int:
-        """Tensor-parallel follower loop (ranks > 0 of the TP group): receive the staging
-        buffer that the scheduling rank broadcasts each step, run the same pass on the local
-        weight shard (the all-reduces inside ``forward`` pair up with the other ranks'), until
-        a stop command arrives.  Returns the number of steps served."""
+        """Tensor-parallel follower loop (ranks > 0 of the TP group): take every step's staged
+        image from the host channel, copy it to the device and enqueue the same pass on the local
+        weight shard (the all-reduces inside ``forward`` pair up with the other ranks').  The loop
+        never waits for the GPU except to reuse a pinned staging buffer two steps later, so it
+        runs ahead of the device exactly as far as the scheduling rank does.  Returns the number
+        of steps served when the stop command arrives."""
         o_h = self._off["header"][0]
         n = 0
         while True:
-            torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
-            t_pad, _n_samples, max_ctx, cmd, dec = self.stage_dev[o_h : o_h + 5].tolist()
+            sb = self.stages[self._cur]
+            self._cur ^= 1
+            if sb.event is not None:
+                sb.event.synchronize()  # the copy that last read this pinned buffer is done
+            self.channel.receive(sb.np)
+            t_pad, _n_samples, max_ctx, cmd, dec = (int(v) for v in sb.np[o_h : o_h + 5])
             if cmd == 1:
                 return n
-            self._run_staged(int(t_pad), int(max_ctx), bool(dec))
+            self.stage_dev.copy_(sb.cpu, non_blocking=True)
+            self._run_staged(t_pad, max_ctx, bool(dec))
+            if self.device.type == "cuda":
+                if sb.event is None:
+                    sb.event = torch.cuda.Event()
+                sb.event.record(torch.cuda.current_stream(self.device))
             n += 1
 
     def stop_followers(self) -> None:
         """Scheduling rank: release the followers from :meth:`follow`."""
-        if self.tp_size <= 1:
+        if self.tp_size <= 1 or self.channel is None:
             return
         o_h = self._off["header"][0]
-        sb = self.stages[0]
-        sb.np[o_h : o_h + 5] = (0, 0, 0, 1, 0)
-        self.stage_dev.copy_(sb.cpu)
-        torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
+        img = np.zeros(self.stages[0].np.size, dtype=np.int32)
+        img[o_h : o_h + 5] = (0, 0, 0, 1, 0)
+        try:
+            self.channel.publish(img, timeout_s=10.0)
+        except TimeoutError:
+            pass
 
     def _stage_dummy(self) -> None:
         """Inputs that are safe for warm-up/capture: every token is padding."""
@@ -488,10 +566,11 @@ class ModelRunner:
         decode_only = all(ch.n_tokens == 1 for ch in batch.chunks)
         o_h = self._off["header"][0]
         st[o_h : o_h + 5] = (t_pad, n_samples, max_ctx, 0, int(decode_only))
+        if self.channel is not None:
+            # every rank runs the same step: hand the staged image to the followers first (host
+            # shared memory, see follow()), so that they enqueue it while this rank does
+            self.channel.publish(st)
         self.stage_dev.copy_(sb.cpu, non_blocking=True)
-        if self.tp_size > 1:
-            # every rank runs the same step: ship the staged inputs to the followers (see follow())
-            torch.distributed.broadcast(self.stage_dev, src=self._tp_src(), group=self.tp_group)
         logits = self._run_staged(t_pad, max_ctx, decode_only)
         if sampler is not None:
             sampler(logits, self.out_ids)

@@ -472,7 +472,10 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--launch-margin-ms", type=float, default=0.7, help="launch-ahead stepping: enqueue the next step this long before the one in flight should end, so late arrivals still make it (0 = at once)")
     ap.add_argument("--ride-along-limit", type=int, default=0, help="prompt backlogs up to this many tokens are fed to the running decodes in steps of <= 64 tokens instead of one wide step (better first-token time under bursts, slightly lower throughput; 0 = off)")
     ap.add_argument("--tune-gemm", action="store_true", help=argparse.SUPPRESS)  # accepted for old command lines: no library GEMM is left to tune
-    ap.add_argument("--tp-graphs", action="store_true", help="capture HIP graphs under tensor parallelism (the RCCL all-reduces are recorded inside them)")
+    ap.add_argument("--tp-graphs", action="store_true", help=argparse.SUPPRESS)  # the default now; kept for old command lines
+    ap.add_argument("--no-tp-graphs", action="store_true", help="tensor parallelism without HIP graphs (eager launches)")
+    ap.add_argument("--tp-rccl-graphs", action="store_true", help="also capture the wide-step buckets whose all-reduce is RCCL's (every rank must capture in step)")
+    ap.add_argument("--tp-allreduce", default="xgmi", choices=["xgmi", "rccl"], help="tensor-parallel all-reduce: hand-written xGMI peer-memory kernels (default) or RCCL")
     ap.add_argument("--honor-eos", action="store_true", help="stop at EOS (default: ignore EOS with random-init weights)")
 
 
@@ -498,7 +501,9 @@ def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
         num_speculative_tokens=a.num_speculative_tokens,
         tp_size=getattr(a, "tensor_parallel_size", 1),
         tp_rank=getattr(a, "tp_rank", 0),
-        tp_graphs=getattr(a, "tp_graphs", False),
+        tp_graphs=not getattr(a, "no_tp_graphs", False),
+        tp_rccl_graphs=getattr(a, "tp_rccl_graphs", False),
+        tp_custom_allreduce=getattr(a, "tp_allreduce", "xgmi") == "xgmi",
         async_scheduling=not getattr(a, "no_async_scheduling", False),
         launch_margin_ms=getattr(a, "launch_margin_ms", 0.7),
         ride_along_limit=getattr(a, "ride_along_limit", 0),

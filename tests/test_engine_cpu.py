@@ -290,8 +290,9 @@ def test_batched_sampling_matches_greedy_under_top_k_1_and_respects_top_p():
 
 def test_tensor_parallel_serving_two_ranks_gloo_matches_single_rank(tmp_path):
     """``kvmini serve --tensor-parallel-size 2`` under torchrun: rank 0 serves HTTP and
-    schedules, rank 1 follows the broadcast steps; the greedy answer equals the single-rank
-    server's, and SIGTERM ends every rank (no one is left blocked in a broadcast)."""
+    schedules, rank 1 follows the step images from the host shared-memory channel; steps are
+    launched ahead under tensor parallelism too; the greedy answers (one request, then four
+    concurrent ones) equal the single-rank server's, and SIGTERM ends every rank."""
     import json
     import signal
     import time
@@ -322,6 +323,21 @@ def test_tensor_parallel_serving_two_ranks_gloo_matches_single_rank(tmp_path):
         wait_ready(8332, one)
         a, b = ask(8331), ask(8332)
         assert a == b and len(a.split()) == 8
+        # four requests in flight at once: continuous batching + launch-ahead stepping across both ranks
+        from concurrent.futures import ThreadPoolExecutor
+
+        def ask_n(args):
+            port, k = args
+            body = json.dumps({"model": "tiny", "messages": [{"role": "user", "content": f"request number {k} " * (k + 1)}], "max_tokens": 10 + k}).encode()
+            req = urllib.request.Request(f"http://127.0.0.1:{port}/v1/chat/completions", data=body, headers={"Content-Type": "application/json"})
+            return json.loads(urllib.request.urlopen(req, timeout=60).read())["choices"][0]["message"]["content"]
+
+        with ThreadPoolExecutor(8) as ex:
+            got = list(ex.map(ask_n, [(8331, k) for k in range(4)]))
+            want = list(ex.map(ask_n, [(8332, k) for k in range(4)]))
+        assert got == want
+        info = json.loads(urllib.request.urlopen("http://127.0.0.1:8331/info", timeout=10).read())["engine"]
+        assert info["pipelined_steps"] > 0, info  # steps were launched ahead under tensor parallelism
     finally:
         one.terminate()
         os.killpg(tp.pid, signal.SIGTERM)  # launcher and both ranks: nobody may be left waiting in a collective

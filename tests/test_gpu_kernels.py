@@ -595,10 +595,11 @@ def test_fused_decode_attention_matches_two_kernel_path(rep):
     assert out[7].abs().max().item() == 0 and out[13].abs().max().item() == 0  # padding rows
 
 
-@pytest.mark.parametrize("graphs", [False, True])
-def test_engine_tp_collective_path_on_one_gpu_through_rccl(graphs):
-    """The tensor-parallel code path (slab reduce -> RCCL all-reduce, optionally captured in
-    HIP graphs) with a one-rank RCCL group must reproduce the plain engine's tokens."""
+@pytest.mark.parametrize("graphs,custom", [(False, True), (True, True), (False, False), (True, False)])
+def test_engine_tp_collective_path_on_one_gpu(graphs, custom):
+    """The tensor-parallel code path with a one-rank group must reproduce the plain engine's
+    tokens: the fused peer-memory epilogue (slab sum -> all-reduce -> residual -> sums of squares;
+    the rank is its own xGMI peer) and the RCCL all-reduce, eager and captured in HIP graphs."""
     import torch.distributed as dist
 
     from kvmini.engine.engine import EngineConfig, LLMEngine
@@ -611,13 +612,13 @@ def test_engine_tp_collective_path_on_one_gpu_through_rccl(graphs):
     if own_pg:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        _tp_one_rank_body(graphs)
+        _tp_one_rank_body(graphs, custom)
     finally:
         if own_pg:
             dist.destroy_process_group()
 
 
-def _tp_one_rank_body(graphs):
+def _tp_one_rank_body(graphs, custom):
     import torch.distributed as dist
 
     from kvmini.engine.engine import EngineConfig, LLMEngine
@@ -629,12 +630,16 @@ def _tp_one_rank_body(graphs):
     params = SamplingParams(max_tokens=8, ignore_eos=True)
     base = LLMEngine(EngineConfig(**common, use_graphs=False), weights=random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3))
     want = base.generate(prompts, params)
-    eng = LLMEngine(EngineConfig(**common, use_graphs=graphs, tp_graphs=graphs, tp_force_collectives=True), weights=random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3), tp_group=dist.group.WORLD)
-    assert eng.runner.tp_active
+    eng = LLMEngine(EngineConfig(**common, use_graphs=graphs, tp_graphs=graphs, tp_rccl_graphs=graphs, tp_custom_allreduce=custom, tp_force_collectives=True),
+                    weights=random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3), tp_group=dist.group.WORLD)
+    assert eng.runner.tp_active and (eng.runner.xgmi is not None) == custom
     if graphs:
         eng.warmup()
-        assert eng.runner.graphs, "graphs with RCCL all-reduces inside were not captured"
+        assert eng.runner.graphs, "graphs with the all-reduces inside were not captured"
     assert eng.generate(prompts, params) == want
+    if custom:
+        assert eng.runner.xgmi.calls > 0 and eng.runner.xgmi.calls % 2 == 0 and eng.runner.xgmi.errors() == 0
+        assert eng.metrics()["tp_allreduce"] == "xgmi-peer-memory"
 
 
 @pytest.mark.parametrize("rep,nkv,chunks", [(r, 2, [(0, 0, 40), (1, 37, 23), (2, 0, 5), (3, 300, 33)]) for r in (1, 2, 3, 4, 7, 8)]
@@ -1006,3 +1011,55 @@ def test_xgmi_collectives_two_rank_processes_share_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["ok"] and all(g["timeouts"] == 0 for g in out["ranks"])
+
+
+TP2_ONE_GPU_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["KV_ROOT"])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+from kvmini.engine.engine import EngineConfig, LLMEngine
+from kvmini.engine.scheduler import SamplingParams
+from kvmini.models.llama import get_config, random_weights
+dist.init_process_group("gloo")  # host-side bootstrap: both ranks share GPU 0, which RCCL refuses
+r, ws = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+cfg = get_config("small-hd128")
+w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=3, tp_rank=r, tp_size=ws)
+eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", tp_size=ws, tp_rank=r,
+                             use_graphs=True), weights=w, tp_group=dist.group.WORLD)
+eng.warmup()
+assert eng.runner.xgmi is not None and eng.runner.graphs
+prompts = [[1, 50, 60, 70, 80], list(range(1, 30)), [1, 9, 8, 7]]
+if r == 0:
+    outs = eng.generate(prompts, SamplingParams(max_tokens=10, ignore_eos=True))
+    eng.release_followers()
+    base = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", use_graphs=False),
+                     weights=random_weights(cfg, "cuda:0", torch.bfloat16, seed=3))
+    want = base.generate(prompts, SamplingParams(max_tokens=10, ignore_eos=True))
+    # two shards sum in a different order than one GEMM: equal lengths, equal first tokens
+    ok = [len(o) for o in outs] == [len(o) for o in want] and all(a[:3] == b[:3] for a, b in zip(outs, want)) and eng.pipelined_steps > 0
+    print("OUTS", outs, want, eng.pipelined_steps, flush=True)
+else:
+    ok = eng.follow() >= 10
+ok = ok and eng.runner.xgmi.errors() == 0 and eng.runner.xgmi.calls % 2 == 0
+print(f"RANK{r} OK={ok} calls={eng.runner.xgmi.calls}", flush=True)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_tensor_parallel_two_rank_processes_share_one_gpu(tmp_path):
+    """TP = 2 end to end on one GPU: two rank processes, each with its shard of the weights on
+    GPU 0; the all-reduce behind every row-parallel projection runs in the fused peer-memory
+    kernel between the two processes (HIP IPC), inside captured HIP graphs; rank 1 follows the
+    step images from the host channel; steps are launched ahead."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "tp2.py"
+    script.write_text(TP2_ONE_GPU_SCRIPT)
+    env = dict(os.environ, KV_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "RANK0 OK=True" in r.stdout and "RANK1 OK=True" in r.stdout
