@@ -126,6 +126,9 @@ class LoadConfig:
     # gate consulted right before a request is sent; returning False records a 429
     # without touching the network (client-side throttling for the fairness guard)
     admit: Optional[Callable[[int], bool]] = None
+    # live inter-token statistics (kvmini.loadgen.live.LiveQuantiles): fed by the SSE parser
+    # while the load runs; its final snapshot is written to live_itl.json
+    live: Any = None
 
 
 _WORDS = (
@@ -203,6 +206,9 @@ async def _one_request(
                 ctype = resp.headers.get("content-type", "")
                 if spec.stream and status == 200 and ("event-stream" in ctype or "json" not in ctype):
                     parser = SSEParser(proto.sse_dialect, keep_text=cfg.keep_text)
+                    if cfg.live is not None:
+                        base_ns, live = int(p_start * 1e9), cfg.live
+                        parser.on_token = lambda idx, t_ms, _rid=rid: live.on_token(_rid, idx, base_ns + int(t_ms * 1e6))
 
                     async def _consume() -> None:
                         async for data in resp.iter_bytes():
@@ -302,6 +308,8 @@ async def _one_request(
             tenant=cfg.extra_headers.get("X-Tenant"),
         )
         results.append(res)
+        if cfg.live is not None:
+            cfg.live.finished(rid)
         if cfg.on_result:
             try:
                 cfg.on_result(res)
@@ -333,6 +341,8 @@ async def run_load(cfg: LoadConfig, tracer: Optional[TraceCollector] = None, cli
 
     t0_wall = time.time()
     t0_perf = time.perf_counter()
+    if cfg.live is not None:
+        cfg.live.start()
     try:
         for i, at in enumerate(arrivals):
             delay = at - (time.perf_counter() - t0_perf)
@@ -344,8 +354,14 @@ async def run_load(cfg: LoadConfig, tracer: Optional[TraceCollector] = None, cli
     finally:
         if own_client:
             await client.aclose()
+    live_final = await cfg.live.stop() if cfg.live is not None else None
 
     results.sort(key=lambda r: r.id)
+    if cfg.run_dir and live_final is not None:
+        os.makedirs(cfg.run_dir, exist_ok=True)
+        write_json(os.path.join(cfg.run_dir, "live_itl.json"), {**live_final, "interval_s": cfg.live.interval_s, "history": [{"t": t, "p50": q[0.5], "p95": q[0.95], "p99": q[0.99]} for t, q in cfg.live.history]})
+    if live_final is not None and not cfg.quiet:
+        print(f"Live inter-token latency ({live_final['engine']}, {live_final['updates']} histogram updates during the run): p50 {live_final['itl_p50_ms']} ms, p95 {live_final['itl_p95_ms']} ms, p99 {live_final['itl_p99_ms']} ms over {live_final['itl_samples']} gaps")
     if cfg.run_dir:
         persist_run(cfg, results, tracer if cfg.trace else None, duration, target_rps, t0_wall, client.connections_opened if client else 0)
     return results
@@ -443,6 +459,10 @@ def build_arg_parser() -> argparse.ArgumentParser:
     ap.add_argument("--timeout", type=float, default=60.0)
     ap.add_argument("--header", action="append", default=[], help="Extra header 'Name: value' (repeatable)")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--live-quantiles", action="store_true", help="rolling inter-token p50/p95/p99 while the load runs (streaming histogram: HIP kernel on a GPU host, numpy otherwise)")
+    ap.add_argument("--live-interval", type=float, default=0.25, help="seconds between histogram updates of --live-quantiles")
+    ap.add_argument("--live-metrics-port", type=int, default=None, help="serve the live quantiles as Prometheus text on this port (0 = any free port)")
+    ap.add_argument("--live-device", default=None, choices=["cuda", "cpu"], help="where the live histogram lives (default: the GPU when one is usable)")
     return ap
 
 
@@ -490,7 +510,17 @@ def config_from_args(args: argparse.Namespace) -> LoadConfig:
         tools=tools,
         response_schema=schema,
     )
+    live = None
+    if getattr(args, "live_quantiles", False) or getattr(args, "live_metrics_port", None) is not None:
+        from .live import LiveQuantiles
+
+        live = LiveQuantiles(interval_s=args.live_interval, device=args.live_device, verbose=not args.quiet)
+        if args.live_metrics_port is not None:
+            port = live.serve_metrics(args.live_metrics_port)
+            if not args.quiet:
+                print(f"live quantiles: http://127.0.0.1:{port}/metrics")
     return LoadConfig(
+        live=live,
         url=args.url,
         run_dir=args.run_dir,
         requests=args.requests,

@@ -82,6 +82,8 @@ class SSEParser:
         self.tool_calls = 0
         self.generated_text: Optional[str] = None  # TGI final event
         self.parse_errors = 0
+        # called as on_token(index, t_ms) for every content event (live inter-token statistics)
+        self.on_token: Optional[Callable[[int, float], None]] = None
 
     def feed(self, data: bytes, t_ms: float) -> None:
         if not data:
@@ -145,6 +147,8 @@ class SSEParser:
                 self.first_token_ms = t_ms
             self.last_token_ms = t_ms
             self.token_times_ms.append(t_ms)
+            if self.on_token is not None:
+                self.on_token(len(self.token_times_ms) - 1, t_ms)
         self._harvest(ev)
 
     def _harvest(self, ev: Dict[str, Any]) -> None:

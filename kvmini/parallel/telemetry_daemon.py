@@ -72,6 +72,9 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--metrics-port", type=int, default=0, help="serve the node table as Prometheus text on rank 0")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"], help="collective backend (default: nccl on GPUs, gloo otherwise)")
     ap.add_argument("--fake", action="store_true", help="synthetic sampler (no GPU needed)")
+    ap.add_argument("--gather-impl", default="torch", choices=["torch", "rccl", "p2p"],
+                    help="how the per-tick snapshots cross the node: torch.distributed all-gather (default; gloo on CPU), the C++ ncclAllGather on its own communicator (rccl), "
+                         "or the one-shot xGMI peer-memory kernel (p2p); rccl and p2p need one GPU per rank")
     a = ap.parse_args(argv)
 
     import torch
@@ -95,8 +98,12 @@ def main(argv: Optional[List[str]] = None) -> int:
 
     source = FakeSampler(base_w=400.0 + 25.0 * rank) if (a.fake or not use_gpu) else None
     sampler = TelemetrySampler(interval_s=a.interval, gpu_indices=None if source else [local_rank], source=source).start()
-    gather = TelemetryGather(device=device)
+    native = a.gather_impl in ("rccl", "p2p")
+    if native and not (use_gpu and backend == "nccl"):
+        ap.error("--gather-impl rccl / p2p needs GPUs (one rank per GPU)")
+    gather = TelemetryGather(device=device, native=native, device_index=local_rank, impl=a.gather_impl if native else "rccl")
     latest: Dict[str, Any] = {"table": None}
+    gather_us: List[float] = []
     if rank == 0 and a.metrics_port:
         serve_metrics(a.metrics_port, latest)
 
@@ -112,8 +119,12 @@ def main(argv: Optional[List[str]] = None) -> int:
 
     def flush() -> None:
         if rank == 0 and tables:
-            doc = table_to_power_json(np.stack(tables, axis=1), a.gather_every)
+            doc = table_to_power_json(np.stack(tables, axis=1), a.gather_every, source=gather.source)
             doc["dropped_ticks"] = gather.dropped_ticks
+            if gather_us:
+                srt = sorted(gather_us)
+                doc["gather_impl"] = a.gather_impl
+                doc["gather_us_p50"], doc["gather_us_p95"] = srt[len(srt) // 2], srt[min(len(srt) - 1, int(0.95 * len(srt)))]
             write_json(a.out, doc)
 
     ticks = 0
@@ -126,7 +137,9 @@ def main(argv: Optional[List[str]] = None) -> int:
             if flag.item() > 0:
                 break
             sample = sampler.samples[-1] if sampler.samples else None
+            t_g = time.perf_counter()
             table = gather.gather_tick(sample)
+            gather_us.append((time.perf_counter() - t_g) * 1e6)
             ticks += 1
             if table is not None and rank == 0:
                 if np.isnan(table[0, 2]):

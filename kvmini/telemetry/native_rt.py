@@ -211,8 +211,15 @@ def records_to_samples(rec: np.ndarray) -> List[Dict[str, Any]]:
 
 
 class NativeGather:
-    """``ncclAllGather`` of telemetry snapshots through the native runtime.  The
-    unique id travels over the already-initialised ``torch.distributed`` group."""
+    """All-gather of telemetry snapshots through native code, two implementations:
+
+    * ``impl="rccl"`` — one ``ncclAllGather`` on a private communicator and stream
+      (``csrc/telemetry_gather.cpp``); the unique id travels over the already-initialised
+      ``torch.distributed`` group.  A ring: W - 1 latency-bound hops for W x 128 bytes.
+    * ``impl="p2p"`` — the one-shot peer-memory kernel (``csrc/xgmi_collectives.hip``): every
+      rank stores its snapshots straight into every peer's buffer over its own xGMI link, one
+      flag per workgroup, one hop.
+    """
 
     def __init__(self, device_index: int, impl: str = "rccl"):
         import torch
@@ -227,6 +234,13 @@ class NativeGather:
         self.impl = impl
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._xgmi = None
+        if impl == "p2p":
+            from kvmini.parallel.xgmi import XgmiComm
+
+            self._dev = torch.device("cuda", device_index)
+            self._xgmi = XgmiComm(group=dist.group.WORLD if dist.is_initialized() else None, device=self._dev)
+            return
         nbytes = int(lib.kvt_unique_id_bytes())
         buf = ctypes.create_string_buffer(nbytes)
         if self.rank == 0:
@@ -246,6 +260,12 @@ class NativeGather:
         """``local``: ``[n_ticks, 16]`` float64 -> ``[world, n_ticks, 16]``."""
         local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1, 16)
         n = local.shape[0]
+        if self._xgmi is not None:
+            import torch
+
+            per = max(1, self._xgmi.slot_bytes // 128)  # ticks per call: a snapshot is 128 bytes
+            parts = [self._xgmi.all_gather(torch.from_numpy(local[i : i + per]).to(self._dev)).cpu().numpy() for i in range(0, n, per)]
+            return np.concatenate(parts, axis=1)
         table = np.empty((self.world, n, 16), dtype=np.float64)
         rc = self._lib.kvt_gather_many(_dp(local), _dp(table), n)
         if rc != 0:
@@ -253,6 +273,10 @@ class NativeGather:
         return table
 
     def close(self) -> None:
+        if self._xgmi is not None:
+            self._xgmi.close()
+            self._xgmi = None
+            return
         self._lib.kvt_destroy()
 
 

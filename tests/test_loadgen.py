@@ -177,3 +177,52 @@ def test_sharded_load_generation_merges_artifacts(mock_server, tmp_path):
     assert meta["generator_processes"] == 2 and meta["requests"] == 21 and meta["concurrency"] == 5
     res = analyze_run(str(run), "ns", "svc", backend=FakeBackend(), quiet=True)
     assert res["requests"] == {"total": 21, "success": 21} and res["itl_samples"] == 21 * 5
+
+
+def test_live_inter_token_quantiles_final_flush_equals_offline(tmp_path):
+    """--live-quantiles: token events go through the ring buffer into the streaming histogram
+    WHILE the load runs (several updates before the last request ends); after the final flush
+    the histogram holds exactly the gaps the offline analysis derives from token_events.npy —
+    same count, same mean, quantiles inside one 1 % bin — and /metrics serves them."""
+    import urllib.request
+
+    import numpy as np
+
+    from kvmini.analysis.reduce import inter_token_latency_metrics
+    from kvmini.loadgen.live import LiveQuantiles
+    from kvmini.loadgen.protocols import RequestSpec
+    from kvmini.loadgen.runner import LoadConfig, run_load_sync
+    from kvmini.server.mock import MockConfig, start_mock_in_thread
+
+    srv, url, stop = start_mock_in_thread(MockConfig(ttft_ms=5.0, tpot_ms=4.0, jitter=0.5, seed=3))
+    try:
+        live = LiveQuantiles(interval_s=0.05, device="cpu")
+        port = live.serve_metrics(0)
+        run_dir = str(tmp_path / "run")
+        cfg = LoadConfig(url=url, run_dir=run_dir, requests=40, concurrency=8, spec=RequestSpec(model="mock", max_tokens=24, stream=True), quiet=True, live=live, seed=1)
+        res = run_load_sync(cfg)
+        assert all(r.status == 200 for r in res)
+        off = inter_token_latency_metrics(run_dir, engine="python")
+        fin = json.load(open(os.path.join(run_dir, "live_itl.json")))
+        assert fin["itl_samples"] == off["itl_samples"] == sum(len(r.token_times_ms) - 1 for r in res)
+        assert abs(fin["itl_mean_ms"] - off["itl_mean_ms"]) < 1e-3 * off["itl_mean_ms"]
+        for k in ("itl_p50_ms", "itl_p95_ms", "itl_p99_ms"):
+            assert abs(fin[k] - off[k]) <= 0.012 * off[k] + 1e-3, (k, fin[k], off[k])
+        assert fin["updates"] >= 3 and fin["dropped_events"] == 0  # binned during the run, not after it
+        assert len(fin["history"]) >= 3 and fin["engine"] == "numpy"
+        assert port > 0 and "kvmini_itl_ms{quantile=\"0.95\"}" in live.metrics_text() and f"kvmini_itl_ms_count {fin['itl_samples']}" in live.metrics_text()
+    finally:
+        stop()
+    # the ring alone: wrap-around keeps order, overflow drops the oldest and counts them
+    from kvmini.loadgen.live import TokenEventRing
+
+    ring = TokenEventRing(8)
+    for i in range(5):
+        ring.append(1, i, 100 + i)
+    assert ring.take()[:, 2].tolist() == [100, 101, 102, 103, 104]
+    for i in range(6):
+        ring.append(2, i, 200 + i)
+    assert ring.take()[:, 2].tolist() == [200, 201, 202, 203, 204, 205]  # wrapped
+    for i in range(20):
+        ring.append(3, i, 300 + i)
+    assert ring.take()[:, 2].tolist() == list(range(312, 320)) and ring.dropped == 12
