@@ -33,6 +33,9 @@ int kv_embed_fed(const void* table, const int* tokens, const int* feed, const lo
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
 int kv_sample_rows(const void* logits, long long row_stride, int V, const long long* rows, int R, const float* temperature, const int* top_k,
                    const float* top_p, const float* uniform, long long* out, hipStream_t stream);
+int kv_guided_mask(void* logits, long long row_stride, int V, int n_cls, const long long* rows, const int* slots, const int* init, int R, int* state,
+                   const unsigned char* cls, int vc, hipStream_t stream);
+int kv_guided_advance(const long long* out_ids, const long long* rows, const int* slots, int R, int* state, const unsigned char* cls, int n_cls, hipStream_t stream);
 int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, void* y, int T, int H, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
 int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
@@ -283,6 +286,33 @@ void sample_rows(at::Tensor logits, at::Tensor rows, at::Tensor temperature, at:
   check(kv_sample_rows(logits.data_ptr(), logits.stride(0), (int)logits.size(1), (const long long*)rows.data_ptr(), (int)R, (const float*)temperature.data_ptr(),
                        (const int*)top_k.data_ptr(), (const float*)top_p.data_ptr(), (const float*)uniform.data_ptr(), (long long*)out.data_ptr(), cur_stream()),
         "kv_sample_rows");
+}
+
+// Guided decoding (csrc/guided.hip).  rows: int64 logits rows, slots: int32 state rows, init: int32 [R, 4]
+// (init[r][0] < 0 keeps the device state), state: int32 [S, 4], cls: uint8 class per token id.
+void guided_mask(at::Tensor logits, at::Tensor rows, at::Tensor slots, at::Tensor init, at::Tensor state, at::Tensor cls, int64_t vc) {
+  CHECK_DEV(logits); CHECK_BF16(logits); CHECK_DEV(rows); CHECK_DEV(slots); CHECK_DEV(init); CHECK_DEV(state); CHECK_DEV(cls);
+  CHECK_CONTIG(rows); CHECK_CONTIG(slots); CHECK_CONTIG(init); CHECK_CONTIG(state); CHECK_CONTIG(cls);
+  TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1, "logits must be [S, V] with unit inner stride");
+  const int64_t R = rows.numel();
+  TORCH_CHECK(rows.scalar_type() == at::kLong && slots.scalar_type() == at::kInt && init.scalar_type() == at::kInt && state.scalar_type() == at::kInt && cls.scalar_type() == at::kByte,
+              "rows int64, slots / init / state int32, cls uint8");
+  TORCH_CHECK(slots.numel() == R && init.numel() == 4 * R && state.dim() == 2 && state.size(1) == 4, "one slot and one init record per row; state is [S, 4]");
+  TORCH_CHECK(cls.numel() <= logits.size(1), "more token classes than logits columns");
+  check(kv_guided_mask(logits.data_ptr(), logits.stride(0), (int)logits.size(1), (int)cls.numel(), (const long long*)rows.data_ptr(), (const int*)slots.data_ptr(),
+                       (const int*)init.data_ptr(), (int)R, (int*)state.data_ptr(), (const unsigned char*)cls.data_ptr(), (int)vc, cur_stream()),
+        "kv_guided_mask");
+}
+
+void guided_advance(at::Tensor out_ids, at::Tensor rows, at::Tensor slots, at::Tensor state, at::Tensor cls) {
+  CHECK_DEV(out_ids); CHECK_DEV(rows); CHECK_DEV(slots); CHECK_DEV(state); CHECK_DEV(cls);
+  CHECK_CONTIG(out_ids); CHECK_CONTIG(rows); CHECK_CONTIG(slots); CHECK_CONTIG(state); CHECK_CONTIG(cls);
+  TORCH_CHECK(out_ids.scalar_type() == at::kLong && rows.scalar_type() == at::kLong && slots.scalar_type() == at::kInt && state.scalar_type() == at::kInt && cls.scalar_type() == at::kByte,
+              "out_ids / rows int64, slots / state int32, cls uint8");
+  TORCH_CHECK(slots.numel() == rows.numel() && state.dim() == 2 && state.size(1) == 4, "one slot per row; state is [S, 4]");
+  check(kv_guided_advance((const long long*)out_ids.data_ptr(), (const long long*)rows.data_ptr(), (const int*)slots.data_ptr(), (int)rows.numel(), (int*)state.data_ptr(),
+                          (const unsigned char*)cls.data_ptr(), (int)cls.numel(), cur_stream()),
+        "kv_guided_advance");
 }
 
 void scale_rows(at::Tensor x, at::Tensor row_ss, double eps, at::Tensor y) {
@@ -592,6 +622,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("swiglu_interleaved", &swiglu_interleaved);
   m.def("scale_rows", &scale_rows);
   m.def("sample_rows", &sample_rows);
+  m.def("guided_mask", &guided_mask);
+  m.def("guided_advance", &guided_advance);
   m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);
   m.def("stream_gemm_plan", &stream_gemm_plan);

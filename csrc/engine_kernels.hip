@@ -25,6 +25,77 @@ template <int CTRL>
 __device__ inline float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// packed bf16 pairs, the operand type of v_dot2_f32_bf16 and the result of the packed FP8 conversions
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+struct bf16x2x4 { bf16x2 p[4]; };
+struct bf16x2x2 { bf16x2 p[2]; };
+typedef __attribute__((ext_vector_type(4))) unsigned short bf16x4;  // 8 bytes
+
+// ---- paged KV cache elements.  KV8 = false: bf16.  KV8 = true: OCP e4m3 bytes holding x / scale
+// (one scale per kv head and per K / V); the bytes are widened to bf16 in registers (exact) with
+// the packed gfx950 conversion, and the scale is applied once per score / output instead of once
+// per element.  Offsets are in ELEMENTS in both layouts.
+template <bool KV8>
+__device__ inline bf16x8 kv_load8(const void* base, long long off) {
+  if constexpr (!KV8) {
+    return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(base) + off);
+  } else {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(base) + off);
+    bf16x2x4 o;
+    o.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.x, 1.0f, false);
+    o.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.x, 1.0f, true);
+    o.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.y, 1.0f, false);
+    o.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.y, 1.0f, true);
+    return __builtin_bit_cast(bf16x8, o);
+  }
+}
+template <bool KV8>
+__device__ inline bf16x4 kv_load4(const void* base, long long off) {
+  if constexpr (!KV8) {
+    return *reinterpret_cast<const bf16x4*>(reinterpret_cast<const unsigned short*>(base) + off);
+  } else {
+    const unsigned int r = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const unsigned char*>(base) + off);
+    bf16x2x2 o;
+    o.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r, 1.0f, false);
+    o.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r, 1.0f, true);
+    return __builtin_bit_cast(bf16x4, o);
+  }
+}
+template <bool KV8, int N>
+__device__ inline auto kv_loadn(const void* base, long long off) {
+  if constexpr (N == 8) return kv_load8<KV8>(base, off);
+  else return kv_load4<KV8>(base, off);
+}
+// 8 values -> e4m3 bytes of v * inv_scale, clamped to the format's range (+-448)
+__device__ inline uint2 fp8_pack8(bf16x8 v, float inv_scale) {
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(__uint_as_float(((unsigned int)v[j]) << 16) * inv_scale, -448.f), 448.f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return make_uint2((unsigned int)lo, (unsigned int)hi);
+}
+// store 8 elements; returns what a later kv_load8 of them yields (bf16: v itself; FP8: the rounded value in stored units)
+template <bool KV8>
+__device__ inline bf16x8 kv_store8(void* base, long long off, bf16x8 v, float inv_scale, bool do_store = true) {
+  if constexpr (!KV8) {
+    if (do_store) *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned short*>(base) + off) = v;
+    return v;
+  } else {
+    const uint2 q = fp8_pack8(v, inv_scale);
+    if (do_store) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(base) + off) = q;
+    bf16x2x4 o;
+    o.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, 1.0f, false);
+    o.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, 1.0f, true);
+    o.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, 1.0f, false);
+    o.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, 1.0f, true);
+    return __builtin_bit_cast(bf16x8, o);
+  }
+}
+
 __device__ inline float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -197,13 +268,14 @@ __global__ __launch_bounds__(64) void residual_reduce_kernel(const float* __rest
 // head together with the matching 8 dims of the second half.
 // SLAB = true: qkv arrives as n_slabs fp32 partial sums [n_slabs][T][width] (split-K GEMM
 // output) that are summed on load, and rotated q is written to q_out [T, nh*hd] (bf16).
-template <bool SLAB>
+// KV8: the cache holds e4m3 bytes of x / kv_scale[head] (kv_scale: [2][nkv], K scales then V scales).
+template <bool SLAB, bool KV8>
 __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __restrict__ qkv, const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                             unsigned short* __restrict__ q_out, const int* __restrict__ positions,
                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                            unsigned short* __restrict__ k_cache, unsigned short* __restrict__ v_cache,
+                                                            void* __restrict__ k_cache, void* __restrict__ v_cache,
                                                             const int* __restrict__ slot_mapping, int nh, int nkv, int hd, int block_size,
-                                                            const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps) {
+                                                            const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps, const float* __restrict__ kv_scale) {
   // grid = (T, ceil(tasks / 64)), one wavefront per workgroup: tasks of a token run on
   // several CUs instead of one 256-thread loop.
   const int t = blockIdx.x, tid = blockIdx.y * 64 + threadIdx.x;
@@ -275,9 +347,10 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
       *reinterpret_cast<bf16x8*>(hp + half + d0) = ob;
     } else if (slot >= 0) {
       const int g = head - nh;
-      unsigned short* kp = k_cache + (((long long)blk * nkv + g) * block_size + off) * hd;
-      *reinterpret_cast<bf16x8*>(kp + d0) = oa;
-      *reinterpret_cast<bf16x8*>(kp + half + d0) = ob;
+      const long long kp = (((long long)blk * nkv + g) * block_size + off) * hd;
+      const float inv_ks = KV8 ? 1.f / kv_scale[g] : 1.f;
+      kv_store8<KV8>(k_cache, kp + d0, oa, inv_ks);
+      kv_store8<KV8>(k_cache, kp + half + d0, ob, inv_ks);
     }
   }
   if (slot >= 0) {
@@ -285,8 +358,8 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
     const int task = tid - rot_tasks;
     if (task >= 0 && task < v_tasks) {
       const int g = task / (hd >> 3), d0 = (task % (hd >> 3)) << 3;
-      unsigned short* vp = v_cache + (((long long)blk * nkv + g) * block_size + off) * hd;
-      *reinterpret_cast<bf16x8*>(vp + d0) = load8((nh + nkv) * hd + g * hd + d0);
+      const long long vp = (((long long)blk * nkv + g) * block_size + off) * hd;
+      kv_store8<KV8>(v_cache, vp + d0, load8((nh + nkv) * hd + g * hd + d0), KV8 ? 1.f / kv_scale[nkv + g] : 1.f);
     }
   }
 }
@@ -310,10 +383,6 @@ __device__ inline float quad_rows_sum(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// packed bf16 pairs, the operand type of v_dot2_f32_bf16
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-struct bf16x2x4 { bf16x2 p[4]; };
-
 // ---------------------------------------------------------------------------------
 // Ragged paged attention.  One workgroup per (token, kv head); the REP = nh/nkv query
 // heads of the group share every K/V load.  Each of the 4 waves walks KV blocks
@@ -325,12 +394,13 @@ struct bf16x2x4 { bf16x2 p[4]; };
 //       against the REP query heads; two xor-shuffles finish the 128-dim dot.
 //   PV: lane = 16*tg + dv; it owns 1/16 of the output dims and tokens {tg, tg+4, tg+8,
 //       tg+12} of the block; the 4 token groups are summed once at the end.
-template <int REP, int HD, int NWAVE>
+template <int REP, int HD, int NWAVE, bool KV8>
 __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
-                                                              const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
+                                                              const void* __restrict__ k_cache, const void* __restrict__ v_cache,
                                                               const int* __restrict__ block_tables, int max_blocks_per_seq,
                                                               const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
-                                                              unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
+                                                              unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e,
+                                                              const float* __restrict__ kv_scale) {
   constexpr int BS = 16, NT = 64 * NWAVE;
   constexpr int DQ = HD / 4;   // dims of the QK dot owned by a lane
   constexpr int NV = DQ / 8;   // 16-byte K loads per lane
@@ -344,6 +414,11 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   // not queue behind (and so do not drain) the K/V loads in flight
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ctx = ctx_lens[t];
+  float v_scale = 1.f;
+  if constexpr (KV8) {  // stored K / V are x / scale: the K scale folds into the score scale, the V scale into the output
+    scale_log2e *= kv_scale[g];
+    v_scale = kv_scale[nkv + g];
+  }
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
   if (ctx <= 0) {  // padding token
     for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
@@ -361,23 +436,23 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   vrow_t vv[4];
   if (wave < n_blocks) {
     const long long base = ((long long)bt[wave] * nkv + g) * BS * HD;
-    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * DQ;
+    const long long kp = base + qk_tok * HD + qk_c * DQ;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-    const unsigned short* vp = v_cache + base + pv_dv * DP;
+    for (int v = 0; v < NV; ++v) kv[v] = kv_load8<KV8>(k_cache, kp + v * 8);
+    const long long vp = base + pv_dv * DP;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
+    for (int i = 0; i < 4; ++i) vv[i] = kv_loadn<KV8, DP>(v_cache, vp + (pv_tg + 4 * i) * HD);
   }
   bf16x8 kn[NV];
   vrow_t vn[4];
   if (wave + NWAVE < n_blocks) {
     const long long base = ((long long)bt[wave + NWAVE] * nkv + g) * BS * HD;
-    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * DQ;
+    const long long kp = base + qk_tok * HD + qk_c * DQ;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-    const unsigned short* vp = v_cache + base + pv_dv * DP;
+    for (int v = 0; v < NV; ++v) kn[v] = kv_load8<KV8>(k_cache, kp + v * 8);
+    const long long vp = base + pv_dv * DP;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
+    for (int i = 0; i < 4; ++i) vn[i] = kv_loadn<KV8, DP>(v_cache, vp + (pv_tg + 4 * i) * HD);
   }
   // this lane's DQ-dim slice of the REP query heads, kept as packed bf16 pairs for
   // v_dot2_f32_bf16 (half the registers and multiplies of an fp32 copy, no unpacking of K)
@@ -409,12 +484,12 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
     vrow_t vf[4];
     if (b + 2 * NWAVE < n_blocks) {
       const long long nbase = ((long long)bt[b + 2 * NWAVE] * nkv + g) * BS * HD;
-      const unsigned short* kp = k_cache + nbase + qk_tok * HD + qk_c * DQ;
+      const long long kp = nbase + qk_tok * HD + qk_c * DQ;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) kf[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-      const unsigned short* vp = v_cache + nbase + pv_dv * DP;
+      for (int v = 0; v < NV; ++v) kf[v] = kv_load8<KV8>(k_cache, kp + v * 8);
+      const long long vp = nbase + pv_dv * DP;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const vrow_t*>(vp + (pv_tg + 4 * i) * HD);
+      for (int i = 0; i < 4; ++i) vf[i] = kv_loadn<KV8, DP>(v_cache, vp + (pv_tg + 4 * i) * HD);
     }
     // ---- QK^T
     float s[REP];
@@ -507,7 +582,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
       num += o_lds[w][h][d] * c;
       den += l_lds[w][h] * c;
     }
-    orow[i] = f2bf(den > 0.f ? num / den : 0.f);
+    orow[i] = f2bf(den > 0.f ? num / den * v_scale : 0.f);
   }
 }
 
@@ -542,10 +617,10 @@ typedef __attribute__((ext_vector_type(4))) float mfma_cd;
 //                 permutation slot(8*q + 4*b + j) = key 16*b + 4*q + j; V^T is staged into LDS
 //                 with its columns in that slot order and read as the A operand.
 // The output accumulator lane holds O[query lr][dims 16*nt + 4*lq .. +4]: 8-byte stores.
-template <int REP, int QT>
-__device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __restrict__ q, long long q_row_stride, const unsigned short* __restrict__ k_cache,
-                                                        const unsigned short* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
-                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, unsigned short* vt_lds,
+template <int REP, int QT, bool KV8>
+__device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
+                                                        const void* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
+                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* vt_lds,
                                                         unsigned short* k_lds) {
   constexpr int HD = 128, BS = 16, KSTEP = 32, VT_STRIDE = 40;  // 80-byte rows: 16-byte aligned fragments
   constexpr int K_STRIDE = HD + 8;                             // 272-byte key rows: the 16 key lanes of a fragment read spread over the banks
@@ -604,10 +679,10 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
     int key = (KB) + sv_key;                                                                  \
     if (key > last_key) key = last_key;                                                       \
     const long long off = (((long long)(B) * nkv + g) * BS + (key & 15)) * HD + sv_d0;        \
-    K0 = *reinterpret_cast<const bf16x8*>(k_cache + off);                                     \
-    K1 = *reinterpret_cast<const bf16x8*>(k_cache + off + 8);                                 \
-    V0 = *reinterpret_cast<const bf16x8*>(v_cache + off);                                     \
-    V1 = *reinterpret_cast<const bf16x8*>(v_cache + off + 8);                                 \
+    K0 = kv_load8<KV8>(k_cache, off);                                                         \
+    K1 = kv_load8<KV8>(k_cache, off + 8);                                                     \
+    V0 = kv_load8<KV8>(v_cache, off);                                                         \
+    V1 = kv_load8<KV8>(v_cache, off + 8);                                                     \
   } while (0)
   // Two LDS buffers: the tiles of step i+1 are written while step i computes, so a step needs
   // ONE workgroup barrier (tiles of i+1 staged, everyone done with those of i).
@@ -734,7 +809,7 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
       l = quad_rows_sum(l);
       const int qi = 16 * qt + lr;
       if (qi >= n_q) continue;
-      const float inv = l > 0.f ? 1.f / l : 0.f;
+      const float inv = l > 0.f ? v_scale / l : 0.f;
       unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + 4 * lq;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -753,14 +828,20 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
 // QT consecutive entries of the tile arrays: when they are consecutive tiles of one chunk
 // (the usual case: the host lists a chunk's tiles in order) they share one pass over the keys,
 // otherwise each gets a pass of its own.
-template <int REP, int QT>
+template <int REP, int QT, bool KV8>
 __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigned short* __restrict__ q, long long q_row_stride,
-                                                                const unsigned short* __restrict__ k_cache, const unsigned short* __restrict__ v_cache,
+                                                                const void* __restrict__ k_cache, const void* __restrict__ v_cache,
                                                                 const int* __restrict__ block_tables, int max_blocks_per_seq,
                                                                 const int* __restrict__ tile_row0, const int* __restrict__ tile_n,
                                                                 const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq, int n_tiles,
-                                                                unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e) {
+                                                                unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e,
+                                                                const float* __restrict__ kv_scale) {
   constexpr int HD = 128, VT_STRIDE = 40;
+  float v_scale = 1.f;
+  if constexpr (KV8) {
+    scale_log2e *= kv_scale[blockIdx.x];
+    v_scale = kv_scale[nkv + blockIdx.x];
+  }
   __shared__ __attribute__((aligned(16))) unsigned short vt_lds[2 * HD * VT_STRIDE];  // V^T [buffer][dim][k-slot]
   __shared__ __attribute__((aligned(16))) unsigned short k_lds[2 * 32 * (HD + 8)];    // K [buffer][key][dim], padded rows
   // later tiles of a chunk see more keys: hand them out first, so the longest passes do not start last
@@ -769,23 +850,23 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
     const int t1 = t0 + 1;
     const int n0 = tile_n[t0], n1 = t1 < n_tiles ? tile_n[t1] : 0;
     if (n0 == 16 && n1 > 0 && tile_seq[t1] == tile_seq[t0] && tile_pos0[t1] == tile_pos0[t0] + 16 && tile_row0[t1] == tile_row0[t0] + 16) {
-      prefill_attention_tiles<REP, 2>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
-                                      16 + n1, out, nh, nkv, scale_log2e, vt_lds, k_lds);
+      prefill_attention_tiles<REP, 2, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
+                                      16 + n1, out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
       return;
     }
     if (n0 > 0)
-      prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
-                                      out, nh, nkv, scale_log2e, vt_lds, k_lds);
+      prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
+                                      out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
     if (n1 > 0) {
       __syncthreads();  // the first pass is done with the LDS tiles
-      prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t1] * max_blocks_per_seq, tile_row0[t1], tile_pos0[t1], n1,
-                                      out, nh, nkv, scale_log2e, vt_lds, k_lds);
+      prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t1] * max_blocks_per_seq, tile_row0[t1], tile_pos0[t1], n1,
+                                      out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
     }
   } else {
     const int n0 = tile_n[t0];
     if (n0 > 0)
-      prefill_attention_tiles<REP, 1>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
-                                      out, nh, nkv, scale_log2e, vt_lds, k_lds);
+      prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
+                                      out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
   }
 }
 
@@ -802,17 +883,28 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
 //            same lane roles as paged_attention_kernel) and wave 0 folds in the token's own
 //            key / value from LDS — nothing written in phase A is read back from memory.
 // Saves one kernel boundary and one slab -> q round trip per layer.  head_dim 128, block 16.
-template <int REP, int NWAVE>
+// KV8: the token's own key / value take part in the attention as they will be read back from
+// the cache by later steps (rounded to e4m3, in stored units), so this kernel and the two-kernel
+// path agree.
+template <int REP, int NWAVE, bool KV8>
 __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                                      const int* __restrict__ positions, const float* __restrict__ cos_t,
-                                                                     const float* __restrict__ sin_t, unsigned short* __restrict__ k_cache,
-                                                                     unsigned short* __restrict__ v_cache, const int* __restrict__ slot_mapping,
+                                                                     const float* __restrict__ sin_t, void* __restrict__ k_cache,
+                                                                     void* __restrict__ v_cache, const int* __restrict__ slot_mapping,
                                                                      const int* __restrict__ block_tables, int max_blocks_per_seq,
                                                                      const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
                                                                      unsigned short* __restrict__ out, int nh, int nkv,
                                                                      const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
-                                                                     float scale_log2e) {
+                                                                     float scale_log2e, const float* __restrict__ kv_scale) {
   constexpr int HD = 128, BS = 16, HALF = 64, NT = 64 * NWAVE;
+  float inv_ks = 1.f, inv_vs = 1.f, v_scale = 1.f;
+  if constexpr (KV8) {
+    const float ks = kv_scale[blockIdx.y];
+    v_scale = kv_scale[nkv + blockIdx.y];
+    inv_ks = 1.f / ks;
+    inv_vs = 1.f / v_scale;
+    scale_log2e *= ks;
+  }
   // rows 0..REP-1: q; row REP: this token's key; row REP+1: its value — the projection output,
   // bf16-rounded like the cache contents.  A.2 leaves q and the key, RoPE'd, as bf16 in xb_lds.
   __shared__ float x_lds[REP + 2][HD];
@@ -839,22 +931,22 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   bf16x8 kv[4], vv[4];
   if (wave < n_blocks) {
     const long long base = ((long long)bt[wave] * nkv + g) * BS * HD;
-    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
+    const long long kp = base + qk_tok * HD + qk_c * 32;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) kv[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-    const unsigned short* vp = v_cache + base + pv_dv * 8;
+    for (int v = 0; v < 4; ++v) kv[v] = kv_load8<KV8>(k_cache, kp + v * 8);
+    const long long vp = base + pv_dv * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+    for (int i = 0; i < 4; ++i) vv[i] = kv_load8<KV8>(v_cache, vp + (pv_tg + 4 * i) * HD);
   }
   bf16x8 kn[4], vn[4];  // the block after that: two blocks (16 KB) per wave in flight at any time
   if (wave + NWAVE < n_blocks) {
     const long long base = ((long long)bt[wave + NWAVE] * nkv + g) * BS * HD;
-    const unsigned short* kp = k_cache + base + qk_tok * HD + qk_c * 32;
+    const long long kp = base + qk_tok * HD + qk_c * 32;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) kn[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-    const unsigned short* vp = v_cache + base + pv_dv * 8;
+    for (int v = 0; v < 4; ++v) kn[v] = kv_load8<KV8>(k_cache, kp + v * 8);
+    const long long vp = base + pv_dv * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vn[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+    for (int i = 0; i < 4; ++i) vn[i] = kv_load8<KV8>(v_cache, vp + (pv_tg + 4 * i) * HD);
   }
   // likewise the RoPE table row of this token (needed in A.2)
   constexpr int ROT = (REP + 1) * 8;  // (q heads + k) x 8 pieces of 8 dims and their partners
@@ -913,18 +1005,22 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
           oa[j] = f2bf(x1 * c - x2 * sv);
           ob[j] = f2bf(x2 * c + x1 * sv);
         }
+        if (hsel == REP) {  // the key: to the cache, and (as the cache will hold it) into LDS
+          oa = kv_store8<KV8>(k_cache, cache_row + d0, oa, inv_ks, cache_row >= 0);
+          ob = kv_store8<KV8>(k_cache, cache_row + HALF + d0, ob, inv_ks, cache_row >= 0);
+        }
         *reinterpret_cast<bf16x8*>(&xb_lds[hsel][d0]) = oa;
         *reinterpret_cast<bf16x8*>(&xb_lds[hsel][HALF + d0]) = ob;
-        if (hsel == REP && cache_row >= 0) {
-          *reinterpret_cast<bf16x8*>(k_cache + cache_row + d0) = oa;
-          *reinterpret_cast<bf16x8*>(k_cache + cache_row + HALF + d0) = ob;
-        }
-      } else if (task < ROT + 16 && cache_row >= 0) {
+      } else if (task < ROT + 16 && (cache_row >= 0 || KV8)) {
         const int d0 = (task - ROT) << 3;
         bf16x8 ov;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = f2bf(x_lds[REP + 1][d0 + j]);
-        *reinterpret_cast<bf16x8*>(v_cache + cache_row + d0) = ov;
+        ov = kv_store8<KV8>(v_cache, cache_row + d0, ov, inv_vs, cache_row >= 0);
+        if constexpr (KV8) {  // this thread's own 8 values: what the cache holds, in stored units
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x_lds[REP + 1][d0 + j] = bf2f(ov[j]);
+        }
       }
     }
   }
@@ -956,12 +1052,12 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     bf16x8 kf[4], vf[4];
     if (b + 2 * NWAVE < n_blocks) {
       const long long nbase = ((long long)bt[b + 2 * NWAVE] * nkv + g) * BS * HD;
-      const unsigned short* kp = k_cache + nbase + qk_tok * HD + qk_c * 32;
+      const long long kp = nbase + qk_tok * HD + qk_c * 32;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) kf[v] = *reinterpret_cast<const bf16x8*>(kp + v * 8);
-      const unsigned short* vp = v_cache + nbase + pv_dv * 8;
+      for (int v = 0; v < 4; ++v) kf[v] = kv_load8<KV8>(k_cache, kp + v * 8);
+      const long long vp = nbase + pv_dv * 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const bf16x8*>(vp + (pv_tg + 4 * i) * HD);
+      for (int i = 0; i < 4; ++i) vf[i] = kv_load8<KV8>(v_cache, vp + (pv_tg + 4 * i) * HD);
     }
     float s[REP];
 #pragma unroll
@@ -1064,7 +1160,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       num += (o_lds[w][0][h][d] + o_lds[w][1][h][d] + o_lds[w][2][h][d] + o_lds[w][3][h][d]) * c;
       den += l_lds[w][h] * c;
     }
-    orow[i] = f2bf(den > 0.f ? num / den : 0.f);
+    orow[i] = f2bf(den > 0.f ? num / den * v_scale : 0.f);
   }
 }
 
@@ -1215,12 +1311,15 @@ static inline int rope_grid_y(int nh, int nkv, int hd) {
 // given, the summed projection is scaled by rsqrt(sum/H_in + eps) (folded RMSNorm).
 int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_stride, void* q_out, const int* positions, const float* cos_t, const float* sin_t,
                            void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, const float* row_ss,
-                           int ss_parts, int h_in, float eps, hipStream_t stream) {
+                           int ss_parts, int h_in, float eps, const float* kv_scale, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd % 16 || n_slabs < 1) return -1;
-  hipLaunchKernelGGL(rope_kv_write_kernel<true>, dim3(T, rope_grid_y(nh, nkv, hd)), dim3(64), 0, stream, (unsigned short*)nullptr, slabs, n_slabs, slab_stride,
-                     (unsigned short*)q_out, positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size,
-                     row_ss, ss_parts, h_in > 0 ? 1.f / (float)h_in : 0.f, eps);
+#define KV_ROPE(K8)                                                                                                                                             \
+  hipLaunchKernelGGL((rope_kv_write_kernel<true, K8>), dim3(T, rope_grid_y(nh, nkv, hd)), dim3(64), 0, stream, (unsigned short*)nullptr, slabs, n_slabs, slab_stride, \
+                     (unsigned short*)q_out, positions, cos_t, sin_t, k_cache, v_cache, slot_mapping, nh, nkv, hd, block_size, row_ss, ss_parts,                  \
+                     h_in > 0 ? 1.f / (float)h_in : 0.f, eps, kv_scale)
+  if (kv_scale) KV_ROPE(true); else KV_ROPE(false);
+#undef KV_ROPE
   return (int)hipGetLastError();
 }
 
@@ -1241,18 +1340,21 @@ int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, c
 }
 
 int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache, const int* slot_mapping, int T,
-                     int nh, int nkv, int hd, int block_size, hipStream_t stream) {
+                     int nh, int nkv, int hd, int block_size, const float* kv_scale, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd % 16) return -1;
-  hipLaunchKernelGGL(rope_kv_write_kernel<false>, dim3(T, rope_grid_y(nh, nkv, hd)), dim3(64), 0, stream, (unsigned short*)qkv, (const float*)nullptr, 0, 0LL,
-                     (unsigned short*)nullptr, positions, cos_t, sin_t, (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, nh, nkv, hd, block_size,
-                     (const float*)nullptr, 0, 0.f, 0.f);
+#define KV_ROPE(K8)                                                                                                                                               \
+  hipLaunchKernelGGL((rope_kv_write_kernel<false, K8>), dim3(T, rope_grid_y(nh, nkv, hd)), dim3(64), 0, stream, (unsigned short*)qkv, (const float*)nullptr, 0, 0LL, \
+                     (unsigned short*)nullptr, positions, cos_t, sin_t, k_cache, v_cache, slot_mapping, nh, nkv, hd, block_size, (const float*)nullptr, 0, 0.f,      \
+                     0.f, kv_scale)
+  if (kv_scale) KV_ROPE(true); else KV_ROPE(false);
+#undef KV_ROPE
   return (int)hipGetLastError();
 }
 
 int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                        const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale,
-                       hipStream_t stream) {
+                       const float* kv_scale, hipStream_t stream) {
   if (T <= 0) return 0;
   if ((hd != 128 && hd != 64) || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
@@ -1261,9 +1363,15 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
   // 2 waves per SIMD and the grid does not fill the 256 CUs on its own
   const bool wide = rep <= 4 && (long long)T * nkv <= 256;
   dim3 grid(T, nkv), block(wide ? 512 : 256);
-#define KV_LAUNCH_W(R, D, W)                                                                                                                        \
-  hipLaunchKernelGGL((paged_attention_kernel<R, D, W>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache, \
-                     (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, sl)
+#define KV_LAUNCH_K(R, D, W, K8)                                                                                                          \
+  hipLaunchKernelGGL((paged_attention_kernel<R, D, W, K8>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, k_cache, v_cache, \
+                     block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, sl, kv_scale)
+#define KV_LAUNCH_W(R, D, W)       \
+  if (kv_scale) {                  \
+    KV_LAUNCH_K(R, D, W, true);    \
+  } else {                         \
+    KV_LAUNCH_K(R, D, W, false);   \
+  }
 #define KV_LAUNCH(R, D)                       \
   if (wide) {                                 \
     KV_LAUNCH_W(R, D, ((R) <= 4 ? 8 : 4));    \
@@ -1285,6 +1393,7 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
 #undef KV_BY_REP
 #undef KV_LAUNCH
 #undef KV_LAUNCH_W
+#undef KV_LAUNCH_K
   return (int)hipGetLastError();
 }
 
@@ -1292,7 +1401,7 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
 // n_tiles entries; rows of `out` not covered by a tile are left untouched.
 int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                          const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
-                         int block_size, float scale, hipStream_t stream) {
+                         int block_size, float scale, const float* kv_scale, hipStream_t stream) {
   if (n_tiles <= 0) return 0;
   if (hd != 128 || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
@@ -1305,10 +1414,15 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   static const int pinned = [] { const char* e = getenv("KVMINI_PREFILL_TILES"); return e ? atoi(e) : 0; }();
   const int qt = rep > 4 ? 1 : (pinned == 1 || pinned == 2 ? pinned : ((long long)nkv * n_tiles >= 512 ? 2 : 1));
   dim3 grid(nkv, (n_tiles + qt - 1) / qt), block(256);
-#define KV_LAUNCH_Q(R, Q)                                                                                                                                  \
-  hipLaunchKernelGGL((prefill_attention_kernel<R, Q>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, (const unsigned short*)k_cache,      \
-                     (const unsigned short*)v_cache, block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, n_tiles, (unsigned short*)out, \
-                     nh, nkv, sl)
+#define KV_LAUNCH_K(R, Q, K8)                                                                                                              \
+  hipLaunchKernelGGL((prefill_attention_kernel<R, Q, K8>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, k_cache, v_cache,   \
+                     block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, n_tiles, (unsigned short*)out, nh, nkv, sl, kv_scale)
+#define KV_LAUNCH_Q(R, Q)       \
+  if (kv_scale) {               \
+    KV_LAUNCH_K(R, Q, true);    \
+  } else {                      \
+    KV_LAUNCH_K(R, Q, false);   \
+  }
 #define KV_LAUNCH(R)                          \
   if (qt == 2) {                              \
     KV_LAUNCH_Q(R, ((R) <= 4 ? 2 : 1));       \
@@ -1327,6 +1441,7 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   }
 #undef KV_LAUNCH
 #undef KV_LAUNCH_Q
+#undef KV_LAUNCH_K
   return (int)hipGetLastError();
 }
 
@@ -1335,7 +1450,7 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              int waves, hipStream_t stream) {
+                              int waves, const float* kv_scale, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1 || n_slabs > 16 || (waves != 4 && waves != 8)) return -1;
   const int rep = nh / nkv;
@@ -1343,10 +1458,16 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
   const float inv_h = h_in > 0 ? 1.f / (float)h_in : 0.f;
   if (rep > 4) waves = 4;  // 8 waves of the wider head groups do not fit the 256 registers per lane that 2 waves per SIMD leave
   dim3 grid(T, nkv), block(64 * waves);
-#define KV_LAUNCH_W(R, W)                                                                                                                              \
-  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t,                   \
-                     (unsigned short*)k_cache, (unsigned short*)v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens,            \
-                     (unsigned short*)out, nh, nkv, row_ss, ss_parts, inv_h, eps, sl)
+#define KV_LAUNCH_K(R, W, K8)                                                                                                                   \
+  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t, k_cache, \
+                     v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, row_ss, ss_parts,    \
+                     inv_h, eps, sl, kv_scale)
+#define KV_LAUNCH_W(R, W)       \
+  if (kv_scale) {               \
+    KV_LAUNCH_K(R, W, true);    \
+  } else {                      \
+    KV_LAUNCH_K(R, W, false);   \
+  }
 #define KV_LAUNCH(R)      \
   if (waves == 8) {       \
     KV_LAUNCH_W(R, ((R) <= 4 ? 8 : 4)); /* wider head groups exist with 4 waves only */ \
@@ -1365,6 +1486,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
   }
 #undef KV_LAUNCH
 #undef KV_LAUNCH_W
+#undef KV_LAUNCH_K
   return (int)hipGetLastError();
 }
 

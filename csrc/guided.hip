@@ -1,0 +1,194 @@
+// Guided JSON decoding on the device (gfx950): the automaton of kvmini/engine/guided.py.
+//
+// guided_mask_kernel     one 1024-thread workgroup per guided logits row: (re)initialise the
+//                        sequence's automaton if the host says so, work out the set of token
+//                        CLASSES that may come next, and overwrite the logit of every token of
+//                        another class with -inf (bf16), 8 logits + 8 class bytes per trip.
+// guided_advance_kernel  one thread per guided row: feed the token that argmax / sampling picked
+//                        from the masked row to the automaton.
+// Both run behind the forward pass on the engine's stream, so a step that is launched before the
+// previous step's token has reached the host still sees the right automaton state.
+//
+// State of a sequence: int32[4] = (state, depth, container stack bits (1 = array), tokens left).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+enum { C_OTHER, C_LBRACE, C_RBRACE, C_LBRACK, C_RBRACK, C_COLON, C_COMMA, C_QUOTE, C_STR, C_DIGIT_NZ, C_DIGIT, C_LIT, C_EOS, N_CLASSES };
+enum { S_OFF, S_START, S_OBJ_FIRST, S_KEY, S_AFTER_KEY, S_VALUE, S_STR, S_NUM, S_AFTER_VALUE, S_OBJ_NEXT, S_ARR_FIRST, S_DONE, S_END };
+constexpr int MAX_DEPTH = 16;
+constexpr int TPB = 1024;
+
+struct St { int s, depth, stack; };
+
+__device__ inline St pop(St a) {
+  a.depth -= 1;
+  a.stack &= ~(1 << a.depth);
+  a.s = a.depth == 0 ? S_DONE : S_AFTER_VALUE;
+  return a;
+}
+
+// the automaton's move on a token of class c; ok = false when the grammar forbids it
+__device__ inline St transition(St a, int c, bool& ok) {
+  ok = true;
+  const bool top_arr = a.depth > 0 && ((a.stack >> (a.depth - 1)) & 1);
+  const bool in_string = c != C_OTHER && c != C_QUOTE && c != C_EOS;
+  St n = a;
+  switch (a.s) {
+    case S_START:
+      if (c == C_LBRACE) { n.s = S_OBJ_FIRST; n.depth = 1; n.stack = 0; return n; }
+      break;
+    case S_OBJ_FIRST:
+      if (c == C_QUOTE) { n.s = S_KEY; return n; }
+      if (c == C_RBRACE) return pop(a);
+      break;
+    case S_KEY:
+      if (c == C_QUOTE) { n.s = S_AFTER_KEY; return n; }
+      if (in_string) return n;
+      break;
+    case S_AFTER_KEY:
+      if (c == C_COLON) { n.s = S_VALUE; return n; }
+      break;
+    case S_VALUE:
+    case S_ARR_FIRST:
+      if (c == C_QUOTE) { n.s = S_STR; return n; }
+      if (c == C_LBRACE && a.depth < MAX_DEPTH) { n.s = S_OBJ_FIRST; n.depth = a.depth + 1; return n; }
+      if (c == C_LBRACK && a.depth < MAX_DEPTH) { n.s = S_ARR_FIRST; n.depth = a.depth + 1; n.stack = a.stack | (1 << a.depth); return n; }
+      if (c == C_DIGIT_NZ) { n.s = S_NUM; return n; }
+      if (c == C_LIT) { n.s = S_AFTER_VALUE; return n; }
+      if (a.s == S_ARR_FIRST && c == C_RBRACK) return pop(a);
+      break;
+    case S_STR:
+      if (c == C_QUOTE) { n.s = S_AFTER_VALUE; return n; }
+      if (in_string) return n;
+      break;
+    case S_NUM:
+    case S_AFTER_VALUE:
+      if (a.s == S_NUM && (c == C_DIGIT || c == C_DIGIT_NZ)) return n;
+      if (c == C_COMMA) { n.s = top_arr ? S_VALUE : S_OBJ_NEXT; return n; }
+      if ((c == C_RBRACK && top_arr) || (c == C_RBRACE && !top_arr)) return pop(a);
+      break;
+    case S_OBJ_NEXT:
+      if (c == C_QUOTE) { n.s = S_KEY; return n; }
+      break;
+    case S_DONE:
+      if (c == C_EOS) { n.s = S_END; n.depth = 0; n.stack = 0; return n; }
+      break;
+    default:
+      break;
+  }
+  ok = false;
+  return a;
+}
+
+// fewest tokens from a state to the end of the sequence (closers + EOS); vc = cost of a value
+__device__ inline int close_cost(int s, int depth, int vc) {
+  const int tail = depth + 1;
+  switch (s) {
+    case S_START: return 3;
+    case S_KEY: return 2 + vc + tail;
+    case S_AFTER_KEY: return 1 + vc + tail;
+    case S_VALUE: return vc + tail;
+    case S_STR: return 1 + tail;
+    case S_OBJ_NEXT: return 3 + vc + tail;
+    case S_OBJ_FIRST:
+    case S_ARR_FIRST:
+    case S_NUM:
+    case S_AFTER_VALUE: return tail;
+    case S_DONE: return 1;
+    default: return 0;
+  }
+}
+
+// Bits 16.. of the stack word restrict the NEXT token to a set of classes (0 = none); the first
+// advance clears them.  The restriction is dropped if the grammar allows none of its classes.
+constexpr int FIRST_SHIFT = 16;
+
+__device__ inline unsigned allowed_classes(St a, int left, int vc) {
+  if (a.s == S_OFF || a.s == S_END) return (1u << N_CLASSES) - 1u;
+  const unsigned first = (unsigned)a.stack >> FIRST_SHIFT;
+  a.stack &= (1 << FIRST_SHIFT) - 1;
+  unsigned fits = 0, grammar = 0;
+#pragma unroll
+  for (int c = 1; c < N_CLASSES; ++c) {
+    bool ok;
+    const St n = transition(a, c, ok);
+    if (!ok) continue;
+    grammar |= 1u << c;
+    if (close_cost(n.s, n.depth, vc) <= left - 1) fits |= 1u << c;
+  }
+  if (first & grammar) {
+    grammar &= first;
+    fits &= first;
+  }
+  return fits ? fits : grammar;
+}
+
+typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+
+__global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __restrict__ logits, long long row_stride, int V, int n_cls, const long long* __restrict__ rows,
+                                                           const int* __restrict__ slots, const int* __restrict__ init, int* __restrict__ state,
+                                                           const unsigned char* __restrict__ cls, int vc) {
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int slot = slots[r];
+  const int* src = init[4 * r] >= 0 ? init + 4 * r : state + 4 * slot;
+  const St a = {src[0], src[1], src[2]};
+  const int left = src[3];
+  if (init[4 * r] >= 0 && tid < 4) state[4 * slot + tid] = init[4 * r + tid];  // nobody reads state[] of this slot in this launch
+  const unsigned allow = allowed_classes(a, left, vc);
+  if (allow == (1u << N_CLASSES) - 1u) return;
+  unsigned short* row = logits + rows[r] * row_stride;
+  constexpr unsigned short NEG_INF = 0xFF80;
+  int done = 0;
+  if ((((uintptr_t)row) & 15) == 0 && (((uintptr_t)cls) & 7) == 0) {
+    const int nv = n_cls >> 3;
+    for (int i = tid; i < nv; i += TPB) {
+      us8 x = reinterpret_cast<const us8*>(row)[i];
+      const unsigned long long c8 = reinterpret_cast<const unsigned long long*>(cls)[i];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned c = (unsigned)(c8 >> (8 * j)) & 0xffu;
+        if (!((allow >> c) & 1u)) { x[j] = NEG_INF; any = true; }
+      }
+      if (any) reinterpret_cast<us8*>(row)[i] = x;
+    }
+    done = nv * 8;
+  }
+  for (int i = done + tid; i < V; i += TPB) {
+    const unsigned c = i < n_cls ? cls[i] : (unsigned)C_OTHER;  // ids past the tokenizer's vocabulary (padding columns) are never allowed
+    if (!((allow >> c) & 1u)) row[i] = NEG_INF;
+  }
+}
+
+__global__ void guided_advance_kernel(const long long* __restrict__ out_ids, const long long* __restrict__ rows, const int* __restrict__ slots, int R,
+                                      int* __restrict__ state, const unsigned char* __restrict__ cls, int n_cls) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  int* st = state + 4 * slots[r];
+  St a = {st[0], st[1], st[2] & ((1 << FIRST_SHIFT) - 1)};
+  if (a.s == S_OFF || a.s == S_END) return;
+  const long long tok = out_ids[rows[r]];
+  const int c = (tok >= 0 && tok < n_cls) ? cls[tok] : (int)C_OTHER;
+  bool ok;
+  const St n = transition(a, c, ok);
+  st[0] = n.s; st[1] = n.depth; st[2] = n.stack; st[3] = st[3] - 1;
+}
+
+}  // namespace
+
+extern "C" int kv_guided_mask(void* logits, long long row_stride, int V, int n_cls, const long long* rows, const int* slots, const int* init, int R, int* state,
+                              const unsigned char* cls, int vc, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (V <= 0 || n_cls > V) return -1;
+  hipLaunchKernelGGL(guided_mask_kernel, dim3(R), dim3(TPB), 0, stream, (unsigned short*)logits, row_stride, V, n_cls, rows, slots, init, state, cls, vc);
+  return (int)hipGetLastError();
+}
+
+extern "C" int kv_guided_advance(const long long* out_ids, const long long* rows, const int* slots, int R, int* state, const unsigned char* cls, int n_cls, hipStream_t stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(guided_advance_kernel, dim3((R + 63) / 64), dim3(64), 0, stream, out_ids, rows, slots, R, state, cls, n_cls);
+  return (int)hipGetLastError();
+}

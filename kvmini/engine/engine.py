@@ -213,6 +213,13 @@ class LLMEngine:
         self._launch_cost = 0.0  # host seconds from the end of the hold to the enqueued step (moving average)
         self._late_penalty = 0.0
         self._t_collect = 0.0  # when the previous step's ids arrived = when the step in flight started
+        # guided decoding: token classes (set by the front-end, which owns the tokenizer), one
+        # automaton state per sequence slot on the device, and who initialised each slot
+        self._guided_cls_np: Any = None
+        self._guided_cls: Optional[torch.Tensor] = None
+        self._guided_vc = 1
+        self._guided_state = torch.zeros((ecfg.max_num_seqs, 4), dtype=torch.int32, device=self.device)
+        self._guided_owner: List[Any] = [None] * ecfg.max_num_seqs
 
     # ------------------------------------------------------------------
     def warmup(self) -> float:
@@ -233,6 +240,22 @@ class LLMEngine:
             n = x.errors()
             if n:
                 raise RuntimeError(f"{n} xGMI collective wait(s) timed out: a tensor-parallel rank did not take part in a step")
+
+    def set_token_classes(self, cls: Any) -> None:
+        """Token classes for guided decoding (``kvmini.engine.guided.token_classes`` of the
+        serving tokenizer): uint8 per token id."""
+        import numpy as np
+
+        from . import guided
+
+        cls = np.ascontiguousarray(cls, dtype=np.uint8)[: self.mcfg.vocab_size]
+        self._guided_cls_np = cls
+        self._guided_cls = torch.from_numpy(cls.copy()).to(self.device)
+        self._guided_vc = guided.value_cost(cls)
+
+    @property
+    def guided_ready(self) -> bool:
+        return self._guided_cls is not None
 
     # --- synchronous API (tests, offline generation) ---------------------
     def make_sequence(self, prompt_ids: List[int], params: Optional[SamplingParams] = None, user: Any = None) -> Sequence:
@@ -276,7 +299,7 @@ class LLMEngine:
             batch = self.scheduler.schedule()
             if batch.chunks:
                 with torch.no_grad():
-                    ids, logits = self.runner.execute(batch)
+                    ids, logits = self.runner.execute(batch, self._device_sampler(batch, guided_only=True))
                 events += self._commit(batch, ids, logits)
                 launched = True
         if launched:
@@ -316,26 +339,70 @@ class LLMEngine:
             return False
         return True
 
-    def _device_sampler(self, batch: Batch) -> Optional[Callable[[torch.Tensor, torch.Tensor], None]]:
-        """For a step that is launched ahead: the rows with temperature > 0 are sampled by device
-        ops queued right behind the forward pass and written over the argmax ids, so that the
-        next step can take them from there like greedy ones.  None when every row is greedy."""
+    def _device_sampler(self, batch: Batch, guided_only: bool = False) -> Optional[Callable[[torch.Tensor, torch.Tensor], None]]:
+        """Device ops queued right behind the forward pass that replace argmax ids in place, so
+        that the next step can be launched on them before the host has seen them:
+
+        * rows with temperature > 0 are sampled (``guided_only``: left to the host, which owns
+          seeded generators and runs after the read-back in the synchronous path);
+        * rows of guided requests first get the automaton's mask over their logits, are then
+          picked (argmax or sampling) from what is left, and the pick is fed to the automaton.
+
+        None when no row needs any of this."""
         rows: List[int] = []
         plist: List[SamplingParams] = []
+        g_rows: List[int] = []
+        g_slots: List[int] = []
+        g_init: List[int] = []
+        g_greedy: List[int] = []
         r = 0
         for ch in batch.chunks:
             if ch.sample:
-                if ch.seq.params.temperature > 0:
+                p = ch.seq.params
+                if p.guided:
+                    self._stage_guided(ch.seq, r, g_rows, g_slots, g_init)
+                    if p.temperature <= 0:
+                        g_greedy.append(r)
+                if p.temperature > 0 and (p.guided or not guided_only):
                     rows.append(r)
-                    plist.append(ch.seq.params)
+                    plist.append(p)
                 r += 1
-        if not rows:
+        if not rows and not g_rows:
             return None
 
         def run(logits: torch.Tensor, out_ids: torch.Tensor) -> None:
-            self._sample_into(logits, rows, plist, out_ids)
+            ops, dev = self.runner.ops, logits.device
+            if g_rows:
+                gr, gs = _host_to_device(g_rows, torch.int64, dev), _host_to_device(g_slots, torch.int32, dev)
+                ops.guided_mask(logits, gr, gs, _host_to_device(g_init, torch.int32, dev), self._guided_state, self._guided_cls, self._guided_vc)
+                if g_greedy:
+                    idx = gr if len(g_greedy) == len(g_rows) else _host_to_device(g_greedy, torch.int64, dev)
+                    out_ids.index_copy_(0, idx, ops.greedy_sample(logits.index_select(0, idx)))
+            if rows:
+                self._sample_into(logits, rows, plist, out_ids)
+            if g_rows:
+                ops.guided_advance(out_ids, gr, gs, self._guided_state, self._guided_cls)
 
         return run
+
+    def _stage_guided(self, seq: Sequence, row: int, g_rows: List[int], g_slots: List[int], g_init: List[int]) -> None:
+        """One guided row of the step being launched.  The automaton of the sequence's slot is
+        (re)initialised by the kernel when this sequence has not used the slot before (first
+        sample, or taken up again after a preemption: replayed over the tokens it already has)."""
+        from . import guided
+        from .scheduler import PLACEHOLDER
+
+        if self._guided_cls is None:
+            raise RuntimeError("guided decoding needs token classes: call set_token_classes() first")
+        key = (seq.req_id, seq.preemptions)
+        g_rows.append(row)
+        g_slots.append(seq.slot)
+        if self._guided_owner[seq.slot] != key:
+            self._guided_owner[seq.slot] = key
+            known = [t for t in seq.output_ids if t != PLACEHOLDER]
+            g_init += list(guided.replay(self._guided_cls_np, seq.params.guided_start, seq.params.max_tokens, known))
+        else:
+            g_init += [-1, 0, 0, 0]
 
     def _sample_into(self, logits: torch.Tensor, rows: List[int], plist: List[SamplingParams], out_ids: torch.Tensor) -> torch.Tensor:
         """Sample rows ``rows`` of ``logits`` (one SamplingParams each, unseeded) into
@@ -354,7 +421,8 @@ class LLMEngine:
     @staticmethod
     def _needs_host_sampling(p: SamplingParams) -> bool:
         # a per-request seed owns a generator that is advanced on the host; logprobs are read back
-        return bool(p.logprobs) or (p.temperature > 0 and p.seed is not None)
+        # (guided rows are always picked on the device: their automaton advances there)
+        return bool(p.logprobs) or (p.temperature > 0 and p.seed is not None and not p.guided)
 
     def _can_pipeline(self) -> bool:
         """Pipelined stepping needs every token of the next step to be either known or already
@@ -367,12 +435,12 @@ class LLMEngine:
         # sampled ones are stepped synchronously (their ids reach the followers staged by the host)
         greedy_only = r.tp_size > 1
         for s in sch.running:
-            if self._needs_host_sampling(s.params) or (greedy_only and s.params.temperature > 0):
+            if self._needs_host_sampling(s.params) or (greedy_only and (s.params.temperature > 0 or s.params.guided)):
                 return False
         room = sch.max_num_seqs - len(sch.running)
         if room > 0 and sch.waiting:
             for s in itertools.islice(sch.waiting, room):
-                if self._needs_host_sampling(s.params) or (greedy_only and s.params.temperature > 0):
+                if self._needs_host_sampling(s.params) or (greedy_only and (s.params.temperature > 0 or s.params.guided)):
                     return False
         return self.bm.num_free >= len(sch.running) + sch.max_batched_tokens // self.bm.block_size + 2
 
@@ -429,7 +497,7 @@ class LLMEngine:
         # unseeded temperature sampling: all such rows of the step in one batched call
         batched: Dict[int, int] = {}
         if logits is not None:
-            rows_b = [r for r, ch in enumerate(c for c in batch.chunks if c.sample) if ch.seq.params.temperature > 0 and ch.seq.params.seed is None]
+            rows_b = [r for r, ch in enumerate(c for c in batch.chunks if c.sample) if ch.seq.params.temperature > 0 and ch.seq.params.seed is None and not ch.seq.params.guided]
             if rows_b:
                 plist = [ch.seq.params for ch in batch.chunks if ch.sample]
                 tmp = torch.zeros(logits.shape[0], dtype=torch.int64, device=logits.device)
@@ -447,7 +515,7 @@ class LLMEngine:
             p = seq.params
             if row in batched:
                 tok = batched[row]
-            elif p.temperature > 0 and logits is not None:
+            elif p.temperature > 0 and logits is not None and not p.guided:
                 gen = self._gens.get(seq.req_id)
                 if gen is None:
                     gen = torch.Generator(device=logits.device)

@@ -460,12 +460,12 @@ class ModelRunner:
         self.stage_dev.copy_(self.stages[0].cpu)
 
     # ------------------------------------------------------------------
-    def execute(self, batch: Batch) -> Tuple[List[int], Optional[torch.Tensor]]:
+    def execute(self, batch: Batch, sampler: Any = None) -> Tuple[List[int], Optional[torch.Tensor]]:
         """Run one step.  Returns (sampled ids, logits) with one row per position
         flagged for sampling, in chunk order: a chunk flagged ``sample`` contributes
         its last position — or, when it carries draft tokens to verify, every
         position from the last accepted token on."""
-        return self.collect(self.launch(batch))
+        return self.collect(self.launch(batch, sampler))
 
     def collect(self, h: StepHandle) -> Tuple[List[int], Optional[torch.Tensor]]:
         """Wait for a launched step and read its sampled ids."""

@@ -16,7 +16,7 @@ import time
 from collections import deque
 from dataclasses import dataclass, field
 from enum import Enum
-from typing import Any, Deque, List, Optional
+from typing import Tuple,  Any, Deque, List, Optional
 
 from .kv_cache import BlockManager
 
@@ -42,6 +42,11 @@ class SamplingParams:
     ignore_eos: bool = False
     logprobs: int = 0
     stop_token_ids: List[int] = field(default_factory=list)
+    # guided decoding: "json" constrains the output to one JSON object (kvmini/engine/guided.py);
+    # guided_start = (state, depth, stack) of the automaton at the first generated token (a server
+    # that pre-writes part of the document into the prompt starts it further in)
+    guided: Optional[str] = None
+    guided_start: Tuple[int, int, int] = (1, 0, 0)
 
 
 @dataclass(eq=False)  # identity semantics: sequences live in lists / sets and are compared per step
@@ -153,6 +158,8 @@ class Scheduler:
             v = getattr(p, name)
             if not isinstance(v, (int, float)) or isinstance(v, bool) or not math.isfinite(v) or v < 0:
                 return f"{name} must be a finite non-negative number, got {v!r}"
+        if p.guided not in (None, "json"):
+            return f"unknown guided decoding mode {p.guided!r}"
         if not isinstance(p.max_tokens, int) or p.max_tokens < 1:
             return f"max_tokens must be a positive integer, got {p.max_tokens!r}"
         bs = self.bm.block_size

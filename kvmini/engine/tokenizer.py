@@ -28,17 +28,30 @@ _WORDS = (
 ).split()
 
 
+# ids [16, 48): the JSON alphabet, one token per piece, so that guided decoding has real structural
+# tokens to allow and the text of a guided completion parses
+_JSON_PIECES = ("{", "}", "[", "]", ":", ",", '"', "true", "false", "null", "0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "42", "100", "2024", "-", ".", "_", "/", "(", ")", "'", "!")
+
+
 class SyntheticTokenizer:
     n_special = 16  # ids [0, 16) are reserved: 0 pad, 1 bos, 2 eos, 3 eot, 4.. headers
+    n_reserved = n_special + len(_JSON_PIECES)
 
     def __init__(self, vocab_size: int, bos_id: int = 1, eos_id: int = 2):
         self.vocab_size = int(vocab_size)
         self.bos_id = min(bos_id, self.vocab_size - 1)
         self.eos_id = min(eos_id, self.vocab_size - 1)
-        self._span = max(1, self.vocab_size - self.n_special)
+        # tiny test vocabularies keep the plain hashed layout
+        self._json = {p: self.n_special + i for i, p in enumerate(_JSON_PIECES)} if self.vocab_size >= 4 * self.n_reserved else {}
+        self._json_text = {i: p for p, i in self._json.items()}
+        self._base = self.n_reserved if self._json else self.n_special
+        self._span = max(1, self.vocab_size - self._base)
 
     def _piece_id(self, piece: str) -> int:
-        return self.n_special + (zlib.crc32(piece.encode("utf-8")) % self._span)
+        fixed = self._json.get(piece)
+        if fixed is not None:
+            return fixed
+        return self._base + (zlib.crc32(piece.encode("utf-8")) % self._span)
 
     def encode(self, text: str, add_bos: bool = False) -> List[int]:
         ids = [self._piece_id(p) for p in _PIECE.findall(text)]
@@ -61,6 +74,9 @@ class SyntheticTokenizer:
     def decode_token(self, tok: int) -> str:
         if tok < self.n_special:
             return ""
+        fixed = self._json_text.get(tok)
+        if fixed is not None:
+            return fixed
         return " " + _WORDS[tok % len(_WORDS)]
 
     def decode(self, ids: List[int]) -> str:

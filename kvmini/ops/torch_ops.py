@@ -143,3 +143,16 @@ def linear_swiglu(x: torch.Tensor, wgu: torch.Tensor) -> torch.Tensor:
 
 def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
     return logits.argmax(dim=-1)
+
+
+def guided_mask(logits: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, init: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, vc: int) -> None:
+    """Reference of the guided-decoding mask: the Python automaton, row by row."""
+    from kvmini.engine.guided import mask_rows_reference
+
+    mask_rows_reference(logits, rows.tolist(), slots.tolist(), init.view(-1, 4).tolist(), state, cls.cpu().numpy(), vc)
+
+
+def guided_advance(out_ids: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, state: torch.Tensor, cls: torch.Tensor) -> None:
+    from kvmini.engine.guided import advance_rows_reference
+
+    advance_rows_reference(out_ids, rows.tolist(), slots.tolist(), state, cls.cpu().numpy())

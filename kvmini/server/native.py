@@ -103,6 +103,68 @@ class NativeServer:
         self.errors_total += 1
         return Response.json({"error": {"message": why, "type": "invalid_request_error"}}, 400)
 
+    # guided decoding ------------------------------------------------------
+    def _schema_start(self, schema: Any) -> Tuple[str, Tuple[int, int, int]]:
+        """(text the server writes itself, automaton start) for a JSON schema: the opening brace
+        and the first required (else first) property key are written by the server and the value
+        that follows is restricted to the property's type; everything after that is free JSON."""
+        from kvmini.engine import guided as G
+
+        props = schema.get("properties") if isinstance(schema, dict) else None
+        if not isinstance(props, dict) or not props:
+            return "", (G.S_START, 0, 0)
+        req_keys = [k for k in (schema.get("required") or []) if k in props]
+        key = req_keys[0] if req_keys else next(iter(props))
+        prefix = "{" + json.dumps(str(key)) + ":"
+        st, depth, stack = G.state_after_text(prefix)
+        ptype = props[key].get("type") if isinstance(props[key], dict) else None
+        first = G.TYPE_CLASSES.get(ptype if isinstance(ptype, str) else "", 0)
+        return prefix, (st, depth, stack | (first << G.FIRST_SHIFT))
+
+    def _guided_plan(self, body: Dict[str, Any], chat: bool) -> Tuple[Optional[List[Dict[str, Any]]], bool]:
+        """What a request asks the automaton for.  Returns (sub-requests, they are tool calls):
+        ``response_format`` json_object / json_schema (or vLLM's ``guided_json``) = one guided
+        sequence per choice; ``tools`` with a ``tool_choice`` other than "none" = one guided
+        sequence per tool that is called (every tool of the list with "auto" / "required" unless
+        ``parallel_tool_calls`` is false, the named one otherwise), each writing the arguments
+        object of its call."""
+        rf = body.get("response_format") or {}
+        tools = body.get("tools") if chat else None
+        choice = body.get("tool_choice", "auto" if tools else "none")
+        if tools and choice != "none":
+            if not isinstance(tools, list) or not all(isinstance(t, dict) and isinstance(t.get("function"), dict) and t["function"].get("name") for t in tools):
+                raise ValueError("tools must be a list of {type: function, function: {name, parameters}}")
+            if isinstance(choice, dict):
+                want = (choice.get("function") or {}).get("name")
+                called = [t for t in tools if t["function"]["name"] == want]
+                if not called:
+                    raise ValueError(f"tool_choice names an unknown function {want!r}")
+            elif choice in ("auto", "required"):
+                called = tools if body.get("parallel_tool_calls", True) else tools[:1]
+            else:
+                raise ValueError(f"tool_choice must be none, auto, required or a function, got {choice!r}")
+            subs = []
+            for t in called[:16]:
+                prefix, start = self._schema_start(t["function"].get("parameters") or {})
+                subs.append({"name": str(t["function"]["name"]), "prefix": prefix, "start": start, "lead": f"call {t['function']['name']} {prefix}"})
+            return subs, True
+        schema = None
+        if isinstance(rf, dict) and rf.get("type") == "json_schema":
+            schema = (rf.get("json_schema") or {}).get("schema") or {}
+        elif body.get("guided_json") is not None:
+            schema = body["guided_json"] if isinstance(body["guided_json"], dict) else json.loads(str(body["guided_json"]))
+        elif not (isinstance(rf, dict) and rf.get("type") == "json_object"):
+            return None, False
+        prefix, start = self._schema_start(schema or {})
+        return [{"name": None, "prefix": prefix, "start": start, "lead": prefix}], False
+
+    def _ensure_guided(self) -> None:
+        if not self.engine.guided_ready:
+            from kvmini.engine.guided import token_classes
+
+            cfg = self.engine.mcfg
+            self.engine.set_token_classes(token_classes(self.tok, cfg.vocab_size, cfg.eos_token_id))
+
     def _auth(self, req: Request) -> Optional[Response]:
         if self.api_key and req.headers.get("authorization", "") != f"Bearer {self.api_key}":
             return Response.json({"error": {"message": "invalid api key", "type": "authentication_error"}}, 401)
@@ -157,11 +219,22 @@ class NativeServer:
         except (TypeError, ValueError) as e:
             self.errors_total += 1
             return Response.json({"error": {"message": f"bad sampling parameter: {e}", "type": "invalid_request_error"}}, 400)
+        try:
+            subs, as_tools = self._guided_plan(body, chat)
+        except (TypeError, ValueError) as e:
+            self.errors_total += 1
+            return Response.json({"error": {"message": f"bad structured-output request: {e}", "type": "invalid_request_error"}}, 400)
+        if subs is not None and self.engine.spec is not None:
+            self.errors_total += 1
+            return Response.json({"error": {"message": "guided decoding is not available on an engine that runs speculative decoding", "type": "invalid_request_error"}}, 400)
         bad = self._reject(prompt_ids, params)
         if bad:
             return bad
         stops = body.get("stop") or []
         stops = [stops] if isinstance(stops, str) else [str(x) for x in stops if x]
+        if subs is not None:
+            self._ensure_guided()
+            stops = []  # the automaton ends the document; stop strings could only cut it short
         stream = bool(body.get("stream"))
         include_usage = bool((body.get("stream_options") or {}).get("include_usage"))
         model = body.get("model") or self.model_name
@@ -171,14 +244,36 @@ class NativeServer:
         # n choices = n sequences that share the prompt (its KV blocks through the prefix cache)
         q: asyncio.Queue = asyncio.Queue()
         rids: List[int] = []
-        for i in range(n):
-            p_i = params if i == 0 else SamplingParams(**{**vars(params), "stop_token_ids": list(params.stop_token_ids), "seed": None if params.seed is None else params.seed + i})
-            rid, _ = await self._run(prompt_ids, p_i, q, i)
-            rids.append(rid)
+        lead_of = [""] * n  # text the server wrote in front of a choice's generated tokens
+        if subs is None:
+            for i in range(n):
+                p_i = params if i == 0 else SamplingParams(**{**vars(params), "stop_token_ids": list(params.stop_token_ids), "seed": None if params.seed is None else params.seed + i})
+                rid, _ = await self._run(prompt_ids, p_i, q, i)
+                rids.append(rid)
+        else:
+            # guided sequences: one per choice (JSON mode) or one per tool call; the text the server
+            # writes itself (schema key, tool name) is appended to the prompt so the model sees it
+            if as_tools:
+                n = len(subs)
+            plan = subs if as_tools else subs * n
+            budget = max(8, params.max_tokens // len(plan)) if as_tools else params.max_tokens
+            lead_of = [sb["prefix"] for sb in plan]
+            for i, sb in enumerate(plan):
+                p_i = SamplingParams(**{**vars(params), "stop_token_ids": list(params.stop_token_ids), "seed": None if params.seed is None else params.seed + i,
+                                        "max_tokens": budget, "ignore_eos": False, "guided": "json", "guided_start": tuple(sb["start"])})
+                ids_i = prompt_ids + (self.tok.encode(sb["lead"]) if sb["lead"] else [])
+                bad = self._reject(ids_i, p_i)
+                if bad:
+                    for rid in rids:
+                        self._queues.pop(rid, None)
+                        self.engine.abort(rid)
+                    return bad
+                rid, _ = await self._run(ids_i, p_i, q, i)
+                rids.append(rid)
         n_prompt = len(prompt_ids)
         obj = "chat.completion" if chat else "text_completion"
         toks_of: List[List[int]] = [[] for _ in range(n)]
-        text_of = [""] * n
+        text_of = list(lead_of)
         reason_of: List[Optional[str]] = [None] * n
         lp_of: List[List[Dict[str, Any]]] = [[] for _ in range(n)]
         open_choices = set(range(n))
@@ -193,7 +288,7 @@ class NativeServer:
             toks_of[idx] += toks
             piece = "".join(self.tok.decode_token(t) or " " for t in toks) if stream else ""
             lps = self._logprob_entries(seq, first, toks) if want_lp else []
-            full = text_of[idx] + piece if stream else self.tok.decode(toks_of[idx])
+            full = text_of[idx] + piece if stream else lead_of[idx] + self.tok.decode(toks_of[idx])
             hit = min((full.find(sx) for sx in stops if sx in full), default=-1)
             if hit >= 0:
                 piece = full[len(text_of[idx]) : hit] if stream else ""
@@ -227,7 +322,11 @@ class NativeServer:
             n_out = sum(len(t) for t in toks_of)
             usage = {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
             choices = []
-            for i in range(n):
+            if as_tools:
+                calls = [{"id": "call_" + uuid.uuid4().hex[:24], "type": "function", "function": {"name": sb["name"], "arguments": text_of[i]}} for i, sb in enumerate(subs or [])]
+                cut = any(r == "length" for r in reason_of)
+                choices.append({"index": 0, "message": {"role": "assistant", "content": None, "tool_calls": calls}, "finish_reason": "length" if cut else "tool_calls"})
+            for i in range(0 if as_tools else n):
                 if chat:
                     ch: Dict[str, Any] = {"index": i, "message": {"role": "assistant", "content": text_of[i]}, "finish_reason": reason_of[i]}
                     if want_lp:
@@ -244,9 +343,30 @@ class NativeServer:
             base = {"id": oid, "object": (obj + ".chunk") if chat else obj, "created": created, "model": model}
             finished = False
             try:
-                if chat:
+                if as_tools:
+                    # one choice; every tool call is an entry of delta.tool_calls that the argument pieces are appended to
+                    yield sse_event({**base, "choices": [{"index": 0, "delta": {"role": "assistant", "content": None}, "finish_reason": None}]})
+                    for i, sb in enumerate(subs or []):
+                        call = {"index": i, "id": "call_" + uuid.uuid4().hex[:24], "type": "function", "function": {"name": sb["name"], "arguments": lead_of[i]}}
+                        yield sse_event({**base, "choices": [{"index": 0, "delta": {"tool_calls": [call]}, "finish_reason": None}]})
+                    while open_choices:
+                        idx, toks, done, reason, seq = await q.get()
+                        toks_of[idx] += toks
+                        piece = "".join(self.tok.decode_token(t) for t in toks)
+                        if piece:
+                            yield sse_event({**base, "choices": [{"index": 0, "delta": {"tool_calls": [{"index": idx, "function": {"arguments": piece}}]}, "finish_reason": None}]})
+                        if done:
+                            reason_of[idx] = reason
+                            open_choices.discard(idx)
+                    cut = any(r == "length" for r in reason_of)
+                    yield sse_event({**base, "choices": [{"index": 0, "delta": {}, "finish_reason": "length" if cut else "tool_calls"}]})
+                elif chat:
                     for i in range(n):
                         yield sse_event({**base, "choices": [{"index": i, "delta": {"role": "assistant", "content": ""}, "finish_reason": None}]})
+                for i in range(n):
+                    if lead_of[i] and not as_tools:
+                        ch = {"index": i, "delta": {"content": lead_of[i]}, "finish_reason": None} if chat else {"index": i, "text": lead_of[i], "finish_reason": None}
+                        yield sse_event({**base, "choices": [ch]})
                 while open_choices:
                     idx, toks, done, reason, seq = await q.get()
                     if not stops and not want_lp:
