@@ -19,16 +19,17 @@ int kv_equal_hist(const void* x, long long n, long long row_stride, int n_metric
 int kv_energy_trapz(const double* ts, const double* watts, const int* n, int n_series, int max_samples, double t0, double t1, double* out, hipStream_t stream);
 int kv_add_rmsnorm(const void* x, void* residual, const void* w, void* y, int T, int H, float eps, hipStream_t stream);
 int kv_rope_kv_write(void* qkv, const int* positions, const float* cos_t, const float* sin_t, void* k_cache, void* v_cache, const int* slot_mapping, int T,
-                     int nh, int nkv, int hd, int block_size, hipStream_t stream);
+                     int nh, int nkv, int hd, int block_size, const float* kv_scale, hipStream_t stream);
 int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
-                       const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale, hipStream_t stream);
+                       const int* tok_seq, const int* ctx_lens, void* out, int T, int nh, int nkv, int hd, int block_size, float scale, const float* kv_scale,
+                       hipStream_t stream);
 int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                          const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
-                         int block_size, float scale, hipStream_t stream);
+                         int block_size, float scale, const float* kv_scale, hipStream_t stream);
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              int waves, hipStream_t stream);
+                              int waves, const float* kv_scale, hipStream_t stream);
 int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
 int kv_sample_rows(const void* logits, long long row_stride, int V, const long long* rows, int R, const float* temperature, const int* top_k,
@@ -74,7 +75,7 @@ int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride,
                          hipStream_t stream);
 int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_stride, void* q_out, const int* positions, const float* cos_t, const float* sin_t,
                            void* k_cache, void* v_cache, const int* slot_mapping, int T, int nh, int nkv, int hd, int block_size, const float* row_ss,
-                           int ss_parts, int h_in, float eps, hipStream_t stream);
+                           int ss_parts, int h_in, float eps, const float* kv_scale, hipStream_t stream);
 }
 
 namespace {
@@ -159,6 +160,22 @@ at::Tensor energy_trapz(at::Tensor ts, at::Tensor watts, at::Tensor n, double t0
 }
 
 // ---- engine ops ----------------------------------------------------------------------
+// The paged KV cache is bf16, or — when kv_scale (fp32 [2, nkv]: K scales, then V scales) is
+// given — one e4m3 byte per element holding x / scale.  Returns the scale pointer (null: bf16).
+const float* check_cache(const at::Tensor& k_cache, const at::Tensor& v_cache, const c10::optional<at::Tensor>& kv_scale) {
+  CHECK_DEV(k_cache); CHECK_DEV(v_cache); CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache);
+  TORCH_CHECK(k_cache.dim() == 4 && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  if (!kv_scale.has_value()) {
+    CHECK_BF16(k_cache); CHECK_BF16(v_cache);
+    return nullptr;
+  }
+  const at::Tensor& sc = *kv_scale;
+  TORCH_CHECK(k_cache.element_size() == 1 && v_cache.element_size() == 1, "with kv_scale the cache holds one byte per element (float8_e4m3fn / uint8)");
+  CHECK_DEV(sc); CHECK_CONTIG(sc);
+  TORCH_CHECK(sc.scalar_type() == at::kFloat && sc.numel() == 2 * k_cache.size(1), "kv_scale must be fp32 [2, nkv]");
+  return (const float*)sc.data_ptr();
+}
+
 void add_rmsnorm(at::Tensor x, at::Tensor residual, at::Tensor w, at::Tensor y, double eps) {
   CHECK_DEV(x); CHECK_BF16(x); CHECK_BF16(residual); CHECK_BF16(w); CHECK_BF16(y);
   CHECK_CONTIG(x); CHECK_CONTIG(residual); CHECK_CONTIG(w); CHECK_CONTIG(y);
@@ -168,9 +185,10 @@ void add_rmsnorm(at::Tensor x, at::Tensor residual, at::Tensor w, at::Tensor y, 
 }
 
 void rope_kv_write(at::Tensor qkv, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache, at::Tensor slot_mapping,
-                   int64_t nh, int64_t nkv, int64_t hd) {
-  CHECK_DEV(qkv); CHECK_BF16(qkv); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_I32(positions); CHECK_I32(slot_mapping);
-  CHECK_CONTIG(qkv); CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t); CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping);
+                   int64_t nh, int64_t nkv, int64_t hd, c10::optional<at::Tensor> kv_scale) {
+  CHECK_DEV(qkv); CHECK_BF16(qkv); CHECK_I32(positions); CHECK_I32(slot_mapping);
+  const float* ksc = check_cache(k_cache, v_cache, kv_scale);
+  CHECK_CONTIG(qkv); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t); CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping);
   const int64_t T = qkv.size(0);
   TORCH_CHECK(qkv.dim() == 2 && qkv.size(1) == (nh + 2 * nkv) * hd, "qkv must be [T, (nh + 2 nkv) * hd]");
   TORCH_CHECK(positions.numel() >= T && slot_mapping.numel() >= T, "positions/slot_mapping shorter than T");
@@ -179,14 +197,15 @@ void rope_kv_write(at::Tensor qkv, at::Tensor positions, at::Tensor cos_t, at::T
   TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(1) == nkv && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
   // positions and slots are device data: bounds are guaranteed by the scheduler (positions < max_model_len = rows of cos/sin; slots < blocks * block_size)
   check(kv_rope_kv_write(qkv.data_ptr(), (const int*)positions.data_ptr(), (const float*)cos_t.data_ptr(), (const float*)sin_t.data_ptr(), k_cache.data_ptr(),
-                         v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), cur_stream()),
+                         v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ksc, cur_stream()),
         "kv_rope_kv_write");
 }
 
 void paged_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor out,
-                     double scale) {
-  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
-  CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tok_seq); CHECK_CONTIG(ctx_lens);
+                     double scale, c10::optional<at::Tensor> kv_scale) {
+  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
+  const float* ksc = check_cache(k_cache, v_cache, kv_scale);
+  CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tok_seq); CHECK_CONTIG(ctx_lens);
   TORCH_CHECK(q.dim() == 3 && q.stride(2) == 1 && q.stride(1) == q.size(2), "q must be [T, nh, hd] with contiguous heads (row stride free)");
   const int64_t T = q.size(0), nh = q.size(1), hd = q.size(2);
   TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
@@ -195,14 +214,16 @@ void paged_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::T
   TORCH_CHECK(tok_seq.numel() >= T && ctx_lens.numel() >= T, "tok_seq/ctx_lens shorter than T");
   check(kv_paged_attention(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1),
                            (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(), out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd,
-                           (int)k_cache.size(2), (float)scale, cur_stream()),
+                           (int)k_cache.size(2), (float)scale, ksc, cur_stream()),
         "kv_paged_attention");
 }
 
 // Tiled MFMA attention for prompt chunks; `tiles` is int32 [4, n_tiles]: row0, n, pos0, block-table row
-void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tiles, at::Tensor out, double scale) {
-  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tiles);
-  CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tiles);
+void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tiles, at::Tensor out, double scale,
+                       c10::optional<at::Tensor> kv_scale) {
+  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tiles);
+  const float* ksc = check_cache(k_cache, v_cache, kv_scale);
+  CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tiles);
   TORCH_CHECK(q.dim() == 3 && q.stride(2) == 1 && q.stride(1) == q.size(2) && q.stride(0) % 8 == 0, "q must be [T, nh, hd] with contiguous heads and 16-byte aligned rows");
   const int64_t T = q.size(0), nh = q.size(1), hd = q.size(2);
   TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
@@ -212,7 +233,7 @@ void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at:
   const int* tp = (const int*)tiles.data_ptr();
   check(kv_prefill_attention(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1), tp,
                              tp + n_tiles, tp + 2 * n_tiles, tp + 3 * n_tiles, out.data_ptr(), (int)n_tiles, (int)nh, (int)k_cache.size(1), (int)hd,
-                             (int)k_cache.size(2), (float)scale, cur_stream()),
+                             (int)k_cache.size(2), (float)scale, ksc, cur_stream()),
         "kv_prefill_attention");
 }
 
@@ -221,10 +242,11 @@ const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* 
 // RoPE + KV write + paged attention in one launch (decode-only steps; see engine_kernels.hip)
 void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
                             at::Tensor slot_mapping, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor out, int64_t nh,
-                            c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale, int64_t waves) {
+                            c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale, int64_t waves, c10::optional<at::Tensor> kv_scale) {
   TORCH_CHECK(waves == 4 || waves == 8, "waves per workgroup must be 4 or 8");
   CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_I32(positions); CHECK_I32(slot_mapping); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
-  CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_BF16(out); CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(out); CHECK_CONTIG(block_tables);
+  const float* ksc = check_cache(k_cache, v_cache, kv_scale);
+  CHECK_BF16(out); CHECK_CONTIG(out); CHECK_CONTIG(block_tables);
   CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping); CHECK_CONTIG(tok_seq); CHECK_CONTIG(ctx_lens); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t);
   TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3, "slabs must be fp32 [S, T, W]");
   TORCH_CHECK(cos_t.scalar_type() == at::kFloat && sin_t.scalar_type() == at::kFloat, "cos/sin tables must be fp32");
@@ -241,7 +263,7 @@ void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor c
                                   (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(),
                                   (const int*)block_tables.data_ptr(), (int)block_tables.size(1), (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(),
                                   out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps, (float)scale,
-                                  (int)waves, cur_stream()),
+                                  (int)waves, ksc, cur_stream()),
         "kv_decode_attention_fused");
 }
 
@@ -503,9 +525,11 @@ void add_rmsnorm_slabs(at::Tensor slabs, at::Tensor residual, at::Tensor w, at::
 }
 
 void rope_kv_write_slabs(at::Tensor slabs, at::Tensor q_out, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
-                         at::Tensor slot_mapping, int64_t nh, int64_t nkv, int64_t hd, c10::optional<at::Tensor> row_ss, int64_t h_in, double eps) {
-  CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_BF16(q_out); CHECK_CONTIG(q_out); CHECK_BF16(k_cache); CHECK_BF16(v_cache); CHECK_I32(positions); CHECK_I32(slot_mapping);
-  CHECK_CONTIG(k_cache); CHECK_CONTIG(v_cache); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t); CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping);
+                         at::Tensor slot_mapping, int64_t nh, int64_t nkv, int64_t hd, c10::optional<at::Tensor> row_ss, int64_t h_in, double eps,
+                         c10::optional<at::Tensor> kv_scale) {
+  CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_BF16(q_out); CHECK_CONTIG(q_out); CHECK_I32(positions); CHECK_I32(slot_mapping);
+  const float* ksc = check_cache(k_cache, v_cache, kv_scale);
+  CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t); CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping);
   TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3 && slabs.size(2) == (nh + 2 * nkv) * hd, "slabs must be fp32 [S, T, (nh + 2 nkv) * hd]");
   const int64_t T = slabs.size(1);
   TORCH_CHECK(q_out.numel() == T * nh * hd, "q_out must hold T*nh*hd elements");
@@ -519,7 +543,7 @@ void rope_kv_write_slabs(at::Tensor slabs, at::Tensor q_out, at::Tensor position
   check(kv_rope_kv_write_slabs((const float*)slabs.data_ptr(), (int)slabs.size(0), T * slabs.size(2), q_out.data_ptr(), (const int*)positions.data_ptr(),
                                (const float*)cos_t.data_ptr(), (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
                                (const int*)slot_mapping.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps,
-                               cur_stream()),
+                               ksc, cur_stream()),
         "kv_rope_kv_write_slabs");
 }
 
@@ -611,12 +635,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("equal_hist", &equal_hist);
   m.def("energy_trapz", &energy_trapz);
   m.def("add_rmsnorm", &add_rmsnorm);
-  m.def("rope_kv_write", &rope_kv_write);
-  m.def("paged_attention", &paged_attention);
-  m.def("prefill_attention", &prefill_attention);
+  m.def("rope_kv_write", &rope_kv_write, py::arg("qkv"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"), py::arg("v_cache"),
+        py::arg("slot_mapping"), py::arg("nh"), py::arg("nkv"), py::arg("hd"), py::arg("kv_scale") = py::none());
+  m.def("paged_attention", &paged_attention, py::arg("q"), py::arg("k_cache"), py::arg("v_cache"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"),
+        py::arg("out"), py::arg("scale"), py::arg("kv_scale") = py::none());
+  m.def("prefill_attention", &prefill_attention, py::arg("q"), py::arg("k_cache"), py::arg("v_cache"), py::arg("block_tables"), py::arg("tiles"), py::arg("out"),
+        py::arg("scale"), py::arg("kv_scale") = py::none());
   m.def("decode_attention_fused", &decode_attention_fused, py::arg("slabs"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
         py::arg("v_cache"), py::arg("slot_mapping"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"), py::arg("out"), py::arg("nh"),
-        py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4);
+        py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4, py::arg("kv_scale") = py::none());
   m.def("argmax", &argmax);
   m.def("embed_fed", &embed_fed);
   m.def("swiglu_interleaved", &swiglu_interleaved);
@@ -650,6 +677,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("xgmi_residual_allreduce", &xgmi_residual_allreduce);
   m.def("prefetch", &prefetch);
   m.def("add_rmsnorm_slabs", &add_rmsnorm_slabs);
-  m.def("rope_kv_write_slabs", &rope_kv_write_slabs);
+  m.def("rope_kv_write_slabs", &rope_kv_write_slabs, py::arg("slabs"), py::arg("q_out"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
+        py::arg("v_cache"), py::arg("slot_mapping"), py::arg("nh"), py::arg("nkv"), py::arg("hd"), py::arg("row_ss"), py::arg("h_in"), py::arg("eps"),
+        py::arg("kv_scale") = py::none());
   m.def("residual_reduce", &residual_reduce);
 }

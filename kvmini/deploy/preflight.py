@@ -20,6 +20,18 @@ def run_preflight(backend: Any, quiet: bool = False) -> int:
     if not backend.available():
         print("kubectl not found", file=sys.stderr)
         return 2
+    if not hasattr(backend, "kubectl"):
+        # local / fake backends: no kubectl, no CRDs — report what the backend knows about its GPUs
+        try:
+            facts = backend.cluster_facts()
+        except Exception as e:
+            print(f"ERROR: preflight failed: {e}", file=sys.stderr)
+            return 2
+        say(f"cluster backend: {getattr(backend, 'name', type(backend).__name__)}")
+        gpu_nodes = [n for n in (facts.get("gpu_nodes") or facts.get("nodes") or []) if n]
+        if not gpu_nodes:
+            say("WARNING: the backend reports no GPU node")
+        return 0
     try:
         ctx = subprocess.run([backend.kubectl, "config", "current-context"], capture_output=True, text=True, timeout=10)
         if ctx.returncode != 0:

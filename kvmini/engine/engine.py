@@ -44,6 +44,7 @@ class EngineConfig:
     enable_prefix_caching: bool = True
     weights_path: Optional[str] = None
     quantization: Optional[str] = None  # None | fp8
+    kv_cache_dtype: str = "auto"  # auto | fp8
     # speculative decoding
     draft_model: Optional[str] = None  # preset name, or "self:<K>" = early exit after K layers of the target
     num_speculative_tokens: int = 0
@@ -181,6 +182,7 @@ class LLMEngine:
             use_graphs=ecfg.use_graphs,
             kernels=ecfg.kernels,
             quantization=ecfg.quantization,
+            kv_cache_dtype=ecfg.kv_cache_dtype,
             tp_graphs=ecfg.tp_graphs,
             tp_rccl_graphs=ecfg.tp_rccl_graphs,
             tp_custom_allreduce=ecfg.tp_custom_allreduce,

@@ -47,6 +47,7 @@ class RunnerConfig:
     kernels: str = "auto"  # auto | hip | torch
     return_logits: bool = False
     quantization: Optional[str] = None  # None | fp8 (weight-only, HIP kernels)
+    kv_cache_dtype: str = "auto"  # auto (the model dtype) | fp8 (e4m3 bytes + one scale per kv head, converted in registers by the attention kernels)
     tp_graphs: bool = True  # capture HIP graphs under tensor parallelism (buckets whose all-reduce runs in the peer-memory kernels)
     tp_rccl_graphs: bool = False  # also capture buckets whose all-reduce is RCCL's (every rank must capture in step)
     tp_custom_allreduce: bool = True  # hand-written xGMI peer-memory kernels for the TP all-reduce (HIP ops on GPUs)
@@ -143,6 +144,9 @@ class ModelRunner:
         self.max_blocks_per_seq = (rcfg.max_model_len + rcfg.block_size - 1) // rcfg.block_size
         self.cos, self.sin = rope_tables(cfg, rcfg.max_model_len, self.device)
 
+        if rcfg.kv_cache_dtype not in ("auto", "fp8", "fp8_e4m3"):
+            raise ValueError(f"kv_cache_dtype must be auto or fp8, got {rcfg.kv_cache_dtype!r}")
+        self.kv_fp8 = rcfg.kv_cache_dtype != "auto"
         self.xgmi = None
         if self.tp_active and self.device.type == "cuda" and rcfg.tp_custom_allreduce and hasattr(self.ops, "prepare_weights"):
             from kvmini.parallel.xgmi import XgmiComm
@@ -158,9 +162,13 @@ class ModelRunner:
             nb = torch.tensor([self.num_blocks], dtype=torch.int64, device=self.device if on_dev else "cpu")
             torch.distributed.all_reduce(nb, op=torch.distributed.ReduceOp.MIN, group=tp_group)
             self.num_blocks = int(nb.item())
-        dt = weights.embed.dtype
+        dt = torch.float8_e4m3fn if self.kv_fp8 else weights.embed.dtype
         # [layer, k/v, block, kv_head, slot_in_block, head_dim]
         self.kv_cache = torch.zeros((cfg.num_layers, 2, self.num_blocks, self.nkv, self.block_size, self.hd), dtype=dt, device=self.device)
+        # FP8 cache: stored byte = e4m3(x / scale), one scale per (layer, K or V, kv head).  1.0
+        # unless calibrated (set_kv_scales): K and V of a normalised residual stream stay far
+        # inside e4m3's +-448.
+        self.kv_scale = torch.ones((cfg.num_layers, 2, self.nkv), dtype=torch.float32, device=self.device) if self.kv_fp8 else None
 
         self.buckets = tuple(b for b in DEFAULT_BUCKETS if b < rcfg.max_batched_tokens) + (rcfg.max_batched_tokens,)
         tmax = self.buckets[-1]
@@ -231,13 +239,21 @@ class ModelRunner:
     # ------------------------------------------------------------------
     def _auto_num_blocks(self) -> int:
         cfg, r = self.cfg, self.rcfg
-        per_block = cfg.num_layers * 2 * self.nkv * r.block_size * self.hd * self.w.embed.element_size()
+        per_block = cfg.num_layers * 2 * self.nkv * r.block_size * self.hd * (1 if self.kv_fp8 else self.w.embed.element_size())
         want = r.max_num_seqs * self.max_blocks_per_seq + 64
         if self.device.type == "cuda":
             free, _total = torch.cuda.mem_get_info(self.device)
             by_mem = int(free * r.kv_memory_fraction) // per_block
             return max(64, min(want, by_mem))
         return max(64, min(want, 4096))
+
+    def set_kv_scales(self, scales: torch.Tensor) -> None:
+        """Per-(layer, K / V, kv head) scales of the FP8 cache (``[layers, 2, nkv]``, e.g. the
+        ``k_scale`` / ``v_scale`` of a calibrated checkpoint).  In place: captured graphs read the
+        same buffer.  The cache must be empty (bytes written under other scales would be misread)."""
+        if self.kv_scale is None:
+            raise RuntimeError("the KV cache is not FP8")
+        self.kv_scale.copy_(scales.to(self.kv_scale))
 
     def _dev(self, name: str, n: Optional[int] = None) -> torch.Tensor:
         off, full = self._off[name]
@@ -276,16 +292,17 @@ class ModelRunner:
             h, residual = self._add_rmsnorm(x, residual, lw.attn_norm, pending_reduce)
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
+            kw = {"kv_scale": self.kv_scale[li]} if self.kv_fp8 else {}
             if decode_only and self._fused_ok(qkv, kc):
-                a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale)
+                a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale, **kw)
             elif not decode_only and self._tiled_ok(kc):
                 # decode tokens: one workgroup per token; prompt chunks: 16-query MFMA tiles
-                q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
-                a = ops.paged_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self.scale, max_blocks)
-                ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale)
+                q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
+                a = ops.paged_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self.scale, max_blocks, **kw)
+                ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale, **kw)
             else:
-                q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd)
-                a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks)
+                q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
+                a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks, **kw)
             x = ops.linear(a, lw.wo, allow_slabs=True)
             h, residual = self._add_rmsnorm(x, residual, lw.mlp_norm, True)
             act = ops.linear_swiglu(h, lw.wgu)

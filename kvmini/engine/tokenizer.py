@@ -72,7 +72,7 @@ class SyntheticTokenizer:
         return [i % self.vocab_size for i in ids]
 
     def decode_token(self, tok: int) -> str:
-        if tok < self.n_special:
+        if tok < self.n_special or tok in (self.eos_id, self.bos_id):  # (model configs put BOS / EOS anywhere in the id space)
             return ""
         fixed = self._json_text.get(tok)
         if fixed is not None:

@@ -43,11 +43,12 @@ def _git(*args: str) -> Optional[str]:
         return None
 
 
-def collect_cluster_facts(namespace: str, service: str, backend: Optional[ClusterBackend] = None) -> Dict[str, Any]:
+def collect_cluster_facts(namespace: str, service: str, backend: Optional[ClusterBackend] = None, at: Optional[float] = None) -> Dict[str, Any]:
     """Kubernetes / GPU-node / serving-stack / git facts for provenance (reference
     ``tools/collect_cluster_facts.sh:52-147``, re-keyed to ``amd.com/gpu`` labels)."""
     backend = backend or get_backend()
-    facts: Dict[str, Any] = {"collected_at": dt.datetime.now(dt.timezone.utc).isoformat(), "namespace": namespace, "service": service}
+    when = dt.datetime.now(dt.timezone.utc) if at is None else dt.datetime.fromtimestamp(at, dt.timezone.utc)
+    facts: Dict[str, Any] = {"collected_at": when.isoformat(), "namespace": namespace, "service": service}
     try:
         facts.update(backend.cluster_facts())
     except Exception as e:
@@ -115,7 +116,9 @@ def sign_images(images: List[str], key: str, dry_run: bool = False) -> int:
     return rc
 
 
-def _summary_md(run_id: str, namespace: str, service: str, results: Dict[str, Any], has_fairness: bool) -> str:
+def _summary_md(run_id: str, namespace: str, service: str, results: Dict[str, Any], has_fairness: bool, at: Optional[float] = None) -> str:
+    when = dt.datetime.now(dt.timezone.utc) if at is None else dt.datetime.fromtimestamp(at, dt.timezone.utc)
+
     def g(k: str, fmt: str = "{}") -> str:
         v = results.get(k)
         return "N/A" if v is None else fmt.format(v)
@@ -127,7 +130,7 @@ def _summary_md(run_id: str, namespace: str, service: str, results: Dict[str, An
         f"**Run ID**: {run_id}",
         f"**Service**: {service}",
         f"**Namespace**: {namespace}",
-        f"**Bundled**: {dt.datetime.now(dt.timezone.utc).strftime('%Y-%m-%d %H:%M:%S UTC')}",
+        f"**Bundled**: {when.strftime('%Y-%m-%d %H:%M:%S UTC')}",
         "",
         "## Key Results",
         "",
@@ -196,10 +199,17 @@ def bundle_run(run_dir: str, namespace: str = "default", service: str = "demo-ll
     results = json.loads(files["results.json"]) if "results.json" in files else {}
     meta = json.loads(files["meta.json"]) if "meta.json" in files else {}
 
-    facts = collect_cluster_facts(namespace, service, backend)
+    # Every time stamp inside the archive is the RUN's (end of its measurement window, else the
+    # newest artifact), not the moment of bundling: bundling the same run twice gives the same
+    # bytes (the reference fixes the tar mtimes, tools/bundle_run.sh:333, but stamps `now` into
+    # provenance.json, so its archives never compare equal).
+    w_end = (results.get("window") or {}).get("end")
+    stamp = float(w_end) if isinstance(w_end, (int, float)) else max((os.path.getmtime(run / f) for f in RUN_FILES if (run / f).exists()), default=float(FIXED_MTIME))
+    stamp = float(int(stamp))
+    facts = collect_cluster_facts(namespace, service, backend, at=stamp)
     files["cluster_facts.json"] = json.dumps(facts, indent=2, default=str).encode()
     prov = {
-        "bundle": {"run_id": run_id, "created": dt.datetime.now(dt.timezone.utc).strftime("%Y-%m-%dT%H:%M:%SZ"), "tool_version": (facts.get("git") or {}).get("sha") or "unknown", "schema_version": "1.0"},
+        "bundle": {"run_id": run_id, "created": dt.datetime.fromtimestamp(stamp, dt.timezone.utc).strftime("%Y-%m-%dT%H:%M:%SZ"), "tool_version": (facts.get("git") or {}).get("sha") or "unknown", "schema_version": "1.0"},
         "run": meta,
         "cluster": facts,
         "reproducibility": {
@@ -254,7 +264,7 @@ def bundle_run(run_dir: str, namespace: str = "default", service: str = "demo-ll
         for w_ in generate_sboms(images, str(tmp)):
             files[f"supply-chain/sboms/{Path(w_).name}"] = Path(w_).read_bytes()
         shutil.rmtree(tmp, ignore_errors=True)
-    files["SUMMARY.md"] = _summary_md(run_id, namespace, service, results, "fairness_summary.json" in files).encode()
+    files["SUMMARY.md"] = _summary_md(run_id, namespace, service, results, "fairness_summary.json" in files, at=stamp).encode()
 
     os.makedirs(os.path.dirname(output) or ".", exist_ok=True)
     raw = io.BytesIO()
@@ -264,6 +274,10 @@ def bundle_run(run_dir: str, namespace: str = "default", service: str = "demo-ll
     with open(output, "wb") as fo:
         with gzip.GzipFile(filename="", mode="wb", fileobj=fo, mtime=FIXED_MTIME) as gz:
             gz.write(raw.getvalue())
+    import hashlib
+
+    with open(output, "rb") as fi, open(output + ".sha256", "w") as fs:
+        fs.write(f"{hashlib.sha256(fi.read()).hexdigest()}  {os.path.basename(output)}\n")
     if not quiet:
         print(f"Bundle created: {output} ({os.path.getsize(output) / 1024:.1f} KiB, {len(files)} files)")
     return output

@@ -101,11 +101,15 @@ def pareto_mask(rows: Sequence[Dict[str, Any]], objectives: Sequence[Tuple[str, 
 
 
 class QuantizationSweepRunner:
-    def __init__(self, config: Dict[str, Any], output_dir: str, local: Optional[str] = None, cluster_backend: Optional[str] = None, runs_root: str = "runs", port: int = 8000, cost_file: str = "cost.yaml"):
+    def __init__(self, config: Dict[str, Any], output_dir: str, local: Optional[str] = None, cluster_backend: Optional[str] = None, runs_root: str = "runs", port: int = 8000, cost_file: str = "cost.yaml",
+                 url: Optional[str] = None, resume: bool = False):
         self.config = config
+        self.url = url  # benchmark this endpoint for every configuration instead of the deployed service's own
+        self.resume = resume
         self.output_dir = output_dir
         self.local = local
         self.backend = get_backend("local" if local else cluster_backend)
+        self.cluster_backend = cluster_backend
         self.runs_root = runs_root
         self.port = port
         self.cost_file = cost_file
@@ -136,6 +140,8 @@ class QuantizationSweepRunner:
                 ns.serve_args = ["--max-model-len", str(config.get("max_model_len", 2048))]
                 if config.get("quantization") == "fp8":
                     ns.serve_args += ["--quantization", "fp8"]
+                if str(config.get("kv_cache_dtype", "auto")).startswith("fp8"):
+                    ns.serve_args += ["--kv-cache-dtype", "fp8"]
             info = start_local_server(ns)
             self._local_pid = info["pid"]
             return info["url"]
@@ -185,9 +191,15 @@ class QuantizationSweepRunner:
             cmd += ["--loadtest-args", " ".join(lt)]
         try:
             url = self.deploy(config)
+            url = self.url or url
             if url:
                 cmd += ["--url", url]
-            proc = subprocess.run(cmd, capture_output=True, text=True, timeout=float(self.config.get("bench_timeout_s", 600)))
+            if self.cluster_backend and not self.local:
+                cmd += ["--cluster-backend", self.cluster_backend]
+            # the child must find this package whatever the working directory is
+            pkg_parent = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            env = {**os.environ, "PYTHONPATH": pkg_parent + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else "")}
+            proc = subprocess.run(cmd, capture_output=True, text=True, timeout=float(self.config.get("bench_timeout_s", 600)), env=env)
             if proc.returncode != 0:
                 sys.stderr.write(proc.stderr[-2000:])
                 return self.error_result(config, "benchmark_failed")
@@ -226,11 +238,38 @@ class QuantizationSweepRunner:
                 w.writerow({k: r.get(k, "") for k in self.FLAT_KEYS})
         return path
 
+    def load_rows(self, path: str) -> List[Dict[str, Any]]:
+        """Rows of an intermediate CSV, numbers as numbers, empty cells as None."""
+        rows: List[Dict[str, Any]] = []
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                r: Dict[str, Any] = {}
+                for k, v in row.items():
+                    if v == "":
+                        r[k] = None if k != "error" else ""
+                    else:
+                        try:
+                            r[k] = float(v) if k not in ("config_name", "quantization", "kv_cache_dtype", "run_id", "error") else v
+                        except ValueError:
+                            r[k] = v
+                rows.append(r)
+        return rows
+
     def run_sweep(self) -> List[Dict[str, Any]]:
         configs = self.config["sweep_configurations"]
+        done: Dict[str, Dict[str, Any]] = {}
+        prev = os.path.join(self.output_dir, "sweep_results_intermediate.csv")
+        if self.resume and os.path.exists(prev):
+            # the reference writes this file after every configuration (sweeps/quantization_sweep.py:343-349)
+            # but cannot pick a sweep up from it; here finished (error-free) configurations are kept
+            done = {r["config_name"]: r for r in self.load_rows(prev) if not r.get("error")}
         for i, c in enumerate(configs, 1):
-            print(f"[{i}/{len(configs)}] Testing: {c['name']}")
-            self.results.append(self.run_benchmark(c))
+            if c["name"] in done:
+                print(f"[{i}/{len(configs)}] {c['name']}: resumed from {prev}")
+                self.results.append(done[c["name"]])
+            else:
+                print(f"[{i}/{len(configs)}] Testing: {c['name']}")
+                self.results.append(self.run_benchmark(c))
             self.save_intermediate()
         self.generate_analysis()
         return self.results
@@ -321,6 +360,9 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--runs-root", default="runs")
     ap.add_argument("--cost-file", default="cost.yaml")
     ap.add_argument("--analyze-only", default=None, metavar="CSV", help="rebuild the analysis from an intermediate CSV")
+    ap.add_argument("--url", default=None, help="benchmark this endpoint for every configuration (already deployed / shared service)")
+    ap.add_argument("--resume", action="store_true", help="keep the configurations that <output-dir>/sweep_results_intermediate.csv already holds without an error")
+    ap.add_argument("--no-quality", action="store_true", help="skip the quality mini-eval even if the config enables it")
     a = ap.parse_args(argv)
     if a.create_config:
         with open(a.config, "w") as f:
@@ -330,20 +372,12 @@ def main(argv: Optional[List[str]] = None) -> int:
     if not os.path.exists(a.config):
         print(f"Config file not found: {a.config}\nRun with --create-config to generate default configuration", file=sys.stderr)
         return 1
-    runner = QuantizationSweepRunner(load_yaml(a.config), a.output_dir, a.local, a.cluster_backend, a.runs_root, a.port, a.cost_file)
+    cfg = load_yaml(a.config)
+    if a.no_quality:
+        cfg["quality_eval"] = {"enabled": False}
+    runner = QuantizationSweepRunner(cfg, a.output_dir, a.local, a.cluster_backend, a.runs_root, a.port, a.cost_file, url=a.url, resume=a.resume)
     if a.analyze_only:
-        with open(a.analyze_only) as f:
-            for row in csv.DictReader(f):
-                r: Dict[str, Any] = {}
-                for k, v in row.items():
-                    if v == "":
-                        r[k] = None if k != "error" else ""
-                    else:
-                        try:
-                            r[k] = float(v) if k not in ("config_name", "quantization", "kv_cache_dtype", "run_id", "error") else v
-                        except ValueError:
-                            r[k] = v
-                runner.results.append(r)
+        runner.results += runner.load_rows(a.analyze_only)
         runner.generate_analysis()
     else:
         runner.run_sweep()

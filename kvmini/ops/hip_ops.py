@@ -420,18 +420,20 @@ def rope_kv_write(
     n_heads: int,
     n_kv: int,
     head_dim: int,
+    kv_scale: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """``qkv``: bf16 ``[T, W]`` (q is rotated in place and returned as a strided
     view) or a :class:`Partial` (slabs are summed, row-scaled, and q is written to a
-    new ``[T, nh, hd]``)."""
+    new ``[T, nh, hd]``).  ``kv_scale`` (fp32 ``[2, nkv]``): the cache holds e4m3 bytes of
+    ``x / scale`` (FP8 KV cache); None: a bf16 cache."""
     if isinstance(qkv, Partial):
         t = qkv.slabs.shape[1]
         q = torch.empty((t, n_heads, head_dim), dtype=torch.bfloat16, device=qkv.slabs.device)
-        native().rope_kv_write_slabs(qkv.slabs, q, positions, cos, sin, k_cache, v_cache, slot_mapping, n_heads, n_kv, head_dim, qkv.ss, qkv.h_in, qkv.eps)
+        native().rope_kv_write_slabs(qkv.slabs, q, positions, cos, sin, k_cache, v_cache, slot_mapping, n_heads, n_kv, head_dim, qkv.ss, qkv.h_in, qkv.eps, kv_scale)
         return q
     if not qkv.is_contiguous():
         qkv = qkv.contiguous()
-    native().rope_kv_write(qkv, positions, cos, sin, k_cache, v_cache, slot_mapping, n_heads, n_kv, head_dim)
+    native().rope_kv_write(qkv, positions, cos, sin, k_cache, v_cache, slot_mapping, n_heads, n_kv, head_dim, kv_scale)
     return qkv[:, : n_heads * head_dim].view(qkv.shape[0], n_heads, head_dim)
 
 
@@ -444,6 +446,7 @@ def paged_attention(
     ctx_lens: torch.Tensor,
     scale: float,
     max_blocks: Optional[int] = None,
+    kv_scale: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     t, nh, hd = q.shape
     if hd not in (64, 128) or k_cache.shape[2] != 16 or nh // k_cache.shape[1] not in GQA_RATIOS:
@@ -453,9 +456,9 @@ def paged_attention(
         _warn_once(f"paged attention: head_dim {hd}, block {k_cache.shape[2]}, {nh // k_cache.shape[1]} query heads per kv head is outside the HIP kernels' "
                    f"specialisation (head_dim 64 / 128, block 16, ratios {GQA_RATIOS}): using the PyTorch reference path, which is far slower")
 
-        return torch_ops.paged_attention(q, k_cache, v_cache, block_tables, tok_seq, ctx_lens, scale, max_blocks)
+        return torch_ops.paged_attention(q, k_cache, v_cache, block_tables, tok_seq, ctx_lens, scale, max_blocks, kv_scale)
     out = torch.empty((t, nh * hd), dtype=q.dtype, device=q.device)
-    native().paged_attention(q, k_cache, v_cache, block_tables, tok_seq, ctx_lens, out, scale)
+    native().paged_attention(q, k_cache, v_cache, block_tables, tok_seq, ctx_lens, out, scale, kv_scale)
     return out
 
 
@@ -493,6 +496,7 @@ def rope_attention_fused(
     ctx_lens: torch.Tensor,
     n_heads: int,
     scale: float,
+    kv_scale: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """RoPE + paged-KV write + attention for a step in which every token is the only new
     token of its sequence (plain decoding).  ``qkv`` must be the split-K slabs of the QKV
@@ -500,7 +504,7 @@ def rope_attention_fused(
     t = qkv.slabs.shape[1]
     hd = k_cache.shape[3]
     out = torch.empty((t, n_heads * hd), dtype=torch.bfloat16, device=qkv.slabs.device)
-    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale, _decode_attention_waves(t, k_cache.shape[1]))
+    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale, _decode_attention_waves(t, k_cache.shape[1]), kv_scale)
     return out
 
 
@@ -509,12 +513,13 @@ def supports_prefill_attention(n_heads: int, k_cache: torch.Tensor) -> bool:
     return hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in GQA_RATIOS
 
 
-def prefill_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor, tiles: torch.Tensor, out: torch.Tensor, scale: float) -> torch.Tensor:
+def prefill_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor, tiles: torch.Tensor, out: torch.Tensor, scale: float,
+                      kv_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Tiled MFMA causal attention for prompt chunks, written into ``out`` ``[T, nh*hd]``
     in place (rows not covered by a tile keep their content).  ``tiles``: int32
     ``[4, n_tiles]`` = first token row, valid queries (0 = unused), first position,
     block-table row of each 16-query tile; K/V of the chunk must be in the cache already."""
-    native().prefill_attention(q, k_cache, v_cache, block_tables, tiles, out, scale)
+    native().prefill_attention(q, k_cache, v_cache, block_tables, tiles, out, scale, kv_scale)
     return out
 
 

@@ -15,7 +15,7 @@ against these in fp32) and the execution path on CPU.  Shapes:
 
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -66,9 +66,11 @@ def rope_kv_write(
     n_heads: int,
     n_kv: int,
     head_dim: int,
+    kv_scale: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Split fused qkv ``[T, (nh + 2 nkv) * hd]``, rotate q and k (rotate-half
-    pairing), scatter k/v into the paged cache, return rotated q ``[T, nh, hd]``."""
+    pairing), scatter k/v into the paged cache, return rotated q ``[T, nh, hd]``.
+    ``kv_scale`` (fp32 ``[2, nkv]``): FP8 cache — e4m3 of ``x / scale``, clamped to +-448."""
     t = qkv.shape[0]
     q, k, v = qkv.split((n_heads * head_dim, n_kv * head_dim, n_kv * head_dim), dim=-1)
     q = q.view(t, n_heads, head_dim)
@@ -90,6 +92,11 @@ def rope_kv_write(
     slots = slot_mapping.clamp_min(0)
     blk = slots // block_size
     off = slots % block_size
+    if kv_scale is not None:
+        # float8 tensors have no indexed assignment on every backend: move the bytes
+        k = (k.float() / kv_scale[0][None, :, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        v = (v.float() / kv_scale[1][None, :, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        k_cache, v_cache = k_cache.view(torch.uint8), v_cache.view(torch.uint8)
     if bool(valid.all()):
         k_cache[blk, :, off] = k
         v_cache[blk, :, off] = v
@@ -108,6 +115,7 @@ def paged_attention(
     ctx_lens: torch.Tensor,
     scale: float,
     max_blocks: int | None = None,
+    kv_scale: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Attention of every token over its sequence's cached K/V (GQA aware).
     Returns ``[T, n_heads * head_dim]``; padding tokens (ctx_len 0) give zeros."""
@@ -118,8 +126,12 @@ def paged_attention(
     if max_blocks is not None:
         bt = bt[:, :max_blocks]
     mb = bt.shape[1]
-    k = k_cache[bt.long()].permute(0, 2, 1, 3, 4).reshape(t, nkv, mb * bs, hd).float()
-    v = v_cache[bt.long()].permute(0, 2, 1, 3, 4).reshape(t, nkv, mb * bs, hd).float()
+    if kv_scale is not None:
+        k = k_cache.view(torch.uint8)[bt.long()].view(torch.float8_e4m3fn).permute(0, 2, 1, 3, 4).reshape(t, nkv, mb * bs, hd).float() * kv_scale[0][None, :, None, None]
+        v = v_cache.view(torch.uint8)[bt.long()].view(torch.float8_e4m3fn).permute(0, 2, 1, 3, 4).reshape(t, nkv, mb * bs, hd).float() * kv_scale[1][None, :, None, None]
+    else:
+        k = k_cache[bt.long()].permute(0, 2, 1, 3, 4).reshape(t, nkv, mb * bs, hd).float()
+        v = v_cache[bt.long()].permute(0, 2, 1, 3, 4).reshape(t, nkv, mb * bs, hd).float()
     qf = q.view(t, nkv, rep, hd).float()
     scores = torch.einsum("tgrd,tgsd->tgrs", qf, k) * scale
     mask = torch.arange(mb * bs, device=q.device)[None, :] < ctx_lens[:, None]

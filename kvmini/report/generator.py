@@ -414,6 +414,13 @@ def generate_grid_report(csv_path: str, output: str) -> str:
             return sum(xs) / len(xs) if xs else None
 
         parts.append("<h2>By traffic pattern</h2>" + svg_bar_chart(patterns, {"mean p95 (ms)": [avg(p, "p95_ms") for p in patterns]}, "Mean p95 by pattern") + svg_bar_chart(patterns, {"mean RPS": [avg(p, "throughput_rps") for p in patterns]}, "Mean RPS by pattern"))
+    if rows:
+        cols = ["concurrency", "max_tokens", "pattern", "p50_ms", "p95_ms", "p99_ms", "throughput_rps", "tokens_per_sec", "error_rate", "ttft_p95_ms", "cost_per_1k_tokens"]
+        body = "".join(
+            "<tr>" + "".join(f"<td>{html.escape(str(r.get(c, '')))}</td>" if c in ("concurrency", "max_tokens", "pattern") else f"<td>{format_number(_f(r.get(c)), 4)}</td>" for c in cols)
+            + f"<td><a href='{html.escape(r.get('run_dir', ''))}/results.json'>{html.escape(r.get('run_dir', ''))}</a></td></tr>"
+            for r in sorted(rows, key=lambda r: _f(r["p95_ms"]) or 1e18))
+        parts.append("<h2>All cells (by p95)</h2><table><tr>" + "".join(f"<th>{c}</th>" for c in cols) + "<th>run</th></tr>" + body + "</table>")
     parts.append("<p class='muted'>Generated by kvmini.</p></body></html>")
     os.makedirs(os.path.dirname(os.path.abspath(output)), exist_ok=True)
     with open(output, "w") as f:

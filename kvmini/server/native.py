@@ -584,6 +584,7 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--kernels", default="auto", choices=["auto", "hip", "torch"])
     ap.add_argument("--no-prefix-caching", action="store_true")
     ap.add_argument("--quantization", default=None, choices=[None, "fp8"])
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8", "fp8_e4m3"], help="fp8: e4m3 KV cache (half the bytes per token, twice the blocks), converted in registers by the attention kernels")
     ap.add_argument("--speculative-model", default=None, help="draft model preset for speculative decoding, or self:<K> (early exit after K layers of the served model)")
     ap.add_argument("--tail-damping", type=float, default=0.0, help="random-init + self:<K> only: damp layers >= K so the early-exit draft agrees with the full model (synthetic)")
     ap.add_argument("--num-speculative-tokens", type=int, default=0)
@@ -616,6 +617,7 @@ def engine_config_from_args(a: argparse.Namespace) -> EngineConfig:
         enable_prefix_caching=not a.no_prefix_caching,
         weights_path=a.weights,
         quantization=a.quantization,
+        kv_cache_dtype=a.kv_cache_dtype,
         draft_model=a.speculative_model,
         tail_damping=a.tail_damping,
         num_speculative_tokens=a.num_speculative_tokens,

@@ -38,3 +38,17 @@ def mock_server():
     mock, url, stop = start_mock_in_thread(MockConfig(ttft_ms=3.0, tpot_ms=0.2, jitter=0.05))
     yield mock, url
     stop()
+
+
+@pytest.fixture()
+def in_tmp(tmp_path, monkeypatch):
+    """Run inside a scratch dir that has the repo's cost/slo files, with an empty local registry."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("cost.yaml", "slo.json"):
+        (tmp_path / name).write_text(open(os.path.join(root, name)).read())
+    os.symlink(os.path.join(root, "runners"), tmp_path / "runners")
+    os.symlink(os.path.join(root, "profiles"), tmp_path / "profiles")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("KVMINI_LOCAL_REGISTRY", str(tmp_path / "registry.json"))
+    monkeypatch.setenv("KVMINI_CLUSTER_BACKEND", "fake")
+    return tmp_path

@@ -102,8 +102,7 @@ def test_engine_guided_generation_is_valid_json_greedy_and_sampled(async_schedul
     json.loads(tok.decode(seqs[1].output_ids))
 
 
-def test_native_server_json_mode_schema_tools_and_parity_matrix(tmp_path, monkeypatch):
-    monkeypatch.chdir(tmp_path)
+def test_native_server_json_mode_schema_tools_and_parity_matrix(in_tmp):
     import httpx
 
     from kvmini.harness import parity_probe
