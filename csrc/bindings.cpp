@@ -29,7 +29,7 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              int waves, const float* kv_scale, hipStream_t stream);
+                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, hipStream_t stream);
 int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
 int kv_sample_rows(const void* logits, long long row_stride, int V, const long long* rows, int R, const float* temperature, const int* top_k,
@@ -242,7 +242,8 @@ const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* 
 // RoPE + KV write + paged attention in one launch (decode-only steps; see engine_kernels.hip)
 void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
                             at::Tensor slot_mapping, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor out, int64_t nh,
-                            c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale, int64_t waves, c10::optional<at::Tensor> kv_scale) {
+                            c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale, int64_t waves, c10::optional<at::Tensor> kv_scale,
+                            int64_t n_split, c10::optional<at::Tensor> split_ws) {
   TORCH_CHECK(waves == 4 || waves == 8, "waves per workgroup must be 4 or 8");
   CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_I32(positions); CHECK_I32(slot_mapping); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
   const float* ksc = check_cache(k_cache, v_cache, kv_scale);
@@ -259,11 +260,28 @@ void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor c
   TORCH_CHECK(block_tables.dim() == 2 && out.dim() == 2 && out.size(0) == T && out.size(1) == nh * hd, "bad block_tables/out shape");
   int parts = 0;
   const float* ssp = ss_ptr(row_ss, T, &parts);
+  // split-KV workspace, one fp32 tensor: 4096 int32 arrival counters first (zero at rest: the kernel resets
+  // them; at a fixed place whatever T is), then (max, sum) pairs [T, nkv, n_split, rep, 2], then partial
+  // outputs [T, nkv, n_split, rep*hd]
+  float *part_o = nullptr, *part_ml = nullptr;
+  int* counters = nullptr;
+  TORCH_CHECK(n_split >= 1 && n_split <= 64, "n_split must be in [1, 64]");
+  if (n_split > 1) {
+    TORCH_CHECK(split_ws.has_value(), "split_ws is required with n_split > 1");
+    const at::Tensor& ws = *split_ws;
+    CHECK_DEV(ws); CHECK_CONTIG(ws);
+    const int64_t rep = nh / nkv, n_o = T * nkv * n_split * rep * hd, n_ml = T * nkv * n_split * rep * 2;
+    TORCH_CHECK(T * nkv <= 4096, "split-KV decode attention: at most 4096 (token, kv head) pairs");
+    TORCH_CHECK(ws.scalar_type() == at::kFloat && ws.numel() >= 4096 + n_o + n_ml, "split_ws too small");
+    counters = (int*)ws.data_ptr();
+    part_ml = (float*)ws.data_ptr() + 4096;
+    part_o = part_ml + n_ml;
+  }
   check(kv_decode_attention_fused((const float*)slabs.data_ptr(), (int)slabs.size(0), T * W, (const int*)positions.data_ptr(), (const float*)cos_t.data_ptr(),
                                   (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(),
                                   (const int*)block_tables.data_ptr(), (int)block_tables.size(1), (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(),
                                   out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps, (float)scale,
-                                  (int)waves, ksc, cur_stream()),
+                                  (int)waves, ksc, (int)n_split, part_o, part_ml, counters, cur_stream()),
         "kv_decode_attention_fused");
 }
 
@@ -643,7 +661,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("scale"), py::arg("kv_scale") = py::none());
   m.def("decode_attention_fused", &decode_attention_fused, py::arg("slabs"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
         py::arg("v_cache"), py::arg("slot_mapping"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"), py::arg("out"), py::arg("nh"),
-        py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4, py::arg("kv_scale") = py::none());
+        py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4, py::arg("kv_scale") = py::none(), py::arg("n_split") = 1,
+        py::arg("split_ws") = py::none());
   m.def("argmax", &argmax);
   m.def("embed_fed", &embed_fed);
   m.def("swiglu_interleaved", &swiglu_interleaved);

@@ -886,7 +886,16 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
 // KV8: the token's own key / value take part in the attention as they will be read back from
 // the cache by later steps (rounded to e4m3, in stored units), so this kernel and the two-kernel
 // path agree.
-template <int REP, int NWAVE, bool KV8>
+//
+// SPLIT (long contexts on small grids): gridDim.z workgroups share one (token, kv head); each walks
+// a contiguous range of the sequence's KV blocks (at least SPLIT_MIN_BLOCKS each: short contexts
+// use fewer workgroups, the rest exit at once), leaves its partial (max, sum, unnormalised output)
+// in a workspace, and the last one to arrive merges them — a 128k-token sequence decoded alone is
+// then streamed by up to 32 x nkv workgroups instead of nkv.  Every workgroup repeats phase A
+// (a few KB of slabs); only split 0 writes the cache and folds in the token's own key / value.
+constexpr int SPLIT_MIN_BLOCKS = 16;
+
+template <int REP, int NWAVE, bool KV8, bool SPLIT>
 __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                                      const int* __restrict__ positions, const float* __restrict__ cos_t,
                                                                      const float* __restrict__ sin_t, void* __restrict__ k_cache,
@@ -895,7 +904,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
                                                                      const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
                                                                      unsigned short* __restrict__ out, int nh, int nkv,
                                                                      const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
-                                                                     float scale_log2e, const float* __restrict__ kv_scale) {
+                                                                     float scale_log2e, const float* __restrict__ kv_scale,
+                                                                     float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ counters) {
   constexpr int HD = 128, BS = 16, HALF = 64, NT = 64 * NWAVE;
   float inv_ks = 1.f, inv_vs = 1.f, v_scale = 1.f;
   if constexpr (KV8) {
@@ -912,25 +922,43 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   __shared__ float p_lds[NWAVE][REP][BS];
   __shared__ float m_lds[NWAVE][REP], l_lds[NWAVE][REP];
   __shared__ float o_lds[NWAVE][4][REP][HD];  // [wave][token group]: partial outputs, summed in the merge
-  const int t = blockIdx.x, g = blockIdx.y;
+  // SPLIT: grid = (splits, kv heads, tokens) — consecutive workgroup ids (which the dispatcher
+  // deals round-robin to the 8 XCDs) are the splits of one pair, so that a lone long sequence
+  // is streamed by every XCD; with the token index fastest, a 16-row step whose only live row
+  // is row 0 would put all its workgroups on one XCD.
+  const int t = SPLIT ? blockIdx.z : blockIdx.x, g = blockIdx.y;
+  const int n_z = SPLIT ? (int)gridDim.x : 1;
   // wave index in a scalar register: block-table reads become scalar loads (see paged_attention_kernel)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ctx = ctx_lens[t];
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
+  // the split index is rotated by the pair index: when short contexts leave only split 0 at work,
+  // the working workgroups of consecutive pairs still sit on different XCDs
+  const int z = SPLIT ? (int)((blockIdx.x + (unsigned)(t * nkv + g)) % (unsigned)n_z) : 0;
   if (ctx <= 0) {  // padding token: no KV write (slot -1), zero output
-    for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
+    if (z == 0)
+      for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
     return;
   }
   // The keys / values of earlier positions do not depend on phase A: each wave loads its
   // first KV block now, so that round trip overlaps the slab loads and the RoPE phase.
   const int prev = ctx - 1;
   const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
-  const int n_blocks = (prev + BS - 1) / BS;
+  const int all_blocks = (prev + BS - 1) / BS;
+  int eff = 1, b0 = 0, n_blocks = all_blocks;  // this workgroup walks blocks [b0, n_blocks)
+  if constexpr (SPLIT) {
+    eff = (all_blocks + SPLIT_MIN_BLOCKS - 1) / SPLIT_MIN_BLOCKS;
+    eff = eff < 1 ? 1 : (eff > n_z ? n_z : eff);
+    if (z >= eff) return;
+    const int per = (all_blocks + eff - 1) / eff;
+    b0 = z * per;
+    n_blocks = b0 + per < all_blocks ? b0 + per : all_blocks;
+  }
   const int qk_tok = lane >> 2, qk_c = lane & 3;
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
   bf16x8 kv[4], vv[4];
-  if (wave < n_blocks) {
-    const long long base = ((long long)bt[wave] * nkv + g) * BS * HD;
+  if (b0 + wave < n_blocks) {
+    const long long base = ((long long)bt[b0 + wave] * nkv + g) * BS * HD;
     const long long kp = base + qk_tok * HD + qk_c * 32;
 #pragma unroll
     for (int v = 0; v < 4; ++v) kv[v] = kv_load8<KV8>(k_cache, kp + v * 8);
@@ -939,8 +967,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     for (int i = 0; i < 4; ++i) vv[i] = kv_load8<KV8>(v_cache, vp + (pv_tg + 4 * i) * HD);
   }
   bf16x8 kn[4], vn[4];  // the block after that: two blocks (16 KB) per wave in flight at any time
-  if (wave + NWAVE < n_blocks) {
-    const long long base = ((long long)bt[wave + NWAVE] * nkv + g) * BS * HD;
+  if (b0 + wave + NWAVE < n_blocks) {
+    const long long base = ((long long)bt[b0 + wave + NWAVE] * nkv + g) * BS * HD;
     const long long kp = base + qk_tok * HD + qk_c * 32;
 #pragma unroll
     for (int v = 0; v < 4; ++v) kn[v] = kv_load8<KV8>(k_cache, kp + v * 8);
@@ -991,7 +1019,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   __syncthreads();
   // ---- phase A.2: RoPE on q and k (pairs d, d + 64), cache write of k and v
   {
-    const long long cache_row = slot >= 0 ? (((long long)(slot / BS) * nkv + g) * BS + slot % BS) * HD : -1;
+    const long long cache_row = (slot >= 0 && z == 0) ? (((long long)(slot / BS) * nkv + g) * BS + slot % BS) * HD : -1;
     static_assert(ROT + 16 <= 256, "one task per thread");
     {
       const int task = tid;
@@ -1046,7 +1074,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
   }
-  for (int b = wave; b < n_blocks; b += NWAVE) {
+  for (int b = b0 + wave; b < n_blocks; b += NWAVE) {
     // this block's K / V and the next one's are in registers or on their way (loaded before
     // phase A, or by earlier iterations); start the loads of the block after those
     bf16x8 kf[4], vf[4];
@@ -1110,8 +1138,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
 #pragma unroll
     for (int v = 0; v < 4; ++v) { kv[v] = kn[v]; vv[v] = vn[v]; kn[v] = kf[v]; vn[v] = vf[v]; }
   }
-  // ---- the token's own key / value (wave 0; one token group adds the value)
-  if (wave == 0) {
+  // ---- the token's own key / value (wave 0 of split 0; one token group adds the value)
+  if (wave == 0 && z == 0) {
     bf16x2 kp2[16];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -1148,6 +1176,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     for (int h = 0; h < REP; ++h) { m_lds[wave][h] = m_run[h]; l_lds[wave][h] = l_run[h]; }
   }
   __syncthreads();
+  const bool direct = !SPLIT || eff == 1;
+  const long long pbase = SPLIT ? ((long long)(t * nkv + g) * n_z) : 0;  // this (token, kv head)'s first partial
   for (int i = tid; i < REP * HD; i += NT) {
     const int h = i / HD, d = i % HD;
     float m = m_lds[0][h];
@@ -1160,7 +1190,60 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       num += (o_lds[w][0][h][d] + o_lds[w][1][h][d] + o_lds[w][2][h][d] + o_lds[w][3][h][d]) * c;
       den += l_lds[w][h] * c;
     }
-    orow[i] = f2bf(den > 0.f ? num / den * v_scale : 0.f);
+    if (direct) {
+      orow[i] = f2bf(den > 0.f ? num / den * v_scale : 0.f);
+    } else {
+      // partials cross XCDs (each has its own L2): the device-scope release fence below writes
+      // them back before the arrival is counted, the merging workgroup's acquire fence drops
+      // its stale lines
+      part_o[(pbase + z) * (REP * HD) + i] = num;
+      if (d == 0) {
+        part_ml[((pbase + z) * REP + h) * 2] = m;
+        part_ml[((pbase + z) * REP + h) * 2 + 1] = den;
+      }
+    }
+  }
+  if constexpr (SPLIT) {
+    if (direct) return;
+    __shared__ int is_last;
+    __threadfence();  // this workgroup's partial is out before its arrival is counted
+    __syncthreads();
+    if (tid == 0) {
+      const int arrived = __hip_atomic_fetch_add(counters + t * nkv + g, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = arrived == eff - 1;
+      if (is_last) __hip_atomic_store(counters + t * nkv + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();  // acquire: the other workgroups' partials, released before their arrival, are visible now
+    __shared__ float w_lds[REP][64];  // per head: weight of every split, 1 / total
+    for (int k = tid; k < REP * 64; k += NT) {  // one wave per head (NT is a multiple of 64: h is uniform in a wave)
+      const int h = k >> 6, s2 = k & 63;
+      float m = -1e30f, den = 0.f;
+      if (s2 < eff) {
+        m = part_ml[((pbase + s2) * REP + h) * 2];
+        den = part_ml[((pbase + s2) * REP + h) * 2 + 1];
+      }
+      float mx = m;
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float c = s2 < eff ? __builtin_amdgcn_exp2f(m - mx) : 0.f;
+      float tot = den * c;
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+      w_lds[h][s2] = tot > 0.f ? c / tot : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < REP * HD; i += NT) {
+      const int h = i / HD;
+      const float* po = part_o + pbase * (REP * HD) + i;
+      float num = 0.f;
+      int s2 = 0;
+      for (; s2 + 4 <= eff; s2 += 4) {
+        const float a0 = po[(long long)(s2 + 0) * (REP * HD)], a1 = po[(long long)(s2 + 1) * (REP * HD)], a2 = po[(long long)(s2 + 2) * (REP * HD)], a3 = po[(long long)(s2 + 3) * (REP * HD)];
+        num += a0 * w_lds[h][s2] + a1 * w_lds[h][s2 + 1] + a2 * w_lds[h][s2 + 2] + a3 * w_lds[h][s2 + 3];
+      }
+      for (; s2 < eff; ++s2) num += po[(long long)s2 * (REP * HD)] * w_lds[h][s2];
+      orow[i] = f2bf(num * v_scale);
+    }
   }
 }
 
@@ -1450,18 +1533,26 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              int waves, const float* kv_scale, hipStream_t stream) {
+                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1 || n_slabs > 16 || (waves != 4 && waves != 8)) return -1;
+  if (n_split < 1 || n_split > 64 || (n_split > 1 && (!part_o || !part_ml || !counters))) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
   const float inv_h = h_in > 0 ? 1.f / (float)h_in : 0.f;
   if (rep > 4) waves = 4;  // 8 waves of the wider head groups do not fit the 256 registers per lane that 2 waves per SIMD leave
   dim3 grid(T, nkv), block(64 * waves);
-#define KV_LAUNCH_K(R, W, K8)                                                                                                                   \
-  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t, k_cache, \
-                     v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, row_ss, ss_parts,    \
-                     inv_h, eps, sl, kv_scale)
+  if (n_split > 1) grid = dim3(n_split, nkv, T);  // splits fastest: see the kernel
+#define KV_LAUNCH_S(R, W, K8, SP)                                                                                                                        \
+  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8, SP>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t, k_cache, \
+                     v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, row_ss, ss_parts,        \
+                     inv_h, eps, sl, kv_scale, part_o, part_ml, counters)
+#define KV_LAUNCH_K(R, W, K8)       \
+  if (n_split > 1) {                \
+    KV_LAUNCH_S(R, W, K8, true);    \
+  } else {                          \
+    KV_LAUNCH_S(R, W, K8, false);   \
+  }
 #define KV_LAUNCH_W(R, W)       \
   if (kv_scale) {               \
     KV_LAUNCH_K(R, W, true);    \
@@ -1487,6 +1578,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
 #undef KV_LAUNCH
 #undef KV_LAUNCH_W
 #undef KV_LAUNCH_K
+#undef KV_LAUNCH_S
   return (int)hipGetLastError();
 }
 

@@ -210,8 +210,8 @@ class LLMEngine:
         self.warm_s = 0.0
         self._pending: Optional[Tuple[Batch, Any]] = None  # (batch, runner handle) of the step in flight
         self.pipelined_steps = 0
-        self._step_dur: Dict[Tuple[int, bool], float] = {}  # measured device time of a step, by runner key
-        self._probe_ctr: Dict[Tuple[int, bool], int] = {}
+        self._step_dur: Dict[Tuple[int, int], float] = {}  # measured device time of a step, by runner key
+        self._probe_ctr: Dict[Tuple[int, int], int] = {}
         self._launch_cost = 0.0  # host seconds from the end of the hold to the enqueued step (moving average)
         self._late_penalty = 0.0
         self._t_collect = 0.0  # when the previous step's ids arrived = when the step in flight started

@@ -92,7 +92,7 @@ class StepHandle:
     n_samples: int
     logits: Optional[torch.Tensor]
     stage: _Stage
-    key: Tuple[int, bool] = (0, False)  # (token bucket, decode-only): steps of one key take alike
+    key: Tuple[int, int] = (0, 0)  # (token bucket, step kind): steps of one key take alike
     timed: bool = False  # launched at once on top of a step in flight: its wall time is its device time
 
 
@@ -210,7 +210,9 @@ class ModelRunner:
         self.spec_width = 1  # positions sampled per sequence per step (k+1 with speculation)
         self.s_cap = tmax
         self.set_spec_width(1)
-        self.graphs: Dict[Tuple[int, bool], Any] = {}  # (token bucket, decode-only variant) -> (graph, logits)
+        # (token bucket, step kind) -> (graph, logits); kind 0 = mixed step, 1 = decode-only (fused
+        # RoPE + attention kernel), 2 = decode-only with the context split over several workgroups
+        self.graphs: Dict[Tuple[int, int], Any] = {}
         self._graph_pool = None
         self.steps = 0
         # tensor parallelism: the scheduling rank publishes every step's staged image to the
@@ -271,10 +273,20 @@ class ModelRunner:
         raise ValueError(f"{t} tokens exceed max_batched_tokens={self.buckets[-1]}")
 
     # ------------------------------------------------------------------
-    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: bool = False) -> torch.Tensor:
+    # contexts from this many tokens on take the split-KV variant of a decode-only step (when the
+    # step's shape has one: few rows); below it the extra workgroups only cost launch time
+    SPLIT_KV_MIN_CTX = 2048
+
+    def step_kind(self, t_pad: int, decode_only: bool, max_ctx: int) -> int:
+        if not decode_only:
+            return 0
+        splits = getattr(self.ops, "decode_attention_splits", None)
+        return 2 if splits is not None and max_ctx >= self.SPLIT_KV_MIN_CTX and splits(t_pad, self.nkv) > 1 else 1
+
+    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: int = 0) -> torch.Tensor:
         """The ragged forward pass over the first ``t_pad`` staged tokens; writes
         sampled ids into ``out_ids[:t_pad]`` and returns the logits ``[t_pad, V]``.
-        ``decode_only``: every staged token is the only new token of its sequence, which
+        ``decode_only`` (a step kind, see ``self.graphs``): every staged token is the only new token of its sequence, which
         allows RoPE + KV write + attention to run as one kernel."""
         ops, cfg, w = self.ops, self.cfg, self.w
         tokens = self._dev("tokens", t_pad)
@@ -294,7 +306,7 @@ class ModelRunner:
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             kw = {"kv_scale": self.kv_scale[li]} if self.kv_fp8 else {}
             if decode_only and self._fused_ok(qkv, kc):
-                a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale, **kw)
+                a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale, n_split=None if decode_only == 2 else 1, **kw)
             elif not decode_only and self._tiled_ok(kc):
                 # decode tokens: one workgroup per token; prompt chunks: 16-query MFMA tiles
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
@@ -387,9 +399,12 @@ class ModelRunner:
         torch.cuda.synchronize(self.device)
 
     def _capture_all(self, buckets: Optional[Sequence[int]]) -> None:
-        variants = [(b, False) for b in sorted(buckets or self.buckets, reverse=True)]
+        variants = [(b, 0) for b in sorted(buckets or self.buckets, reverse=True)]
         # decode-sized buckets also get the decode-only variant (fused RoPE + attention kernel)
-        variants += [(b, True) for b, _ in variants if b <= self.rcfg.max_num_seqs and b <= 64 and hasattr(self.ops, "rope_attention_fused")]
+        # (up to the bucket that holds max_num_seqs one-token rows: with 2 sequences that is still the 16-row bucket)
+        dec_max = self.bucket_for(min(self.rcfg.max_num_seqs, self.tmax))
+        variants += [(b, 1) for b, _ in variants if b <= dec_max and b <= 64 and hasattr(self.ops, "rope_attention_fused")]
+        variants += [(b, 2) for b, k in variants if k == 1 and self.step_kind(b, True, self.rcfg.max_model_len) == 2]
         for b, dec in variants:
             key = (b, dec)
             if key in self.graphs:
@@ -413,8 +428,8 @@ class ModelRunner:
                 self._graph_pool = g.pool()
             self.graphs[key] = (g, logits)
 
-    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: bool = False) -> torch.Tensor:
-        entry = self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, False))
+    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: int = 0) -> torch.Tensor:
+        entry = self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, 0))
         if entry is not None:
             g, logits = entry
             g.replay()
@@ -448,7 +463,7 @@ class ModelRunner:
             if cmd == 1:
                 return n
             self.stage_dev.copy_(sb.cpu, non_blocking=True)
-            self._run_staged(t_pad, max_ctx, bool(dec))
+            self._run_staged(t_pad, max_ctx, dec)
             if self.device.type == "cuda":
                 if sb.event is None:
                     sb.event = torch.cuda.Event()
@@ -580,9 +595,9 @@ class ModelRunner:
         st[o_tl + mt + n_tiles : o_tl + 2 * mt] = 0  # unused tiles: zero valid queries
 
         # plain decoding step: every chunk is one token (no prompt chunk, no drafts to verify)
-        decode_only = all(ch.n_tokens == 1 for ch in batch.chunks)
+        decode_only = self.step_kind(t_pad, all(ch.n_tokens == 1 for ch in batch.chunks), max_ctx)
         o_h = self._off["header"][0]
-        st[o_h : o_h + 5] = (t_pad, n_samples, max_ctx, 0, int(decode_only))
+        st[o_h : o_h + 5] = (t_pad, n_samples, max_ctx, 0, decode_only)
         if self.channel is not None:
             # every rank runs the same step: hand the staged image to the followers first (host
             # shared memory, see follow()), so that they enqueue it while this rank does

@@ -25,7 +25,7 @@ from __future__ import annotations
 import functools
 import os
 
-from typing import Any, Optional, Tuple, Union
+from typing import Any, Dict, Optional, Tuple, Union
 
 import torch
 import torch.nn.functional as F
@@ -483,6 +483,44 @@ def _decode_attention_waves(tokens: int, n_kv_heads: int) -> int:
     return 8 if tokens * n_kv_heads <= _NUM_CUS else 4
 
 
+# Split-KV decode attention: with few (token, kv head) pairs in a step the grid cannot fill the
+# chip and a long context is streamed by a handful of workgroups (a 128k-token sequence decoded
+# alone: 8 workgroups, 0.28 TB/s).  Such steps run several workgroups per pair, each over a
+# contiguous part of the context (the kernel uses fewer for short contexts), merged by the last
+# one to finish.  The choice depends only on the step's shape, so a captured graph keeps it.
+SPLIT_KV_MAX_PAIRS = 128  # the smallest token bucket (16 rows, padding included) of an 8-kv-head model
+SPLIT_KV_MAX = 32
+_split_ws: Dict[Any, torch.Tensor] = {}
+
+
+def decode_attention_splits(tokens: int, n_kv_heads: int) -> int:
+    """Workgroups per (token, kv head) for a decode step of ``tokens`` rows (padding rows count:
+    they are part of the captured grid and exit at once)."""
+    forced = int(os.environ.get("KVMINI_DECODE_SPLITS", "0"))
+    if forced > 0:
+        return forced
+    pairs = tokens * n_kv_heads
+    if pairs > SPLIT_KV_MAX_PAIRS:
+        return 1
+    return max(1, min(SPLIT_KV_MAX, 8 * _NUM_CUS // pairs))
+
+
+_SPLIT_WS_FLOATS = 4 << 20  # 16 MiB: 4096 counters + partials of up to ~4000 (pair, split) combinations of an 8-head group
+
+
+def _split_workspace(device: torch.device, floats: int) -> torch.Tensor:
+    """One workspace per device, allocated once at a fixed size: captured graphs keep its address."""
+    if floats > _SPLIT_WS_FLOATS:
+        raise ValueError(f"split-KV decode attention needs {floats} workspace floats, more than the fixed {_SPLIT_WS_FLOATS}: use fewer splits")
+    ws = _split_ws.get(device)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the split-KV workspace must exist before graph capture (run the step eagerly once)")
+        ws = torch.zeros(_SPLIT_WS_FLOATS, dtype=torch.float32, device=device)
+        _split_ws[device] = ws
+    return ws
+
+
 def rope_attention_fused(
     qkv: Partial,
     positions: torch.Tensor,
@@ -497,14 +535,19 @@ def rope_attention_fused(
     n_heads: int,
     scale: float,
     kv_scale: Optional[torch.Tensor] = None,
+    n_split: Optional[int] = None,
 ) -> torch.Tensor:
     """RoPE + paged-KV write + attention for a step in which every token is the only new
     token of its sequence (plain decoding).  ``qkv`` must be the split-K slabs of the QKV
-    projection; returns the attention output ``[T, nh*hd]``."""
+    projection; returns the attention output ``[T, nh*hd]``.  ``n_split``: workgroups per
+    (token, kv head) (None: by the step's shape, see :func:`decode_attention_splits`)."""
     t = qkv.slabs.shape[1]
-    hd = k_cache.shape[3]
+    nkv, hd = k_cache.shape[1], k_cache.shape[3]
     out = torch.empty((t, n_heads * hd), dtype=torch.bfloat16, device=qkv.slabs.device)
-    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale, _decode_attention_waves(t, k_cache.shape[1]), kv_scale)
+    ns = decode_attention_splits(t, nkv) if n_split is None else n_split
+    ws = _split_workspace(out.device, 4096 + t * n_heads * ns * (hd + 2)) if ns > 1 else None
+    native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale,
+                                    _decode_attention_waves(t, nkv), kv_scale, ns, ws)
     return out
 
 

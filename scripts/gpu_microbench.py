@@ -361,6 +361,47 @@ def prefill_bench(out, model):
         torch.cuda.empty_cache()
 
 
+def longctx_bench(out, model, lens=(8192, 32768, 131072), kv_dtypes=("auto", "fp8"), batch=1):
+    """The long-context axis (runners/profiles/long-context.yaml): ``batch`` prompts of N tokens
+    through the engine — prefill tokens/s, then 32 decode steps at that context (ms per step, host
+    staging time per step), and the KV bytes the sequences hold; bf16 and e4m3 KV cache."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    for kv in kv_dtypes:
+        for plen in lens:
+            eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=max(2, batch), max_batched_tokens=2048, max_model_len=plen + 64, kernels="hip", kv_memory_fraction=0.6,
+                                         kv_cache_dtype=kv, enable_prefix_caching=False))
+            eng.warmup()
+            seqs = [eng.make_sequence([1] + [(7 * i + 13 * b) % 5000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=33, ignore_eos=True)) for b in range(batch)]
+            for s_ in seqs:
+                assert eng.scheduler.add(s_) is None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while any(s_.first_token_time is None for s_ in seqs):
+                eng.step()
+            torch.cuda.synchronize()
+            t_prefill = time.perf_counter() - t0
+            n = 0
+            t0 = time.perf_counter()
+            while eng.scheduler.has_work():
+                eng.step()
+                n += 1
+            torch.cuda.synchronize()
+            t_dec = (time.perf_counter() - t0) / max(1, n)
+            r = eng.runner
+            per_tok = r.cfg.num_layers * 2 * r.nkv * r.hd * r.kv_cache.element_size()
+            # host side of one decode step: staging the image (block tables included) without running it
+            batch_obj = None
+            row = {"bench": "long_context", "model": model, "kv_cache_dtype": kv, "prompt_tokens": plen, "batch": batch, "prefill_s": round(t_prefill, 3), "prefill_tok_per_s": round(batch * plen / t_prefill),
+                   "decode_ms_per_step": round(t_dec * 1e3, 3), "decode_steps": n, "kv_GB_held": round(batch * plen * per_tok / 1e9, 3), "kv_bytes_per_token": per_tok,
+                   "kv_blocks_total": r.num_blocks, "stage_ints": int(r.stage_dev.numel()), "mem_GB": round(torch.cuda.memory_allocated() / 1e9, 1)}
+            print(json.dumps(row), flush=True)
+            out.append(row)
+            del eng, seqs, batch_obj
+            torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="gemm,step")
@@ -369,6 +410,8 @@ def main():
     ap.add_argument("--kernels", default="hip,torch")
     ap.add_argument("--out", default="gpurun_out/microbench.json")
     ap.add_argument("--quantization", default=None)
+    ap.add_argument("--lens", default="8192,32768,131072")
+    ap.add_argument("--kv-dtypes", default="auto,fp8")
     a = ap.parse_args()
     out = []
     if "gemm" in a.what:
@@ -385,8 +428,10 @@ def main():
         nw_bench(out)
     if "wide" in a.what.split(","):
         nw_bench(out, rows=(128, 256))
-    if "prefill" in a.what:
+    if "prefill" in a.what.split(","):
         prefill_bench(out, a.model)
+    if "longctx" in a.what.split(","):
+        longctx_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")), batch=a.batch if a.batch < 20 else 1)
     if "step" in a.what:
         step_bench(out, a.model, a.batch, a.kernels.split(","), a.quantization)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)

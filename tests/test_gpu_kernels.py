@@ -1216,3 +1216,80 @@ def test_engine_fp8_kv_cache_tracks_the_bf16_engine(graphs):
     le = eng.runner.execute(eng.scheduler.schedule())[1].float()
     rel = (lb - le).norm() / lb.norm()
     assert rel.item() < 0.08, rel.item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rep,kv8", [(4, False), (8, False), (1, False), (4, True)])
+def test_split_kv_decode_attention_matches_the_unsplit_kernel(rep, kv8):
+    """Several workgroups per (token, kv head), merged by the last to arrive, against one workgroup
+    per pair: contexts from one token (one split does everything) to 3000 tokens (12 splits of 16
+    blocks), a padding row, repeated launches on the same workspace (counters reset themselves)."""
+    from kvmini.models.llama import LlamaConfig, rope_tables
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(9)
+    nkv, hd, bs = 2, 128, 16
+    nh = nkv * rep
+    ctx = torch.tensor([1, 2, 255, 257, 600, 0, 3000, 1024], device=_dev(), dtype=torch.int32)
+    T = ctx.numel()
+    max_blocks = 3008 // bs
+    nb = T * max_blocks + 8
+    width = (nh + 2 * nkv) * hd
+    cos, sin = rope_tables(LlamaConfig(head_dim=hd), 3072, _dev())
+    positions = (ctx - 1).clamp(min=0)
+    tok_seq = torch.arange(T, device=_dev(), dtype=torch.int32)
+    bt = torch.randperm(nb, device=_dev())[: T * max_blocks].view(T, max_blocks).int()
+    slots = torch.where(ctx > 0, bt[torch.arange(T, device=_dev()), (positions // bs).long()] * bs + positions % bs, torch.full_like(ctx, -1)).int()
+    slabs = torch.randn(3, T, width, device=_dev()) * 0.4
+    part = hip_ops.Partial(slabs, torch.rand(T, 1, device=_dev()) * 512 + 1.0, 1e-5, 512)
+    sc = torch.tensor([[0.5, 1.5], [1.25, 0.75]], device=_dev()) if kv8 else None
+
+    def caches():
+        if kv8:
+            return _fp8_cache(nb, nkv, bs, hd, 1), _fp8_cache(nb, nkv, bs, hd, 2)
+        g = torch.Generator(device=_dev()); g.manual_seed(1)
+        return (torch.randn(nb, nkv, bs, hd, device=_dev(), generator=g).bfloat16(), torch.randn(nb, nkv, bs, hd, device=_dev(), generator=g).bfloat16())
+
+    kc1, vc1 = caches()
+    ref = hip_ops.rope_attention_fused(part, positions, cos, sin, kc1, vc1, slots, bt, tok_seq, ctx, nh, 1 / math.sqrt(hd), kv_scale=sc, n_split=1)
+    for n_split in (2, 12, 32):
+        for _ in range(3):
+            kc2, vc2 = caches()
+            out = hip_ops.rope_attention_fused(part, positions, cos, sin, kc2, vc2, slots, bt, tok_seq, ctx, nh, 1 / math.sqrt(hd), kv_scale=sc, n_split=n_split)
+            assert torch.equal(kc1.view(torch.uint8), kc2.view(torch.uint8)) and torch.equal(vc1.view(torch.uint8), vc2.view(torch.uint8))
+            assert (out.float() - ref.float()).abs().max().item() <= 8e-3, n_split
+            assert out[5].abs().max().item() == 0
+    torch.cuda.synchronize()
+    assert int(hip_ops._split_ws[_dev()][:4096].view(torch.int32).abs().sum()) == 0  # every arrival counter is back at zero
+    assert hip_ops.decode_attention_splits(1, 8) == 32 and hip_ops.decode_attention_splits(16, 8) == 16 and hip_ops.decode_attention_splits(32, 8) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_engine_long_context_decode_takes_the_split_kv_graph_and_matches_eager(kv):
+    """A 3000-token sequence decoded alone: the engine replays the split-KV variant of the
+    decode-only graph (context >= 2048 tokens on a 16-row step) and produces the tokens of the
+    eager, unsplit path; a short request next to it still runs on the plain variant."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=4, max_batched_tokens=512, max_model_len=4096, kernels="hip", kv_cache_dtype=kv, kv_memory_fraction=0.02)
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # noqa: E731
+    prompts = [[1] + [(7 * i) % 900 + 10 for i in range(2999)]]
+    params = SamplingParams(max_tokens=24, ignore_eos=True)
+    os.environ["KVMINI_DECODE_SPLITS"] = "1"
+    try:
+        want = LLMEngine(EngineConfig(**common, use_graphs=False), weights=w()).generate(prompts, params)
+    finally:
+        del os.environ["KVMINI_DECODE_SPLITS"]
+    eng = LLMEngine(EngineConfig(**common), weights=w())
+    eng.warmup()
+    assert (16, 2) in eng.runner.graphs and (16, 1) in eng.runner.graphs
+    assert eng.runner.step_kind(16, True, 3000) == 2 and eng.runner.step_kind(16, True, 500) == 1 and eng.runner.step_kind(16, False, 3000) == 0
+    got = eng.generate(prompts, params)
+    agree = sum(a == b for a, b in zip(want[0], got[0])) / len(want[0])
+    assert agree >= 0.9, (agree, want, got)  # fp32 partial sums are merged in another order: a near-tie may flip late in the sequence
+    assert got[0][:8] == want[0][:8]
+    short = eng.generate([[1, 5, 9, 11]], SamplingParams(max_tokens=8, ignore_eos=True))
+    assert len(short[0]) == 8
