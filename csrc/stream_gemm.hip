@@ -66,6 +66,23 @@ __device__ inline frag_ab a_frag(const raw16* raw, int u) {
   }
 }
 
+// MXFP4 weights (OCP microscaling: e2m1 values, one E8M0 scale per 32 elements along K, i.e.
+// per (row, k-step)): a lane's 8 values of a k-step are 4 bytes, so one 16-byte load carries
+// FOUR k-steps, and `sc` holds their four scale bytes (byte u = k-step u).  Each pair of
+// nibbles is widened to bf16 with the scale applied by the packed gfx950 conversion (exact:
+// e2m1 times a power of two fits in bf16).
+__device__ inline frag_ab a_frag4(const raw16 raw, unsigned int sc, int u) {
+  const unsigned int w = raw[u];
+  const float scale = __uint_as_float(((sc >> (8 * u)) & 0xffu) << 23);  // 2^(e - 127)
+  const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 0);
+  const bf16x2 p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 1);
+  const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 2);
+  const bf16x2 p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 3);
+  frag_ab a;
+  a[0] = p0[0]; a[1] = p0[1]; a[2] = p1[0]; a[3] = p1[1]; a[4] = p2[0]; a[5] = p2[1]; a[6] = p3[0]; a[7] = p3[1];
+  return a;
+}
+
 // Shared epilogue.  Lane holds y[token j*16 + r][feature tile*16 + 4q + e], e = 0..3, in acc[j][e].
 template <int MT, int EPI, bool W8>
 __device__ inline void gemm_epilogue(frag_cd (&acc)[MT], unsigned char* lds_raw, void* __restrict__ out, long long tile, int wave, int lane, long long ldy,
@@ -225,12 +242,16 @@ __device__ inline raw16 ldw16(const raw16* p) {
   else return *p;
 }
 
-template <int MT, int KS, int NB, int EPI, bool W8, bool NT, int NW>
+// WB = weight bits: 16 (bf16), 8 (e4m3 + one fp32 scale per row, applied in the epilogue) or
+// 4 (MXFP4: w_scale then points at the packed E8M0 block scales, uint32 [N/16][K/128][16 rows]).
+template <int MT, int KS, int NB, int EPI, int WB, bool NT, int NW>
 __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
                                                            long long ldx, long long ldy, int groups_per_split, long long slab_stride,
                                                            const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps,
                                                            const float* __restrict__ w_scale) {
-  constexpr int AL = W8 ? KS / 2 : KS;
+  constexpr bool W8 = WB == 8, W4 = WB == 4;
+  static_assert(!W4 || KS % 4 == 0, "an MXFP4 load carries four k-steps");
+  constexpr int AL = W4 ? KS / 4 : W8 ? KS / 2 : KS;
   constexpr int XF = KS * MT;
   constexpr int XL = (XF + NW - 1) / NW;  // x fragments of a chunk per wave
   constexpr int PD = NB - 1;
@@ -243,7 +264,9 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
   const int g0 = blockIdx.y * groups_per_split;
   const int g1 = g0 + groups_per_split < ngroups ? g0 + groups_per_split : ngroups;
   const long long tile = (long long)blockIdx.x * NW + wave;
-  const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * (W8 ? ksteps / 2 : ksteps) * 64 + lane;
+  const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * (ksteps * AL / KS) * 64 + lane;
+  const unsigned int* scp = reinterpret_cast<const unsigned int*>(w_scale) + (W4 ? tile * (ksteps / 4) * 16 + r : 0);  // W4: one word per chunk
+  unsigned int sc[NB][W4 ? AL : 1];
 
   const __bf16* xsrc[XL];
 #pragma unroll
@@ -265,6 +288,9 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
     _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + NW * i < XF)                                      \
         xr[slot][i] = *reinterpret_cast<const frag_ab*>(xsrc[i] + (long long)(chunk) * KS * 32);                \
     _Pragma("unroll") for (int u = 0; u < AL; ++u) a[slot][u] = ldw16<NT>(wp + ((long long)(chunk) * AL + u) * 64); \
+    if constexpr (W4) {                                                                                         \
+      _Pragma("unroll") for (int u = 0; u < AL; ++u) sc[slot][u] = scp[((long long)(chunk) * AL + u) * 16];     \
+    }                                                                                                           \
   } while (0)
 
 #define KV_CONSUME(slot, chunk)                                                                                 \
@@ -276,7 +302,9 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
     _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                            \
       frag_ab b[MT];                                                                                            \
       _Pragma("unroll") for (int j = 0; j < MT; ++j) b[j] = xs[(buf * XF + u * MT + j) * 64 + lane];            \
-      const frag_ab af = a_frag<W8>(a[slot], u);                                                                \
+      frag_ab af;                                                                                               \
+      if constexpr (W4) af = a_frag4(a[slot][u >> 2], sc[slot][u >> 2], u & 3);                                 \
+      else af = a_frag<W8>(a[slot], u);                                                                         \
       _Pragma("unroll") for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[j], acc[j], 0, 0, 0); \
     }                                                                                                           \
   } while (0)
@@ -337,31 +365,42 @@ int dispatch_ks(int epi, int ks, bool w8, const Args& a) {
   return ks == 4 ? dispatch_epi<MT, 4, false>(epi, a) : dispatch_epi<MT, 8, false>(epi, a);
 }
 
-template <int MT, int NB, int EPI, bool W8, bool NT, int NW>
+// k-steps per chunk.  Measured with MXFP4 weights on the Llama-3-8B gate/up projection (32 rows):
+// 16-k-step chunks (one barrier per 4 KB of weights per wave) 24.0 us, 4-k-step chunks in a ring of
+// 8 21.8 us — the barrier is not what holds 4-bit weights back; the x fragments are (every wave
+// reads 2 KB of them from LDS per 256 B of weights).  So every format uses 4-k-step chunks.
+constexpr int chunk_ksteps(int mt, int wb) { return 4; }
+
+template <int MT, int NB, int EPI, int WB, bool NT, int NW>
 int launch3(const Args& a) {
   dim3 grid(a.N / (16 * NW), a.splits), block(NW * 64);
-  hipLaunchKernelGGL((stream_gemm3_kernel<MT, 4, NB, EPI, W8, NT, NW>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
+  hipLaunchKernelGGL((stream_gemm3_kernel<MT, chunk_ksteps(MT, WB), NB, EPI, WB, NT, NW>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
                      a.slab_stride, a.row_ss, a.ss_parts, 1.f / (float)a.K, a.eps, a.w_scale);
   return (int)hipGetLastError();
 }
 
-template <int MT, int NB, bool W8, bool NT, int NW>
+template <int MT, int NB, int WB, bool NT, int NW>
 int dispatch3_epi(int epi, const Args& a) {
   switch (epi) {
-    case EPI_BF16: return launch3<MT, NB, EPI_BF16, W8, NT, NW>(a);
-    case EPI_SLAB: return launch3<MT, NB, EPI_SLAB, W8, NT, NW>(a);
-    case EPI_SWIGLU: return launch3<MT, NB, EPI_SWIGLU, W8, NT, NW>(a);
+    case EPI_BF16: return launch3<MT, NB, EPI_BF16, WB, NT, NW>(a);
+    case EPI_SLAB: return launch3<MT, NB, EPI_SLAB, WB, NT, NW>(a);
+    case EPI_SWIGLU: return launch3<MT, NB, EPI_SWIGLU, WB, NT, NW>(a);
   }
   return -1;
 }
 
-template <int MT, bool W8, int NW>
+template <int MT, int WB, int NW>
 int dispatch3_nb(int epi, int nb, const Args& a) {
   // weight loads are always non-temporal here: measured 8-12 % faster than the default
   // policy on every decode shape (each weight byte is read once, by one CU)
   switch (nb) {
-    case 2: return dispatch3_epi<MT, 2, W8, true, NW>(epi, a);
-    case 4: return dispatch3_epi<MT, 4, W8, true, NW>(epi, a);
+    case 2: return dispatch3_epi<MT, 2, WB, true, NW>(epi, a);
+    case 4: return dispatch3_epi<MT, 4, WB, true, NW>(epi, a);
+    case 8:
+      // quantised weights only: a chunk of e4m3 / MXFP4 weights is 2 KB / 1 KB per wave, so the
+      // ring has to be deeper for the same bytes in flight
+      if constexpr (WB != 16 && MT <= 2) return dispatch3_epi<MT, 8, WB, true, NW>(epi, a);
+      return -1;
   }
   return -1;
 }
@@ -370,33 +409,38 @@ int dispatch3_nb(int epi, int nb, const Args& a) {
 // Llama-3-8B gate/up projection) exactly one workgroup per CU of a 256-CU part, 6 does the
 // same for 384 tiles x 4 K-splits (its QKV projection); 8 halves the x traffic per weight
 // byte for wide token batches.
-template <int MT, bool W8>
+template <int MT, int WB>
 int dispatch3_nw(int epi, int nb, int nw, const Args& a) {
   switch (nw) {
-    case 4: return dispatch3_nb<MT, W8, 4>(epi, nb, a);
-    case 6: return dispatch3_nb<MT, W8, 6>(epi, nb, a);
-    case 7: return dispatch3_nb<MT, W8, 7>(epi, nb, a);
-    case 8: return dispatch3_nb<MT, W8, 8>(epi, nb, a);
+    case 4: return dispatch3_nb<MT, WB, 4>(epi, nb, a);
+    case 6: return dispatch3_nb<MT, WB, 6>(epi, nb, a);
+    case 7: return dispatch3_nb<MT, WB, 7>(epi, nb, a);
+    case 8: return dispatch3_nb<MT, WB, 8>(epi, nb, a);
   }
   return -1;
 }
 
 // 128 / 256-row steps (prompt chunks): every weight fragment feeds 8 / 16 MFMAs, the x chunk in
 // LDS is 32 / 64 KiB per buffer, one workgroup per CU.
-template <int MT, bool W8>
+template <int MT, int WB>
 int dispatch3_wide(int epi, int nw, const Args& a) {
   switch (nw) {
-    case 4: return dispatch3_epi<MT, 2, W8, true, 4>(epi, a);
-    case 6: return dispatch3_epi<MT, 2, W8, true, 6>(epi, a);
-    case 7: return dispatch3_epi<MT, 2, W8, true, 7>(epi, a);
-    case 8: return dispatch3_epi<MT, 2, W8, true, 8>(epi, a);
+    case 4: return dispatch3_epi<MT, 2, WB, true, 4>(epi, a);
+    case 6: return dispatch3_epi<MT, 2, WB, true, 6>(epi, a);
+    case 7: return dispatch3_epi<MT, 2, WB, true, 7>(epi, a);
+    case 8: return dispatch3_epi<MT, 2, WB, true, 8>(epi, a);
   }
   return -1;
 }
 
 template <int MT>
-int dispatch3_w8(int epi, int nb, int nw, bool w8, const Args& a) {
-  return w8 ? dispatch3_nw<MT, true>(epi, nb, nw, a) : dispatch3_nw<MT, false>(epi, nb, nw, a);
+int dispatch3_wb(int epi, int nb, int nw, int wb, const Args& a) {
+  return wb == 4 ? dispatch3_nw<MT, 4>(epi, nb, nw, a) : wb == 8 ? dispatch3_nw<MT, 8>(epi, nb, nw, a) : dispatch3_nw<MT, 16>(epi, nb, nw, a);
+}
+
+template <int MT>
+int dispatch3_wide_wb(int epi, int nw, int wb, const Args& a) {
+  return wb == 4 ? dispatch3_wide<MT, 4>(epi, nw, a) : wb == 8 ? dispatch3_wide<MT, 8>(epi, nw, a) : dispatch3_wide<MT, 16>(epi, nw, a);
 }
 
 // W[N, K] fp8 bytes (row-major) -> [N/16][K/64][64 lanes][16 bytes]: lane l of a tile holds
@@ -481,23 +525,27 @@ int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int targe
 }
 
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
-                    int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, hipStream_t stream) {
+                    int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int weight_bits,
+                    hipStream_t stream) {
+  // weight_bits: 16, 8 (w_scale = fp32 per-row scales), 4 (MXFP4; w_scale = packed E8M0 block scales) or 0 = 8 if w_scale else 16
+  const int wb = weight_bits ? weight_bits : (w_scale != nullptr ? 8 : 16);
+  if ((wb != 16 && wb != 8 && wb != 4) || ((wb != 16) != (w_scale != nullptr))) return -1;
   const bool wide = M == 128 || M == 256;  // 8 / 16 row tiles per wave: 2-chunk groups only (registers)
-  if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4) || (K % (128 * nb))) return -1;
+  const int chunk_cols = 32 * chunk_ksteps(M >> 4, wb);
+  if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4 && nb != 8) || (K % (chunk_cols * nb))) return -1;
   if (wide && nb != 2) return -1;
   if (epi == EPI_SWIGLU && (N & 15)) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
-  const int ngroups = K / (128 * nb);
+  const int ngroups = K / (chunk_cols * nb);
   if (splits < 1 || groups_per_split < 1 || (long long)splits * groups_per_split < ngroups || (long long)(splits - 1) * groups_per_split >= ngroups) return -1;
   const Args a{Wp, x, out, N, K, ldx, ldy, splits, groups_per_split, slab_stride, row_ss, ss_parts, eps, w_scale, stream};
-  const bool w8 = w_scale != nullptr;
   switch (M >> 4) {
-    case 1: return dispatch3_w8<1>(epi, nb, nw, w8, a);
-    case 2: return dispatch3_w8<2>(epi, nb, nw, w8, a);
-    case 3: return dispatch3_w8<3>(epi, nb, nw, w8, a);
-    case 4: return dispatch3_w8<4>(epi, nb, nw, w8, a);
-    case 8: return w8 ? dispatch3_wide<8, true>(epi, nw, a) : dispatch3_wide<8, false>(epi, nw, a);
-    case 16: return w8 ? dispatch3_wide<16, true>(epi, nw, a) : dispatch3_wide<16, false>(epi, nw, a);
+    case 1: return dispatch3_wb<1>(epi, nb, nw, wb, a);
+    case 2: return dispatch3_wb<2>(epi, nb, nw, wb, a);
+    case 3: return dispatch3_wb<3>(epi, nb, nw, wb, a);
+    case 4: return dispatch3_wb<4>(epi, nb, nw, wb, a);
+    case 8: return dispatch3_wide_wb<8>(epi, nw, wb, a);
+    case 16: return wb == 4 ? -1 : (wb == 8 ? dispatch3_wide<16, 8>(epi, nw, a) : dispatch3_wide<16, 16>(epi, nw, a));  // (256-row tiles are not built for MXFP4: callers use 128-row passes)
   }
   return -1;
 }

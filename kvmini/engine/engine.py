@@ -121,10 +121,10 @@ def _host_to_device(values: List[Any], dtype: torch.dtype, dev: torch.device) ->
     return t.pin_memory().to(dev, non_blocking=True)
 
 
-def _sample_rows_device(logits: torch.Tensor, params: List[SamplingParams]) -> torch.Tensor:
-    """Temperature / top-k / top-p sampling of many rows at once (``logits``: ``[R, V]``, one
-    SamplingParams per row, unseeded): one softmax / sort / multinomial over the batch, every
-    op on the device and nothing read back — the ids stay there (int64 ``[R]``)."""
+def _probs_rows(logits: torch.Tensor, params: List[SamplingParams]) -> torch.Tensor:
+    """The distributions tokens are drawn from: softmax of ``logits`` (``[R, V]``, one
+    SamplingParams per row) after temperature, top-k and top-p — fp32 ``[R, V]``, rows sum to
+    one; every op on the device, nothing read back."""
     dev = logits.device
     temps = _host_to_device([max(p.temperature, 1e-5) for p in params], torch.float32, dev)
     x = logits.float() / temps[:, None]
@@ -143,7 +143,13 @@ def _sample_rows_device(logits: torch.Tensor, params: List[SamplingParams]) -> t
         sp = sp * keep
         probs = torch.zeros_like(probs).scatter_(1, si, sp)
         probs = probs / probs.sum(-1, keepdim=True)
-    return torch.multinomial(probs, 1).view(-1)
+    return probs
+
+
+def _sample_rows_device(logits: torch.Tensor, params: List[SamplingParams]) -> torch.Tensor:
+    """Temperature / top-k / top-p sampling of many rows at once (unseeded): one softmax / sort /
+    multinomial over the batch; the ids stay on the device (int64 ``[R]``)."""
+    return torch.multinomial(_probs_rows(logits, params), 1).view(-1)
 
 
 def _sample_rows(logits: torch.Tensor, params: List[SamplingParams]) -> List[int]:
@@ -446,6 +452,17 @@ class LLMEngine:
                     return False
         return self.bm.num_free >= len(sch.running) + sch.max_batched_tokens // self.bm.block_size + 2
 
+    def generator_for(self, seq: Sequence) -> Optional[torch.Generator]:
+        """The request's own random generator (requests with a seed), created on first use."""
+        if seq.params.seed is None:
+            return None
+        gen = self._gens.get(seq.req_id)
+        if gen is None:
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(int(seq.params.seed))
+            self._gens[seq.req_id] = gen
+        return gen
+
     def _finalize_pending(self, held: bool = False) -> List[TokenEvent]:
         """Read back the step in flight (if any) and commit its tokens.  ``held``: the launch
         that preceded this read-back was delayed on purpose (see :meth:`_hold_launch`)."""
@@ -518,12 +535,7 @@ class LLMEngine:
             if row in batched:
                 tok = batched[row]
             elif p.temperature > 0 and logits is not None and not p.guided:
-                gen = self._gens.get(seq.req_id)
-                if gen is None:
-                    gen = torch.Generator(device=logits.device)
-                    gen.manual_seed(p.seed)
-                    self._gens[seq.req_id] = gen
-                tok = _sample_row(logits[row], p, gen)
+                tok = _sample_row(logits[row], p, self.generator_for(seq))
             lp_entry = None
             if p.logprobs > 0 and logits is not None:
                 lp = torch.log_softmax(logits[row].float(), -1)

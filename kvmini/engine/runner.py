@@ -46,7 +46,7 @@ class RunnerConfig:
     use_graphs: bool = True
     kernels: str = "auto"  # auto | hip | torch
     return_logits: bool = False
-    quantization: Optional[str] = None  # None | fp8 (weight-only, HIP kernels)
+    quantization: Optional[str] = None  # None | fp8 | mxfp4 (weight-only, HIP kernels; int4 / awq / gptq are served as mxfp4)
     kv_cache_dtype: str = "auto"  # auto (the model dtype) | fp8 (e4m3 bytes + one scale per kv head, converted in registers by the attention kernels)
     tp_graphs: bool = True  # capture HIP graphs under tensor parallelism (buckets whose all-reduce runs in the peer-memory kernels)
     tp_rccl_graphs: bool = False  # also capture buckets whose all-reduce is RCCL's (every rank must capture in step)
@@ -135,6 +135,10 @@ class ModelRunner:
             from kvmini.models.llama import fake_quantize_fp8
 
             fake_quantize_fp8(weights)
+        elif rcfg.quantization in ("mxfp4", "int4", "awq", "autoawq", "gptq", "fp4"):
+            from kvmini.models.llama import fake_quantize_mxfp4
+
+            fake_quantize_mxfp4(weights)
         cfg = self.cfg
         self.nh = cfg.num_heads // self.tp_size
         self.nkv = cfg.num_kv_heads // self.tp_size

@@ -1,4 +1,5 @@
-"""Draft-model speculative decoding with greedy verification.
+"""Draft-model speculative decoding: greedy verification, and rejection sampling for
+requests that sample.
 
 Each engine iteration for a decoding sequence is *propose* (a small draft model
 runs ``k`` cheap autoregressive steps) then *verify* (the target model scores
@@ -11,8 +12,16 @@ decode step costs (≈16 GB of bf16 weights per step for an 8B model, and up to
 
 The draft runner has its own KV-cache tensor but shares block ids and slots with
 the target (one BlockManager), so no second allocator is needed: a block id is
-valid in both caches.  Sequences that sample with temperature > 0 fall back to
-one-token steps (rejection sampling is not implemented).
+valid in both caches.
+
+Requests with temperature > 0 are verified by speculative *rejection sampling* (Leviathan et
+al., "Fast Inference from Transformers via Speculative Decoding", 2023; Chen et al., 2023): the
+draft token x_i is drawn from the draft's distribution q_i (after the request's temperature /
+top-k / top-p), the target's distribution p_i at the same position comes out of the one verify
+pass, x_i is kept with probability min(1, p_i(x_i) / q_i(x_i)); the first rejected position is
+re-drawn from normalise(max(0, p_i - q_i)), and if nothing is rejected a bonus token is drawn
+from p_k.  The tokens that come out are distributed exactly as if the target had sampled them
+one by one.
 
 The reference exposes speculation only as vLLM flags in a profile
 (``runners/profiles/speculative-decoding.yaml``); this is the native-engine
@@ -23,7 +32,7 @@ from __future__ import annotations
 
 import time
 from dataclasses import replace
-from typing import TYPE_CHECKING, Dict, List
+from typing import TYPE_CHECKING, Dict, List, Optional, Tuple
 
 import torch
 
@@ -34,6 +43,26 @@ from .scheduler import Batch, ScheduledChunk, SeqStatus, Sequence
 
 if TYPE_CHECKING:
     from .engine import LLMEngine, TokenEvent
+
+
+def rejection_sample(p: torch.Tensor, q: torch.Tensor, drafts: torch.Tensor, gen: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One sequence's verification.  ``p``: target distributions ``[k + 1, V]`` at the k draft
+    positions and the one after them, ``q``: draft distributions ``[k, V]``, ``drafts``: the k
+    draft tokens (int64), each drawn from its ``q`` row.  Returns (number of accepted drafts a,
+    the token that follows them) as 0-dim device tensors — nothing is read back here."""
+    k = drafts.numel()
+    idx = torch.arange(k, device=p.device)
+    px, qx = p[idx, drafts], q[idx, drafts]
+    u = torch.rand(k, device=p.device, generator=gen)
+    ok = u * qx < px  # u < p/q without the division (q(x) > 0: x was drawn from q)
+    a = torch.cumprod(ok.to(torch.int64), 0).sum()  # leading accepts
+    # distribution of the token after the accepted prefix: residual at the rejected position, p_k if none was
+    resid = torch.clamp(p[:k] - q, min=0.0)
+    resid = torch.cat((resid, p[k:]), 0)  # row k: the bonus position
+    row = resid[a]
+    tot = row.sum()
+    row = torch.where(tot > 0, row / tot.clamp_min(1e-30), p[a])  # p == q there (nothing left over): any draw from p is right
+    return a, torch.multinomial(row, 1, generator=gen).view(())
 
 
 class SpeculativeDecoder:
@@ -67,6 +96,8 @@ class SpeculativeDecoder:
         tgt.set_spec_width(self.k + 1)
         # positions whose K/V are valid in the draft cache, per request id
         self.draft_computed: Dict[int, int] = {}
+        # sampling requests: the draft distributions their draft tokens were drawn from, [k, V] per request id
+        self.draft_q: Dict[int, torch.Tensor] = {}
 
     def load_draft_weights(self, weights) -> None:
         """Swap in real draft weights (same architecture as the random-init ones)."""
@@ -112,9 +143,15 @@ class SpeculativeDecoder:
             self.draft.execute(Batch(group, used))
 
     def _propose(self, seqs: List[Sequence]) -> None:
-        """k draft steps for every sequence in ``seqs`` (batched across sequences)."""
+        """k draft steps for every sequence in ``seqs`` (batched across sequences).  Greedy
+        requests take the draft's argmax; sampling requests draw from the draft's distribution
+        (all of a step's draws in one batched call) and keep that distribution for the verifier."""
+        from .engine import _probs_rows
+
         for s in seqs:
             s.draft_ids = []
+        sampled = [i for i, s in enumerate(seqs) if s.params.temperature > 0]
+        qs: List[torch.Tensor] = []
         for _ in range(self.k):
             chunks = []
             total = 0
@@ -123,10 +160,24 @@ class SpeculativeDecoder:
                 n = s.num_tokens + len(s.draft_ids) - start
                 chunks.append(ScheduledChunk(s, start, n, True, 1))
                 total += n
-            ids, _ = self.draft.execute(Batch(chunks, total))
+            ids, logits = self.draft.execute(Batch(chunks, total))
+            if sampled:
+                q = _probs_rows(logits[sampled], [seqs[i].params for i in sampled])
+                gens = [self.engine.generator_for(seqs[i]) for i in sampled]
+                if any(g is not None for g in gens):  # seeded requests own their generator
+                    drawn = torch.stack([torch.multinomial(q[j], 1, generator=g).view(()) for j, g in enumerate(gens)]).tolist()
+                else:
+                    drawn = torch.multinomial(q, 1).view(-1).tolist()
+                qs.append(q)
+                for i, tok in zip(sampled, drawn):
+                    ids[i] = tok
             for s, tok in zip(seqs, ids):
                 self.draft_computed[s.req_id] = s.num_tokens + len(s.draft_ids)
                 s.draft_ids.append(int(tok))
+        if sampled:
+            stack = torch.stack(qs, 1)  # [sampled, k, V]
+            for j, i in enumerate(sampled):
+                self.draft_q[seqs[i].req_id] = stack[j]
 
     # ------------------------------------------------------------------
     def step(self) -> "List[TokenEvent]":
@@ -137,7 +188,7 @@ class SpeculativeDecoder:
         # sequences that can take k drafts: decoding, greedy, room for k+1 more tokens, draft cache in step
         cands = [
             s for s in sch.running
-            if not s.is_prefilling and s.params.temperature <= 0 and s.req_id in self.draft_computed
+            if not s.is_prefilling and not s.params.logprobs and not s.params.guided and s.req_id in self.draft_computed
             and s.params.max_tokens - len(s.output_ids) > 1 and s.num_tokens + k + 1 <= sch.max_model_len
         ]
         # keep the verify pass within the token budget
@@ -174,7 +225,7 @@ class SpeculativeDecoder:
         return events
 
     def _commit(self, batch: Batch, ids: List[int], logits) -> "List[TokenEvent]":
-        from .engine import _sample_row
+        from .engine import _probs_rows, _sample_row
 
         eng = self.engine
         sch = eng.scheduler
@@ -196,12 +247,24 @@ class SpeculativeDecoder:
             if drafts and ch.start + ch.n_tokens == seq.num_tokens + len(drafts):
                 n_rows = seq.num_tokens + len(drafts) - max(ch.start, seq.num_tokens - 1)
                 rows = ids[row : row + n_rows]
+                q = self.draft_q.pop(seq.req_id, None)
+                if seq.params.temperature > 0 and q is not None and logits is not None and n_rows == len(drafts) + 1:
+                    # rejection sampling: rows of `logits` are the target's outputs after (last accepted, d0..d_{i-1})
+                    p = _probs_rows(logits[row : row + n_rows], [seq.params] * n_rows)
+                    a_t, tok_t = rejection_sample(p, q, torch.tensor(drafts, dtype=torch.int64, device=p.device), eng.generator_for(seq))
+                    a, nxt = (int(v) for v in torch.stack((a_t, tok_t)).tolist())
+                    new_tokens = list(drafts[:a]) + [nxt]
+                else:
+                    # greedy: rows[i] = target's argmax after (last accepted, d0..d_{i-1})
+                    a = 0
+                    while a < len(drafts) and a < len(rows) - 1 and drafts[a] == rows[a]:
+                        a += 1
+                    nxt = int(rows[a])
+                    if seq.params.temperature > 0 and logits is not None:  # (a verify chunk the budget cut short)
+                        a = 0
+                        nxt = _sample_row(logits[row], seq.params, eng.generator_for(seq))
+                    new_tokens = list(drafts[:a]) + [nxt]
                 row += n_rows
-                # rows[i] = target's greedy token after (last accepted, d0..d_{i-1})
-                a = 0
-                while a < len(drafts) and a < len(rows) - 1 and drafts[a] == rows[a]:
-                    a += 1
-                new_tokens = list(drafts[:a]) + [int(rows[a])]
                 eng.stats.spec_proposed += len(drafts)
                 eng.stats.spec_accepted += a
                 old_n = seq.num_tokens
@@ -215,7 +278,7 @@ class SpeculativeDecoder:
                 tok = ids[row]
                 p = seq.params
                 if p.temperature > 0 and logits is not None:
-                    tok = _sample_row(logits[row], p, None)
+                    tok = _sample_row(logits[row], p, eng.generator_for(seq))
                 row += 1
                 new = sch.commit(ch, [int(tok)])
                 self.draft_computed.setdefault(seq.req_id, min(len(seq.prompt_ids), seq.num_computed))
@@ -224,9 +287,12 @@ class SpeculativeDecoder:
             if done:
                 eng.stats.requests_finished += 1
                 self.draft_computed.pop(seq.req_id, None)
+                self.draft_q.pop(seq.req_id, None)
+                eng._gens.pop(seq.req_id, None)
             events.append((seq.req_id, new, done, seq.finish_reason, seq))
         # forget draft state of sequences that left the running set (abort / preemption)
         live = {s.req_id for s in sch.running}
         for rid in [r for r in self.draft_computed if r not in live]:
             del self.draft_computed[rid]
+            self.draft_q.pop(rid, None)
         return events

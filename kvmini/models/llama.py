@@ -386,6 +386,49 @@ def quantize_fp8_rows(w: torch.Tensor) -> "tuple[torch.Tensor, torch.Tensor]":
     return q, scale.float()
 
 
+E2M1_VALUES = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)  # magnitudes of the 4-bit float, code = index (+ 8 for negative)
+MX_BLOCK = 32
+
+
+def quantize_mxfp4(w: torch.Tensor) -> "tuple[torch.Tensor, torch.Tensor]":
+    """OCP microscaling FP4 (MXFP4) of a ``[N, K]`` weight, blocks of 32 along K: one E8M0
+    scale 2^(floor(log2(amax)) - 2) per block (2 = the exponent of e2m1's largest value, 6 =
+    1.5 * 2^2), elements rounded to the nearest e2m1 value and saturated at +-6.  Returns
+    (codes uint8 ``[N, K]`` in 0..15, scale bytes uint8 ``[N, K/32]``)."""
+    n, k = w.shape
+    if k % MX_BLOCK:
+        raise ValueError(f"in_features {k} must be a multiple of {MX_BLOCK} for MXFP4")
+    x = w.float().view(n, k // MX_BLOCK, MX_BLOCK)
+    amax = x.abs().amax(-1)
+    e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -120))) - 2.0
+    e = e.clamp(-127.0, 127.0)
+    y = x / torch.exp2(e)[..., None]
+    mids = torch.tensor([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0], device=w.device)
+    mag = torch.bucketize(y.abs(), mids)  # index of the nearest magnitude; beyond 5 -> 6 (saturation)
+    codes = (mag + 8 * (y < 0)).to(torch.uint8).view(n, k)
+    return codes, (e + 127.0).to(torch.uint8)
+
+
+def dequantize_mxfp4(codes: torch.Tensor, scales: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    n, k = codes.shape
+    lut = torch.tensor(E2M1_VALUES + tuple(-v for v in E2M1_VALUES), device=codes.device)
+    vals = lut[codes.long()].view(n, k // MX_BLOCK, MX_BLOCK) * torch.exp2(scales.float() - 127.0)[..., None]
+    return vals.view(n, k).to(dtype)
+
+
+def fake_quantize_mxfp4(weights: "LlamaWeights") -> None:
+    """Round every layer projection through MXFP4 and back (in place): the numerics of 4-bit
+    weight-only quantisation for the reference ops, and the oracle of the MXFP4 kernel tests."""
+    if getattr(weights, "quantization", None) == "mxfp4":
+        return
+    for lw in weights.layers:
+        for name in ("wqkv", "wo", "wgu", "wdown"):
+            w = getattr(lw, name)
+            if w.shape[1] % MX_BLOCK == 0:
+                setattr(lw, name, dequantize_mxfp4(*quantize_mxfp4(w), dtype=w.dtype))
+    weights.quantization = "mxfp4"
+
+
 def fake_quantize_fp8(weights: "LlamaWeights") -> None:
     """Round every layer projection through per-row e4m3 and back (in place): the
     numerics of weight-only FP8 for the reference (non-HIP) ops, and the oracle the

@@ -54,12 +54,15 @@ class PackedLinear:
     """A bf16 ``[N, K]`` weight re-ordered into MFMA fragment order
     ``[N/16][K/32][64][8]`` (N zero-padded to a multiple of 64)."""
 
-    __slots__ = ("wp", "n", "k", "n_pad", "ks", "wscale")
+    __slots__ = ("wp", "n", "k", "n_pad", "ks", "wscale", "bits")
 
-    def __init__(self, w: torch.Tensor, fp8: bool = False):
+    def __init__(self, w: torch.Tensor, fp8: bool = False, mxfp4: bool = False):
         """``fp8=True`` stores the weight as OCP e4m3 bytes with one fp32 scale per
         output row (weight-only quantisation: activations and accumulation stay
-        bf16 / fp32), halving the bytes the decode GEMM streams from HBM."""
+        bf16 / fp32), halving the bytes the decode GEMM streams from HBM.
+        ``mxfp4=True`` stores OCP MXFP4: two e2m1 values per byte and one E8M0 scale byte per
+        32 values along K (0.53 bytes per weight), widened to bf16 in registers by the
+        streaming GEMM (``in_features`` must be a multiple of 256)."""
         n, k = w.shape
         if w.dtype != torch.bfloat16 or not w.is_cuda:
             raise ValueError("PackedLinear needs a bf16 GPU weight")
@@ -70,7 +73,14 @@ class PackedLinear:
         if n_pad != n:
             w = torch.cat((w, torch.zeros(n_pad - n, k, dtype=w.dtype, device=w.device)), 0)
         self.wscale: Optional[torch.Tensor] = None
-        if fp8:
+        self.bits = 4 if mxfp4 else 8 if fp8 else 16
+        if mxfp4:
+            from kvmini.models.llama import quantize_mxfp4
+
+            if k % 256:
+                raise ValueError(f"in_features {k} must be a multiple of 256 for MXFP4 weights")
+            self.wp, self.wscale = pack_mxfp4(*quantize_mxfp4(w))
+        elif fp8:
             from kvmini.models.llama import quantize_fp8_rows
 
             q, scale = quantize_fp8_rows(w)
@@ -89,6 +99,21 @@ class PackedLinear:
 
     def element_size(self) -> int:
         return self.wp.element_size()
+
+
+def pack_mxfp4(codes: torch.Tensor, scales: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """MXFP4 codes ``[N, K]`` (0..15) and scale bytes ``[N, K/32]`` in the streaming GEMM's
+    fragment order.  Weights: uint8 ``[N/16, K/128, 64 lanes, 16]`` — lane ``l`` holds, for each
+    of the four k-steps ``u`` of a 128-column group, ``W[row l & 15][32 u + 8 (l >> 4) .. + 8)`` as
+    4 bytes (low nibble = the even element).  Scales: int32 ``[N/16, K/128, 16 rows]``, byte ``u``
+    of a word = the E8M0 scale of k-step ``u``."""
+    n, k = codes.shape
+    c = codes.view(n // 16, 16, k // 128, 4, 4, 4, 2)  # tile, row, group, u, q, byte, half
+    c = c.permute(0, 2, 4, 1, 3, 5, 6)                # tile, group, q, row, u, byte, half
+    packed = (c[..., 0] | (c[..., 1] << 4)).contiguous().view(n // 16, k // 128, 64, 16)
+    sc = scales.view(n // 16, 16, k // 128, 4).permute(0, 2, 1, 3).contiguous().to(torch.int32)  # tile, group, row, u
+    words = sc[..., 0] | (sc[..., 1] << 8) | (sc[..., 2] << 16) | (sc[..., 3] << 24)
+    return packed, words.contiguous()
 
 
 Weight = Union[torch.Tensor, PackedLinear]
@@ -129,14 +154,15 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
     bf16, as serving stacks do, to keep the logits exact)."""
     if getattr(weights, "_hip_prepared", False):
         return
-    if quantization not in (None, "none", "fp8"):
-        raise ValueError(f"unsupported quantization {quantization!r} (native engine: fp8)")
-    fp8 = quantization == "fp8"
+    quantization = FOUR_BIT_ALIASES.get(quantization or "none", quantization)
+    if quantization not in (None, "none", "fp8", "mxfp4"):
+        raise ValueError(f"unsupported quantization {quantization!r} (native engine: fp8, mxfp4; int4 / awq / gptq checkpoints' 4-bit slot is served as mxfp4)")
+    fp8, fp4 = quantization == "fp8", quantization == "mxfp4"
 
-    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor], q: bool = fp8) -> PackedLinear:
+    def fold_pack(w: torch.Tensor, gain: Optional[torch.Tensor], q: bool = True) -> PackedLinear:
         if gain is not None:
             w = (w.float() * gain.float()[None, :]).to(torch.bfloat16)
-        return PackedLinear(w, fp8=q and w.shape[1] % 64 == 0)
+        return PackedLinear(w, fp8=q and fp8 and w.shape[1] % 64 == 0, mxfp4=q and fp4 and w.shape[1] % 256 == 0)
 
     for lw in weights.layers:
         lw.wqkv = fold_pack(lw.wqkv, lw.attn_norm)
@@ -148,9 +174,13 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
     weights.lm_head = fold_pack(weights.lm_head, weights.final_norm, False)  # a tied embedding stays untouched: fold_pack copies
     weights.final_norm = torch.ones_like(weights.final_norm)
     weights._hip_prepared = True
-    weights.quantization = "fp8" if fp8 else None
+    weights.quantization = "fp8" if fp8 else "mxfp4" if fp4 else None
     torch.cuda.empty_cache()
 
+
+# the reference's 4-bit profiles (runners/profiles/quantization/{int4,autoawq,gptq}.yaml:17) name checkpoint
+# formats; with random-init or bf16 weights quantised at load there is one 4-bit weight format here
+FOUR_BIT_ALIASES = {"int4": "mxfp4", "awq": "mxfp4", "autoawq": "mxfp4", "gptq": "mxfp4", "fp4": "mxfp4"}
 
 _NUM_CUS = 256
 
@@ -173,7 +203,7 @@ def _waves_per_workgroup(n_pad: int) -> int:
 
 
 @functools.lru_cache(maxsize=None)
-def _plan_slabs(n_pad: int, k: int, m: int = 32) -> Tuple[int, int, int]:
+def _plan_slabs(n_pad: int, k: int, m: int = 32, group_cols: int = 256) -> Tuple[int, int, int]:
     """(waves per workgroup, K splits, 2-chunk groups per split) of a split-K streaming GEMM,
     by a three-term cost model fitted to the measured shapes (32 token rows):
     the weight stream costs 1 / (share of the CU rounds the grid fills) — the kernel's time
@@ -181,7 +211,7 @@ def _plan_slabs(n_pad: int, k: int, m: int = 32) -> Tuple[int, int, int]:
     the CUs, splits as equal as K allows; every slab is written and read back once (2 m splits / K of the
     weight bytes for m token rows, at half price: it stays on chip); x is fetched once per
     workgroup (m / (32 waves-per-workgroup), likewise)."""
-    ngroups = k // 256
+    ngroups = k // group_cols  # a group = the columns of K one pass of the kernel's register ring covers (2 chunks of 128 by default)
     best: Optional[Tuple[float, int, int, int]] = None
     for nw in (4, 6, 7, 8):
         if n_pad % (16 * nw):
@@ -286,7 +316,10 @@ def _pad_rows(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
 
 
 def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_slabs: bool) -> Union[torch.Tensor, Partial]:
-    if (h.x if isinstance(h, Normed) else h).shape[0] > STREAM_MAX_M and w.k % 64 == 0:
+    rows = (h.x if isinstance(h, Normed) else h).shape[0]
+    if w.bits == 4:
+        return _stream_fp4(w, h, epi, allow_slabs)
+    if rows > STREAM_MAX_M and w.k % 64 == 0:
         return _wide(w, h, epi, allow_slabs)
     C = native()
     ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
@@ -345,6 +378,49 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
             r1 = min(mp, r0 + MAX_M)
             C.stream_gemm(w.wp, w.n_pad, w.k, x[r0:r1], out[r0:r1], epi, ks, 1, nchunks, None if ss is None else ss[r0:r1].contiguous(), eps, w.wscale)
     n_true = w.n // 2 if epi == 2 else w.n
+    if m != mp or n_true != n_out:
+        out = out[:m, :n_true]
+    return out
+
+
+def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_slabs: bool) -> Union[torch.Tensor, Partial]:
+    """MXFP4 weights: the deep-pipeline streaming kernel for every row count — up to 64 rows as
+    the bf16 / FP8 path (split-K slabs where that pays), 65..128 rows in one 8-tile pass, more in
+    128-row passes (the tiled GEMM does not read 4-bit weights)."""
+    C = native()
+    ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
+    x = h.x if isinstance(h, Normed) else h
+    if x.stride(1) != 1 or x.stride(0) % 8:
+        x = x.contiguous()
+    m = x.shape[0]
+    n_out = w.n_pad // 2 if epi == 2 else w.n_pad
+    n_true = w.n // 2 if epi == 2 else w.n
+    if m > 128:
+        out = torch.empty((m, n_true), dtype=torch.bfloat16, device=x.device)
+        for r0 in range(0, m, 128):
+            r1 = min(m, r0 + 128)
+            part = Normed(x[r0:r1], ss[r0:r1].contiguous(), eps) if ss is not None else x[r0:r1]
+            out[r0:r1] = _stream_fp4(w, part, epi, False)
+        return out
+    mp = (m + 15) // 16 * 16 if m <= MAX_M else 128
+    cols = 128  # columns of K per chunk of the kernel's register ring
+    if mp != m:
+        xp = torch.zeros((mp, x.shape[1]), dtype=x.dtype, device=x.device)
+        xp[:m] = x
+        x = xp
+        if ss is not None:
+            ss = torch.cat((ss, torch.ones((mp - m, ss.shape[1]), dtype=ss.dtype, device=ss.device)), 0)
+    if allow_slabs and epi == 0 and m == mp and w.n == w.n_pad:
+        nbs = 4 if (mp <= 32 and w.k % (4 * cols) == 0) else 2
+        nw, splits, gps = _plan_slabs(w.n_pad, w.k, mp, nbs * cols)
+        if splits > 1:
+            out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
+            C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, nbs, splits, gps, None, 0.0, w.wscale, nw, 4)
+            return Partial(out, ss, eps, w.k)
+    # a chunk of 4-bit weights is 1 KB per wave: a ring of 8 keeps as many bytes in flight as 2 chunks of bf16
+    nb = 8 if (mp <= 32 and w.k % (8 * cols) == 0) else 4 if (mp <= 32 and w.k % (4 * cols) == 0) else 2
+    out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
+    C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, nb, 1, w.k // (cols * nb), ss, eps, w.wscale, _waves_per_workgroup(w.n_pad), 4)
     if m != mp or n_true != n_out:
         out = out[:m, :n_true]
     return out

@@ -583,7 +583,8 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--no-graphs", action="store_true", help="disable HIP-graph capture (eager launches)")
     ap.add_argument("--kernels", default="auto", choices=["auto", "hip", "torch"])
     ap.add_argument("--no-prefix-caching", action="store_true")
-    ap.add_argument("--quantization", default=None, choices=[None, "fp8"])
+    ap.add_argument("--quantization", default=None, choices=[None, "fp8", "mxfp4", "int4", "awq", "gptq"],
+                    help="weight-only quantisation at load: fp8 (e4m3, per-row scale) or mxfp4 (OCP microscaling FP4; int4 / awq / gptq select the same 4-bit format)")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8", "fp8_e4m3"], help="fp8: e4m3 KV cache (half the bytes per token, twice the blocks), converted in registers by the attention kernels")
     ap.add_argument("--speculative-model", default=None, help="draft model preset for speculative decoding, or self:<K> (early exit after K layers of the served model)")
     ap.add_argument("--tail-damping", type=float, default=0.0, help="random-init + self:<K> only: damp layers >= K so the early-exit draft agrees with the full model (synthetic)")

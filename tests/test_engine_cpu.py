@@ -654,3 +654,68 @@ def test_llama3_rope_scaling_tables_and_checkpoint_config_check(tmp_path):
     p.write_text(json.dumps({**good, "num_key_value_heads": 4}))
     with pytest.raises(ValueError, match="num_key_value_heads"):
         check_hf_config(str(p), c31)
+
+
+def test_rejection_sampling_reproduces_the_target_distribution():
+    """Monte Carlo over the verifier alone: whatever the draft distribution is, the first emitted
+    token is distributed as the target's p_0 and, given that the first draft was kept, the second
+    as p_1 (Leviathan et al. 2023, theorem 1)."""
+    from kvmini.engine.speculative import rejection_sample
+
+    g = torch.Generator().manual_seed(5)
+    V, k, N = 6, 2, 30000
+    p = torch.softmax(torch.randn(k + 1, V, generator=g) * 1.5, -1)
+    q = torch.softmax(torch.randn(k, V, generator=g) * 1.5, -1)
+    q[0, 2] = 0.0  # a token the draft never proposes
+    q[0] /= q[0].sum()
+    first = torch.zeros(V)
+    second = torch.zeros(V)
+    n_second = 0
+    accepted = 0
+    for _ in range(N):
+        drafts = torch.stack([torch.multinomial(q[i], 1, generator=g).view(()) for i in range(k)])
+        a, tok = rejection_sample(p, q, drafts, g)
+        a, tok = int(a), int(tok)
+        out = drafts[:a].tolist() + [tok]
+        first[out[0]] += 1
+        accepted += a
+        if a >= 1:
+            second[out[1]] += 1
+            n_second += 1
+    assert (first / N - p[0]).abs().sum().item() / 2 < 0.015  # total variation
+    assert (second / n_second - p[1]).abs().sum().item() / 2 < 0.02
+    # expected acceptance of the first draft = sum_x min(p_0, q_0)
+    assert abs(n_second / N - torch.minimum(p[0], q[0]).sum().item()) < 0.015
+    # identical distributions: everything is accepted and the bonus token comes from p_k
+    a, tok = rejection_sample(p, p[:k].clone(), torch.tensor([1, 3]), g)
+    assert int(a) == k and 0 <= int(tok) < V
+
+
+def test_speculative_decoding_with_temperature_uses_rejection_sampling():
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
+    common = dict(model="tiny", device="cpu", dtype="fp32", max_num_seqs=4, max_batched_tokens=64, max_model_len=128, num_blocks=64)
+    prompts = [[1, 5, 9, 200, 31], [1, 77, 4]]
+    eng = LLMEngine(EngineConfig(**common, draft_model="tiny-draft", num_speculative_tokens=3))
+    out = eng.generate(prompts, SamplingParams(max_tokens=20, ignore_eos=True, temperature=0.9, top_p=0.95, seed=7))
+    assert [len(o) for o in out] == [20, 20] and eng.stats.spec_proposed > 0
+    again = LLMEngine(EngineConfig(**common, draft_model="tiny-draft", num_speculative_tokens=3)).generate(prompts, SamplingParams(max_tokens=20, ignore_eos=True, temperature=0.9, top_p=0.95, seed=7))
+    assert again == out  # seeded requests are reproducible through the speculative path too
+    # a draft that IS the target: p == q at every position, so every draft token is kept
+    same = LLMEngine(EngineConfig(**common, draft_model="tiny", num_speculative_tokens=3))
+    same.spec.load_draft_weights(random_weights(get_config("tiny"), "cpu", torch.float32, same.ecfg.seed))
+    out = same.generate(prompts, SamplingParams(max_tokens=21, ignore_eos=True, temperature=1.0))
+    assert [len(o) for o in out] == [21, 21]
+    assert same.stats.spec_accepted == same.stats.spec_proposed > 0
+    assert same.stats.steps < 21  # far fewer target passes than tokens
+    # greedy and sampling requests side by side in one engine
+    mixed = LLMEngine(EngineConfig(**common, draft_model="tiny-draft", num_speculative_tokens=2))
+    seqs = [mixed.make_sequence(prompts[0], SamplingParams(max_tokens=10, ignore_eos=True)), mixed.make_sequence(prompts[1], SamplingParams(max_tokens=10, ignore_eos=True, temperature=0.7))]
+    for s_ in seqs:
+        assert mixed.scheduler.add(s_) is None
+    while mixed.scheduler.has_work():
+        mixed.step()
+    plain = LLMEngine(EngineConfig(**common)).generate([prompts[0]], SamplingParams(max_tokens=10, ignore_eos=True))[0]
+    assert seqs[0].output_ids == plain and len(seqs[1].output_ids) == 10

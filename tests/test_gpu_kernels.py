@@ -1293,3 +1293,91 @@ def test_engine_long_context_decode_takes_the_split_kv_graph_and_matches_eager(k
     assert got[0][:8] == want[0][:8]
     short = eng.generate([[1, 5, 9, 11]], SamplingParams(max_tokens=8, ignore_eos=True))
     assert len(short[0]) == 8
+
+
+# ---------------------------------------------------------------- MXFP4 (4-bit) weights
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32, 64, 20, 100, 128, 300])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (4096, 14336), (256, 256), (1000, 512)])
+def test_stream_gemm_mxfp4_weights(M, N, K):
+    """y = x @ dequant(W_mxfp4)^T against an fp32 matmul with the SAME quantised weights (the
+    tolerance covers accumulation order only): nibble order, E8M0 scales per (row, 32 columns),
+    every row-count path (16..64 rows, padded rows, the 128-row pass, several passes), slabs."""
+    from kvmini.models.llama import dequantize_mxfp4, quantize_mxfp4
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(5)
+    W = (torch.randn(N, K, device=_dev()) * 0.05).bfloat16()
+    W[3] *= 37.0           # blocks with very different scales
+    W[:, 64:96] *= 1e-3
+    W[5, 32:64] = 0.0      # an all-zero block
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    codes, scales = quantize_mxfp4(W)
+    Wdq = dequantize_mxfp4(codes, scales, torch.float32)
+    ref = x.float() @ Wdq.T
+    tol = 1e-2 * ref.abs().max().item() + 1e-2
+    pw = hip_ops.PackedLinear(W, mxfp4=True)
+    assert pw.bits == 4 and pw.wp.dtype == torch.uint8 and pw.wp.numel() * 2 == pw.n_pad * K and pw.wscale.numel() * 128 == pw.n_pad * K
+    y = hip_ops.linear(x, pw)
+    assert y.shape == (M, N)
+    assert (y.float() - ref).abs().max().item() <= tol
+    s = hip_ops.linear(x, pw, allow_slabs=True)
+    got = s.slabs.sum(0) if isinstance(s, hip_ops.Partial) else s.float()
+    assert (got - ref).abs().max().item() <= tol
+    # the quantisation error itself: e2m1 has one mantissa bit (relative step up to 1/3 inside a block)
+    full = x.float() @ W.float().T
+    assert ((ref - full).norm() / full.norm()).item() < 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 48, 200])
+def test_stream_gemm_mxfp4_swiglu_and_folded_norm(M):
+    from kvmini.models.llama import GU_GROUP, dequantize_mxfp4, quantize_mxfp4
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(6)
+    K, I = 1024, 2048
+    W = (torch.randn(2 * I, K, device=_dev()) * 0.04).bfloat16()
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    Wdq = dequantize_mxfp4(*quantize_mxfp4(W), torch.float32)
+    pw = hip_ops.PackedLinear(W, mxfp4=True)
+    ref = torch_ops.swiglu_interleaved((x.float() @ Wdq.T))
+    y = hip_ops.linear_swiglu(x, pw)
+    assert y.shape == (M, I)
+    assert (y.float() - ref.float()).abs().max().item() <= 2e-2 * ref.abs().max().item() + 2e-2
+    # a Normed input: the row scale 1/rms is applied by the epilogue
+    ss = (x.float() ** 2).view(M, -1, 512).sum(-1)
+    yn = hip_ops.linear(hip_ops.Normed(x, ss.contiguous(), 1e-5), pw)
+    refn = (x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)) @ Wdq.T
+    assert (yn.float() - refn).abs().max().item() <= 2e-2 * refn.abs().max().item() + 2e-2
+    assert GU_GROUP > 0
+
+
+@pytest.mark.gpu
+def test_engine_mxfp4_matches_fake_quantised_oracle():
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import fake_quantize_mxfp4, get_config, random_weights
+    from kvmini.models.reference import dense_logits
+
+    cfg = get_config("small-hd128")
+    w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=4)
+    oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=4)
+    proj_bf16 = sum(t.numel() * 2 for lw in oracle.layers for t in (lw.wqkv, lw.wo, lw.wgu, lw.wdown))
+    fake_quantize_mxfp4(oracle)
+    for alias in ("mxfp4", "awq"):  # the reference's 4-bit profile names select the same format
+        eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=512, max_model_len=2048, num_blocks=256, kernels="hip", quantization=alias),
+                        weights=w if alias == "mxfp4" else random_weights(cfg, "cuda:0", torch.bfloat16, seed=4))
+        assert eng.weights.quantization == "mxfp4" and eng.weights.layers[0].wqkv.bits == 4
+    eng.warmup()
+    proj_fp4 = sum(t.wp.numel() + t.wscale.numel() * 4 for lw in eng.weights.layers for t in (lw.wqkv, lw.wo, lw.wgu, lw.wdown))
+    assert proj_fp4 <= 0.27 * proj_bf16, (proj_fp4, proj_bf16)  # 4 bits + one scale byte per 32 weights = 0.266 of bf16
+    prompts = [[1, 50, 60, 70, 80], list(range(1, 30)), [1] + [(7 * i) % 900 + 20 for i in range(299)]]
+    outs = eng.generate(prompts, SamplingParams(max_tokens=8, ignore_eos=True))
+    for p, o in zip(prompts, outs):
+        ids = list(p)
+        for tok in o:
+            lg = dense_logits(oracle, ids)[-1]
+            top = lg.max().item()
+            assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05, (p, o)
+            ids.append(tok)
