@@ -1,5 +1,6 @@
 SHELL := /bin/bash
 PY ?= python3
+CXX ?= g++
 CHART := charts/kserve-vllm-mini
 NS ?= ml-prod
 RELEASE ?= demo
@@ -7,7 +8,7 @@ AIRGAP_DIR ?= airgap-bundle
 
 .PHONY: help demo build build-native native test test-gpu lint fmt fmt-check typecheck yaml-lint validate-configs dashboards \
         helm-lint helm-install-minimal helm-install-with-kvmini helm-install-runtime helm-uninstall helm-package helm-test \
-        airgap airgap-clean airgap-images airgap-charts airgap-wheels airgap-artifacts airgap-docs airgap-dashboards airgap-finalize dev-setup clean
+        airgap airgap-clean airgap-images airgap-charts airgap-wheels airgap-artifacts airgap-docs airgap-dashboards airgap-finalize dev-setup clean sanitize
 
 help: ## Show this help
 	@grep -E '^[a-zA-Z_-]+:.*## ' $(MAKEFILE_LIST) | awk 'BEGIN{FS=":.*## "}{printf "  %-26s %s\n", $$1, $$2}'
@@ -24,6 +25,20 @@ build: ## Build the harness container image
 
 build-native: ## Build the serving image (native engine)
 	docker build -f Dockerfile.native -t kvmini-native:latest .
+
+SAN_DIR := build/sanitize
+SAN_SRC := csrc/amdsmi_sampler.cpp csrc/tests/ring_stress.cpp
+SAN_SECONDS ?= 3
+
+sanitize: ## Host runtime (telemetry sampler ring) under ThreadSanitizer and ASan+UBSan: build + two-thread stress test
+	@mkdir -p $(SAN_DIR)
+	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=thread $(SAN_SRC) -lpthread -ldl -o $(SAN_DIR)/ring_stress_tsan
+	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all $(SAN_SRC) -lpthread -ldl -o $(SAN_DIR)/ring_stress_asan
+	$(CXX) -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined csrc/amdsmi_sampler.cpp -lpthread -ldl -o $(SAN_DIR)/libkvmini_rt_asan.so
+	$(CXX) -std=c++17 -O1 -g -fPIC -shared -fsanitize=thread csrc/amdsmi_sampler.cpp -lpthread -ldl -o $(SAN_DIR)/libkvmini_rt_tsan.so
+	TSAN_OPTIONS=halt_on_error=1 $(SAN_DIR)/ring_stress_tsan $(SAN_SECONDS)
+	ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 $(SAN_DIR)/ring_stress_asan $(SAN_SECONDS)
+	@echo "sanitize: clean"
 
 test: ## CPU test-suite
 	$(PY) -m pytest tests -x -q -m "not gpu"

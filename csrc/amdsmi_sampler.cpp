@@ -4,6 +4,13 @@
 // Python interpreter (the load generator and the engine thread both hold the GIL in bursts
 // and a Python sampler at 10 ms period shows 30-50 ms holes under load).
 //
+// The ring is written by the sampler thread and read by whoever calls kvs_read, with no lock
+// between them: every field is a relaxed atomic word (free on x86-64), the record count `head`
+// is published with release / read with acquire, and a reader that was overtaken while copying
+// (the writer wrapped around onto the oldest records) drops exactly those records.  `make
+// sanitize` runs a two-thread stress test of this protocol under ThreadSanitizer and
+// AddressSanitizer + UBSan (csrc/tests/ring_stress.cpp).
+//
 // libamd_smi.so is opened with dlopen at start-up: a machine without the library (CPU-only
 // CI) can still load this runtime; kvs_start() then returns -2 and the caller falls back.
 // The structs below copy the leading fields of the amdsmi.h definitions this file was
@@ -15,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <dlfcn.h>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -76,17 +84,41 @@ struct Api {
 
 // One record per (tick, gpu): 8 doubles.
 struct Record { double ts_s, gpu, watts, gfx_util, vram_used_bytes, temp_c, sclk_mhz, energy_uj; };
+constexpr int RECORD_WORDS = 8;
+static_assert(sizeof(Record) == RECORD_WORDS * sizeof(double), "a record is 8 doubles");
+
+// Ring slot: the same 8 doubles as bit patterns in atomic words.
+struct Slot {
+  std::atomic<uint64_t> w[RECORD_WORDS];
+  void put(const Record& r) {
+    uint64_t bits[RECORD_WORDS];
+    std::memcpy(bits, &r, sizeof r);
+    for (int i = 0; i < RECORD_WORDS; ++i) w[i].store(bits[i], std::memory_order_relaxed);
+  }
+  void get(double* out) const {
+    uint64_t bits[RECORD_WORDS];
+    for (int i = 0; i < RECORD_WORDS; ++i) bits[i] = w[i].load(std::memory_order_relaxed);
+    std::memcpy(out, bits, sizeof bits);
+  }
+};
 
 struct Sampler {
   Api api;
   std::thread th;
   std::atomic<bool> stop{false};
   std::atomic<uint64_t> head{0};  // records written
-  std::vector<Record> ring;
+  std::unique_ptr<Slot[]> ring;
+  std::atomic<uint64_t> cap{0};  // slots in `ring` (0: none yet)
   std::vector<int> gpu_idx;
   double period_s = 0.05;
   std::mutex mu;
   bool running = false;
+  bool synthetic = false;  // records come from a counter instead of the SMI library (tests, dry runs)
+
+  ~Sampler() {  // a process that exits with the thread still sampling (no kvs_stop) must not abort in std::thread's destructor
+    stop.store(true);
+    if (th.joinable()) th.join();
+  }
 
   static double now_s() {
     using namespace std::chrono;
@@ -116,22 +148,45 @@ struct Sampler {
     if (api.energy && api.energy(h, &acc, &res, &ts) == 0) r->energy_uj = (double)acc * (double)res;
   }
 
+  // Synthetic record number n of gpu gi: every field is a function of n, so a reader can tell a
+  // torn record (fields of two different n) from a whole one.
+  static void synth_one(int gi, uint64_t n, Record* r) {
+    const double x = (double)n;
+    *r = Record{x, (double)gi, 100.0 + x, x * 0.5, x * 1024.0, 40.0 + (double)(n % 50), 2400.0 - (double)(n % 7), x * 3.0};
+  }
+
   void loop() {
     using clock = std::chrono::steady_clock;
     auto next = clock::now();
     const auto period = std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(period_s));
+    const uint64_t n_slots = cap.load(std::memory_order_relaxed);
     while (!stop.load(std::memory_order_relaxed)) {
       for (int gi : gpu_idx) {
         Record r;
-        read_one(gi, &r);
         const uint64_t h = head.load(std::memory_order_relaxed);
-        ring[h % ring.size()] = r;
+        if (synthetic) synth_one(gi, h, &r); else read_one(gi, &r);
+        ring[h % n_slots].put(r);
         head.store(h + 1, std::memory_order_release);
       }
+      if (period_s <= 0.0) continue;  // synthetic stress mode: as fast as the thread can go
       next += period;
       const auto now = clock::now();
       if (next > now) std::this_thread::sleep_until(next); else next = now;
     }
+  }
+
+  void begin(double period, long long capacity) {
+    period_s = period;
+    const uint64_t n = (uint64_t)(capacity < 64 ? 64 : capacity);
+    cap.store(0, std::memory_order_release);  // readers see an empty ring while it is replaced
+    ring.reset(new Slot[n]);
+    for (uint64_t i = 0; i < n; ++i)
+      for (int j = 0; j < RECORD_WORDS; ++j) ring[i].w[j].store(0, std::memory_order_relaxed);
+    head.store(0, std::memory_order_relaxed);
+    cap.store(n, std::memory_order_release);
+    stop.store(false);
+    th = std::thread([this] { loop(); });
+    running = true;
   }
 };
 
@@ -160,12 +215,21 @@ int kvs_start(double period_s, const int* gpus, int n_gpus, long long capacity) 
   if (n_gpus <= 0) for (size_t i = 0; i < g.api.gpus.size(); ++i) g.gpu_idx.push_back((int)i);
   else for (int i = 0; i < n_gpus; ++i) if (gpus[i] >= 0 && gpus[i] < (int)g.api.gpus.size()) g.gpu_idx.push_back(gpus[i]);
   if (g.gpu_idx.empty()) return -3;
-  g.period_s = period_s < 0.001 ? 0.001 : period_s;
-  g.ring.assign((size_t)(capacity < 64 ? 64 : capacity), Record{});
-  g.head.store(0);
-  g.stop.store(false);
-  g.th = std::thread([] { g.loop(); });
-  g.running = true;
+  g.synthetic = false;
+  g.begin(period_s < 0.001 ? 0.001 : period_s, capacity);
+  return 0;
+}
+
+// The same sampler thread and ring fed from a counter instead of the SMI library: `n_gpus` fake
+// devices, record n of a device carries f(n) in every field.  period_s <= 0: no sleep between
+// ticks (stress test).  0 on success, -1 already running.
+int kvs_start_synthetic(double period_s, int n_gpus, long long capacity) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.running) return -1;
+  g.gpu_idx.clear();
+  for (int i = 0; i < (n_gpus < 1 ? 1 : n_gpus); ++i) g.gpu_idx.push_back(i);
+  g.synthetic = true;
+  g.begin(period_s, capacity);
   return 0;
 }
 
@@ -175,14 +239,21 @@ long long kvs_count() { return (long long)g.head.load(std::memory_order_acquire)
 // Copy up to `max_records` of the most recent records (oldest first) into `out`
 // (8 doubles each: ts_s, gpu, watts, gfx_util, vram_used_bytes, temp_c, sclk_mhz, energy_uj).
 long long kvs_read(double* out, long long max_records) {
+  const uint64_t cap = g.cap.load(std::memory_order_acquire);
+  if (cap == 0 || max_records <= 0) return 0;
   const uint64_t h = g.head.load(std::memory_order_acquire);
-  const uint64_t cap = g.ring.size();
-  if (cap == 0) return 0;
   uint64_t n = h < cap ? h : cap;
   if ((long long)n > max_records) n = (uint64_t)max_records;
   const uint64_t first = h - n;
-  for (uint64_t i = 0; i < n; ++i) std::memcpy(out + i * 8, &g.ring[(first + i) % cap], sizeof(Record));
-  return (long long)n;
+  for (uint64_t i = 0; i < n; ++i) g.ring[(first + i) % cap].get(out + i * RECORD_WORDS);
+  // The writer kept going: record i's slot is reused by record i + cap, whose write starts as soon
+  // as head reaches i + cap.  Everything at or below (head now) - cap may be torn: drop it.
+  const uint64_t h2 = g.head.load(std::memory_order_acquire);
+  uint64_t lost = 0;
+  if (h2 >= cap && first <= h2 - cap) lost = h2 - cap - first + 1;
+  if (lost >= n) return 0;
+  if (lost) std::memmove(out, out + lost * RECORD_WORDS, (size_t)(n - lost) * RECORD_WORDS * sizeof(double));
+  return (long long)(n - lost);
 }
 
 int kvs_stop() {

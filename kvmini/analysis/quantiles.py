@@ -19,6 +19,9 @@ Engines:
 
 from __future__ import annotations
 
+import bisect
+import collections
+
 import math
 from typing import Iterable, List, Optional, Sequence
 
@@ -111,7 +114,11 @@ class RollingQuantile:
     """Windowed quantile over the most recent ``window`` observations.
 
     Default ``method='floor'`` reproduces the fairness guard's rolling p95
-    (reference ``scripts/fairness_dual_tenant.py:46-65``)."""
+    (reference ``scripts/fairness_dual_tenant.py:46-65``, which sorts the window on every
+    read).  Here the window is kept twice: a deque in arrival order and a list that stays
+    sorted — an observation enters by binary insertion and the one that falls out of the window
+    leaves by binary search, so ``add`` is O(log w) comparisons (plus the list shift) and
+    ``value`` reads the order statistic directly; nothing is re-sorted per response."""
 
     def __init__(self, window: int = 50, p: float = 0.95, method: str = "floor"):
         if window < 1:
@@ -119,17 +126,21 @@ class RollingQuantile:
         self.window = int(window)
         self.p = float(p)
         self.method = method
-        self._buf: List[float] = []
+        self._fifo: "collections.deque[float]" = collections.deque()
+        self._sorted: List[float] = []
 
     def add(self, x: float) -> None:
-        self._buf.append(float(x))
-        if len(self._buf) > self.window:
-            del self._buf[0 : len(self._buf) - self.window]
+        x = float(x)
+        self._fifo.append(x)
+        bisect.insort(self._sorted, x)
+        if len(self._fifo) > self.window:
+            old = self._fifo.popleft()
+            del self._sorted[bisect.bisect_left(self._sorted, old)]
 
     def value(self) -> Optional[float]:
-        if not self._buf:
+        if not self._sorted:
             return None
-        return percentile(self._buf, self.p, self.method)
+        return _from_sorted(self._sorted, self.p, self.method)
 
     def __len__(self) -> int:
-        return len(self._buf)
+        return len(self._fifo)

@@ -45,6 +45,8 @@ def load() -> Optional[ctypes.CDLL]:
     lib.kvs_gpu_count.restype = ctypes.c_int
     lib.kvs_start.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_longlong]
     lib.kvs_start.restype = ctypes.c_int
+    lib.kvs_start_synthetic.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_longlong]
+    lib.kvs_start_synthetic.restype = ctypes.c_int
     lib.kvs_count.restype = ctypes.c_longlong
     lib.kvs_read.argtypes = [dp, ctypes.c_longlong]
     lib.kvs_read.restype = ctypes.c_longlong
@@ -131,7 +133,10 @@ class NativeSampler:
 
     RECORD = 8  # ts_s, gpu, watts, gfx_util, vram_used_bytes, temp_c, sclk_mhz, energy_uj
 
-    def __init__(self, interval_s: float = 0.05, gpu_indices: Optional[Sequence[int]] = None, capacity: int = 1 << 20):
+    def __init__(self, interval_s: float = 0.05, gpu_indices: Optional[Sequence[int]] = None, capacity: int = 1 << 20, synthetic: int = 0):
+        """``synthetic`` > 0: that many fake GPUs fed from a counter instead of the SMI library
+        (the same thread and ring; for dry runs and tests on machines without an AMD GPU)."""
+        self.synthetic = int(synthetic)
         self.interval_s = max(0.001, float(interval_s))
         self.gpu_indices = list(gpu_indices) if gpu_indices is not None else None
         self.capacity = capacity
@@ -140,14 +145,17 @@ class NativeSampler:
         self._started = False
 
     def working(self) -> bool:
-        return self._lib is not None and native_gpu_count() > 0
+        return self._lib is not None and (self.synthetic > 0 or native_gpu_count() > 0)
 
     def start(self) -> "NativeSampler":
         if not self.working():
             raise RuntimeError("native telemetry runtime unavailable (library missing or no AMD GPU visible)")
         idx = self.gpu_indices or []
         arr = (ctypes.c_int * max(1, len(idx)))(*idx)
-        rc = self._lib.kvs_start(self.interval_s, arr, len(idx), self.capacity)
+        if self.synthetic > 0:
+            rc = self._lib.kvs_start_synthetic(self.interval_s, self.synthetic, self.capacity)
+        else:
+            rc = self._lib.kvs_start(self.interval_s, arr, len(idx), self.capacity)
         if rc != 0:
             raise RuntimeError(f"kvs_start failed: {rc}")
         self._started = True
@@ -174,7 +182,7 @@ class NativeSampler:
         return self.samples
 
     def to_power_json(self) -> Dict[str, Any]:
-        return {"samples": self.samples, "interval_s": self.interval_s, "source": "amd-smi (native sampler thread)"}
+        return {"samples": self.samples, "interval_s": self.interval_s, "source": "synthetic (native sampler thread)" if self.synthetic else "amd-smi (native sampler thread)"}
 
 
 def records_to_samples(rec: np.ndarray) -> List[Dict[str, Any]]:

@@ -127,3 +127,25 @@ def test_analyze_run_with_fake_cluster(tmp_path):
 def test_alias_keys_do_not_clobber_with_none():
     r = add_alias_keys({"p95_ms": 10.0, "requests": {"total": 1, "success": 1}, "avg_ttft_ms": 3.0})
     assert r["avg_ttft_ms"] == 3.0 and r["p95_latency_ms"] == 10.0
+
+
+def test_rolling_quantile_incremental_equals_resorting_the_window():
+    """The windowed quantile kept by insertion / removal equals sorting the last `window`
+    observations on every read (what the reference's RollingP95 does,
+    scripts/fairness_dual_tenant.py:46-65), duplicates and all three definitions included."""
+    import random
+
+    from kvmini.analysis.quantiles import RollingQuantile, percentile
+
+    rng = random.Random(3)
+    for method in ("floor", "linear", "nearest_rank"):
+        for window in (1, 7, 50):
+            rq = RollingQuantile(window=window, p=0.95, method=method)
+            seen = []
+            assert rq.value() is None and len(rq) == 0
+            for i in range(400):
+                x = float(rng.choice([1, 2, 2, 3, 5, 8, 13])) if i % 3 else rng.random() * 100
+                rq.add(x)
+                seen.append(x)
+                assert rq.value() == percentile(seen[-window:], 0.95, method)
+                assert len(rq) == min(window, len(seen))
