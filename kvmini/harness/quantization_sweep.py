@@ -138,8 +138,11 @@ class QuantizationSweepRunner:
             ns = argparse.Namespace(local_server=self.local, port=self.port, model_name=b["model"] if self.local == "native" else None, service=self.service_name(config), namespace=b["namespace"], profile=None, timeout=900.0)
             if self.local == "native":
                 ns.serve_args = ["--max-model-len", str(config.get("max_model_len", 2048))]
-                if config.get("quantization") == "fp8":
-                    ns.serve_args += ["--quantization", "fp8"]
+                q = str(config.get("quantization", "none") or "none")
+                if q in ("fp8", "mxfp4", "int4", "awq", "gptq"):  # the native engine's weight formats (4-bit names all select MXFP4)
+                    ns.serve_args += ["--quantization", q]
+                if config.get("max_num_seqs"):
+                    ns.serve_args += ["--max-num-seqs", str(config["max_num_seqs"])]
                 if str(config.get("kv_cache_dtype", "auto")).startswith("fp8"):
                     ns.serve_args += ["--kv-cache-dtype", "fp8"]
             info = start_local_server(ns)

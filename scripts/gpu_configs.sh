@@ -1,7 +1,7 @@
 #!/bin/bash
 # The benchmark configurations of BASELINE.json on ONE MI355X box, through the harness CLI
 # (native server + load generator + analyzer + cost + reports).  Artifacts: gpurun_out/configs/.
-# Usage: scripts/gpu_configs.sh [headline] [grid] [quant] [70b] [ab] [spec] [probes] [build]   (default: all but probes and build)
+# Usage: scripts/gpu_configs.sh [headline] [grid] [quant] [70b] [ab] [spec] [probes] [build] [structured]   (default: all but probes, build and structured)
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
@@ -79,6 +79,16 @@ probes)    # prefix-cache probe, OpenAI parity matrix and the fairness guard aga
   timeout -k 10 200 python -m kvmini fairness --url http://127.0.0.1:8108 --model "$MODEL" --max-tokens 64 --tenant-a-requests 200 --tenant-b-requests 600 --tenant-a-concurrency 8 \
     --tenant-b-concurrency 40 --p95-budget-ms 280 --run-dir "$OUT/fairness" > "$OUT/fairness.log" 2>&1
   tail -12 "$OUT/fairness.log"
+  stop_server ;;
+structured) # the structured-output and tool-calling profiles (guided JSON on the device) and the capability matrix
+  start_server structured 8110 --model "$MODEL" --max-num-seqs 32 || exit 1
+  for prof in structured-output tool-calling; do
+    timeout -k 10 400 python -m kvmini bench --profile "$prof" --url http://127.0.0.1:8110 --model "$MODEL" --service structured --namespace local --cluster-backend local \
+      --report --run-dir "$OUT/$prof" > "$OUT/$prof.log" 2>&1 || { tail -30 "$OUT/$prof.log"; exit 1; }
+    tail -14 "$OUT/$prof.log"
+  done
+  timeout -k 10 120 python -m kvmini parity --url http://127.0.0.1:8110 --model "$MODEL" --out "$OUT/parity/capability_matrix.json" --html "$OUT/parity/capability_matrix.html" > "$OUT/parity.log" 2>&1
+  tail -8 "$OUT/parity.log"
   stop_server ;;
 build)     # engine "build" (start -> healthy: weight re-ordering, KV sizing, graph capture) vs served performance, per engine profile
   for prof in profiles/engine/*.yaml; do
