@@ -66,7 +66,8 @@ int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, 
                  hipStream_t stream);
 int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int target_wgs, int* groups_per_split);
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
-                    int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int weight_bits, hipStream_t stream);
+                    int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int weight_bits, void* residual, int has_residual,
+                    float* ss_out, int* counters, hipStream_t stream);
 int kv_prefetch(const void* p, long long bytes, int workgroups, unsigned int* sink, hipStream_t stream);
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
@@ -460,7 +461,8 @@ std::pair<int64_t, int64_t> stream_gemm3_plan(int64_t N, int64_t K, int64_t nb, 
 }
 
 void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t nb, int64_t splits, int64_t groups_per_split,
-                  c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale, int64_t nw, int64_t weight_bits) {
+                  c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale, int64_t nw, int64_t weight_bits,
+                  c10::optional<at::Tensor> residual, bool has_residual, c10::optional<at::Tensor> ss_out, c10::optional<at::Tensor> counters) {
   CHECK_DEV(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
   const float* wsp = nullptr;
   if (weight_bits == 4) {
@@ -488,10 +490,25 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
   int parts = 0;
   const float* ssp = ss_ptr(row_ss, M, &parts);
   long long ldy = 0, slab_stride = 0;
-  if (epi == 1) {
+  void* resp = nullptr;
+  float* ssop = nullptr;
+  int* cntp = nullptr;
+  if (epi == 1 || epi == 3) {
     TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && out.dim() == 3 && out.size(0) == splits && out.size(1) == M && out.size(2) == N,
                 "slab output must be contiguous fp32 [splits, M, N]");
     ldy = N; slab_stride = M * N;
+    if (epi == 3) {
+      // residual epilogue: residual bf16 [M, N] in/out, ss_out fp32 [M, N / (16 nw)], counters int32 (>= N / (16 nw), zero at rest)
+      TORCH_CHECK(residual.has_value() && ss_out.has_value() && counters.has_value(), "the residual epilogue needs residual, ss_out and counters");
+      const at::Tensor &rs = *residual, &so = *ss_out, &ct = *counters;
+      CHECK_DEV(rs); CHECK_BF16(rs); CHECK_CONTIG(rs); CHECK_DEV(so); CHECK_CONTIG(so); CHECK_DEV(ct); CHECK_CONTIG(ct);
+      const int64_t groups = N / (16 * nw);
+      TORCH_CHECK(rs.dim() == 2 && rs.size(0) == M && rs.size(1) == N, "residual must be bf16 [M, N]");
+      TORCH_CHECK(so.scalar_type() == at::kFloat && so.numel() == M * groups, "ss_out must be fp32 [M, N / (16 nw)]");
+      TORCH_CHECK(ct.scalar_type() == at::kInt && ct.numel() >= groups, "counters must be int32 with one entry per feature group");
+      TORCH_CHECK(M <= 64, "the residual epilogue serves up to 64 rows");
+      resp = rs.data_ptr(); ssop = (float*)so.data_ptr(); cntp = (int*)ct.data_ptr();
+    }
   } else {
     CHECK_BF16(out);
     TORCH_CHECK(out.dim() == 2 && out.size(0) == M && out.size(1) == (epi == 2 ? N / 2 : N) && out.stride(1) == 1 && out.stride(0) % 4 == 0, "bad output shape");
@@ -499,7 +516,7 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
     ldy = out.stride(0);
   }
   check(kv_stream_gemm3(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)nb, (int)nw, (int)splits,
-                        (int)groups_per_split, slab_stride, ssp, parts, (float)eps, wsp, (int)weight_bits, cur_stream()),
+                        (int)groups_per_split, slab_stride, ssp, parts, (float)eps, wsp, (int)weight_bits, resp, has_residual ? 1 : 0, ssop, cntp, cur_stream()),
         "kv_stream_gemm3");
 }
 
@@ -687,7 +704,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pack_weight_fp8", &pack_weight_fp8);
   m.def("stream_gemm3_plan", &stream_gemm3_plan, py::arg("N"), py::arg("K"), py::arg("nb"), py::arg("max_splits"), py::arg("target_wgs") = 512, py::arg("nw") = 4);
   m.def("stream_gemm3", &stream_gemm3, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("nb"), py::arg("splits"),
-        py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4, py::arg("weight_bits") = 0);
+        py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4, py::arg("weight_bits") = 0,
+        py::arg("residual") = py::none(), py::arg("has_residual") = true, py::arg("ss_out") = py::none(), py::arg("counters") = py::none());
   m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);

@@ -1193,36 +1193,35 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     if (direct) {
       orow[i] = f2bf(den > 0.f ? num / den * v_scale : 0.f);
     } else {
-      // partials cross XCDs (each has its own L2): the device-scope release fence below writes
-      // them back before the arrival is counted, the merging workgroup's acquire fence drops
-      // its stale lines
-      part_o[(pbase + z) * (REP * HD) + i] = num;
+      // partials cross XCDs (each has its own L2): device-scope stores write through and the
+      // merging workgroup reads with device-scope loads, so no cache write-back / invalidate
+      // (a walk over the whole L2 per workgroup) is needed around the arrival counter
+      __hip_atomic_store(part_o + (pbase + z) * (REP * HD) + i, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d == 0) {
-        part_ml[((pbase + z) * REP + h) * 2] = m;
-        part_ml[((pbase + z) * REP + h) * 2 + 1] = den;
+        __hip_atomic_store(part_ml + ((pbase + z) * REP + h) * 2, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part_ml + ((pbase + z) * REP + h) * 2 + 1, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
   if constexpr (SPLIT) {
     if (direct) return;
     __shared__ int is_last;
-    __threadfence();  // this workgroup's partial is out before its arrival is counted
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the write-through stores of this wave have completed ...
+    __syncthreads();                                        // ... of every wave, before the arrival is counted
     if (tid == 0) {
-      const int arrived = __hip_atomic_fetch_add(counters + t * nkv + g, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const int arrived = __hip_atomic_fetch_add(counters + t * nkv + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       is_last = arrived == eff - 1;
       if (is_last) __hip_atomic_store(counters + t * nkv + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();  // acquire: the other workgroups' partials, released before their arrival, are visible now
     __shared__ float w_lds[REP][64];  // per head: weight of every split, 1 / total
     for (int k = tid; k < REP * 64; k += NT) {  // one wave per head (NT is a multiple of 64: h is uniform in a wave)
       const int h = k >> 6, s2 = k & 63;
       float m = -1e30f, den = 0.f;
       if (s2 < eff) {
-        m = part_ml[((pbase + s2) * REP + h) * 2];
-        den = part_ml[((pbase + s2) * REP + h) * 2 + 1];
+        m = __hip_atomic_load(part_ml + ((pbase + s2) * REP + h) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        den = __hip_atomic_load(part_ml + ((pbase + s2) * REP + h) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       float mx = m;
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1238,10 +1237,13 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       float num = 0.f;
       int s2 = 0;
       for (; s2 + 4 <= eff; s2 += 4) {
-        const float a0 = po[(long long)(s2 + 0) * (REP * HD)], a1 = po[(long long)(s2 + 1) * (REP * HD)], a2 = po[(long long)(s2 + 2) * (REP * HD)], a3 = po[(long long)(s2 + 3) * (REP * HD)];
+        const float a0 = __hip_atomic_load(po + (long long)(s2 + 0) * (REP * HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float a1 = __hip_atomic_load(po + (long long)(s2 + 1) * (REP * HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float a2 = __hip_atomic_load(po + (long long)(s2 + 2) * (REP * HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float a3 = __hip_atomic_load(po + (long long)(s2 + 3) * (REP * HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         num += a0 * w_lds[h][s2] + a1 * w_lds[h][s2 + 1] + a2 * w_lds[h][s2 + 2] + a3 * w_lds[h][s2 + 3];
       }
-      for (; s2 < eff; ++s2) num += po[(long long)s2 * (REP * HD)] * w_lds[h][s2];
+      for (; s2 < eff; ++s2) num += __hip_atomic_load(po + (long long)s2 * (REP * HD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w_lds[h][s2];
       orow[i] = f2bf(num * v_scale);
     }
   }

@@ -43,7 +43,15 @@ __device__ inline unsigned short f2bf(float f) {
 typedef __attribute__((ext_vector_type(4))) unsigned int raw16;  // one 16-byte weight load
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
-enum Epilogue { EPI_BF16 = 0, EPI_SLAB = 1, EPI_SWIGLU = 2 };
+// EPI_RESID: split-K slabs as EPI_SLAB, then the LAST workgroup of a feature group to arrive folds
+// them into the residual stream (residual' = bf16(residual + bf16(sum of slabs)), sums of squares
+// of residual' per row) — the residual add + RMSNorm statistics without a kernel of their own.
+enum Epilogue { EPI_BF16 = 0, EPI_SLAB = 1, EPI_SWIGLU = 2, EPI_RESID = 3 };
+
+// What EPI_RESID needs besides the slabs: the residual stream (bf16 [M, N], updated in place;
+// has_residual = 0: treated as zero), the per-row partial sums of squares it leaves for the next
+// projection ([M][feature groups]) and one arrival counter per feature group (zero at rest).
+struct ResidArgs { unsigned short* residual; int has_residual; float* ss_out; int* counters; };
 
 // A fragment for k-step u out of the raw weight registers.  bf16: one 16-byte load per
 // k-step.  FP8 (OCP e4m3, weight-only): one 16-byte load carries TWO k-steps (8 bytes each);
@@ -100,7 +108,7 @@ __device__ inline void gemm_epilogue(frag_cd (&acc)[MT], unsigned char* lds_raw,
   }
   // Folded RMSNorm: x is the un-normalised residual stream and W carries the norm gain,
   // so rows are scaled by 1/rms(x[m]) here (slabs are scaled by their consumer).
-  if (EPI != EPI_SLAB && row_ss != nullptr) {
+  if (EPI != EPI_SLAB && EPI != EPI_RESID && row_ss != nullptr) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
       float ssum = 0.f;
@@ -114,6 +122,15 @@ __device__ inline void gemm_epilogue(frag_cd (&acc)[MT], unsigned char* lds_raw,
     float* o = reinterpret_cast<float*>(out) + (long long)blockIdx.y * slab_stride;
 #pragma unroll
     for (int j = 0; j < MT; ++j) *reinterpret_cast<frag_cd*>(o + (long long)(j * 16 + r) * ldy + n_base) = acc[j];
+  } else if (EPI == EPI_RESID) {
+    // These slabs are read back by ANOTHER workgroup of this launch, possibly on another XCD (own
+    // L2): device-scope stores write through, so no cache write-back is needed before the arrival
+    // is counted (a release fence would walk the whole L2 once per workgroup: measured +60 us per call).
+    float* o = reinterpret_cast<float*>(out) + (long long)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) __hip_atomic_store(o + (long long)(j * 16 + r) * ldy + n_base + e, acc[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else if (EPI == EPI_BF16) {
     unsigned short* o = reinterpret_cast<unsigned short*>(out);
 #pragma unroll
@@ -248,7 +265,7 @@ template <int MT, int KS, int NB, int EPI, int WB, bool NT, int NW>
 __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
                                                            long long ldx, long long ldy, int groups_per_split, long long slab_stride,
                                                            const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps,
-                                                           const float* __restrict__ w_scale) {
+                                                           const float* __restrict__ w_scale, ResidArgs ra) {
   constexpr bool W8 = WB == 8, W4 = WB == 4;
   static_assert(!W4 || KS % 4 == 0, "an MXFP4 load carries four k-steps");
   constexpr int AL = W4 ? KS / 4 : W8 ? KS / 2 : KS;
@@ -334,11 +351,57 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
 #undef KV_CONSUME
 
   gemm_epilogue<MT, EPI, W8>(acc, lds_raw, out, tile, wave, lane, ldy, slab_stride, row_ss, ss_parts, inv_k, eps, w_scale);
+
+  if constexpr (EPI == EPI_RESID) {
+    // ---- fix-up by the last split of this feature group (16 * NW features x 16 * MT rows)
+    constexpr int GC = 16 * NW, ROWS = 16 * MT, NTH = 64 * NW;
+    __shared__ int is_last;
+    float* ss_lds = reinterpret_cast<float*>(lds_raw);  // the x staging area is free once every wave is past its last chunk
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every write-through store of this wave has completed ...
+    __syncthreads();                                        // ... of every wave, before the arrival is counted
+    if (tid == 0) {
+      const int arrived = __hip_atomic_fetch_add(ra.counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = arrived == (int)gridDim.y - 1;
+      if (is_last) __hip_atomic_store(ra.counters + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    if (tid < ROWS) ss_lds[tid] = 0.f;
+    __syncthreads();
+    if (!is_last) return;
+    const float* slab0 = reinterpret_cast<const float*>(out);  // read with device-scope loads: past this XCD's L2
+    const long long col0 = (long long)blockIdx.x * GC;
+    const int n_splits = (int)gridDim.y;
+    for (int idx = tid; idx < ROWS * (GC / 4); idx += NTH) {
+      const int t = idx / (GC / 4), c4 = (idx % (GC / 4)) * 4;
+      const long long off = (long long)t * ldy + col0 + c4;
+      frag_cd a = (frag_cd){0.f, 0.f, 0.f, 0.f};
+      for (int sidx = 0; sidx < n_splits; ++sidx) {  // slab order: the sum does not depend on who arrived last
+        const float* sp = slab0 + (long long)sidx * slab_stride + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += __hip_atomic_load(sp + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      us4 c;
+      float ssq = 0.f;
+      us4 b = (us4){0, 0, 0, 0};
+      if (ra.has_residual) b = *reinterpret_cast<const us4*>(ra.residual + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = __uint_as_float(((unsigned int)f2bf(a[e])) << 16) + __uint_as_float(((unsigned int)b[e]) << 16);
+        c[e] = f2bf(v);
+        const float f = __uint_as_float(((unsigned int)c[e]) << 16);
+        ssq += f * f;
+      }
+      *reinterpret_cast<us4*>(ra.residual + off) = c;
+      atomicAdd(&ss_lds[t], ssq);
+    }
+    __syncthreads();
+    if (tid < ROWS) ra.ss_out[(long long)tid * gridDim.x + blockIdx.x] = ss_lds[tid];
+  }
 }
 
 struct Args {
   const void* Wp; const void* x; void* out; int N, K; long long ldx, ldy; int splits, cps; long long slab_stride;
   const float* row_ss; int ss_parts; float eps; const float* w_scale; hipStream_t stream;
+  ResidArgs ra{nullptr, 0, nullptr, nullptr};
 };
 
 template <int MT, int KS, int EPI, bool W8>
@@ -375,7 +438,7 @@ template <int MT, int NB, int EPI, int WB, bool NT, int NW>
 int launch3(const Args& a) {
   dim3 grid(a.N / (16 * NW), a.splits), block(NW * 64);
   hipLaunchKernelGGL((stream_gemm3_kernel<MT, chunk_ksteps(MT, WB), NB, EPI, WB, NT, NW>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
-                     a.slab_stride, a.row_ss, a.ss_parts, 1.f / (float)a.K, a.eps, a.w_scale);
+                     a.slab_stride, a.row_ss, a.ss_parts, 1.f / (float)a.K, a.eps, a.w_scale, a.ra);
   return (int)hipGetLastError();
 }
 
@@ -385,6 +448,9 @@ int dispatch3_epi(int epi, const Args& a) {
     case EPI_BF16: return launch3<MT, NB, EPI_BF16, WB, NT, NW>(a);
     case EPI_SLAB: return launch3<MT, NB, EPI_SLAB, WB, NT, NW>(a);
     case EPI_SWIGLU: return launch3<MT, NB, EPI_SWIGLU, WB, NT, NW>(a);
+    case EPI_RESID:
+      if constexpr (MT <= 4) return launch3<MT, NB, EPI_RESID, WB, NT, NW>(a);
+      return -1;
   }
   return -1;
 }
@@ -526,7 +592,7 @@ int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int targe
 
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int weight_bits,
-                    hipStream_t stream) {
+                    void* residual, int has_residual, float* ss_out, int* counters, hipStream_t stream) {
   // weight_bits: 16, 8 (w_scale = fp32 per-row scales), 4 (MXFP4; w_scale = packed E8M0 block scales) or 0 = 8 if w_scale else 16
   const int wb = weight_bits ? weight_bits : (w_scale != nullptr ? 8 : 16);
   if ((wb != 16 && wb != 8 && wb != 4) || ((wb != 16) != (w_scale != nullptr))) return -1;
@@ -535,10 +601,12 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
   if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4 && nb != 8) || (K % (chunk_cols * nb))) return -1;
   if (wide && nb != 2) return -1;
   if (epi == EPI_SWIGLU && (N & 15)) return -1;
-  if (epi != EPI_SLAB && splits != 1) return -1;
+  if (epi != EPI_SLAB && epi != EPI_RESID && splits != 1) return -1;
+  if (epi == EPI_RESID && (!residual || !ss_out || !counters || M > 64 || ldy != N)) return -1;
   const int ngroups = K / (chunk_cols * nb);
   if (splits < 1 || groups_per_split < 1 || (long long)splits * groups_per_split < ngroups || (long long)(splits - 1) * groups_per_split >= ngroups) return -1;
-  const Args a{Wp, x, out, N, K, ldx, ldy, splits, groups_per_split, slab_stride, row_ss, ss_parts, eps, w_scale, stream};
+  Args a{Wp, x, out, N, K, ldx, ldy, splits, groups_per_split, slab_stride, row_ss, ss_parts, eps, w_scale, stream};
+  a.ra = ResidArgs{(unsigned short*)residual, has_residual, ss_out, counters};
   switch (M >> 4) {
     case 1: return dispatch3_wb<1>(epi, nb, nw, wb, a);
     case 2: return dispatch3_wb<2>(epi, nb, nw, wb, a);

@@ -304,8 +304,10 @@ class ModelRunner:
         x = ops.embed_tokens(w.embed, tokens, self._dev("feed", t_pad), self.out_ids)
         residual = None  # the first residual add is a copy
         pending_reduce = False  # x is a row-parallel projection's partial output that still has to be summed over the TP ranks
+        h = None  # set when a projection already folded its output into the residual stream (fused epilogue)
         for li, lw in enumerate(w.layers):
-            h, residual = self._add_rmsnorm(x, residual, lw.attn_norm, pending_reduce)
+            if h is None:
+                h, residual = self._add_rmsnorm(x, residual, lw.attn_norm, pending_reduce)
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             kw = {"kv_scale": self.kv_scale[li]} if self.kv_fp8 else {}
@@ -319,16 +321,36 @@ class ModelRunner:
             else:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks, **kw)
-            x = ops.linear(a, lw.wo, allow_slabs=True)
-            h, residual = self._add_rmsnorm(x, residual, lw.mlp_norm, True)
+            h, residual = self._proj_residual(a, lw.wo, residual, lw.mlp_norm)
             act = ops.linear_swiglu(h, lw.wgu)
-            x = ops.linear(act, lw.wdown, allow_slabs=True)
-            pending_reduce = True
-        h, residual = self._add_rmsnorm(x, residual, w.final_norm, pending_reduce)
+            fused = self._fused_residual(act, lw.wdown, residual)
+            if fused is not None:
+                h, residual = fused
+            else:
+                h = None
+                x = ops.linear(act, lw.wdown, allow_slabs=True)
+                pending_reduce = True
+        if h is None:
+            h, residual = self._add_rmsnorm(x, residual, w.final_norm, pending_reduce)
         hs = ops.select_rows(h, sample_idx[: self.sample_rows(t_pad)])
         logits = ops.linear(hs, w.lm_head)
         self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
         return logits
+
+    def _fused_residual(self, x: torch.Tensor, w: Any, residual: Optional[torch.Tensor]) -> Optional[Tuple[Any, torch.Tensor]]:
+        """Row-parallel projection + residual update + RMSNorm statistics in one launch, where the
+        ops have it (HIP: split-K GEMM whose last workgroup per feature group folds the slabs into
+        the residual) and no cross-rank sum has to happen in between."""
+        fn = getattr(self.ops, "linear_residual", None)
+        if fn is None or self.tp_active or residual is None:
+            return None
+        return fn(x, w, residual, self.cfg.rms_eps)
+
+    def _proj_residual(self, x: torch.Tensor, w: Any, residual: torch.Tensor, norm_w: torch.Tensor) -> Tuple[Any, torch.Tensor]:
+        fused = self._fused_residual(x, w, residual)
+        if fused is not None:
+            return fused
+        return self._add_rmsnorm(self.ops.linear(x, w, allow_slabs=True), residual, norm_w, True)
 
     def _add_rmsnorm(self, x: Any, residual: Optional[torch.Tensor], norm_w: torch.Tensor, partial: bool) -> Tuple[Any, torch.Tensor]:
         """Residual update + norm in front of a projection.  ``partial``: ``x`` is this rank's

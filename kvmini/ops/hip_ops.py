@@ -426,6 +426,41 @@ def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow
     return out
 
 
+_resid_counters: Dict[Any, torch.Tensor] = {}
+FUSE_RESIDUAL = os.environ.get("KVMINI_FUSE_RESIDUAL", "0") == "1"  # measured slower than the two-kernel path (see linear_residual): off unless asked for
+
+
+def linear_residual(x: torch.Tensor, w: Weight, residual: torch.Tensor, eps: float) -> Optional[Tuple[Normed, torch.Tensor]]:
+    """``residual += x @ W^T`` plus the sums of squares of the new residual rows, in ONE launch:
+    the split-K streaming GEMM writes its slabs and the last workgroup of each feature group to
+    finish folds them into ``residual`` (bf16, in place) — the separate residual / RMSNorm-statistics
+    kernel between a row-parallel projection and the next one disappears.  Returns
+    ``(Normed(residual, ss, eps), residual)``, or None when the step is outside what the fused
+    epilogue serves (more than 64 rows, rows not a multiple of 16, padded features, 4-bit weights):
+    the caller then runs the projection and the residual update separately."""
+    if not FUSE_RESIDUAL or not isinstance(w, PackedLinear) or isinstance(x, Normed) or w.bits == 4:
+        return None
+    m = x.shape[0]
+    if m > MAX_M or m % 16 or w.n != w.n_pad or w.k % 256 or residual is None or residual.shape != (m, w.n):
+        return None
+    if x.stride(1) != 1 or x.stride(0) % 8:
+        x = x.contiguous()
+    nw, splits, gps = _plan_slabs(w.n_pad, w.k, m)
+    dev = x.device
+    cnt = _resid_counters.get(dev)
+    if cnt is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        cnt = _resid_counters[dev] = torch.zeros(4096, dtype=torch.int32, device=dev)
+    groups = w.n_pad // (16 * nw)
+    if groups > cnt.numel():
+        return None
+    slabs = torch.empty((splits, m, w.n_pad), dtype=torch.float32, device=dev)
+    ss = torch.empty((m, groups), dtype=torch.float32, device=dev)
+    native().stream_gemm3(w.wp, w.n_pad, w.k, x, slabs, 3, 2, splits, gps, None, 0.0, w.wscale, nw, 0, residual, True, ss, cnt)
+    return Normed(residual, ss, eps), residual
+
+
 def add_rmsnorm(x: Union[torch.Tensor, Partial], residual: Optional[torch.Tensor], w: torch.Tensor, eps: float) -> Tuple[Normed, torch.Tensor]:
     """Residual update of the folded-norm pipeline.  ``x``: bf16 ``[T, H]`` or a
     :class:`Partial` (split-K slabs of the previous projection); ``residual``: bf16

@@ -1381,3 +1381,38 @@ def test_engine_mxfp4_matches_fake_quantised_oracle():
             top = lg.max().item()
             assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05, (p, o)
             ids.append(tok)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32, 64])
+@pytest.mark.parametrize("N,K,fp8", [(4096, 4096, False), (4096, 14336, False), (2048, 8192, False), (4096, 4096, True), (256, 256, False)])
+def test_linear_residual_epilogue_is_bit_equal_to_the_two_kernel_path(M, N, K, fp8):
+    """Split-K GEMM whose last workgroup folds the slabs into the residual == the same GEMM
+    followed by residual_reduce: same slab order, same roundings, so bit-equal residual and (up to
+    the grouping of the partial sums) equal sums of squares; repeated calls reuse the counters."""
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(12)
+    W = (torch.randn(N, K, device=_dev()) * 0.03).bfloat16()
+    pw = hip_ops.PackedLinear(W, fp8=fp8)
+    for rep in range(3):
+        x = torch.randn(M, K, device=_dev()).bfloat16()
+        res0 = torch.randn(M, N, device=_dev()).bfloat16()
+        want_res = res0.clone()
+        part = hip_ops.linear(x, pw, allow_slabs=True)
+        normed_ref, _ = hip_ops.add_rmsnorm(part, want_res, torch.ones(N, device=_dev(), dtype=torch.bfloat16), 1e-5)
+        got_res = res0.clone()
+        out = hip_ops.linear_residual(x, pw, got_res, 1e-5)
+        assert out is not None
+        normed, r2 = out
+        assert r2 is got_res and normed.x is got_res
+        if isinstance(part, hip_ops.Partial):  # same split plan on both sides: bit-equal
+            assert torch.equal(got_res, want_res)
+        else:
+            assert (got_res.float() - want_res.float()).abs().max().item() <= 2e-2 * want_res.float().abs().max().item()
+        ss_ref = (got_res.float() ** 2).sum(-1)
+        assert torch.allclose(normed.ss.sum(-1), ss_ref, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(normed_ref.ss.sum(-1), normed.ss.sum(-1), rtol=1e-4, atol=1e-3)
+    torch.cuda.synchronize()
+    assert int(hip_ops._resid_counters[_dev()].abs().sum()) == 0
+    assert hip_ops.linear_residual(torch.randn(20, K, device=_dev()).bfloat16(), pw, torch.zeros(20, N, device=_dev(), dtype=torch.bfloat16), 1e-5) is None  # 20 rows: not served
