@@ -8,7 +8,7 @@ AIRGAP_DIR ?= airgap-bundle
 
 .PHONY: help demo build build-native native test test-gpu lint fmt fmt-check typecheck yaml-lint validate-configs dashboards \
         helm-lint helm-install-minimal helm-install-with-kvmini helm-install-runtime helm-uninstall helm-package helm-test \
-        airgap airgap-clean airgap-images airgap-charts airgap-wheels airgap-artifacts airgap-docs airgap-dashboards airgap-finalize dev-setup clean sanitize
+        airgap airgap-clean airgap-images airgap-charts airgap-wheels airgap-artifacts airgap-docs airgap-dashboards airgap-finalize dev-setup clean sanitize docs
 
 help: ## Show this help
 	@grep -E '^[a-zA-Z_-]+:.*## ' $(MAKEFILE_LIST) | awk 'BEGIN{FS=":.*## "}{printf "  %-26s %s\n", $$1, $$2}'
@@ -65,6 +65,9 @@ yaml-lint: ## Parse every YAML file outside Helm templates
 
 validate-configs: ## Validate profiles, cost file, SLO file, reference matrix, chart values vs schema
 	$(PY) -m kvmini validate --all
+
+docs: ## Static documentation site from README + docs/ (site/index.html)
+	$(PY) -m kvmini docs-site --out site
 
 dashboards: ## Regenerate dashboards/*.json
 	$(PY) -m kvmini.report.dashboards --out dashboards

@@ -54,6 +54,7 @@ COMMANDS: Dict[str, Tuple[str, str, str]] = {
     "spec-delta": ("kvmini.harness.spec_delta", "main", "speculative decoding TTFT / inter-token delta report"),
     "quality": ("kvmini.harness.quality", "main", "quality mini-eval + Pareto bucket"),
     "telemetry": ("kvmini.parallel.telemetry_daemon", "main", "lock-step multi-GPU telemetry over RCCL"),
+    "docs-site": ("kvmini.report.docsite", "main", "render README + docs/ into a static documentation site"),
     # servers
     "serve": ("kvmini.server.native", "main", "native MI355X OpenAI-compatible server"),
     "router": ("kvmini.server.router", "main", "data-parallel front-end over N engine replicas"),
