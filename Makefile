@@ -28,16 +28,19 @@ build-native: ## Build the serving image (native engine)
 
 SAN_DIR := build/sanitize
 SAN_SRC := csrc/amdsmi_sampler.cpp csrc/tests/ring_stress.cpp
+SAN_HOST := csrc/host_routines.cpp csrc/tests/host_routines_check.cpp
 SAN_SECONDS ?= 3
 
-sanitize: ## Host runtime (telemetry sampler ring) under ThreadSanitizer and ASan+UBSan: build + two-thread stress test
+sanitize: ## Host runtime (sampler ring, analysis routines) under ThreadSanitizer and ASan+UBSan: build + stress / self-check
 	@mkdir -p $(SAN_DIR)
 	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=thread $(SAN_SRC) -lpthread -ldl -o $(SAN_DIR)/ring_stress_tsan
 	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all $(SAN_SRC) -lpthread -ldl -o $(SAN_DIR)/ring_stress_asan
-	$(CXX) -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined csrc/amdsmi_sampler.cpp -lpthread -ldl -o $(SAN_DIR)/libkvmini_rt_asan.so
-	$(CXX) -std=c++17 -O1 -g -fPIC -shared -fsanitize=thread csrc/amdsmi_sampler.cpp -lpthread -ldl -o $(SAN_DIR)/libkvmini_rt_tsan.so
+	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all $(SAN_HOST) -o $(SAN_DIR)/host_routines_asan
+	$(CXX) -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined csrc/amdsmi_sampler.cpp csrc/host_routines.cpp -lpthread -ldl -o $(SAN_DIR)/libkvmini_rt_asan.so
+	$(CXX) -std=c++17 -O1 -g -fPIC -shared -fsanitize=thread csrc/amdsmi_sampler.cpp csrc/host_routines.cpp -lpthread -ldl -o $(SAN_DIR)/libkvmini_rt_tsan.so
 	TSAN_OPTIONS=halt_on_error=1 $(SAN_DIR)/ring_stress_tsan $(SAN_SECONDS)
 	ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 $(SAN_DIR)/ring_stress_asan $(SAN_SECONDS)
+	ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 $(SAN_DIR)/host_routines_asan
 	@echo "sanitize: clean"
 
 test: ## CPU test-suite

@@ -95,17 +95,17 @@ def gather_path() -> Path:
 
 
 def build_rt(force: bool = False) -> Path:
-    """Two torch-free libraries.  ``libkvmini_rt.so`` (amd-smi sampler thread; opens
-    libamd_smi with dlopen) links no GPU runtime at all, so it can be loaded into any process
+    """Two torch-free libraries.  ``libkvmini_rt.so`` (amd-smi sampler thread, which opens
+    libamd_smi with dlopen, and the analysis host routines) links no GPU runtime at all, so it can be loaded into any process
     at any time.  ``libkvmini_gather.so`` (RCCL telemetry all-gather) uses HIP + RCCL but is
     linked WITHOUT them: its loader (kvmini/telemetry/native_rt.py) first makes the process's
     one HIP runtime and RCCL global — the copies bundled with torch when torch is imported,
     the system ones otherwise — so a process never ends up with two HIP runtimes."""
     BUILD.mkdir(exist_ok=True)
     out = rt_path()
-    src = CSRC / "amdsmi_sampler.cpp"
-    if src.exists() and (force or stale(out, [src])):
-        run([CXX, "-O2", "-std=c++17", "-fPIC", "-shared", str(src), "-lpthread", "-ldl", "-o", str(out)])
+    srcs = [s for s in (CSRC / "amdsmi_sampler.cpp", CSRC / "host_routines.cpp") if s.exists()]
+    if srcs and (force or stale(out, srcs)):
+        run([CXX, "-O2", "-std=c++17", "-fPIC", "-shared", *map(str, srcs), "-lpthread", "-ldl", "-o", str(out)])
     gout = gather_path()
     gsrc = CSRC / "telemetry_gather.cpp"
     if gsrc.exists() and (force or stale(gout, [gsrc])):

@@ -26,6 +26,30 @@ def is_success(row: Dict[str, Any]) -> bool:
         return False
 
 
+_NATIVE_MIN_ROWS = 2048  # below this the per-row bisect is as fast as marshalling the columns
+
+
+def _seconds(row: Dict[str, Any], key: str) -> float:
+    try:
+        return float(row.get(key, 0) or 0) / 1000.0
+    except (TypeError, ValueError):
+        if key == "start_ms":
+            raise
+        return 0.0
+
+
+def _classify_native(rows: List[Dict[str, Any]], cold_sorted: List[float], window: float, spanning: bool):
+    """The same predicate in C++ (csrc/host_routines.cpp) on the two columns; None when the
+    host runtime library is not built."""
+    from . import native_host
+
+    if not native_host.available():
+        return None
+    starts = [_seconds(r, "start_ms") for r in rows]
+    lats = [_seconds(r, "latency_ms") for r in rows] if spanning else None
+    return native_host.classify_cold(starts, lats, cold_sorted, window, spanning)
+
+
 def classify_requests_cold_warm(
     rows: List[Dict[str, Any]], cold_start_times: Sequence[float], cold_window_sec: float = 30.0, spanning: bool = True
 ) -> List[Dict[str, Any]]:
@@ -34,6 +58,12 @@ def classify_requests_cold_warm(
     restarted server) is cold as well — under the reference's predicate the request that
     paid for the whole cold start counts as warm."""
     cold_sorted = sorted(float(t) for t in cold_start_times)
+    if len(rows) >= _NATIVE_MIN_ROWS and cold_sorted:
+        flags = _classify_native(rows, cold_sorted, cold_window_sec, spanning)
+        if flags is not None:
+            for row, f in zip(rows, flags):
+                row["is_cold_start"] = bool(f)
+            return rows
     for row in rows:
         t = float(row.get("start_ms", 0) or 0) / 1000.0
         cold = False

@@ -144,3 +144,19 @@ class RollingQuantile:
 
     def __len__(self) -> int:
         return len(self._fifo)
+
+
+def rolling_quantile(window: int = 50, p: float = 0.95, method: str = "floor", engine: str = "auto"):
+    """A rolling quantile: the C++ one (``csrc/host_routines.cpp``; the window never touches the
+    interpreter) for windows of 512 and more when the host runtime is built, else
+    :class:`RollingQuantile`.  ``engine``: ``auto`` | ``python`` | ``native``."""
+    if engine not in ("auto", "python", "native"):
+        raise ValueError(f"unknown engine {engine!r}")
+    if engine == "native" or (engine == "auto" and window >= 512):
+        from . import native_host
+
+        if native_host.available():
+            return native_host.NativeRollingQuantile(window, p, method)
+        if engine == "native":
+            raise RuntimeError("libkvmini_rt.so is not built (python build_native.py --only rt)")
+    return RollingQuantile(window, p, method)

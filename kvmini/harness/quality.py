@@ -135,6 +135,11 @@ class ParetoAnalyzer:
         p = np.asarray(points, dtype=np.float64)
         if p.size == 0:
             return np.zeros(0, dtype=bool)
+        if p.shape[0] >= 64:  # the broadcast below is n*n*d doubles; the C++ loop exits early instead
+            from kvmini.analysis import native_host
+
+            if native_host.available():
+                return native_host.pareto_mask(p)
         le = (p[None, :, :] <= p[:, None, :]).all(-1)  # le[i, j]: j <= i everywhere
         lt = (p[None, :, :] < p[:, None, :]).any(-1)
         dominated = (le & lt).any(1)

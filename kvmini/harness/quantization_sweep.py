@@ -92,6 +92,11 @@ def pareto_mask(rows: Sequence[Dict[str, Any]], objectives: Sequence[Tuple[str, 
             except (TypeError, ValueError):
                 continue
             mat[i, j] = v if d == "minimize" else -v
+    if n >= 64:
+        from kvmini.analysis import native_host
+
+        if native_host.available():
+            return [bool(x) for x in native_host.pareto_mask(mat, nan_neutral=True)]
     a, b = mat[:, None, :], mat[None, :, :]  # is i dominated by j ?
     known = ~np.isnan(a) & ~np.isnan(b)
     le = np.where(known, b <= a, True).all(-1)
