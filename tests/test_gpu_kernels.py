@@ -1386,11 +1386,14 @@ def test_engine_mxfp4_matches_fake_quantised_oracle():
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 32, 64])
 @pytest.mark.parametrize("N,K,fp8", [(4096, 4096, False), (4096, 14336, False), (2048, 8192, False), (4096, 4096, True), (256, 256, False)])
-def test_linear_residual_epilogue_is_bit_equal_to_the_two_kernel_path(M, N, K, fp8):
+def test_linear_residual_epilogue_is_bit_equal_to_the_two_kernel_path(M, N, K, fp8, monkeypatch):
     """Split-K GEMM whose last workgroup folds the slabs into the residual == the same GEMM
     followed by residual_reduce: same slab order, same roundings, so bit-equal residual and (up to
-    the grouping of the partial sums) equal sums of squares; repeated calls reuse the counters."""
+    the grouping of the partial sums) equal sums of squares; repeated calls reuse the counters.
+    (The engine leaves this epilogue off by default; the switch is turned on for the test.)"""
     from kvmini.ops import hip_ops
+
+    monkeypatch.setattr(hip_ops, "FUSE_RESIDUAL", True)
 
     torch.manual_seed(12)
     W = (torch.randn(N, K, device=_dev()) * 0.03).bfloat16()
