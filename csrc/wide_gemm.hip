@@ -106,8 +106,12 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
   constexpr int X_BYTES = BM * XROW;
   constexpr int STAGE = A_BYTES + X_BYTES;
   constexpr int PA = A_BYTES / 1024, PX = X_BYTES / 1024;  // 1 KiB LDS-DMA pieces per stage
-  static_assert(PA % NW == 0 && PX % NW == 0, "every wave issues the same number of LDS-DMA pieces (exact vmcnt counts)");
-  constexpr int PA_W = PA / NW, PX_W = PX / NW;
+  // Every wave issues the same number of LDS-DMA pieces per stage (the vmcnt counts are exact).
+  // When the W pieces do not divide by the waves (224- and 192-feature tiles), the surplus slots
+  // copy a piece a second time: same source, same destination, same bytes.
+  static_assert(PX % NW == 0, "x pieces divide by the waves");
+  constexpr int PA_W = (PA + NW - 1) / NW, PX_W = PX / NW;
+  static_assert(PA_W * NW - PA <= PA, "a surplus slot repeats a real piece");
   constexpr int G = PA_W + PX_W;         // LDS-DMA instructions per wave and stage
   constexpr int AR = W8 ? FA : KS * FA;  // 16-byte LDS reads of W per wave and stage
   constexpr int NREAD = AR + KS * FB;    // LDS reads per wave and stage
@@ -145,9 +149,11 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
   // ---- per-lane LDS-DMA source pointers of stage s0 (a stage further = + A_TILE / + XROW bytes)
   const unsigned char* asrc[PA_W];
   const unsigned char* xsrc[PX_W];
+  int apc[PA_W];  // W piece of slot i of this wave
 #pragma unroll
   for (int i = 0; i < PA_W; ++i) {
-    const int pc = wave + NW * i;
+    const int pc = wave + NW * i < PA ? wave + NW * i : wave + NW * i - PA;
+    apc[i] = pc;
     if constexpr (W8) {
       asrc[i] = p.Wp + ((((long long)(n0 >> 4) + pc) * nst + s0) * 64 + lane) * 16;
     } else {
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
   // of the stage at `src` into register set SET
 #define WG_MEMOP(m, SET, dst, src, st)                                                                                                   \
   do {                                                                                                                                  \
-    if ((m) < PA_W) dma16(asrc[(m) < PA_W ? (m) : 0] + (long long)(st) * A_TILE, (dst) + (wave + NW * (m)) * 1024);                     \
+    if ((m) < PA_W) dma16(asrc[(m) < PA_W ? (m) : 0] + (long long)(st) * A_TILE, (dst) + apc[(m) < PA_W ? (m) : 0] * 1024);             \
     else if ((m) < G) dma16(xsrc[(m) >= PA_W && (m) < G ? (m) - PA_W : 0] + (long long)(st) * XROW, (dst) + A_BYTES + (wave + NW * ((m) - PA_W)) * 1024); \
     else if ((m) - G < AR) ra[SET][(m) >= G && (m) - G < AR ? (m) - G : 0] = *reinterpret_cast<const raw16*>((src) + a_off + ((m) - G) * 1024); \
     else {                                                                                                                              \
@@ -336,6 +342,10 @@ int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStre
   switch (key * 10 + variant) {
     // 256 x 256, 8 waves (wave: 64 tokens x 128 features)
     case 2562560: return dispatch_epi<256, 256, 4, 2, 2, 2, W8>(epi, p, s);
+    // 256 x 224 and 256 x 192, 8 waves (wave: 64 x 112 / 64 x 96): feature counts that are a
+    // multiple of 7 x 32 or 3 x 64 but leave a ragged last round of 256-wide tiles over the CUs
+    case 2562240: return dispatch_epi<256, 224, 4, 2, 2, 2, W8>(epi, p, s);
+    case 2561920: return dispatch_epi<256, 192, 4, 2, 2, 2, W8>(epi, p, s);
     // 256 x 128, 8 waves (wave: 64 x 64)
     case 2561280: return dispatch_epi<256, 128, 4, 2, 2, 3, W8>(epi, p, s);
     case 2561282: return dispatch_epi<256, 128, 4, 2, 2, 2, W8>(epi, p, s);
@@ -352,6 +362,10 @@ int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStre
       case 2562561: return dispatch_epi<256, 256, 4, 2, 1, 4, false>(epi, p, s);
       case 2562563: return dispatch_epi<256, 256, 4, 2, 1, 5, false>(epi, p, s);
       case 2561281: return dispatch_epi<256, 128, 4, 2, 1, 6, false>(epi, p, s);
+      case 2562241: return dispatch_epi<256, 224, 4, 2, 1, 4, false>(epi, p, s);
+      case 2562243: return dispatch_epi<256, 224, 4, 2, 1, 5, false>(epi, p, s);
+      case 2561921: return dispatch_epi<256, 192, 4, 2, 1, 4, false>(epi, p, s);
+      case 2561923: return dispatch_epi<256, 192, 4, 2, 1, 5, false>(epi, p, s);
       // 256 x 64, 8 waves (wave: 32 x 64); an FP8 stage of it would be 4 pieces for 8 waves
       case 2560640: return dispatch_epi<256, 64, 8, 1, 2, 3, false>(epi, p, s);
       case 2560642: return dispatch_epi<256, 64, 8, 1, 2, 2, false>(epi, p, s);
@@ -368,7 +382,7 @@ extern "C" {
 int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant) { (void)bm; (void)bn; return (variant == 1 || variant == 3) ? 1 : 2; }
 
 // epi: 0 = bf16 y[M, N], 1 = fp32 slabs out[splits][M][N], 2 = SwiGLU bf16 y[M, N/2].
-// (bm, bn): workgroup tile, one of (256,256) (256,128) (256,64) (128,128) (128,256); variant: see
+// (bm, bn): workgroup tile, one of (256,256) (256,224) (256,192) (256,128) (256,64) (128,128) (128,256); variant: see
 // dispatch_tile.  N % bn == 0, K % 64 == 0; with S = K / (32 * stage k-steps) stages in all,
 // splits * stages_per_split >= S > (splits - 1) * stages_per_split.
 // w_scale != nullptr: Wp holds e4m3 bytes packed by kv_pack_weight_fp8, w_scale[N] the row scales.

@@ -238,9 +238,15 @@ def _plan_slabs(n_pad: int, k: int, m: int = 32, group_cols: int = 256) -> Tuple
 # Tiled (wide) GEMM: (token tile, feature tile, pipeline variant) -> measured microseconds per
 # 64-wide K step of one workgroup with every CU busy (Llama-3-8B shapes, 1 x MI355X).  Per FLOP
 # 256 x 256 and 256 x 128 are alike (~1.28 PFLOP/s with every CU busy); the smaller tiles trade
-# efficiency for more workgroups.
-_WIDE_TILES_BF16 = (((256, 256, 1), 1.66), ((256, 128, 0), 0.845), ((128, 256, 0), 0.87), ((128, 128, 0), 0.62), ((256, 64, 0), 0.65))
-_WIDE_TILES_FP8 = (((256, 256, 0), 1.9), ((256, 128, 0), 0.845), ((128, 256, 0), 0.87), ((128, 128, 0), 0.62))
+# efficiency for more workgroups; 256 x 224 and 256 x 192 exist for feature counts whose
+# 256-wide tiles leave a ragged last round over the 256 CUs (28672 = 128 x 224: 1024 tiles at
+# 2048 rows instead of 896; 6144 = 32 x 192: 256 tiles instead of 192).
+_WIDE_TILES_BF16 = (((256, 256, 1), 1.68), ((256, 224, 1), 1.615), ((256, 192, 0), 1.36), ((256, 128, 0), 0.84), ((128, 256, 0), 0.87), ((128, 128, 0), 0.62), ((256, 64, 0), 0.65))
+_WIDE_TILES_FP8 = (((256, 256, 0), 1.9), ((256, 224, 0), 1.85), ((256, 192, 0), 1.55), ((256, 128, 0), 0.84), ((128, 256, 0), 0.87), ((128, 128, 0), 0.62))
+# The 128-wide tiles move 1.5 x the operand bytes per MAC of the 256-wide ones from L2 into LDS; on
+# grids of many rounds that traffic shows: + this many microseconds per step and round
+# (28672 x 4096 at 2048 rows: 1.01 us per step over 7 rounds, 0.86 over 1-2 rounds).
+_WIDE_ROUND_SLOPE = {(256, 128): 0.025, (128, 256): 0.025}
 _WIDE_STAGE_KSTEPS = {1: 1, 3: 1}  # pipeline variants with 32-wide stages (kv_wide_gemm_stage_ksteps)
 
 
@@ -264,7 +270,7 @@ def _plan_wide(m: int, n_pad: int, k: int, fp8: bool, may_split: bool) -> Tuple[
             if (splits - 1) * sps >= nst:
                 continue
             rounds = -(-tiles * splits // _NUM_CUS)
-            t = rounds * (sps * per_stage / 64.0) * step_us + (2.0 * splits * m * n_pad * 4 / 2.5e6 if splits > 1 else 0.0)
+            t = rounds * (sps * per_stage / 64.0) * (step_us + _WIDE_ROUND_SLOPE.get((bm, bn), 0.0) * rounds) + (2.0 * splits * m * n_pad * 4 / 2.5e6 if splits > 1 else 0.0)
             # token rows of the last tile that are padding still cost MFMAs
             if best is None or t < best[0] - 1e-9:
                 best = (t, (bm, bn, variant, splits, sps))

@@ -20,10 +20,10 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F
 
-TILES = ((256, 256), (256, 128), (256, 64), (128, 128), (128, 256))
+TILES = ((256, 256), (256, 224), (256, 192), (256, 128), (256, 64), (128, 128), (128, 256))
 # pipeline variants compiled per tile (csrc/wide_gemm.hip::dispatch_tile); FP8 has no 256 x 64 tile and no 32-wide stages
-VARIANTS = {(256, 256): (0, 1, 3), (256, 128): (0, 1, 2), (128, 256): (0, 2), (256, 64): (0, 2), (128, 128): (0, 2)}
-VARIANTS_FP8 = {(256, 256): (0,), (256, 128): (0, 2), (128, 256): (0, 2), (128, 128): (0, 2)}
+VARIANTS = {(256, 256): (0, 1, 3), (256, 224): (0, 1, 3), (256, 192): (0, 1, 3), (256, 128): (0, 1, 2), (128, 256): (0, 2), (256, 64): (0, 2), (128, 128): (0, 2)}
+VARIANTS_FP8 = {(256, 256): (0,), (256, 224): (0,), (256, 192): (0,), (256, 128): (0, 2), (128, 256): (0, 2), (128, 128): (0, 2)}
 
 
 def time_fns(fns, rounds=8, inner=4):
@@ -51,7 +51,7 @@ def check(C, dev, log):
     torch.manual_seed(0)
     worst = 0.0
     for (bm, bn), variant in [(t, v) for t in TILES for v in VARIANTS[t]]:
-        for M, N, K in ((200, 512, 256), (513, 256, 1024)):
+        for M, N, K in ((200, 512, 256), (513, 256, 1024)) if bn in (256, 128, 64) else ((200, 2 * bn, 256), (513, bn, 1024)):
             x = torch.randn(M, K, device=dev).bfloat16()
             W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
             ss = (x.float() ** 2).sum(-1, keepdim=True).contiguous()
@@ -130,6 +130,8 @@ def bench(C, dev, rows, out, fp8, only=None):
                 if (bm, bn) not in vmap:
                     continue
                 mt, ntl = -(-M // bm), N // bn
+                if N % bn:
+                    continue
                 for variant in vmap[(bm, bn)]:
                     nst = K // (32 * C.wide_gemm_stage_ksteps(bm, bn, variant))
                     for mf in (True, False):

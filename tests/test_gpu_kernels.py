@@ -971,6 +971,46 @@ def test_tiled_gemm_every_tile_and_pipeline_shape(C, tile, variant):
     assert (sl.sum(0) - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("bn,variant", [(224, 0), (224, 1), (224, 3), (192, 0), (192, 1), (192, 3)])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_tiled_gemm_224_and_192_feature_tiles(C, bn, variant, fp8):
+    """Feature tiles of 224 and 192 (whole rounds over the CUs for 28672 and 6144 features): the
+    W pieces of a stage do not divide by the eight waves, surplus DMA slots repeat a piece.  bf16,
+    slabs and SwiGLU epilogues against fp32, bf16 and FP8 weights."""
+    import torch.nn.functional as F
+
+    from kvmini.models.llama import quantize_fp8_rows
+
+    if fp8 and variant != 0:
+        pytest.skip("FP8 weights use 64-wide stages only")
+    dev = _dev()
+    torch.manual_seed(bn + variant)
+    M, N, K = 300, 2 * bn, 448
+    x = torch.randn(M, K, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    if fp8:
+        q, scale = quantize_fp8_rows(W)
+        wp, ws, wref = C.pack_weight_fp8(q.view(torch.uint8).contiguous()), scale.contiguous(), q.float() * scale[:, None]
+    else:
+        wp, ws, wref = C.pack_weight(W), None, W.float()
+    ref = x.float() @ wref.T
+    nst = K // (32 * C.wide_gemm_stage_ksteps(256, bn, variant))
+    for mf in (True, False):
+        y = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        C.wide_gemm(wp, N, K, x, y, 0, 256, bn, variant, 1, nst, None, 0.0, ws, mf)
+        assert (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    sps = (nst + 2) // 3
+    nsp = -(-nst // sps)
+    sl = torch.full((nsp, M, N), float("nan"), device=dev, dtype=torch.float32)
+    C.wide_gemm(wp, N, K, x, sl, 1, 256, bn, variant, nsp, sps, None, 0.0, ws, True)
+    assert (sl.sum(0) - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    act = torch.full((M, N // 2), float("nan"), device=dev, dtype=torch.bfloat16)
+    C.wide_gemm(wp, N, K, x, act, 2, 256, bn, variant, 1, nst, None, 0.0, ws, True)
+    g = ref.view(M, N // 16, 2, 8)
+    want = (F.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)
+    assert (act.float() - want).abs().max().item() <= 1.5e-2 * want.abs().max().item() + 1e-3
+
+
 def test_xgmi_collectives_single_rank_is_its_own_peer(C):
     """The peer-memory collectives with a group of one rank (the rank's buffer is its own peer):
     all-gather, one-shot and two-shot all-reduce are identities, and the fused TP epilogue equals
