@@ -125,6 +125,86 @@ class QualityEvaluator:
         }
 
 
+AGREEMENT_TOPICS = ("the harbour at dawn", "a recipe for flat bread", "how rivers shape valleys", "the rules of a card game", "repairing a bicycle chain", "a letter to a landlord",
+                    "the history of a small town", "why the sky is blue", "a train timetable", "packing for a week in the mountains", "a job interview", "the inventory of a hardware shop")
+AGREEMENT_FORMS = ("Write two sentences about {t}.", "List three facts about {t}.", "Explain {t} to a child.", "Summarise what you know about {t} in one paragraph.",
+                   "What is surprising about {t}?", "Give a short title for an essay on {t}.", "Ask a question about {t}.", "Describe {t} in five words.")
+
+
+def agreement_prompts(n: int) -> List[str]:
+    """``n`` distinct fixed prompts from the topic x form grid (96 cells), forms and topics both
+    changing from one prompt to the next."""
+    nf, nt = len(AGREEMENT_FORMS), len(AGREEMENT_TOPICS)
+    return [AGREEMENT_FORMS[i % nf].format(t=AGREEMENT_TOPICS[(i // nf + i % nf) % nt]) for i in range(min(n, nf * nt))]
+
+
+def prefix_agreement(reference: Sequence[str], got: Sequence[str]) -> float:
+    """Mean over prompts of (words of the greedy continuation that match the reference's before
+    the first difference) / (words of the reference).  Greedy decoding is a deterministic chain, so
+    the first difference is where the two models' argmax parted; what follows is conditioned on
+    different text and says nothing more."""
+    if not reference:
+        return float("nan")
+    total = 0.0
+    for ref, out in zip(reference, got):
+        a, b = ref.split(), out.split()
+        if not a:
+            total += 1.0 if not b else 0.0
+            continue
+        k = 0
+        while k < len(a) and k < len(b) and a[k] == b[k]:
+            k += 1
+        total += k / len(a)
+    return total / len(reference)
+
+
+def first_word_agreement(reference: Sequence[str], got: Sequence[str]) -> float:
+    """Share of prompts whose greedy continuation starts with the reference's first word: both
+    models saw exactly the same context there, so this is their top-1 agreement."""
+    if not reference:
+        return float("nan")
+    same = sum(1 for ref, out in zip(reference, got) if ref.split()[:1] == out.split()[:1])
+    return same / len(reference)
+
+
+class AgreementEvaluator:
+    """Fidelity of a quantised configuration measured against a reference configuration of the
+    SAME model on greedy continuations of fixed prompts.  ``quality_score`` = 100 x
+    ``first_word_agreement`` (top-1 agreement on identical contexts); ``prefix_agreement`` (how far
+    the two deterministic chains run together) is reported next to it — with random-init weights
+    the logits are nearly flat and a chain parts at its first flipped argmax, so the prefix score
+    collapses towards 0 for every quantised format while the top-1 score still ranks them.
+
+    The task-accuracy score of :class:`QualityEvaluator` needs trained weights; with random-init
+    weights (no checkpoint on the machine) it is noise, while agreement with the unquantised
+    engine still ranks weight and KV formats by how much they disturb the logits — the quality
+    axis of the quantisation sweep's Pareto analysis (reference ``sweeps/quantization_sweep.py:286-310``
+    merges ``quality_score`` into each row the same way)."""
+
+    def __init__(self, endpoint: str, model_name: str, num_prompts: int = 96, max_tokens: int = 8, timeout: float = 60.0, call_fn: Optional[CallFn] = None):
+        self.inner = QualityEvaluator(endpoint, model_name, [], 0, timeout=timeout, call_fn=call_fn)
+        self.prompts = agreement_prompts(num_prompts)
+        self.max_tokens = max_tokens
+
+    def continuations(self) -> Tuple[List[str], float]:
+        texts, lat = [], 0.0
+        for p in self.prompts:
+            text, dt, _ = self.inner._call(p, self.max_tokens)
+            texts.append(text)
+            lat += dt
+        return texts, lat / max(1, len(self.prompts))
+
+    def evaluate(self, reference: Optional[Sequence[str]]) -> Dict[str, Any]:
+        """``reference`` None: this IS the reference configuration (score 100, continuations returned
+        for the others to be compared with)."""
+        texts, lat = self.continuations()
+        if not any(texts):
+            raise RuntimeError("the endpoint returned no text for any agreement prompt")
+        score = 100.0 if reference is None else round(100.0 * first_word_agreement(reference, texts), 2)
+        prefix = 100.0 if reference is None else round(100.0 * prefix_agreement(reference, texts), 2)
+        return {"quality_score": score, "prefix_agreement": prefix, "avg_quality_latency_ms": round(lat * 1000, 1), "quality_metric": "greedy_top1_agreement", "continuations": texts}
+
+
 class ParetoAnalyzer:
     """3-D frontier on (-quality, p95_ms, cost_per_1k_tokens): a point is
     dominated when another is <= in all three and < in at least one."""

@@ -34,9 +34,9 @@ import yaml
 
 from kvmini.cluster import get_backend
 from kvmini.deploy import manifests as mf
-from kvmini.harness.quality import ParetoAnalyzer, QualityEvaluator
+from kvmini.harness.quality import AgreementEvaluator, ParetoAnalyzer, QualityEvaluator
 from kvmini.report.generator import CSS, format_number, svg_heatmap, svg_scatter
-from kvmini.utils import load_json, load_yaml
+from kvmini.utils import load_json, load_yaml, write_json
 
 OBJECTIVES: List[Tuple[str, str]] = [("p95_ms", "minimize"), ("cost_per_1k_tokens", "minimize"), ("quality_score", "maximize"), ("throughput_rps", "maximize")]
 # quantization modes the ROCm vLLM build accepts; fp8 / mxfp4 run natively on gfx950 matrix cores
@@ -219,10 +219,14 @@ class QuantizationSweepRunner:
                 "config_name": config["name"], "quantization": q, "kv_cache_dtype": config.get("kv_cache_dtype", "auto"), "max_model_len": config.get("max_model_len", 2048),
                 "gpu_memory_utilization": config.get("gpu_memory_utilization", 0.9), "tensor_parallel_size": config.get("tensor_parallel_size", 1), "run_id": run_id, "error": "",
             })
-            if (self.config.get("quality_eval") or {}).get("enabled"):
+            qe = self.config.get("quality_eval") or {}
+            if qe.get("enabled"):
                 endpoint = url or self.backend.get_isvc_url(b["namespace"], self.service_name(config))
                 try:
-                    res.update(QualityEvaluator(endpoint, b["model"], ["hellaswag", "boolq", "math"], 10).evaluate())
+                    if qe.get("mode") == "agreement":
+                        res.update(self.agreement_quality(config, endpoint, qe))
+                    else:
+                        res.update(QualityEvaluator(endpoint, b["model"], ["hellaswag", "boolq", "math"], 10).evaluate())
                 except Exception as e:
                     print(f"  quality evaluation failed: {e}", file=sys.stderr)
                     res["quality_score"] = None
@@ -234,8 +238,29 @@ class QuantizationSweepRunner:
         finally:
             self.cleanup(config)
 
+    def reference_config_name(self) -> str:
+        """The configuration the others are compared with in ``quality_eval.mode: agreement``: the
+        one marked ``reference: true``, else the first."""
+        configs = self.config["sweep_configurations"]
+        return next((c["name"] for c in configs if c.get("reference")), configs[0]["name"])
+
+    def agreement_quality(self, config: Dict[str, Any], endpoint: str, qe: Dict[str, Any]) -> Dict[str, Any]:
+        """Greedy continuations of fixed prompts against the reference configuration's (kept in
+        ``agreement_reference.json`` so that a resumed sweep still has them)."""
+        ev = AgreementEvaluator(endpoint, self.config["benchmark"]["model"], int(qe.get("prompts", 96)), int(qe.get("max_tokens", 8)))
+        ref_path = os.path.join(self.output_dir, "agreement_reference.json")
+        if config["name"] == self.reference_config_name():
+            out = ev.evaluate(None)
+            write_json(ref_path, {"config_name": config["name"], "prompts": ev.prompts, "continuations": out["continuations"]})
+        else:
+            if not os.path.exists(ref_path):
+                raise RuntimeError(f"no reference continuations yet ({self.reference_config_name()} must run first and succeed)")
+            out = ev.evaluate(load_json(ref_path)["continuations"])
+        out.pop("continuations")
+        return out
+
     # -- sweep + analysis ------------------------------------------------------------
-    FLAT_KEYS = ["config_name", "quantization", "kv_cache_dtype", "max_model_len", "gpu_memory_utilization", "tensor_parallel_size", "run_id", "error", "p50_ms", "p95_ms", "p99_ms", "ttft_p50_ms", "ttft_p95_ms", "throughput_rps", "tokens_per_sec", "error_rate", "cost_per_1k_tokens", "cost_per_request", "energy_wh_per_1k_tokens", "quality_score", "avg_quality_latency_ms"]
+    FLAT_KEYS = ["config_name", "quantization", "kv_cache_dtype", "max_model_len", "gpu_memory_utilization", "tensor_parallel_size", "run_id", "error", "p50_ms", "p95_ms", "p99_ms", "ttft_p50_ms", "ttft_p95_ms", "throughput_rps", "tokens_per_sec", "error_rate", "cost_per_1k_tokens", "cost_per_request", "energy_wh_per_1k_tokens", "quality_score", "prefix_agreement", "avg_quality_latency_ms"]
 
     def save_intermediate(self) -> str:
         path = os.path.join(self.output_dir, "sweep_results_intermediate.csv")

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""A 2048-token prompt through the engine (Llama-3-8B, 1024-token step budget), three times:
-the workload for `rocprofv3 --kernel-trace --stats` of the prefill path.  Prints ms per prompt."""
+"""A 2048-token prompt through the engine (Llama-3-8B, step budget = argv[1], default 1024), four
+times: the workload for `rocprofv3 --kernel-trace --stats` of the prefill path.  Prints ms per
+prompt.  The last prompt sits between two `arange` launches (the only ones of the process), so a
+kernel trace can be cut to exactly one prompt (scripts/trace_between_markers.py)."""
 import os
 import sys
 import time
@@ -18,9 +20,13 @@ eng.warmup()
 for rep in range(4):
     seq = eng.make_sequence([1] + [(7 * i + rep) % 1000 + 10 for i in range(2047)], SamplingParams(max_tokens=1, ignore_eos=True))
     eng.scheduler.add(seq)
+    if rep == 3:
+        torch.arange(0, 4099, device="cuda:0")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while eng.scheduler.has_work():
         eng.step()
+    if rep == 3:
+        torch.arange(0, 4099, device="cuda:0")
     torch.cuda.synchronize()
     print(f"prompt {rep}: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)

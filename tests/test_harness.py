@@ -460,3 +460,25 @@ def test_router_fails_over_when_a_replica_goes_away():
     finally:
         stop_router()
         stop1()
+
+
+def test_prefix_agreement_and_agreement_evaluator():
+    """Fidelity score of the quantisation sweep: words that match the reference's greedy
+    continuation before the first difference."""
+    from kvmini.harness.quality import AgreementEvaluator, agreement_prompts, prefix_agreement
+
+    assert prefix_agreement(["a b c d"], ["a b c d"]) == 1.0
+    assert prefix_agreement(["a b c d"], ["a b x d"]) == 0.5  # what follows the first difference does not count
+    assert prefix_agreement(["a b", ""], ["a b c", ""]) == 1.0
+    assert prefix_agreement(["a b c d", "e f"], ["z", "e f"]) == 0.5
+    ps = agreement_prompts(96)
+    assert len(ps) == len(set(ps)) == 96
+    ps = agreement_prompts(24)
+
+    ref_texts = {p: f"w{i} x y z" for i, p in enumerate(ps)}
+    ref = AgreementEvaluator("http://unused", "m", 24, 8, call_fn=lambda p, n: (ref_texts[p], 0.001, 4)).evaluate(None)
+    assert ref["quality_score"] == 100.0 and len(ref["continuations"]) == 24
+    half = AgreementEvaluator("http://unused", "m", 24, 8, call_fn=lambda p, n: (ref_texts[p].replace("y", "q"), 0.001, 4)).evaluate(ref["continuations"])
+    assert half["quality_score"] == 100.0 and half["prefix_agreement"] == 50.0 and half["quality_metric"] == "greedy_top1_agreement"
+    none = AgreementEvaluator("http://unused", "m", 24, 8, call_fn=lambda p, n: ("other " + ref_texts[p], 0.001, 4)).evaluate(ref["continuations"])
+    assert none["quality_score"] == 0.0 and none["prefix_agreement"] == 0.0

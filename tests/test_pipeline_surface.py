@@ -197,6 +197,31 @@ def test_quant_sweep_resume_skips_finished_configs(in_tmp, mock_url, dead_url, m
     assert [(r["config_name"], r["p95_ms"]) for r in again] == [(r["config_name"], r["p95_ms"]) for r in first]
 
 
+def test_quant_sweep_agreement_quality_axis(in_tmp, mock_url, monkeypatch):
+    """``quality_eval.mode: agreement``: the reference configuration scores 100 and leaves its
+    greedy continuations behind; the others are scored against them (the mock answers every
+    configuration alike, so they agree fully) and the score reaches the CSV and the report."""
+    import yaml
+
+    from kvmini.harness import quantization_sweep as qs
+
+    monkeypatch.setenv("DISABLE_IO_PROBE", "1")
+    base = {"max_model_len": 512, "gpu_memory_utilization": 0.5, "tensor_parallel_size": 1}
+    cfg = {"benchmark": {"namespace": "bench", "service": "sweep", "requests": 6, "concurrency": 2, "model": "mock-llm"},
+           "quality_eval": {"enabled": True, "mode": "agreement", "prompts": 5, "max_tokens": 8},
+           "sweep_configurations": [{"name": "fp8", "quantization": "fp8", "kv_cache_dtype": "fp8", **base}, {"name": "bf16", "reference": True, "quantization": "none", "kv_cache_dtype": "auto", **base},
+                                    {"name": "fp8-again", "quantization": "fp8", "kv_cache_dtype": "auto", **base}]}
+    with open("q.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    assert qs.main(["--config", "q.yaml", "--output-dir", "qs", "--cluster-backend", "fake", "--url", mock_url]) == 0
+    rows = {r["config_name"]: r for r in csv.DictReader(open("qs/sweep_results_intermediate.csv"))}
+    assert rows["fp8"]["quality_score"] == ""  # ran before the reference: no score, not an error
+    assert float(rows["bf16"]["quality_score"]) == 100.0 and float(rows["fp8-again"]["quality_score"]) == 100.0
+    ref = load_json("qs/agreement_reference.json")
+    assert ref["config_name"] == "bf16" and len(ref["continuations"]) == 5 and all(ref["continuations"])
+    assert "quality" in open("qs/sweep_report.html").read()
+
+
 # ---------------------------------------------------------------- (c): reports
 def test_single_report_links_the_p95_trace_and_writes_the_viewer(in_tmp, mock_url, monkeypatch):
     from kvmini.report.generator import generate_single_report
