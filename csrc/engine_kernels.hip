@@ -420,8 +420,9 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
     v_scale = kv_scale[nkv + g];
   }
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
-  if (ctx <= 0) {  // padding token
-    for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
+  if (ctx <= 0) {  // 0: padding token, zero output; negative: a prompt-chunk row that the tiled kernel writes
+    if (ctx == 0)
+      for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
     return;
   }
   const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
                                                                 const int* __restrict__ tile_row0, const int* __restrict__ tile_n,
                                                                 const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq, int n_tiles,
                                                                 unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e,
-                                                                const float* __restrict__ kv_scale) {
+                                                                const float* __restrict__ kv_scale, int order) {
   constexpr int HD = 128, VT_STRIDE = 40;
   float v_scale = 1.f;
   if constexpr (KV8) {
@@ -844,8 +845,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
   }
   __shared__ __attribute__((aligned(16))) unsigned short vt_lds[2 * HD * VT_STRIDE];  // V^T [buffer][dim][k-slot]
   __shared__ __attribute__((aligned(16))) unsigned short k_lds[2 * 32 * (HD + 8)];    // K [buffer][key][dim], padded rows
-  // later tiles of a chunk see more keys: hand them out first, so the longest passes do not start last
-  const int t0 = (gridDim.y - 1 - blockIdx.y) * QT;
+  // Later tiles of a chunk see more keys.  order 0: longest first, so the longest passes do not
+  // start last.  order 1 (grids of at most two workgroups per CU, all resident at once): the
+  // first half of the ids takes the tiles from the longest down, the second half from the
+  // shortest up, so the two workgroups that share a CU add up to about the same number of keys
+  // (2048 queries at 2048..4095: 158 -> 150 us; pairing neighbouring ids instead: 171 us).
+  const int ny = gridDim.y, yi = blockIdx.y;
+  const int half = (ny + 1) >> 1;
+  const int t0 = (order == 1 && yi >= half ? yi - half : ny - 1 - yi) * QT;
   if constexpr (QT == 2) {
     const int t1 = t0 + 1;
     const int n0 = tile_n[t0], n1 = t1 < n_tiles ? tile_n[t1] : 0;
@@ -1499,9 +1506,10 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   static const int pinned = [] { const char* e = getenv("KVMINI_PREFILL_TILES"); return e ? atoi(e) : 0; }();
   const int qt = rep > 4 ? 1 : (pinned == 1 || pinned == 2 ? pinned : ((long long)nkv * n_tiles >= 512 ? 2 : 1));
   dim3 grid(nkv, (n_tiles + qt - 1) / qt), block(256);
+  const int order = (long long)grid.x * grid.y <= 512 ? 1 : 0;
 #define KV_LAUNCH_K(R, Q, K8)                                                                                                              \
   hipLaunchKernelGGL((prefill_attention_kernel<R, Q, K8>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, k_cache, v_cache,   \
-                     block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, n_tiles, (unsigned short*)out, nh, nkv, sl, kv_scale)
+                     block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, n_tiles, (unsigned short*)out, nh, nkv, sl, kv_scale, order)
 #define KV_LAUNCH_Q(R, Q)       \
   if (kv_scale) {               \
     KV_LAUNCH_K(R, Q, true);    \

@@ -597,7 +597,7 @@ class ModelRunner:
                 st[o_slot + i : o_slot + i + n] = blk * bs + pos % bs
                 st[o_seq + i : o_seq + i + n] = seq.slot
                 st[o_ctx + i : o_ctx + i + n] = pos + 1
-                st[o_cd + i : o_cd + i + n] = 0
+                st[o_cd + i : o_cd + i + n] = -1  # rows of a prompt chunk: left to the tiled kernel (0 = padding row, zeroed)
                 st[o_fd + i : o_fd + i + n] = 0
                 for off in range(0, n, 16):
                     st[o_tl + n_tiles], st[o_tl + mt + n_tiles], st[o_tl + 2 * mt + n_tiles], st[o_tl + 3 * mt + n_tiles] = i + off, min(16, n - off), p0 + off, seq.slot
