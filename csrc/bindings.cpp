@@ -29,7 +29,8 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, hipStream_t stream);
+                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, const void* pf_base,
+                              const long long* pf, unsigned int* pf_sink, hipStream_t stream);
 int kv_embed_fed(const void* table, const int* tokens, const int* feed, const long long* prev_ids, int n_prev, void* out, int T, int H, int V, hipStream_t stream);
 int kv_argmax(const void* logits, long long row_stride, int S, int V, long long* out, hipStream_t stream);
 int kv_sample_rows(const void* logits, long long row_stride, int V, const long long* rows, int R, const float* temperature, const int* top_k,
@@ -71,7 +72,7 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
 int kv_prefetch(const void* p, long long bytes, int workgroups, unsigned int* sink, hipStream_t stream);
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
-                       hipStream_t stream);
+                       const void* pf_base, const long long* pf, unsigned int* pf_sink, hipStream_t stream);
 int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride, void* residual, const void* w, void* y, int T, int H, float eps,
                          hipStream_t stream);
 int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_stride, void* q_out, const int* positions, const float* cos_t, const float* sin_t,
@@ -240,12 +241,35 @@ void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at:
 
 const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* parts);
 
+// Optional weight prefetch beside a latency-bound kernel (PrefetchPlan in engine_kernels.hip):
+// `w` = the packed weights of the GEMM that runs next, `plan` = {gx, gy, nw, kib, tile_bytes,
+// split_bytes, prefetch workgroups}, `sink` = an int32 scratch word.  Fills v[8] (the plan plus
+// the byte size of `w`, against which the kernel launcher checks every range) and returns w's
+// address, or nullptr when no prefetch was asked for.
+const void* prefetch_args(const c10::optional<at::Tensor>& w, const c10::optional<std::vector<int64_t>>& plan, const c10::optional<at::Tensor>& sink, long long* v,
+                          unsigned int** sink_ptr) {
+  *sink_ptr = nullptr;
+  if (!w.has_value() || !plan.has_value()) return nullptr;
+  TORCH_CHECK(plan->size() == 7, "prefetch plan must have 7 entries");
+  TORCH_CHECK(sink.has_value(), "prefetch needs a sink tensor");
+  CHECK_DEV((*w)); CHECK_CONTIG((*w)); CHECK_DEV((*sink));
+  TORCH_CHECK(sink->scalar_type() == at::kInt && sink->numel() >= 1, "sink must be an int32 tensor");
+  for (int i = 0; i < 7; ++i) v[i] = (*plan)[i];
+  v[7] = (long long)w->numel() * w->element_size();
+  *sink_ptr = (unsigned int*)sink->data_ptr();
+  return w->data_ptr();
+}
+
 // RoPE + KV write + paged attention in one launch (decode-only steps; see engine_kernels.hip)
 void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t, at::Tensor k_cache, at::Tensor v_cache,
                             at::Tensor slot_mapping, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor out, int64_t nh,
                             c10::optional<at::Tensor> row_ss, int64_t h_in, double eps, double scale, int64_t waves, c10::optional<at::Tensor> kv_scale,
-                            int64_t n_split, c10::optional<at::Tensor> split_ws) {
+                            int64_t n_split, c10::optional<at::Tensor> split_ws, c10::optional<at::Tensor> pf_w, c10::optional<std::vector<int64_t>> pf_plan,
+                            c10::optional<at::Tensor> pf_sink) {
   TORCH_CHECK(waves == 4 || waves == 8, "waves per workgroup must be 4 or 8");
+  long long pfv[8];
+  unsigned int* pfs = nullptr;
+  const void* pfb = prefetch_args(pf_w, pf_plan, pf_sink, pfv, &pfs);
   CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_I32(positions); CHECK_I32(slot_mapping); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
   const float* ksc = check_cache(k_cache, v_cache, kv_scale);
   CHECK_BF16(out); CHECK_CONTIG(out); CHECK_CONTIG(block_tables);
@@ -282,7 +306,7 @@ void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor c
                                   (const float*)sin_t.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)slot_mapping.data_ptr(),
                                   (const int*)block_tables.data_ptr(), (int)block_tables.size(1), (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(),
                                   out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps, (float)scale,
-                                  (int)waves, ksc, (int)n_split, part_o, part_ml, counters, cur_stream()),
+                                  (int)waves, ksc, (int)n_split, part_o, part_ml, counters, pfb, pfb ? pfv : nullptr, pfs, cur_stream()),
         "kv_decode_attention_fused");
 }
 
@@ -593,8 +617,12 @@ void rope_kv_write_slabs(at::Tensor slabs, at::Tensor q_out, at::Tensor position
 
 // residual' = residual + x (x: bf16 [T, H] or fp32 slabs [S, T, H]); returns the per-row
 // partial sums of squares [T, ceil(H/512)] of residual'.
-at::Tensor residual_reduce(at::Tensor x, at::Tensor residual, bool has_residual) {
+at::Tensor residual_reduce(at::Tensor x, at::Tensor residual, bool has_residual, c10::optional<at::Tensor> pf_w, c10::optional<std::vector<int64_t>> pf_plan,
+                           c10::optional<at::Tensor> pf_sink) {
   CHECK_DEV(x); CHECK_CONTIG(x); CHECK_BF16(residual); CHECK_CONTIG(residual);
+  long long pfv[8];
+  unsigned int* pfs = nullptr;
+  const void* pfb = prefetch_args(pf_w, pf_plan, pf_sink, pfv, &pfs);
   TORCH_CHECK(residual.dim() == 2, "residual must be [T, H]");
   const int64_t T = residual.size(0), H = residual.size(1);
   TORCH_CHECK(H % 8 == 0, "hidden size must be a multiple of 8");
@@ -602,12 +630,13 @@ at::Tensor residual_reduce(at::Tensor x, at::Tensor residual, bool has_residual)
   if (x.dim() == 3) {
     TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(1) == T && x.size(2) == H && x.size(0) >= 1, "slabs must be fp32 [S, T, H]");
     check(kv_residual_reduce((const float*)x.data_ptr(), (int)x.size(0), T * H, nullptr, residual.data_ptr(), has_residual ? 1 : 0, (float*)ss.data_ptr(), (int)T, (int)H,
-                             cur_stream()),
+                             pfb, pfb ? pfv : nullptr, pfs, cur_stream()),
           "kv_residual_reduce");
   } else {
     CHECK_BF16(x);
     TORCH_CHECK(x.dim() == 2 && x.size(0) == T && x.size(1) == H, "x must be bf16 [T, H]");
-    check(kv_residual_reduce(nullptr, 0, 0, x.data_ptr(), residual.data_ptr(), has_residual ? 1 : 0, (float*)ss.data_ptr(), (int)T, (int)H, cur_stream()),
+    check(kv_residual_reduce(nullptr, 0, 0, x.data_ptr(), residual.data_ptr(), has_residual ? 1 : 0, (float*)ss.data_ptr(), (int)T, (int)H, pfb, pfb ? pfv : nullptr, pfs,
+                             cur_stream()),
           "kv_residual_reduce");
   }
   return ss;
@@ -688,7 +717,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("decode_attention_fused", &decode_attention_fused, py::arg("slabs"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
         py::arg("v_cache"), py::arg("slot_mapping"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"), py::arg("out"), py::arg("nh"),
         py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4, py::arg("kv_scale") = py::none(), py::arg("n_split") = 1,
-        py::arg("split_ws") = py::none());
+        py::arg("split_ws") = py::none(), py::arg("pf_w") = py::none(), py::arg("pf_plan") = py::none(), py::arg("pf_sink") = py::none());
   m.def("argmax", &argmax);
   m.def("embed_fed", &embed_fed);
   m.def("swiglu_interleaved", &swiglu_interleaved);
@@ -726,5 +755,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rope_kv_write_slabs", &rope_kv_write_slabs, py::arg("slabs"), py::arg("q_out"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
         py::arg("v_cache"), py::arg("slot_mapping"), py::arg("nh"), py::arg("nkv"), py::arg("hd"), py::arg("row_ss"), py::arg("h_in"), py::arg("eps"),
         py::arg("kv_scale") = py::none());
-  m.def("residual_reduce", &residual_reduce);
+  m.def("residual_reduce", &residual_reduce, py::arg("x"), py::arg("residual"), py::arg("has_residual"), py::arg("pf_w") = py::none(), py::arg("pf_plan") = py::none(),
+        py::arg("pf_sink") = py::none());
 }

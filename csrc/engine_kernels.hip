@@ -102,6 +102,60 @@ __device__ inline float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------
+// Weight prefetch beside a latency-bound kernel.  The residual / RMSNorm-statistics kernel and
+// the decode attention kernel at short contexts are chains of dependent loads: HBM idles while
+// they run, and the weight-streaming GEMM that follows them is bound by HBM.  Such a launch can
+// carry extra workgroups (after its own in dispatch order) that do nothing but read the START of
+// the byte ranges the next GEMM's workgroups will stream, so the GEMM finds them in cache.
+// Which cache decides the gain: every XCD has an L2 of its own, and the dispatcher deals
+// workgroups to the 8 XCDs round-robin by linear id, in this launch and in the GEMM's alike — a
+// prefetch workgroup whose linear id is x (mod 8) therefore reads only what the GEMM workgroups
+// with id x (mod 8) will read, and the bytes land in the L2 those will look in (4 MiB per XCD:
+// the caller sizes `kib` so that the prefix fits; what L2 drops is still in the Infinity Cache).
+// Were the placement different, the result would be the same and only the speed-up smaller.
+//
+// The plan mirrors the grid of stream_gemm3_kernel (csrc/stream_gemm.hip): workgroup (bx, by) of
+// a (gx, gy) grid streams, for each of its nw waves w, the bytes
+//     base + (bx * nw + w) * tile_bytes + by * split_bytes + [0, split_bytes)
+// of the packed weights; the first `kib` KiB of each such range are fetched here.
+struct PrefetchPlan {
+  const unsigned char* base;  // packed weights of the next GEMM (nullptr: no prefetch workgroups were launched)
+  int gx, gy, nw, kib;
+  long long tile_bytes, split_bytes;
+  int wgs;                    // prefetch workgroups in this launch, a multiple of 8
+  unsigned int* sink;         // never written in practice; keeps the loads alive
+};
+
+// j0: index of this workgroup among the launch's prefetch workgroups; lin: its linear id in the
+// whole grid; a wave takes whole ranges (one per trip, all of a range's loads in flight at once).
+__device__ inline void prefetch_role(const PrefetchPlan& pf, int j0, int lin, int wave, int nwaves, int lane) {
+  if (pf.base == nullptr || j0 >= pf.wgs) return;
+  const int x = lin & 7;
+  const int workers = (pf.wgs >> 3) * nwaves;  // prefetch waves that share this XCD
+  const int worker = (j0 >> 3) * nwaves + wave;
+  const int G = pf.gx * pf.gy;
+  const int ranges = ((G - x + 7) >> 3) * pf.nw;  // GEMM workgroups x, x + 8, ... < G, nw ranges each
+  // The data is never used, so nothing waits for it: every load targets the same scratch
+  // registers (returns are in order, the last one wins) and the wave issues all its ranges back
+  // to back — one memory round trip per wave instead of one per range (measured: with a wait per
+  // range, a range cost 2-3 us whatever its size, and a wave's ranges lie far apart).  The
+  // hardware's own limit on outstanding loads per wave is the only throttle.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 scratch = {0u, 0u, 0u, 0u};
+  for (int rg = worker; rg < ranges; rg += workers) {
+    const int ii = rg / pf.nw, w = rg - ii * pf.nw;
+    const int g = 8 * ii + x;
+    const int by = g / pf.gx, bx = g - by * pf.gx;
+    const uint4* p = reinterpret_cast<const uint4*>(pf.base + ((long long)bx * pf.nw + w) * pf.tile_bytes + (long long)by * pf.split_bytes) + lane;
+    for (int k = 0; k < pf.kib; ++k) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(scratch) : "v"(p + k * 64) : "memory");
+  }
+  // `scratch` is an in/out operand of every load and of this wait, so it is live from the first
+  // load to here and the compiler keeps other values out of the registers the loads land in.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(scratch) : : "memory");  // the wave ends with nothing in flight
+  (void)pf.sink;
+}
+
+// ---------------------------------------------------------------------------------
 // residual' = bf16(residual + x);  y = bf16(rmsnorm(residual') * w).  One workgroup per
 // token row; H must be a multiple of 8.  x/residual/y may not alias each other except
 // that residual is updated in place.
@@ -198,13 +252,17 @@ __global__ __launch_bounds__(256) void add_rmsnorm_slab_kernel(const float* __re
 // projection's epilogue, so what is left of "residual add + RMSNorm" is
 //     residual' = bf16(residual + bf16(sum of slabs))      (or + x for a bf16 input)
 //     ss_part[t][p] = sum of residual'^2 over the p-th 512-column segment of row t.
-// grid = (ceil(H/512), T), one wavefront per workgroup, 8 columns per lane: a [32, 4096]
-// activation is 256 independent waves instead of 32 serial row loops.
+// grid = (ceil(H/512), T + prefetch rows), one wavefront per workgroup, 8 columns per lane: a
+// [32, 4096] activation is 256 independent waves instead of 32 serial row loops.
 template <bool SLAB>
 __global__ __launch_bounds__(64) void residual_reduce_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                              const unsigned short* __restrict__ x, unsigned short* __restrict__ residual, int has_residual,
-                                                             float* __restrict__ ss_part, int H) {
+                                                             float* __restrict__ ss_part, int H, int T, PrefetchPlan pf) {
   const int t = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
+  if (t >= T) {  // rows past the last token: weight prefetch for the next GEMM (see prefetch_role)
+    prefetch_role(pf, (t - T) * (int)gridDim.x + p, t * (int)gridDim.x + p, 0, 1, lane);
+    return;
+  }
   const int col = (p * 64 + lane) * 8;
   float ss = 0.f;
   if (col < H) {
@@ -912,8 +970,19 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
                                                                      unsigned short* __restrict__ out, int nh, int nkv,
                                                                      const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
                                                                      float scale_log2e, const float* __restrict__ kv_scale,
-                                                                     float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ counters) {
+                                                                     float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ counters,
+                                                                     PrefetchPlan pf) {
   constexpr int HD = 128, BS = 16, HALF = 64, NT = 64 * NWAVE;
+  if constexpr (!SPLIT) {
+    // grid rows past the kv heads: weight prefetch for the output projection (see prefetch_role).
+    // A workgroup of this kernel fills a CU's registers, so these run where the step's (token, kv
+    // head) pairs leave CUs free and queue behind them otherwise.
+    if ((int)blockIdx.y >= nkv) {
+      prefetch_role(pf, ((int)blockIdx.y - nkv) * (int)gridDim.x + (int)blockIdx.x, (int)(blockIdx.y * gridDim.x + blockIdx.x),
+                    __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), NWAVE, (int)threadIdx.x & 63);
+      return;
+    }
+  }
   float inv_ks = 1.f, inv_vs = 1.f, v_scale = 1.f;
   if constexpr (KV8) {
     const float ks = kv_scale[blockIdx.y];
@@ -1349,6 +1418,19 @@ __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const unsigned 
   *reinterpret_cast<bf16x8*>(act + (long long)t * I + (long long)grp * 8) = o;
 }
 
+// Host-side check of a prefetch plan against the weight allocation it points into: every range
+// the prefetch workgroups will read must lie inside [base, base + bytes).
+int make_prefetch_plan(const void* base, const long long* v, unsigned int* sink, PrefetchPlan* out) {
+  const long long gx = v[0], gy = v[1], nw = v[2], kib = v[3], tile_bytes = v[4], split_bytes = v[5], wgs = v[6], bytes = v[7];
+  if (gx < 1 || gy < 1 || nw < 1 || kib < 1 || wgs < 8 || (wgs & 7) || wgs > 65536 || gx * gy > (1 << 20)) return -1;
+  if (tile_bytes < 1024 || (tile_bytes & 1023) || split_bytes < 1024 || (split_bytes & 1023) || ((uintptr_t)base & 15)) return -1;
+  if (kib * 1024 > split_bytes) return -1;
+  // the last range starts at ((gx * nw - 1) * tile_bytes + (gy - 1) * split_bytes) and is kib KiB long
+  if ((gx * nw - 1) * tile_bytes + (gy - 1) * split_bytes + kib * 1024 > bytes) return -1;
+  *out = PrefetchPlan{(const unsigned char*)base, (int)gx, (int)gy, (int)nw, (int)kib, tile_bytes, split_bytes, (int)wgs, sink};
+  return 0;
+}
+
 }  // namespace
 
 // Pull a byte range through the memory hierarchy without using it: reads allocate in the
@@ -1417,17 +1499,24 @@ int kv_rope_kv_write_slabs(const float* slabs, int n_slabs, long long slab_strid
 
 // x: bf16 [T, H] (n_slabs == 0) or fp32 slabs [n_slabs][T][H]; residual: bf16 [T, H] in/out
 // (has_residual == 0: treated as zero and only written); ss_part: float [T][ceil(H/512)].
+// pf_base / pf (optional): the packed weights of the GEMM that runs next and its plan
+// {gx, gy, nw, kib, tile_bytes, split_bytes, prefetch workgroups, weight bytes}; see PrefetchPlan.
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
-                       hipStream_t stream) {
+                       const void* pf_base, const long long* pf, unsigned int* pf_sink, hipStream_t stream) {
   if (T <= 0) return 0;
   if (H % 8) return -1;
   dim3 grid((H + 511) / 512, T);
+  PrefetchPlan plan{};
+  if (pf_base != nullptr && pf != nullptr) {
+    if (make_prefetch_plan(pf_base, pf, pf_sink, &plan) != 0) return -1;
+    grid.y += (plan.wgs + grid.x - 1) / grid.x;
+  }
   if (n_slabs > 0)
     hipLaunchKernelGGL(residual_reduce_kernel<true>, grid, dim3(64), 0, stream, slabs, n_slabs, slab_stride, (const unsigned short*)nullptr,
-                       (unsigned short*)residual, has_residual, ss_part, H);
+                       (unsigned short*)residual, has_residual, ss_part, H, T, plan);
   else
     hipLaunchKernelGGL(residual_reduce_kernel<false>, grid, dim3(64), 0, stream, (const float*)nullptr, 0, 0LL, (const unsigned short*)x,
-                       (unsigned short*)residual, has_residual, ss_part, H);
+                       (unsigned short*)residual, has_residual, ss_part, H, T, plan);
   return (int)hipGetLastError();
 }
 
@@ -1543,7 +1632,8 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
-                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, hipStream_t stream) {
+                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, const void* pf_base,
+                              const long long* pf, unsigned int* pf_sink, hipStream_t stream) {
   if (T <= 0) return 0;
   if (hd != 128 || block_size != 16 || nh % nkv || n_slabs < 1 || n_slabs > 16 || (waves != 4 && waves != 8)) return -1;
   if (n_split < 1 || n_split > 64 || (n_split > 1 && (!part_o || !part_ml || !counters))) return -1;
@@ -1552,11 +1642,17 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
   const float inv_h = h_in > 0 ? 1.f / (float)h_in : 0.f;
   if (rep > 4) waves = 4;  // 8 waves of the wider head groups do not fit the 256 registers per lane that 2 waves per SIMD leave
   dim3 grid(T, nkv), block(64 * waves);
-  if (n_split > 1) grid = dim3(n_split, nkv, T);  // splits fastest: see the kernel
+  PrefetchPlan plan{};
+  if (n_split > 1) {
+    grid = dim3(n_split, nkv, T);  // splits fastest: see the kernel
+  } else if (pf_base != nullptr && pf != nullptr) {  // (long-context steps are bound by the KV stream themselves: no prefetch beside the split variant)
+    if (make_prefetch_plan(pf_base, pf, pf_sink, &plan) != 0) return -1;
+    grid.y += (plan.wgs + T - 1) / T;
+  }
 #define KV_LAUNCH_S(R, W, K8, SP)                                                                                                                        \
   hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8, SP>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t, k_cache, \
                      v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, row_ss, ss_parts,        \
-                     inv_h, eps, sl, kv_scale, part_o, part_ml, counters)
+                     inv_h, eps, sl, kv_scale, part_o, part_ml, counters, plan)
 #define KV_LAUNCH_K(R, W, K8)       \
   if (n_split > 1) {                \
     KV_LAUNCH_S(R, W, K8, true);    \

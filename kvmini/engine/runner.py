@@ -301,18 +301,29 @@ class ModelRunner:
         sample_idx = self._dev("sample_idx", t_pad)
         bt = self._dev("block_tables").view(self.rcfg.max_num_seqs, self.max_blocks_per_seq)
 
+        # Steps the weight-streaming GEMM serves: the residual kernels and the fused decode attention
+        # read the next projection's weights ahead while HBM would idle (hip_ops.prefetch_plan).
+        plan = getattr(ops, "prefetch_plan", None)
+        if self.tp_active or self.device.type != "cuda":
+            plan = None
+
+        def pf(wt: Any, site: str) -> Dict[str, Any]:
+            p = plan(wt, t_pad, site) if plan is not None else None
+            return {"prefetch": p} if p is not None else {}
+
         x = ops.embed_tokens(w.embed, tokens, self._dev("feed", t_pad), self.out_ids)
         residual = None  # the first residual add is a copy
         pending_reduce = False  # x is a row-parallel projection's partial output that still has to be summed over the TP ranks
         h = None  # set when a projection already folded its output into the residual stream (fused epilogue)
         for li, lw in enumerate(w.layers):
             if h is None:
-                h, residual = self._add_rmsnorm(x, residual, lw.attn_norm, pending_reduce)
+                h, residual = self._add_rmsnorm(x, residual, lw.attn_norm, pending_reduce, **pf(lw.wqkv, "qkv"))
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             kw = {"kv_scale": self.kv_scale[li]} if self.kv_fp8 else {}
             if decode_only and self._fused_ok(qkv, kc):
-                a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale, n_split=None if decode_only == 2 else 1, **kw)
+                a = ops.rope_attention_fused(qkv, positions, self.cos, self.sin, kc, vc, slots, bt, tok_seq, ctx, self.nh, self.scale, n_split=None if decode_only == 2 else 1, **kw,
+                                             **(pf(lw.wo, "o") if decode_only == 1 else {}))
             elif not decode_only and self._tiled_ok(kc):
                 # decode tokens: one workgroup per token; prompt chunks: 16-query MFMA tiles
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
@@ -321,7 +332,7 @@ class ModelRunner:
             else:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks, **kw)
-            h, residual = self._proj_residual(a, lw.wo, residual, lw.mlp_norm)
+            h, residual = self._proj_residual(a, lw.wo, residual, lw.mlp_norm, **pf(lw.wgu, "gu"))
             act = ops.linear_swiglu(h, lw.wgu)
             fused = self._fused_residual(act, lw.wdown, residual)
             if fused is not None:
@@ -331,7 +342,7 @@ class ModelRunner:
                 x = ops.linear(act, lw.wdown, allow_slabs=True)
                 pending_reduce = True
         if h is None:
-            h, residual = self._add_rmsnorm(x, residual, w.final_norm, pending_reduce)
+            h, residual = self._add_rmsnorm(x, residual, w.final_norm, pending_reduce, **pf(w.lm_head, "head"))
         hs = ops.select_rows(h, sample_idx[: self.sample_rows(t_pad)])
         logits = ops.linear(hs, w.lm_head)
         self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
@@ -346,20 +357,20 @@ class ModelRunner:
             return None
         return fn(x, w, residual, self.cfg.rms_eps)
 
-    def _proj_residual(self, x: torch.Tensor, w: Any, residual: torch.Tensor, norm_w: torch.Tensor) -> Tuple[Any, torch.Tensor]:
+    def _proj_residual(self, x: torch.Tensor, w: Any, residual: torch.Tensor, norm_w: torch.Tensor, **kw: Any) -> Tuple[Any, torch.Tensor]:
         fused = self._fused_residual(x, w, residual)
         if fused is not None:
             return fused
-        return self._add_rmsnorm(self.ops.linear(x, w, allow_slabs=True), residual, norm_w, True)
+        return self._add_rmsnorm(self.ops.linear(x, w, allow_slabs=True), residual, norm_w, True, **kw)
 
-    def _add_rmsnorm(self, x: Any, residual: Optional[torch.Tensor], norm_w: torch.Tensor, partial: bool) -> Tuple[Any, torch.Tensor]:
+    def _add_rmsnorm(self, x: Any, residual: Optional[torch.Tensor], norm_w: torch.Tensor, partial: bool, **kw: Any) -> Tuple[Any, torch.Tensor]:
         """Residual update + norm in front of a projection.  ``partial``: ``x`` is this rank's
         share of a row-parallel projection and is summed over the TP ranks on the way — in the
         fused peer-memory kernel (slab sum -> all-reduce -> residual add -> sums of squares, one
         launch) when the message fits its slots, else all-reduced first."""
         ops, eps = self.ops, self.cfg.rms_eps
         if not (partial and self.tp_active):
-            return ops.add_rmsnorm(x, residual, norm_w, eps)
+            return ops.add_rmsnorm(x, residual, norm_w, eps, **kw)
         if self.xgmi is not None:
             src = x.slabs if hasattr(x, "slabs") else (x if x.is_contiguous() else x.contiguous())
             t, hdim = (src.shape[1], src.shape[2]) if src.dim() == 3 else src.shape

@@ -432,6 +432,72 @@ def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow
     return out
 
 
+# ---- weight prefetch beside the latency-bound kernels of a decode step -------------------------
+# KVMINI_PREFETCH="site=KiB:workgroups,..." — KiB = how much of the start of every (16-feature
+# tile, K split) range of the NEXT streaming GEMM is read ahead, workgroups = extra workgroups the
+# carrying kernel gets for it.  qkv / gu / head ride on the residual kernel in front of the QKV,
+# gate/up and LM-head projections (one-wave workgroups), o rides on the fused decode attention
+# kernel (8-wave workgroups).  Example that keeps each XCD's share within its 4 MiB L2:
+# "qkv=16:1536,o=16:64,gu=12:1792,head=4:1024".
+# OFF by default.  Measured on MI355X (Llama-3-8B, batch 20): the GEMMs do get faster — output
+# projection 9.2 -> 4.6 us from L2, QKV 10.6 -> 8.6, gate/up 40.6 -> 39.5 — but the carriers pay
+# more than that: the attention kernel fills a CU per workgroup, so its prefetch rows only get
+# the ~64-96 CUs the step leaves idle (~45 GB/s each: 32 MB take 12 us, 9.1 -> 21.5 us), and
+# the residual kernels' idle window inside a replayed graph is shorter than the GEMM time
+# saved (+1.7 us each).  Decode step 3.37 -> 3.41 (one residual site) ... 3.64 ms (all sites).
+_PREFETCH_DEFAULT = "0"
+_prefetch_sinks: Dict[Any, torch.Tensor] = {}
+
+
+@functools.lru_cache(maxsize=None)
+def _prefetch_config(spec: Optional[str] = None) -> Dict[str, Tuple[int, int]]:
+    spec = os.environ.get("KVMINI_PREFETCH", _PREFETCH_DEFAULT) if spec is None else spec
+    out: Dict[str, Tuple[int, int]] = {}
+    if spec.strip() in ("", "0", "off", "none"):
+        return out
+    for item in spec.split(","):
+        site, _, val = item.strip().partition("=")
+        kib, _, wgs = val.partition(":")
+        if int(kib) > 0 and int(wgs) >= 8:
+            out[site] = (int(kib), int(wgs) // 8 * 8)
+    return out
+
+
+def prefetch_plan(w: Weight, rows: int, site: str) -> Optional[Tuple[torch.Tensor, list, torch.Tensor]]:
+    """What a latency-bound kernel needs to read ahead for the streaming GEMM that follows it:
+    ``(packed weights, [gx, gy, nw, kib, tile_bytes, split_bytes, workgroups], sink)`` — the grid
+    :func:`_stream` will launch for ``w`` at ``rows`` token rows (feature groups x K splits, waves
+    per workgroup, bytes of a 16-feature tile and of one K split inside it), or None when the
+    site is switched off or the step is not one the streaming kernel's main path serves.
+    ``site``: 'qkv' / 'o' (split-K slabs), 'gu' / 'head' (unsplit)."""
+    cfg = _prefetch_config().get(site)
+    if cfg is None or not isinstance(w, PackedLinear) or rows > MAX_M or rows % 16 or w.k % 256:
+        return None
+    kib, wgs = cfg
+    col_bytes = 2 * w.bits  # bytes of one K column of a 16-feature tile
+    tile_bytes = w.k * col_bytes
+    nw, gy, split_bytes = 0, 1, tile_bytes
+    if site in ("qkv", "o") and w.n == w.n_pad:
+        if w.bits == 4:
+            group_cols = 128 * (4 if (rows <= 32 and w.k % 512 == 0) else 2)
+            nw, gy, gps = _plan_slabs(w.n_pad, w.k, rows, group_cols)
+        else:
+            group_cols = 256
+            nw, gy, gps = _plan_slabs(w.n_pad, w.k)
+        split_bytes = gps * group_cols * col_bytes
+    if gy <= 1:
+        nw, gy, split_bytes = _waves_per_workgroup(w.n_pad), 1, tile_bytes
+    if tile_bytes % 1024 or split_bytes % 1024:
+        return None
+    dev = w.wp.device
+    sink = _prefetch_sinks.get(dev)
+    if sink is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        sink = _prefetch_sinks[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return w.wp, [w.n_pad // (16 * nw), gy, nw, min(kib, split_bytes // 1024), tile_bytes, split_bytes, wgs], sink
+
+
 _resid_counters: Dict[Any, torch.Tensor] = {}
 FUSE_RESIDUAL = os.environ.get("KVMINI_FUSE_RESIDUAL", "0") == "1"  # measured slower than the two-kernel path (see linear_residual): off unless asked for
 
@@ -467,11 +533,13 @@ def linear_residual(x: torch.Tensor, w: Weight, residual: torch.Tensor, eps: flo
     return Normed(residual, ss, eps), residual
 
 
-def add_rmsnorm(x: Union[torch.Tensor, Partial], residual: Optional[torch.Tensor], w: torch.Tensor, eps: float) -> Tuple[Normed, torch.Tensor]:
+def add_rmsnorm(x: Union[torch.Tensor, Partial], residual: Optional[torch.Tensor], w: torch.Tensor, eps: float,
+                prefetch: Optional[Tuple[torch.Tensor, list, torch.Tensor]] = None) -> Tuple[Normed, torch.Tensor]:
     """Residual update of the folded-norm pipeline.  ``x``: bf16 ``[T, H]`` or a
     :class:`Partial` (split-K slabs of the previous projection); ``residual``: bf16
     ``[T, H]`` updated in place, or None for the first layer.  ``w`` (the gain) must
-    already be folded into the consuming projection (:func:`prepare_weights`)."""
+    already be folded into the consuming projection (:func:`prepare_weights`).
+    ``prefetch``: a :func:`prefetch_plan` for the projection that runs next."""
     C = native()
     if isinstance(x, Partial):
         assert x.ss is None, "slabs that still need a row scale cannot feed a residual add"
@@ -483,7 +551,7 @@ def add_rmsnorm(x: Union[torch.Tensor, Partial], residual: Optional[torch.Tensor
     has_res = residual is not None
     if residual is None:
         residual = torch.empty((t, hdim), dtype=torch.bfloat16, device=src.device)
-    ss = C.residual_reduce(src, residual, has_res)
+    ss = C.residual_reduce(src, residual, has_res, *(prefetch or ()))
     return Normed(residual, ss, eps), residual
 
 
@@ -653,18 +721,20 @@ def rope_attention_fused(
     scale: float,
     kv_scale: Optional[torch.Tensor] = None,
     n_split: Optional[int] = None,
+    prefetch: Optional[Tuple[torch.Tensor, list, torch.Tensor]] = None,
 ) -> torch.Tensor:
     """RoPE + paged-KV write + attention for a step in which every token is the only new
     token of its sequence (plain decoding).  ``qkv`` must be the split-K slabs of the QKV
     projection; returns the attention output ``[T, nh*hd]``.  ``n_split``: workgroups per
-    (token, kv head) (None: by the step's shape, see :func:`decode_attention_splits`)."""
+    (token, kv head) (None: by the step's shape, see :func:`decode_attention_splits`).
+    ``prefetch``: a :func:`prefetch_plan` for the output projection (unsplit launches only)."""
     t = qkv.slabs.shape[1]
     nkv, hd = k_cache.shape[1], k_cache.shape[3]
     out = torch.empty((t, n_heads * hd), dtype=torch.bfloat16, device=qkv.slabs.device)
     ns = decode_attention_splits(t, nkv) if n_split is None else n_split
     ws = _split_workspace(out.device, 4096 + t * n_heads * ns * (hd + 2)) if ns > 1 else None
     native().decode_attention_fused(qkv.slabs, positions, cos, sin, k_cache, v_cache, slot_mapping, block_tables, tok_seq, ctx_lens, out, n_heads, qkv.ss, qkv.h_in, qkv.eps, scale,
-                                    _decode_attention_waves(t, nkv), kv_scale, ns, ws)
+                                    _decode_attention_waves(t, nkv), kv_scale, ns, ws, *((prefetch if ns == 1 else None) or ()))
     return out
 
 

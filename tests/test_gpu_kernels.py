@@ -259,6 +259,85 @@ def test_engine_hip_matches_dense_reference(graphs):
             ids.append(tok)
 
 
+# ---- weight prefetch rows of the residual / decode attention kernels ---------------------
+def test_residual_reduce_prefetch_rows_do_not_change_the_result(C):
+    """The extra (prefetch) workgroups of residual_reduce only read weights: residual and sums
+    of squares equal the plain launch bit for bit, for slab and bf16 inputs; plans whose ranges
+    would leave the weight allocation are refused on the host."""
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(5)
+    T, H = 32, 4096
+    w = hip_ops.PackedLinear((torch.randn(6144, 4096, device=_dev()) * 0.02).bfloat16())
+    hip_ops._prefetch_config.cache_clear()
+    os.environ["KVMINI_PREFETCH"] = "qkv=16:1536,gu=12:1792"
+    try:
+        plan = hip_ops.prefetch_plan(w, T, "qkv")
+        gu_plan = hip_ops.prefetch_plan(w, T, "gu")
+        assert hip_ops.prefetch_plan(w, T, "o") is None  # site not configured
+        assert hip_ops.prefetch_plan(w, 20, "qkv") is None  # not a whole number of 16-row tiles
+    finally:
+        del os.environ["KVMINI_PREFETCH"]
+        hip_ops._prefetch_config.cache_clear()
+    assert hip_ops.prefetch_plan(w, T, "qkv") is None  # off by default
+    assert plan is not None and gu_plan is not None
+    gx, gy, nw, kib, tile_bytes, split_bytes, wgs = plan[1]
+    assert gx * nw * 16 == 6144 and tile_bytes == 4096 * 32 and split_bytes * gy == tile_bytes and wgs % 8 == 0
+    slabs = torch.randn(4, T, H, device=_dev())
+    xb = torch.randn(T, H, device=_dev()).bfloat16()
+    for src in (slabs, xb):
+        for pf in (plan, gu_plan):
+            r0 = torch.randn(T, H, device=_dev()).bfloat16()
+            r1 = r0.clone()
+            ss0 = C.residual_reduce(src, r0, True)
+            ss1 = C.residual_reduce(src, r1, True, *pf)
+            torch.cuda.synchronize()
+            assert torch.equal(r0, r1) and torch.equal(ss0, ss1)
+    bad = list(plan[1])
+    bad[3] = split_bytes // 1024 + 1  # more KiB than a range holds
+    with pytest.raises(RuntimeError):
+        C.residual_reduce(xb, xb.clone(), True, plan[0], bad, plan[2])
+    bad = list(plan[1])
+    bad[0] = gx + 1  # one feature group more than the weights have
+    with pytest.raises(RuntimeError):
+        C.residual_reduce(xb, xb.clone(), True, plan[0], bad, plan[2])
+    bad = list(plan[1])
+    bad[6] = 12  # not a multiple of 8
+    with pytest.raises(RuntimeError):
+        C.residual_reduce(xb, xb.clone(), True, plan[0], bad, plan[2])
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_engine_with_weight_prefetch_generates_the_same_tokens(graphs):
+    """KVMINI_PREFETCH on (all four sites, incl. the rows of the fused decode attention launch):
+    same tokens as with it off."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.ops import hip_ops
+
+    prompts = [[1, 50, 60, 70, 80], list(range(1, 41)), [1, 9, 8, 7, 6, 5, 4, 3, 2]]
+    outs = {}
+    for spec in ("0", "qkv=2:64,o=2:16,gu=2:64,head=2:64"):
+        hip_ops._prefetch_config.cache_clear()
+        os.environ["KVMINI_PREFETCH"] = spec
+        try:
+            w = random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)
+            eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, use_graphs=graphs, kernels="hip"), weights=w)
+            if graphs:
+                eng.warmup()
+            if spec != "0":
+                lw = eng.weights.layers[0]
+                assert hip_ops.prefetch_plan(lw.wo, 16, "o") is not None and hip_ops.prefetch_plan(lw.wqkv, 16, "qkv") is not None
+            outs[spec] = eng.generate(prompts, SamplingParams(max_tokens=8, ignore_eos=True))
+            del eng
+        finally:
+            del os.environ["KVMINI_PREFETCH"]
+            hip_ops._prefetch_config.cache_clear()
+    a, b = outs.values()
+    assert a == b
+
+
 # ---- weight-streaming GEMM v2 ---------------------------------------------------------
 @pytest.mark.parametrize("M", [16, 32, 48, 64, 20, 100])
 @pytest.mark.parametrize("N,K", [(256, 128), (4096, 4096), (6144, 4096), (4096, 14336), (1000, 512)])
