@@ -68,7 +68,7 @@ int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, 
 int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int target_wgs, int* groups_per_split);
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int weight_bits, void* residual, int has_residual,
-                    float* ss_out, int* counters, hipStream_t stream);
+                    float* ss_out, int* counters, int ft, hipStream_t stream);
 int kv_prefetch(const void* p, long long bytes, int workgroups, unsigned int* sink, hipStream_t stream);
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
@@ -486,8 +486,9 @@ std::pair<int64_t, int64_t> stream_gemm3_plan(int64_t N, int64_t K, int64_t nb, 
 
 void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out, int64_t epi, int64_t nb, int64_t splits, int64_t groups_per_split,
                   c10::optional<at::Tensor> row_ss, double eps, c10::optional<at::Tensor> w_scale, int64_t nw, int64_t weight_bits,
-                  c10::optional<at::Tensor> residual, bool has_residual, c10::optional<at::Tensor> ss_out, c10::optional<at::Tensor> counters) {
+                  c10::optional<at::Tensor> residual, bool has_residual, c10::optional<at::Tensor> ss_out, c10::optional<at::Tensor> counters, int64_t ft) {
   CHECK_DEV(Wp); CHECK_BF16(x); CHECK_CONTIG(Wp); CHECK_DEV(out);
+  TORCH_CHECK(ft == 1 || ft == 2, "ft (16-feature tiles per wave) must be 1 or 2");
   const float* wsp = nullptr;
   if (weight_bits == 4) {
     // MXFP4: two e2m1 values per byte, block scales as int32 [N/16, K/128, 16] (four E8M0 bytes each)
@@ -508,7 +509,7 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
   }
   TORCH_CHECK(weight_bits == 0 || weight_bits == 4 || weight_bits == 8 || weight_bits == 16, "weight_bits must be 0 (by w_scale), 4, 8 or 16");
   TORCH_CHECK(nw == 4 || nw == 6 || nw == 7 || nw == 8, "nw (waves per workgroup) must be 4, 6, 7 or 8");
-  TORCH_CHECK(N % (16 * nw) == 0, "N must be a multiple of 16 * nw");
+  TORCH_CHECK(N % (16 * nw * ft) == 0, "N must be a multiple of 16 * nw * ft");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
   const int64_t M = x.size(0);
   int parts = 0;
@@ -540,7 +541,7 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
     ldy = out.stride(0);
   }
   check(kv_stream_gemm3(Wp.data_ptr(), x.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), ldy, (int)epi, (int)nb, (int)nw, (int)splits,
-                        (int)groups_per_split, slab_stride, ssp, parts, (float)eps, wsp, (int)weight_bits, resp, has_residual ? 1 : 0, ssop, cntp, cur_stream()),
+                        (int)groups_per_split, slab_stride, ssp, parts, (float)eps, wsp, (int)weight_bits, resp, has_residual ? 1 : 0, ssop, cntp, (int)ft, cur_stream()),
         "kv_stream_gemm3");
 }
 
@@ -734,7 +735,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_gemm3_plan", &stream_gemm3_plan, py::arg("N"), py::arg("K"), py::arg("nb"), py::arg("max_splits"), py::arg("target_wgs") = 512, py::arg("nw") = 4);
   m.def("stream_gemm3", &stream_gemm3, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("nb"), py::arg("splits"),
         py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4, py::arg("weight_bits") = 0,
-        py::arg("residual") = py::none(), py::arg("has_residual") = true, py::arg("ss_out") = py::none(), py::arg("counters") = py::none());
+        py::arg("residual") = py::none(), py::arg("has_residual") = true, py::arg("ss_out") = py::none(), py::arg("counters") = py::none(), py::arg("ft") = 1);
   m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);

@@ -261,13 +261,18 @@ __device__ inline raw16 ldw16(const raw16* p) {
 
 // WB = weight bits: 16 (bf16), 8 (e4m3 + one fp32 scale per row, applied in the epilogue) or
 // 4 (MXFP4: w_scale then points at the packed E8M0 block scales, uint32 [N/16][K/128][16 rows]).
-template <int MT, int KS, int NB, int EPI, int WB, bool NT, int NW>
+// FT = 16-feature tiles per wave (consecutive tiles).  Every x fragment a wave reads from LDS
+// feeds FT MFMAs instead of one: with many token rows (MT = 8, 16) or few weight bytes per MFMA
+// (FP8, MXFP4) the x fragment reads, not HBM, bound the kernel at FT = 1 — a wave reads
+// MT KiB of x per k-step whatever the weights weigh.
+template <int MT, int KS, int NB, int EPI, int WB, bool NT, int NW, int FT = 1>
 __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __restrict__ Wp, const __bf16* __restrict__ x, void* __restrict__ out, int N, int K,
                                                            long long ldx, long long ldy, int groups_per_split, long long slab_stride,
                                                            const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps,
                                                            const float* __restrict__ w_scale, ResidArgs ra) {
   constexpr bool W8 = WB == 8, W4 = WB == 4;
   static_assert(!W4 || KS % 4 == 0, "an MXFP4 load carries four k-steps");
+  static_assert(FT == 1 || EPI != EPI_RESID, "the fused residual fix-up is built for one tile per wave");
   constexpr int AL = W4 ? KS / 4 : W8 ? KS / 2 : KS;
   constexpr int XF = KS * MT;
   constexpr int XL = (XF + NW - 1) / NW;  // x fragments of a chunk per wave
@@ -280,10 +285,12 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
   const int ngroups = ksteps / (KS * NB);
   const int g0 = blockIdx.y * groups_per_split;
   const int g1 = g0 + groups_per_split < ngroups ? g0 + groups_per_split : ngroups;
-  const long long tile = (long long)blockIdx.x * NW + wave;
-  const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * (ksteps * AL / KS) * 64 + lane;
-  const unsigned int* scp = reinterpret_cast<const unsigned int*>(w_scale) + (W4 ? tile * (ksteps / 4) * 16 + r : 0);  // W4: one word per chunk
-  unsigned int sc[NB][W4 ? AL : 1];
+  const long long tile = ((long long)blockIdx.x * NW + wave) * FT;  // the wave's first tile
+  const long long tile_units = (long long)(ksteps * AL / KS) * 64;    // 16-byte units of one tile's weights
+  const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * tile_units + lane;
+  const long long sc_units = (long long)(ksteps / 4) * 16;            // scale words of one tile (W4)
+  const unsigned int* scp = reinterpret_cast<const unsigned int*>(w_scale) + (W4 ? tile * sc_units + r : 0);  // W4: one word per chunk
+  unsigned int sc[NB][FT][W4 ? AL : 1];
 
   const __bf16* xsrc[XL];
 #pragma unroll
@@ -293,20 +300,24 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
     xsrc[i] = x + (long long)(j * 16 + r) * ldx + ks * 32 + q * 8;
   }
 
-  frag_cd acc[MT];
+  frag_cd acc[FT][MT];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) acc[j] = (frag_cd){0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < FT; ++f)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[f][j] = (frag_cd){0.f, 0.f, 0.f, 0.f};
 
-  raw16 a[NB][AL];
+  raw16 a[NB][FT][AL];
   frag_ab xr[NB][XL];
 
 #define KV_ISSUE(slot, chunk)                                                                                   \
   do {                                                                                                          \
     _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + NW * i < XF)                                      \
         xr[slot][i] = *reinterpret_cast<const frag_ab*>(xsrc[i] + (long long)(chunk) * KS * 32);                \
-    _Pragma("unroll") for (int u = 0; u < AL; ++u) a[slot][u] = ldw16<NT>(wp + ((long long)(chunk) * AL + u) * 64); \
-    if constexpr (W4) {                                                                                         \
-      _Pragma("unroll") for (int u = 0; u < AL; ++u) sc[slot][u] = scp[((long long)(chunk) * AL + u) * 16];     \
+    _Pragma("unroll") for (int f = 0; f < FT; ++f) {                                                            \
+      _Pragma("unroll") for (int u = 0; u < AL; ++u) a[slot][f][u] = ldw16<NT>(wp + f * tile_units + ((long long)(chunk) * AL + u) * 64); \
+      if constexpr (W4) {                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < AL; ++u) sc[slot][f][u] = scp[f * sc_units + ((long long)(chunk) * AL + u) * 16]; \
+      }                                                                                                         \
     }                                                                                                           \
   } while (0)
 
@@ -319,10 +330,12 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
     _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                            \
       frag_ab b[MT];                                                                                            \
       _Pragma("unroll") for (int j = 0; j < MT; ++j) b[j] = xs[(buf * XF + u * MT + j) * 64 + lane];            \
-      frag_ab af;                                                                                               \
-      if constexpr (W4) af = a_frag4(a[slot][u >> 2], sc[slot][u >> 2], u & 3);                                 \
-      else af = a_frag<W8>(a[slot], u);                                                                         \
-      _Pragma("unroll") for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[j], acc[j], 0, 0, 0); \
+      _Pragma("unroll") for (int f = 0; f < FT; ++f) {                                                          \
+        frag_ab af;                                                                                             \
+        if constexpr (W4) af = a_frag4(a[slot][f][u >> 2], sc[slot][f][u >> 2], u & 3);                         \
+        else af = a_frag<W8>(a[slot][f], u);                                                                    \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[j], acc[f][j], 0, 0, 0); \
+      }                                                                                                         \
     }                                                                                                           \
   } while (0)
 
@@ -350,7 +363,8 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
 #undef KV_ISSUE
 #undef KV_CONSUME
 
-  gemm_epilogue<MT, EPI, W8>(acc, lds_raw, out, tile, wave, lane, ldy, slab_stride, row_ss, ss_parts, inv_k, eps, w_scale);
+#pragma unroll
+  for (int f = 0; f < FT; ++f) gemm_epilogue<MT, EPI, W8>(acc[f], lds_raw, out, tile + f, wave, lane, ldy, slab_stride, row_ss, ss_parts, inv_k, eps, w_scale);
 
   if constexpr (EPI == EPI_RESID) {
     // ---- fix-up by the last split of this feature group (16 * NW features x 16 * MT rows)
@@ -434,23 +448,45 @@ int dispatch_ks(int epi, int ks, bool w8, const Args& a) {
 // reads 2 KB of them from LDS per 256 B of weights).  So every format uses 4-k-step chunks.
 constexpr int chunk_ksteps(int mt, int wb) { return 4; }
 
-template <int MT, int NB, int EPI, int WB, bool NT, int NW>
+template <int MT, int NB, int EPI, int WB, bool NT, int NW, int FT = 1>
 int launch3(const Args& a) {
-  dim3 grid(a.N / (16 * NW), a.splits), block(NW * 64);
-  hipLaunchKernelGGL((stream_gemm3_kernel<MT, chunk_ksteps(MT, WB), NB, EPI, WB, NT, NW>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
+  dim3 grid(a.N / (16 * NW * FT), a.splits), block(NW * 64);
+  hipLaunchKernelGGL((stream_gemm3_kernel<MT, chunk_ksteps(MT, WB), NB, EPI, WB, NT, NW, FT>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
                      a.slab_stride, a.row_ss, a.ss_parts, 1.f / (float)a.K, a.eps, a.w_scale, a.ra);
   return (int)hipGetLastError();
 }
 
-template <int MT, int NB, int WB, bool NT, int NW>
+template <int MT, int NB, int WB, bool NT, int NW, int FT = 1>
 int dispatch3_epi(int epi, const Args& a) {
   switch (epi) {
-    case EPI_BF16: return launch3<MT, NB, EPI_BF16, WB, NT, NW>(a);
-    case EPI_SLAB: return launch3<MT, NB, EPI_SLAB, WB, NT, NW>(a);
-    case EPI_SWIGLU: return launch3<MT, NB, EPI_SWIGLU, WB, NT, NW>(a);
+    case EPI_BF16: return launch3<MT, NB, EPI_BF16, WB, NT, NW, FT>(a);
+    case EPI_SLAB: return launch3<MT, NB, EPI_SLAB, WB, NT, NW, FT>(a);
+    case EPI_SWIGLU: return launch3<MT, NB, EPI_SWIGLU, WB, NT, NW, FT>(a);
     case EPI_RESID:
-      if constexpr (MT <= 4) return launch3<MT, NB, EPI_RESID, WB, NT, NW>(a);
+      if constexpr (MT <= 4 && FT == 1) return launch3<MT, NB, EPI_RESID, WB, NT, NW>(a);
       return -1;
+  }
+  return -1;
+}
+
+// Two feature tiles per wave (FT = 2), built where the x fragment reads bound the kernel: MXFP4
+// weights at up to 64 rows (every ring depth), and 128 / 256-row steps of every weight format
+// (2-chunk rings); workgroups of 4 or 8 waves (128 or 256 features).
+template <int MT>
+int dispatch3_ft2_w4(int epi, int nb, int nw, const Args& a) {
+#define KV_FT2(NBv, NWv) \
+  if (nb == NBv && nw == NWv) return dispatch3_epi<MT, NBv, 4, true, NWv, 2>(epi, a)
+  KV_FT2(2, 4); KV_FT2(2, 8); KV_FT2(4, 4); KV_FT2(4, 8);
+  if constexpr (MT <= 2) { KV_FT2(8, 4); KV_FT2(8, 8); }
+#undef KV_FT2
+  return -1;
+}
+
+template <int MT, int WB>
+int dispatch3_ft2_wide(int epi, int nw, const Args& a) {
+  if (nw == 4) return dispatch3_epi<MT, 2, WB, true, 4, 2>(epi, a);
+  if constexpr (MT <= 8) {  // 16 row tiles x 2 feature tiles need 512 registers per lane: 4-wave workgroups only
+    if (nw == 8) return dispatch3_epi<MT, 2, WB, true, 8, 2>(epi, a);
   }
   return -1;
 }
@@ -592,13 +628,15 @@ int kv_stream_gemm3_plan(int N, int K, int nb, int nw, int max_splits, int targe
 
 int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int nb, int nw, int splits,
                     int groups_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int weight_bits,
-                    void* residual, int has_residual, float* ss_out, int* counters, hipStream_t stream) {
+                    void* residual, int has_residual, float* ss_out, int* counters, int ft, hipStream_t stream) {
+  // ft: 16-feature tiles per wave, 1 or 2 (2: see dispatch3_ft2_w4 / dispatch3_ft2_wide for the shapes built)
+  if (ft != 1 && ft != 2) return -1;
   // weight_bits: 16, 8 (w_scale = fp32 per-row scales), 4 (MXFP4; w_scale = packed E8M0 block scales) or 0 = 8 if w_scale else 16
   const int wb = weight_bits ? weight_bits : (w_scale != nullptr ? 8 : 16);
   if ((wb != 16 && wb != 8 && wb != 4) || ((wb != 16) != (w_scale != nullptr))) return -1;
   const bool wide = M == 128 || M == 256;  // 8 / 16 row tiles per wave: 2-chunk groups only (registers)
   const int chunk_cols = 32 * chunk_ksteps(M >> 4, wb);
-  if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw)) || (nb != 2 && nb != 4 && nb != 8) || (K % (chunk_cols * nb))) return -1;
+  if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw * ft)) || (nb != 2 && nb != 4 && nb != 8) || (K % (chunk_cols * nb))) return -1;
   if (wide && nb != 2) return -1;
   if (epi == EPI_SWIGLU && (N & 15)) return -1;
   if (epi != EPI_SLAB && epi != EPI_RESID && splits != 1) return -1;
@@ -607,6 +645,18 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
   if (splits < 1 || groups_per_split < 1 || (long long)splits * groups_per_split < ngroups || (long long)(splits - 1) * groups_per_split >= ngroups) return -1;
   Args a{Wp, x, out, N, K, ldx, ldy, splits, groups_per_split, slab_stride, row_ss, ss_parts, eps, w_scale, stream};
   a.ra = ResidArgs{(unsigned short*)residual, has_residual, ss_out, counters};
+  if (ft == 2) {
+    if (epi == EPI_RESID) return -1;
+    switch (M >> 4) {
+      case 1: return wb == 4 ? dispatch3_ft2_w4<1>(epi, nb, nw, a) : -1;
+      case 2: return wb == 4 ? dispatch3_ft2_w4<2>(epi, nb, nw, a) : -1;
+      case 3: return wb == 4 ? dispatch3_ft2_w4<3>(epi, nb, nw, a) : -1;
+      case 4: return wb == 4 ? dispatch3_ft2_w4<4>(epi, nb, nw, a) : -1;
+      case 8: return wb == 4 ? dispatch3_ft2_wide<8, 4>(epi, nw, a) : wb == 8 ? dispatch3_ft2_wide<8, 8>(epi, nw, a) : dispatch3_ft2_wide<8, 16>(epi, nw, a);
+      case 16: return wb == 4 ? -1 : wb == 8 ? dispatch3_ft2_wide<16, 8>(epi, nw, a) : dispatch3_ft2_wide<16, 16>(epi, nw, a);
+    }
+    return -1;
+  }
   switch (M >> 4) {
     case 1: return dispatch3_wb<1>(epi, nb, nw, wb, a);
     case 2: return dispatch3_wb<2>(epi, nb, nw, wb, a);

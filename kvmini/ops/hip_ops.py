@@ -389,6 +389,41 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
     return out
 
 
+@functools.lru_cache(maxsize=None)
+def _plan_slabs_w4(n_pad: int, k: int, rows: int) -> Optional[Tuple[int, int, int, int, int]]:
+    """(waves per workgroup, ring depth, K splits, groups per split, feature tiles per wave) of a
+    split-K streaming GEMM on MXFP4 weights, or None when the shape does not fit the rule.  A 4-bit
+    projection of Llama-3-8B is 9-60 MB: the kernel is bound by launch and memory latency, not by
+    the weight stream, so — unlike bf16 (:func:`_plan_slabs`) — it wants many small workgroups
+    with equal K ranges.  Measured on MI355X (scripts/ft2_gemm_bench.py, microseconds, before -> after):
+    32 rows, 8-wave workgroups, 4-chunk rings, the most splits that divide K evenly with at most
+    384 workgroups: QKV 8.7 -> 8.0, output 7.9 -> 6.5, down 16.0 -> 12.2; 128 rows, two feature
+    tiles per wave (the x fragment reads from LDS bound the one-tile form there), at most one
+    workgroup per CU: QKV 18.4 -> 15.9, output 13.7 -> 12.2, down 27.7 -> 23.0."""
+    wide = rows > MAX_M
+    ft = 2 if wide else 1
+    nb = 2 if (wide or rows > 32 or k % 512) else 4
+    ngroups = k // (128 * nb)
+    if k % (128 * nb) or ngroups < 1:
+        return None
+    best: Optional[Tuple[int, int, int, int, int]] = None
+    for nw in (8, 4):
+        if n_pad % (16 * nw * ft):
+            continue
+        tiles = n_pad // (16 * nw * ft)
+        for splits in range(min(ngroups, MAX_SPLITS), 0, -1):
+            if ngroups % splits or (wide and ngroups // splits < 2):
+                continue
+            if tiles * splits <= (_NUM_CUS if wide else 384):
+                cand = (nw, nb, splits, ngroups // splits, ft)
+                if best is None or (wide and best[0] == 8 and (n_pad // (16 * 8 * ft)) * best[2] < 192 and tiles * splits > (n_pad // (16 * 8 * ft)) * best[2]):
+                    best = cand  # 128 rows: 8-wave workgroups unless they leave a quarter of the CUs idle
+                break
+        if best is not None and not wide:
+            break
+    return best if best is not None and best[2] > 1 else None
+
+
 def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_slabs: bool) -> Union[torch.Tensor, Partial]:
     """MXFP4 weights: the deep-pipeline streaming kernel for every row count — up to 64 rows as
     the bf16 / FP8 path (split-K slabs where that pays), 65..128 rows in one 8-tile pass, more in
@@ -417,16 +452,28 @@ def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow
         if ss is not None:
             ss = torch.cat((ss, torch.ones((mp - m, ss.shape[1]), dtype=ss.dtype, device=ss.device)), 0)
     if allow_slabs and epi == 0 and m == mp and w.n == w.n_pad:
-        nbs = 4 if (mp <= 32 and w.k % (4 * cols) == 0) else 2
-        nw, splits, gps = _plan_slabs(w.n_pad, w.k, mp, nbs * cols)
+        plan = _plan_slabs_w4(w.n_pad, w.k, mp)
+        if plan is not None:
+            nw, nbs, splits, gps, ft = plan
+        else:
+            nbs, ft = 4 if (mp <= 32 and w.k % (4 * cols) == 0) else 2, 1
+            nw, splits, gps = _plan_slabs(w.n_pad, w.k, mp, nbs * cols)
         if splits > 1:
             out = torch.empty((splits, mp, w.n_pad), dtype=torch.float32, device=x.device)
-            C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, nbs, splits, gps, None, 0.0, w.wscale, nw, 4)
+            C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, 1, nbs, splits, gps, None, 0.0, w.wscale, nw, 4, ft=ft)
             return Partial(out, ss, eps, w.k)
-    # a chunk of 4-bit weights is 1 KB per wave: a ring of 8 keeps as many bytes in flight as 2 chunks of bf16
-    nb = 8 if (mp <= 32 and w.k % (8 * cols) == 0) else 4 if (mp <= 32 and w.k % (4 * cols) == 0) else 2
+    # Unsplit (gate/up, LM head).  Up to 32 rows a ring of 4 chunks (measured 18.4 us on the gate/up
+    # projection against 18.9 for a ring of 8 and 29.6 for 2); at 128 rows two feature tiles per
+    # wave in 4-wave workgroups when that fills the CUs at least as well (gate/up 58.1 -> 49.6 us).
+    nb = 4 if (mp <= 32 and w.k % (4 * cols) == 0) else 2
+    nw, ft = _waves_per_workgroup(w.n_pad), 1
+    if mp == 128 and w.n_pad % 128 == 0:
+        wgs1, wgs2 = w.n_pad // (16 * nw), w.n_pad // 128
+        fill = lambda g: g / (-(-g // _NUM_CUS) * _NUM_CUS)  # noqa: E731
+        if fill(wgs2) >= fill(wgs1) - 1e-9:
+            nw, ft = 4, 2
     out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
-    C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, nb, 1, w.k // (cols * nb), ss, eps, w.wscale, _waves_per_workgroup(w.n_pad), 4)
+    C.stream_gemm3(w.wp, w.n_pad, w.k, x, out, epi, nb, 1, w.k // (cols * nb), ss, eps, w.wscale, nw, 4, ft=ft)
     if m != mp or n_true != n_out:
         out = out[:m, :n_true]
     return out
@@ -478,7 +525,11 @@ def prefetch_plan(w: Weight, rows: int, site: str) -> Optional[Tuple[torch.Tenso
     tile_bytes = w.k * col_bytes
     nw, gy, split_bytes = 0, 1, tile_bytes
     if site in ("qkv", "o") and w.n == w.n_pad:
-        if w.bits == 4:
+        p4 = _plan_slabs_w4(w.n_pad, w.k, rows) if w.bits == 4 else None
+        if p4 is not None:
+            nw, nb, gy, gps, ft = p4
+            nw, group_cols = nw * ft, 128 * nb  # ranges (16-feature tiles) per workgroup
+        elif w.bits == 4:
             group_cols = 128 * (4 if (rows <= 32 and w.k % 512 == 0) else 2)
             nw, gy, gps = _plan_slabs(w.n_pad, w.k, rows, group_cols)
         else:

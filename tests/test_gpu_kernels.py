@@ -1449,6 +1449,53 @@ def test_stream_gemm_mxfp4_weights(M, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,bits,nw,nb", [(128, 16, 4, 2), (128, 16, 8, 2), (256, 16, 4, 2), (128, 8, 4, 2), (128, 8, 8, 2), (256, 8, 4, 2), (128, 4, 4, 2), (128, 4, 8, 2),
+                                          (16, 4, 4, 8), (32, 4, 8, 4), (48, 4, 4, 2), (64, 4, 8, 4)])
+def test_stream_gemm3_two_feature_tiles_per_wave(C, M, bits, nw, nb):
+    """ft = 2 (a wave owns two consecutive 16-feature tiles that share every x fragment read):
+    bf16 output, split-K slabs and the SwiGLU epilogue against an fp32 matmul on the same
+    (quantised) weights, for every weight format and both workgroup sizes."""
+    from kvmini.models.llama import dequantize_mxfp4, quantize_fp8_rows, quantize_mxfp4
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(M + bits + nw)
+    N, K = 16 * nw * 2 * 3, 2048
+    W = (torch.randn(N, K, device=_dev()) * 0.05).bfloat16()
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    if bits == 4:
+        Wd = dequantize_mxfp4(*quantize_mxfp4(W), torch.float32)
+    elif bits == 8:
+        q, sc = quantize_fp8_rows(W)
+        Wd = q.float() * sc[:, None]
+    else:
+        Wd = W.float()
+    pw = hip_ops.PackedLinear(W, fp8=bits == 8, mxfp4=bits == 4)
+    wb = 4 if bits == 4 else 0
+    ref = x.float() @ Wd.T
+    tol = 1e-2 * ref.abs().max().item() + 1e-2
+    y = torch.full((M, N), float("nan"), device=_dev(), dtype=torch.bfloat16)
+    C.stream_gemm3(pw.wp, N, K, x, y, 0, nb, 1, K // (128 * nb), None, 0.0, pw.wscale, nw, wb, ft=2)
+    assert (y.float() - ref).abs().max().item() <= tol
+    ngroups = K // (128 * nb)
+    for splits in (2, 3):  # 3: the last split is shorter
+        gps = -(-ngroups // splits)
+        n_s = -(-ngroups // gps)
+        slabs = torch.full((n_s, M, N), float("nan"), device=_dev(), dtype=torch.float32)
+        C.stream_gemm3(pw.wp, N, K, x, slabs, 1, nb, n_s, gps, None, 0.0, pw.wscale, nw, wb, ft=2)
+        err = (slabs.sum(0) - ref).abs().max().item()
+        assert err <= (2e-3 if bits != 8 else 1e-2) * ref.abs().max().item() + 1e-3, (splits, err)  # fp32 slabs (FP8: the row scale is applied per slab)
+    ss = (x.float() ** 2).view(M, -1, 512).sum(-1).contiguous()
+    act = torch.full((M, N // 2), float("nan"), device=_dev(), dtype=torch.bfloat16)
+    C.stream_gemm3(pw.wp, N, K, x, act, 2, nb, 1, K // (128 * nb), ss, 1e-5, pw.wscale, nw, wb, ft=2)
+    xn = x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)
+    ref_act = torch_ops.swiglu_interleaved(xn @ Wd.T).float()
+    assert (act.float() - ref_act).abs().max().item() <= 2e-2 * ref_act.abs().max().item() + 2e-2
+    # shapes the two-tile form is not built for are refused, not mis-launched
+    with pytest.raises(RuntimeError):
+        C.stream_gemm3(pw.wp, N, K, x, y, 0, nb, 1, K // (128 * nb), None, 0.0, pw.wscale, 7, wb, ft=2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 48, 200])
 def test_stream_gemm_mxfp4_swiglu_and_folded_norm(M):
     from kvmini.models.llama import GU_GROUP, dequantize_mxfp4, quantize_mxfp4
