@@ -79,6 +79,57 @@ struct Params {
   int n_mtiles, n_ntiles, m_fastest;
 };
 
+// Epilogue shared by the kernels below:
+// acc[i][j][e] = y[token m0 + wm TM + 16 j + r][feature n0 + wn TN + 16 i + 4 q + e]
+template <int FA, int FB, int TM, int TN, int EPI, bool W8>
+__device__ inline void wide_epilogue(frag_cd (&acc)[FA][FB], const Params& p, int m0, int n0, int wm, int wn, int r, int q, int split) {
+  const int tok0 = m0 + wm * TM + r;
+  const int feat0 = n0 + wn * TN + 4 * q;
+  float rs[FB];
+#pragma unroll
+  for (int j = 0; j < FB; ++j) {
+    rs[j] = 1.f;
+    if (EPI != EPI_SLAB && p.row_ss != nullptr) {
+      const int t = tok0 + 16 * j < p.M ? tok0 + 16 * j : p.M - 1;
+      float ssum = 0.f;
+      for (int k = 0; k < p.ss_parts; ++k) ssum += p.row_ss[(long long)t * p.ss_parts + k];
+      rs[j] = rsqrtf(ssum * p.inv_k + p.eps);
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < FA; ++ii) {
+    const int f = feat0 + 16 * ii;
+    frag_cd ws = (frag_cd){1.f, 1.f, 1.f, 1.f};
+    if constexpr (W8) ws = *reinterpret_cast<const frag_cd*>(p.w_scale + f);
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      const int t = tok0 + 16 * j;
+      frag_cd v = acc[ii][j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= ws[e] * rs[j];
+      if constexpr (EPI == EPI_SLAB) {
+        if (t < p.M) *reinterpret_cast<frag_cd*>(reinterpret_cast<float*>(p.out) + (long long)split * p.slab_stride + (long long)t * p.ldy + f) = v;
+      } else if constexpr (EPI == EPI_BF16) {
+        us4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        if (t < p.M) *reinterpret_cast<us4*>(reinterpret_cast<unsigned short*>(p.out) + (long long)t * p.ldy + f) = o;
+      } else {
+        // a 16-row weight tile = 8 gate rows + the 8 up rows of the same features: lanes q < 2
+        // hold gate[4q + e], lanes q + 2 the matching up values
+        us4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = v[e], up = __shfl_xor(v[e], 32, 64);
+          o[e] = f2bf(g / (1.f + __expf(-g)) * up);
+        }
+        const int fi = ((n0 + wn * TN + 16 * ii) >> 1) + 4 * q;
+        if (q < 2 && t < p.M) *reinterpret_cast<us4*>(reinterpret_cast<unsigned short*>(p.out) + (long long)t * p.ldy + fi) = o;
+      }
+    }
+  }
+}
+
 // KS = k-steps (of 32) per LDS stage: 2 -> 128-byte x rows (full cache lines), 1 -> 64-byte rows
 // NS = LDS stages in the ring
 //
@@ -260,52 +311,211 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
 #undef WG_MEMOP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-read stages of the tail
 
-  // ---- epilogue: acc[i][j][e] = y[token m0 + wm TM + 16 j + r][feature n0 + wn TN + 16 i + 4 q + e]
-  const int tok0 = m0 + wm * TM + r;
-  const int feat0 = n0 + wn * TN + 4 * q;
-  float rs[FB];
-#pragma unroll
-  for (int j = 0; j < FB; ++j) {
-    rs[j] = 1.f;
-    if (EPI != EPI_SLAB && p.row_ss != nullptr) {
-      const int t = tok0 + 16 * j < p.M ? tok0 + 16 * j : p.M - 1;
-      float ssum = 0.f;
-      for (int k = 0; k < p.ss_parts; ++k) ssum += p.row_ss[(long long)t * p.ss_parts + k];
-      rs[j] = rsqrtf(ssum * p.inv_k + p.eps);
-    }
+  wide_epilogue<FA, FB, TM, TN, EPI, W8>(acc, p, m0, n0, wm, wn, r, q, split);
+}
+
+// ---------------------------------------------------------------------------------------
+// Role-split rings (129 .. ~512 token rows).  With few token tiles the weights of a tile column
+// are used once or twice: W comes from HBM, x from L2, and the time is set by the W bytes a CU
+// keeps in flight.  In the kernel above both operands share one ring, and x takes most of
+// every stage (256 x 128 tile: 32 KiB of x next to 16 KiB of W), so only 32 KiB of W are ever
+// in flight per CU (measured on the Llama-3-8B gate/up projection at 256 rows: 82 us with one
+// stage in flight, 69 us with two, 54 us when the weights are already in cache).  The rings
+// cannot simply be given different depths: a wave's s_waitcnt vmcnt retires its loads in issue
+// order, so waiting for a shallow x stage would also wait for every W stage issued before it.
+// Here the waves split the copying: the first half issue ONLY W pieces into a deep ring of NSW
+// stages, the second half ONLY x pieces into a ring of NSX stages; each wave's counter then
+// covers one ring, and all waves multiply as before.  64-wide stages (KS = 2).
+template <int BM, int BN, int WM, int WN, int NSX, int NSW, int EPI, bool W8>
+__global__ __launch_bounds__(WM * WN * 64) void wide_gemm_rs_kernel(const Params p) {
+  constexpr int KS = 2;
+  constexpr int NW = WM * WN, NL = NW / 2;  // waves, loader waves per operand
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FB = TM / 16, FA = TN / 16;
+  static_assert(NSX >= 2 && NSW >= 2 && (NW % 2) == 0, "two roles, rings of at least two stages");
+  constexpr int A_TILE = W8 ? 1024 : KS * 1024;
+  constexpr int A_BYTES = (BN / 16) * A_TILE;
+  constexpr int XROW = KS * 64;
+  constexpr int X_BYTES = BM * XROW;
+  constexpr int PA = A_BYTES / 1024, PX = X_BYTES / 1024;
+  static_assert(PA % NL == 0 && PX % NL == 0, "pieces divide by the loader waves of their operand");
+  constexpr int GA = PA / NL, GX = PX / NL;  // LDS-DMA instructions per stage of a W / an x loader wave
+  constexpr int GMAX = GA > GX ? GA : GX;
+  constexpr int AR = W8 ? FA : KS * FA;
+  constexpr int NREAD = AR + KS * FB;
+  constexpr int NGRP = KS * FA;
+  constexpr int MEM = NREAD + GMAX;
+  constexpr int PER = (MEM + NGRP - 1) / NGRP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const a_ring = smem;                  // NSW stages of A_BYTES
+  unsigned char* const x_ring = smem + NSW * A_BYTES;  // NSX stages of X_BYTES
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int r = lane & 15, q = lane >> 4;
+  const bool w_role = wave < NL;  // wave-uniform
+  const int lw = w_role ? wave : wave - NL;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int xcd = id & 7, qd = nwg >> 3, rm = nwg & 7;
+    id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
   }
+  int mt, nt, split;
+  if (p.m_fastest) {
+    mt = id % p.n_mtiles; id /= p.n_mtiles;
+    split = id % p.splits; nt = id / p.splits;
+  } else {
+    nt = id % p.n_ntiles; id /= p.n_ntiles;
+    split = id % p.splits; mt = id / p.splits;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nst = p.K / (32 * KS);
+  const int s0 = split * p.stages_per_split;
+  const int s1 = s0 + p.stages_per_split < nst ? s0 + p.stages_per_split : nst;
+  const int n = s1 - s0;
+
+  // ---- this wave's LDS-DMA pieces: source pointer at stage s0, byte offset inside a ring stage
+  const unsigned char* src[GMAX];
+  int doff[GMAX];
 #pragma unroll
-  for (int ii = 0; ii < FA; ++ii) {
-    const int f = feat0 + 16 * ii;
-    frag_cd ws = (frag_cd){1.f, 1.f, 1.f, 1.f};
-    if constexpr (W8) ws = *reinterpret_cast<const frag_cd*>(p.w_scale + f);
-#pragma unroll
-    for (int j = 0; j < FB; ++j) {
-      const int t = tok0 + 16 * j;
-      frag_cd v = acc[ii][j];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= ws[e] * rs[j];
-      if constexpr (EPI == EPI_SLAB) {
-        if (t < p.M) *reinterpret_cast<frag_cd*>(reinterpret_cast<float*>(p.out) + (long long)split * p.slab_stride + (long long)t * p.ldy + f) = v;
-      } else if constexpr (EPI == EPI_BF16) {
-        us4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        if (t < p.M) *reinterpret_cast<us4*>(reinterpret_cast<unsigned short*>(p.out) + (long long)t * p.ldy + f) = o;
-      } else {
-        // a 16-row weight tile = 8 gate rows + the 8 up rows of the same features: lanes q < 2
-        // hold gate[4q + e], lanes q + 2 the matching up values
-        us4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = v[e], up = __shfl_xor(v[e], 32, 64);
-          o[e] = f2bf(g / (1.f + __expf(-g)) * up);
+  for (int i = 0; i < GMAX; ++i) {
+    src[i] = p.Wp;
+    doff[i] = 0;
+    if (w_role) {
+      if (i < GA) {
+        const int pc = lw + NL * i;
+        if constexpr (W8) {
+          src[i] = p.Wp + ((((long long)(n0 >> 4) + pc) * nst + s0) * 64 + lane) * 16;
+        } else {
+          const int ti = pc / KS, sl = pc % KS;
+          src[i] = p.Wp + ((((long long)(n0 >> 4) + ti) * (nst * KS) + (long long)s0 * KS + sl) * 64 + lane) * 16;
         }
-        const int fi = ((n0 + wn * TN + 16 * ii) >> 1) + 4 * q;
-        if (q < 2 && t < p.M) *reinterpret_cast<us4*>(reinterpret_cast<unsigned short*>(p.out) + (long long)t * p.ldy + fi) = o;
+        doff[i] = pc * 1024;
       }
+    } else if (i < GX) {
+      const int pc = lw + NL * i;
+      int row = 8 * pc + (lane >> 3);  // 8 rows x 128 B per piece; chunk ^= (row >> 1) & 7
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      row += m0;
+      row = row < p.M ? row : p.M - 1;
+      src[i] = reinterpret_cast<const unsigned char*>(p.x + (long long)row * p.ldx + (long long)s0 * (32 * KS)) + chunk * 16;
+      doff[i] = pc * 1024;
     }
   }
+  const int n_mine = w_role ? GA : GX;           // pieces per stage of this wave
+  const int sstride = w_role ? A_TILE : XROW;    // source bytes from one stage to the next
+  const int depth = w_role ? NSW : NSX;
+  unsigned char* const ring = w_role ? a_ring : x_ring;
+  const int ring_stage = w_role ? A_BYTES : X_BYTES;
+
+  frag_cd acc[FA][FB];
+#pragma unroll
+  for (int i = 0; i < FA; ++i)
+#pragma unroll
+    for (int j = 0; j < FB; ++j) acc[i][j] = (frag_cd){0.f, 0.f, 0.f, 0.f};
+
+  const int a_off = wn * (FA * A_TILE) + lane * 16;
+  int x_off[KS];
+  x_off[0] = (wm * TM + r) * 128 + (((0 + q) ^ (r >> 1)) << 4);
+  x_off[1] = (wm * TM + r) * 128 + (((4 + q) ^ (r >> 1)) << 4);
+
+  raw16 ra[2][AR];
+  frag_ab fb[2][KS][FB];
+
+  // mem op m of a step: m < GMAX -> this wave's LDS-DMA piece m of stage `st` into ring buffer
+  // `lb`; else fragment read m - GMAX of the stage in buffers (sa, sx) into register set SET
+#define RS_MEMOP(m, SET, lb, sa, sx, st)                                                                                          \
+  do {                                                                                                                           \
+    if ((m) < GMAX) {                                                                                                            \
+      if ((m) < n_mine) dma16(src[(m) < GMAX ? (m) : 0] + (long long)(st) * sstride, ring + (lb) * ring_stage + doff[(m) < GMAX ? (m) : 0]); \
+    } else if ((m) - GMAX < AR) {                                                                                                \
+      ra[SET][(m) >= GMAX && (m) - GMAX < AR ? (m) - GMAX : 0] = *reinterpret_cast<const raw16*>((sa) + a_off + ((m) - GMAX) * 1024); \
+    } else {                                                                                                                     \
+      const int kk_ = (m) - GMAX - AR;                                                                                           \
+      const int ss_ = kk_ >= 0 && kk_ < KS * FB ? kk_ / FB : 0, jj_ = kk_ >= 0 ? kk_ % FB : 0;                                   \
+      fb[SET][ss_][jj_] = *reinterpret_cast<const frag_ab*>((sx) + x_off[ss_] + jj_ * (16 * XROW));                              \
+    }                                                                                                                            \
+  } while (0)
+
+  // ---- prologue: every ring in flight, then stage 0 into register set 0
+  for (int s = 0; s < depth; ++s) {
+    const int st = s < n ? s : n - 1;
+#pragma unroll
+    for (int m = 0; m < GMAX; ++m) RS_MEMOP(m, 0, s, a_ring, x_ring, st);
+  }
+  if (w_role) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSW - 1) * GA) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSX - 1) * GX) : "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int m = GMAX; m < MEM; ++m) RS_MEMOP(m, 0, 0, a_ring, x_ring, 0);
+
+  int lb = 0;          // ring buffer of stage i in this wave's own ring: refilled with stage i + depth
+  int ba = 1 % NSW, bx = 1 % NSX;  // buffers of stage i + 1 in the W and x rings
+#define RS_STEP(CUR, NXT, I)                                                                                          \
+  do {                                                                                                               \
+    const int i_ = (I);                                                                                              \
+    if (w_role) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSW - 2) * GA) : "memory");                                \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSX - 2) * GX) : "memory");                                       \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    const unsigned char* sa_ = a_ring + ba * A_BYTES;                                                                \
+    const unsigned char* sx_ = x_ring + bx * X_BYTES;                                                                \
+    const int st_ = i_ + depth < n ? i_ + depth : n - 1;                                                             \
+    _Pragma("unroll") for (int g = 0; g < NGRP; ++g) {                                                               \
+      const int s = g / FA, ii = g % FA;                                                                             \
+      frag_ab af;                                                                                                    \
+      if constexpr (W8) af = s == 0 ? fp8x8_to_bf16(ra[CUR][ii][0], ra[CUR][ii][1]) : fp8x8_to_bf16(ra[CUR][ii][2], ra[CUR][ii][3]); \
+      else af = __builtin_bit_cast(frag_ab, ra[CUR][(ii * KS + s) < AR ? ii * KS + s : 0]);                           \
+      _Pragma("unroll") for (int j = 0; j < FB; ++j)                                                                 \
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, fb[CUR][s][j], acc[ii][j], 0, 0, 0);               \
+      _Pragma("unroll") for (int m = g * PER; m < (g + 1) * PER; ++m)                                                \
+          if (m < MEM) RS_MEMOP(m, NXT, lb, sa_, sx_, st_);                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }                                                                                                                \
+    lb = lb + 1 == depth ? 0 : lb + 1;                                                                               \
+    ba = ba + 1 == NSW ? 0 : ba + 1;                                                                                 \
+    bx = bx + 1 == NSX ? 0 : bx + 1;                                                                                 \
+  } while (0)
+
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    RS_STEP(0, 1, i);
+    RS_STEP(1, 0, i + 1);
+  }
+  if (i < n) RS_STEP(0, 1, i);
+#undef RS_STEP
+#undef RS_MEMOP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  wide_epilogue<FA, FB, TM, TN, EPI, W8>(acc, p, m0, n0, wm, wn, r, q, split);
+}
+
+template <int BM, int BN, int WM, int WN, int NSX, int NSW, int EPI, bool W8>
+int launch_rs(const Params& p, hipStream_t stream) {
+  constexpr int A_BYTES = (BN / 16) * (W8 ? 1024 : 2048);
+  constexpr int LDS = NSW * A_BYTES + NSX * BM * 128;
+  static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
+  auto kern = wide_gemm_rs_kernel<BM, BN, WM, WN, NSX, NSW, EPI, W8>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
+    attr_set = true;
+  }
+  const int grid = p.n_mtiles * p.n_ntiles * p.splits;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, stream, p);
+  return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int NSX, int NSW, bool W8>
+int dispatch_epi_rs(int epi, const Params& p, hipStream_t s) {
+  switch (epi) {
+    case EPI_BF16: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_BF16, W8>(p, s);
+    case EPI_SLAB: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_SLAB, W8>(p, s);
+    case EPI_SWIGLU: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_SWIGLU, W8>(p, s);
+  }
+  return -1;
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, bool W8>
@@ -335,7 +545,8 @@ int dispatch_epi(int epi, const Params& p, hipStream_t s) {
 }
 
 // variant = pipeline shape of a tile: 0 = 64-wide stages in the deepest ring the LDS holds,
-// 1 / 3 = 32-wide stages (bf16 weights only), 2 = 64-wide stages in a two-stage ring
+// 1 / 3 = 32-wide stages (bf16 weights only), 2 = 64-wide stages in a two-stage ring,
+// 4 / 5 = role-split rings (64-wide stages; W and x in rings of different depth)
 template <bool W8>
 int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStream_t s) {
   const int key = bm * 1000 + bn;
@@ -355,6 +566,15 @@ int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStre
     // 128 x 128, 4 waves (wave: 64 x 64); two workgroups per CU with two stages
     case 1281280: return dispatch_epi<128, 128, 2, 2, 2, 4, W8>(epi, p, s);
     case 1281282: return dispatch_epi<128, 128, 2, 2, 2, 2, W8>(epi, p, s);
+  }
+  switch (key * 10 + variant) {
+    // role-split rings (wide_gemm_rs_kernel): 4 = x ring of 3 + the deepest W ring the LDS holds,
+    // 5 = x ring of 2 and a deeper W ring still (128 x 128: small enough for two workgroups per CU)
+    case 2561284: return dispatch_epi_rs<256, 128, 4, 2, 3, 4, W8>(epi, p, s);
+    case 2561285: return dispatch_epi_rs<256, 128, 4, 2, 2, 6, W8>(epi, p, s);
+    case 1281284: return dispatch_epi_rs<128, 128, 2, 2, 3, 6, W8>(epi, p, s);
+    case 1281285: return dispatch_epi_rs<128, 128, 2, 2, 2, 3, W8>(epi, p, s);
+    case 1282564: return dispatch_epi_rs<128, 256, 2, 4, 2, 4, W8>(epi, p, s);
   }
   if constexpr (!W8) {
     switch (key * 10 + variant) {

@@ -22,8 +22,8 @@ import torch.nn.functional as F
 
 TILES = ((256, 256), (256, 224), (256, 192), (256, 128), (256, 64), (128, 128), (128, 256))
 # pipeline variants compiled per tile (csrc/wide_gemm.hip::dispatch_tile); FP8 has no 256 x 64 tile and no 32-wide stages
-VARIANTS = {(256, 256): (0, 1, 3), (256, 224): (0, 1, 3), (256, 192): (0, 1, 3), (256, 128): (0, 1, 2), (128, 256): (0, 2), (256, 64): (0, 2), (128, 128): (0, 2)}
-VARIANTS_FP8 = {(256, 256): (0,), (256, 224): (0,), (256, 192): (0,), (256, 128): (0, 2), (128, 256): (0, 2), (128, 128): (0, 2)}
+VARIANTS = {(256, 256): (0, 1, 3), (256, 224): (0, 1, 3), (256, 192): (0, 1, 3), (256, 128): (0, 1, 2, 4, 5), (128, 256): (0, 2, 4), (256, 64): (0, 2), (128, 128): (0, 2, 4, 5)}
+VARIANTS_FP8 = {(256, 256): (0,), (256, 224): (0,), (256, 192): (0,), (256, 128): (0, 2, 4, 5), (128, 256): (0, 2, 4), (128, 128): (0, 2, 4, 5)}
 
 
 def time_fns(fns, rounds=8, inner=4):
@@ -141,8 +141,7 @@ def bench(C, dev, rows, out, fp8, only=None):
                                 C.wide_gemm(Wps[i], N, K, x, y, epi, bm, bn, variant, 1, nst, None, 0.0, scales[i], mf)
                             return f
                         fns[f"wide_{bm}x{bn}_v{variant}_{'m' if mf else 'n'}"] = mk()
-                if epi == 0 and M <= 512:
-                    variant = 0
+                for variant in ((0,) + tuple(v for v in vmap[(bm, bn)] if v >= 4)) if epi == 0 and M <= 512 else ():
                     nst = K // (32 * C.wide_gemm_stage_ksteps(bm, bn, variant))
                     for splits in (2, 4, 8):
                         if mt * ntl * splits > 1024 or mt * ntl >= 256:

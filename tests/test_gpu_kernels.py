@@ -1090,6 +1090,49 @@ def test_tiled_gemm_224_and_192_feature_tiles(C, bn, variant, fp8):
     assert (act.float() - want).abs().max().item() <= 1.5e-2 * want.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("tile,variant", [((256, 128), 4), ((256, 128), 5), ((128, 128), 4), ((128, 128), 5), ((128, 256), 4)])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("K", [128, 448, 1024])
+def test_tiled_gemm_role_split_rings(C, tile, variant, fp8, K):
+    """The role-split form of the tiled kernel (half the waves copy W into a deep ring, half copy
+    x into a shallow one): bf16, slab and SwiGLU epilogues against fp32 with bf16 and FP8 weights,
+    M not a multiple of the tile, both block orders, K shorter than the W ring (128 = 2 stages),
+    odd stage counts (448) and uneven K splits."""
+    import torch.nn.functional as F
+
+    from kvmini.models.llama import quantize_fp8_rows
+
+    dev = _dev()
+    torch.manual_seed(K + variant)
+    bm, bn = tile
+    M, N = 300, 2 * bn
+    x = torch.randn(M, K, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    if fp8:
+        q, scale = quantize_fp8_rows(W)
+        wp, ws, wref = C.pack_weight_fp8(q.view(torch.uint8).contiguous()), scale.contiguous(), q.float() * scale[:, None]
+    else:
+        wp, ws, wref = C.pack_weight(W), None, W.float()
+    ref = x.float() @ wref.T
+    nst = K // (32 * C.wide_gemm_stage_ksteps(bm, bn, variant))
+    assert nst == K // 64
+    for mf in (True, False):
+        y = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        C.wide_gemm(wp, N, K, x, y, 0, bm, bn, variant, 1, nst, None, 0.0, ws, mf)
+        assert (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    sps = (nst + 2) // 3
+    nsp = -(-nst // sps)
+    sl = torch.full((nsp, M, N), float("nan"), device=dev, dtype=torch.float32)
+    C.wide_gemm(wp, N, K, x, sl, 1, bm, bn, variant, nsp, sps, None, 0.0, ws, True)
+    assert (sl.sum(0) - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    ss = (x.float() ** 2).sum(-1, keepdim=True).contiguous()
+    act = torch.full((M, N // 2), float("nan"), device=dev, dtype=torch.bfloat16)
+    C.wide_gemm(wp, N, K, x, act, 2, bm, bn, variant, 1, nst, ss, 1e-5, ws, True)
+    g = (ref * torch.rsqrt(ss / K + 1e-5)).view(M, N // 16, 2, 8)
+    want = (F.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)
+    assert (act.float() - want).abs().max().item() <= 1.5e-2 * want.abs().max().item() + 1e-3
+
+
 def test_xgmi_collectives_single_rank_is_its_own_peer(C):
     """The peer-memory collectives with a group of one rank (the rank's buffer is its own peer):
     all-gather, one-shot and two-shot all-reduce are identities, and the fused TP epilogue equals
