@@ -436,6 +436,7 @@ def main() -> int:
             "itl_quantile_engine": itl_engine,
             "collective_backend": (dist.get_backend() if world > 1 else None),
             "telemetry": pj["source"] if watts else "unavailable",
+            **({"telemetry_native_fallback": tg.native_error} if tg.native_error else {}),
             "resource_seconds": {"gpu": gpu_s, "cpu_core": cpu_s, "mem_gib": mem_s},
         }
         if n_ok == 0:

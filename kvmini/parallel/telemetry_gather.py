@@ -90,10 +90,34 @@ class TelemetryGather:
         self.stream = torch.cuda.Stream(device, priority=0) if device.type == "cuda" else None
         self.seq = 0
         self.dropped_ticks = 0
+        self.native_error: Optional[str] = None
         if native and self.world > 1:
             from kvmini.telemetry.native_rt import NativeGather
 
-            self.native = NativeGather(device_index, impl=impl)
+            # The native path is taken by every rank or by none: a rank that cannot set it up
+            # (library missing, communicator not created) must not leave the others waiting in
+            # a collective it never joins, so the ranks agree over the torch group first.
+            try:
+                self.native = NativeGather(device_index, impl=impl)
+            except Exception as e:  # noqa: BLE001 - any failure means "use the torch path"
+                self.native_error = f"{type(e).__name__}: {e}"
+            if not self._all_ranks_ok(self.native is not None):
+                self._drop_native()
+
+    def _all_ranks_ok(self, ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def _drop_native(self) -> None:
+        if self.native is not None:
+            try:
+                self.native.close()
+            except Exception:  # noqa: BLE001
+                pass
+            self.native = None
+        if self.native_error is None:
+            self.native_error = "another rank could not set up the native gather"
 
     @property
     def source(self) -> str:
@@ -117,7 +141,15 @@ class TelemetryGather:
         if self.world == 1:
             return local.unsqueeze(0)
         if self.native is not None:
-            return torch.from_numpy(self.native.gather(local.cpu().numpy().reshape(-1, SNAPSHOT_F64))).reshape((self.world,) + tuple(local.shape))
+            got = None
+            try:
+                got = self.native.gather(local.cpu().numpy().reshape(-1, SNAPSHOT_F64))
+            except Exception as e:  # noqa: BLE001
+                self.native_error = f"{type(e).__name__}: {e}"
+            if self._all_ranks_ok(got is not None):
+                return torch.from_numpy(got).reshape((self.world,) + tuple(local.shape))
+            self._drop_native()  # some rank's native exchange failed: all ranks repeat it over torch.distributed
+            local = local.to(self.device)
         out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))

@@ -251,15 +251,20 @@ class NativeGather:
             return
         nbytes = int(lib.kvt_unique_id_bytes())
         buf = ctypes.create_string_buffer(nbytes)
-        if self.rank == 0:
-            if lib.kvt_unique_id(buf) != 0:
-                raise RuntimeError("ncclGetUniqueId failed")
+        id_ok = True
+        if self.rank == 0 and lib.kvt_unique_id(buf) != 0:
+            id_ok = False  # still broadcast (zeros): the other ranks are waiting in the collective
+            buf = ctypes.create_string_buffer(nbytes)
         if self.world > 1:
             t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
             if dist.get_backend() == "nccl":
                 t = t.cuda(device_index)
             dist.broadcast(t, 0)
-            buf = ctypes.create_string_buffer(bytes(t.cpu().numpy().tobytes()), nbytes)
+            raw = bytes(t.cpu().numpy().tobytes())
+            id_ok = any(raw)  # an all-zero id = rank 0 could not create one: every rank sees that
+            buf = ctypes.create_string_buffer(raw, nbytes)
+        if not id_ok:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
         rc = lib.kvt_init(self.rank, self.world, buf, device_index)
         if rc != 0:
             raise RuntimeError(f"kvt_init failed: {rc}")

@@ -199,6 +199,30 @@ table = tg.gather_table(samples, 10.0, 12.0, 0.5)
 pj = table_to_power_json(table, 0.5)
 ok = ok and tick is not None and tick.shape == (ws, 16) and list(tick[:, 0]) == list(range(ws)) and table.shape == (ws, 5, 16)
 ok = ok and abs(pj["samples"][2]["watts"] - sum(400.0 + 10 * k for k in range(ws))) < 1e-9
+# the native (C++) gather is all-or-nothing: a rank that cannot set it up, or whose exchange fails,
+# sends EVERY rank to the torch.distributed path instead of leaving the others in a collective alone
+import numpy as np
+import kvmini.telemetry.native_rt as nrt
+class SetupFailsOnRank1:
+    def __init__(self, device_index, impl="rccl"):
+        if dist.get_rank() == 1:
+            raise RuntimeError("no communicator on this rank")
+    def gather(self, local):
+        raise AssertionError("must not be used once a rank failed to set up")
+    def close(self):
+        pass
+class ExchangeFailsOnRank0(SetupFailsOnRank1):
+    def __init__(self, device_index, impl="rccl"):
+        pass
+    def gather(self, local):
+        if dist.get_rank() == 0:
+            raise RuntimeError("exchange failed")
+        return np.zeros((dist.get_world_size(),) + local.shape)  # what a lone rank would be left with
+for fake in (SetupFailsOnRank1, ExchangeFailsOnRank0):
+    nrt.NativeGather = fake
+    tg2 = TelemetryGather(native=True)
+    t2 = tg2.gather_table(samples, 10.0, 12.0, 0.5)
+    ok = ok and tg2.native is None and tg2.native_error is not None and np.array_equal(np.nan_to_num(t2), np.nan_to_num(table)) and "gloo" in tg2.source
 print(f"RANK{r} OK={ok}", flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
