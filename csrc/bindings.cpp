@@ -36,8 +36,9 @@ int kv_argmax(const void* logits, long long row_stride, int S, int V, long long*
 int kv_sample_rows(const void* logits, long long row_stride, int V, const long long* rows, int R, const float* temperature, const int* top_k,
                    const float* top_p, const float* uniform, long long* out, hipStream_t stream);
 int kv_guided_mask(void* logits, long long row_stride, int V, int n_cls, const long long* rows, const int* slots, const int* init, int R, int* state,
-                   const unsigned char* cls, int vc, hipStream_t stream);
-int kv_guided_advance(const long long* out_ids, const long long* rows, const int* slots, int R, int* state, const unsigned char* cls, int n_cls, hipStream_t stream);
+                   const unsigned char* cls, int vc, const int* script, int* cursor, const int* cur_init, int L, hipStream_t stream);
+int kv_guided_advance(const long long* out_ids, const long long* rows, const int* slots, int R, int* state, const unsigned char* cls, int n_cls, const int* script,
+                      int* cursor, int L, hipStream_t stream);
 int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, void* y, int T, int H, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
 int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
@@ -353,9 +354,26 @@ void sample_rows(at::Tensor logits, at::Tensor rows, at::Tensor temperature, at:
         "kv_sample_rows");
 }
 
+// the optional script tensors of guided decoding: script int32 [S, 2, L] (entries, rest), cursor int32 [S]
+static const int* script_args(const c10::optional<at::Tensor>& script, const c10::optional<at::Tensor>& cursor, const at::Tensor& state, int** cur_ptr, int* L) {
+  *cur_ptr = nullptr;
+  *L = 0;
+  if (!script.has_value()) return nullptr;
+  TORCH_CHECK(cursor.has_value(), "a script needs its cursor tensor");
+  const at::Tensor &sc = *script, &cu = *cursor;
+  CHECK_DEV(sc); CHECK_CONTIG(sc); CHECK_DEV(cu); CHECK_CONTIG(cu);
+  TORCH_CHECK(sc.scalar_type() == at::kInt && cu.scalar_type() == at::kInt, "script and cursor must be int32");
+  TORCH_CHECK(sc.dim() == 3 && sc.size(0) == state.size(0) && sc.size(1) == 2 && sc.size(2) >= 1 && cu.numel() == state.size(0), "script is [S, 2, L] and cursor [S] for a state of [S, 4]");
+  *cur_ptr = (int*)cu.data_ptr();
+  *L = (int)sc.size(2);
+  return (const int*)sc.data_ptr();
+}
+
 // Guided decoding (csrc/guided.hip).  rows: int64 logits rows, slots: int32 state rows, init: int32 [R, 4]
-// (init[r][0] < 0 keeps the device state), state: int32 [S, 4], cls: uint8 class per token id.
-void guided_mask(at::Tensor logits, at::Tensor rows, at::Tensor slots, at::Tensor init, at::Tensor state, at::Tensor cls, int64_t vc) {
+// (init[r][0] < 0 keeps the device state), state: int32 [S, 4], cls: uint8 class per token id; script /
+// cursor / cur_init (optional): the skeleton scripts of schema-guided sequences (cur_init: int32 [R]).
+void guided_mask(at::Tensor logits, at::Tensor rows, at::Tensor slots, at::Tensor init, at::Tensor state, at::Tensor cls, int64_t vc, c10::optional<at::Tensor> script,
+                 c10::optional<at::Tensor> cursor, c10::optional<at::Tensor> cur_init) {
   CHECK_DEV(logits); CHECK_BF16(logits); CHECK_DEV(rows); CHECK_DEV(slots); CHECK_DEV(init); CHECK_DEV(state); CHECK_DEV(cls);
   CHECK_CONTIG(rows); CHECK_CONTIG(slots); CHECK_CONTIG(init); CHECK_CONTIG(state); CHECK_CONTIG(cls);
   TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1, "logits must be [S, V] with unit inner stride");
@@ -364,19 +382,34 @@ void guided_mask(at::Tensor logits, at::Tensor rows, at::Tensor slots, at::Tenso
               "rows int64, slots / init / state int32, cls uint8");
   TORCH_CHECK(slots.numel() == R && init.numel() == 4 * R && state.dim() == 2 && state.size(1) == 4, "one slot and one init record per row; state is [S, 4]");
   TORCH_CHECK(cls.numel() <= logits.size(1), "more token classes than logits columns");
+  int* curp = nullptr;
+  int L = 0;
+  const int* scp = script_args(script, cursor, state, &curp, &L);
+  const int* cip = nullptr;
+  if (scp != nullptr) {
+    TORCH_CHECK(cur_init.has_value(), "a script needs cur_init");
+    const at::Tensor& ci = *cur_init;
+    CHECK_DEV(ci); CHECK_CONTIG(ci);
+    TORCH_CHECK(ci.scalar_type() == at::kInt && ci.numel() == R, "cur_init must be int32 [R]");
+    cip = (const int*)ci.data_ptr();
+  }
   check(kv_guided_mask(logits.data_ptr(), logits.stride(0), (int)logits.size(1), (int)cls.numel(), (const long long*)rows.data_ptr(), (const int*)slots.data_ptr(),
-                       (const int*)init.data_ptr(), (int)R, (int*)state.data_ptr(), (const unsigned char*)cls.data_ptr(), (int)vc, cur_stream()),
+                       (const int*)init.data_ptr(), (int)R, (int*)state.data_ptr(), (const unsigned char*)cls.data_ptr(), (int)vc, scp, curp, cip, L, cur_stream()),
         "kv_guided_mask");
 }
 
-void guided_advance(at::Tensor out_ids, at::Tensor rows, at::Tensor slots, at::Tensor state, at::Tensor cls) {
+void guided_advance(at::Tensor out_ids, at::Tensor rows, at::Tensor slots, at::Tensor state, at::Tensor cls, c10::optional<at::Tensor> script,
+                    c10::optional<at::Tensor> cursor) {
   CHECK_DEV(out_ids); CHECK_DEV(rows); CHECK_DEV(slots); CHECK_DEV(state); CHECK_DEV(cls);
   CHECK_CONTIG(out_ids); CHECK_CONTIG(rows); CHECK_CONTIG(slots); CHECK_CONTIG(state); CHECK_CONTIG(cls);
   TORCH_CHECK(out_ids.scalar_type() == at::kLong && rows.scalar_type() == at::kLong && slots.scalar_type() == at::kInt && state.scalar_type() == at::kInt && cls.scalar_type() == at::kByte,
               "out_ids / rows int64, slots / state int32, cls uint8");
   TORCH_CHECK(slots.numel() == rows.numel() && state.dim() == 2 && state.size(1) == 4, "one slot per row; state is [S, 4]");
+  int* curp = nullptr;
+  int L = 0;
+  const int* scp = script_args(script, cursor, state, &curp, &L);
   check(kv_guided_advance((const long long*)out_ids.data_ptr(), (const long long*)rows.data_ptr(), (const int*)slots.data_ptr(), (int)rows.numel(), (int*)state.data_ptr(),
-                          (const unsigned char*)cls.data_ptr(), (int)cls.numel(), cur_stream()),
+                          (const unsigned char*)cls.data_ptr(), (int)cls.numel(), scp, curp, L, cur_stream()),
         "kv_guided_advance");
 }
 
@@ -724,8 +757,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("swiglu_interleaved", &swiglu_interleaved);
   m.def("scale_rows", &scale_rows);
   m.def("sample_rows", &sample_rows);
-  m.def("guided_mask", &guided_mask);
-  m.def("guided_advance", &guided_advance);
+  m.def("guided_mask", &guided_mask, py::arg("logits"), py::arg("rows"), py::arg("slots"), py::arg("init"), py::arg("state"), py::arg("cls"), py::arg("vc"),
+        py::arg("script") = py::none(), py::arg("cursor") = py::none(), py::arg("cur_init") = py::none());
+  m.def("guided_advance", &guided_advance, py::arg("out_ids"), py::arg("rows"), py::arg("slots"), py::arg("state"), py::arg("cls"), py::arg("script") = py::none(),
+        py::arg("cursor") = py::none());
   m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);
   m.def("stream_gemm_plan", &stream_gemm_plan);

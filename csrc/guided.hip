@@ -10,13 +10,23 @@
 // previous step's token has reached the host still sees the right automaton state.
 //
 // State of a sequence: int32[4] = (state, depth, container stack bits (1 = array), tokens left).
+//
+// Scripts (JSON schemas): a sequence may carry a script, int32 [2][L] = (entries, rest), and a
+// cursor into it.  Entry >= 0: a literal token of the document's skeleton (a required key with its
+// punctuation, the closing brace), FORCED — the mask leaves only that token — once the value in
+// front of it is complete at the top level; entry <= -2: a value slot whose first token is
+// restricted to the class set (-2 - entry); entry -1: end.  rest[i] = fewest tokens from entry i
+// to the end of the sequence, which keeps the "can still be closed within the tokens left" rule.
+// The automaton is SET at the end of a literal (merged tokens such as '":' have no class to
+// follow).  kvmini/engine/guided.py::allowed_scripted / advance_scripted are the reference.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace {
 
-enum { C_OTHER, C_LBRACE, C_RBRACE, C_LBRACK, C_RBRACK, C_COLON, C_COMMA, C_QUOTE, C_STR, C_DIGIT_NZ, C_DIGIT, C_LIT, C_EOS, N_CLASSES };
+enum { C_OTHER, C_LBRACE, C_RBRACE, C_LBRACK, C_RBRACK, C_COLON, C_COMMA, C_QUOTE, C_STR, C_DIGIT_NZ, C_DIGIT, C_LIT, C_EOS, C_NULL, N_CLASSES };  // C_LIT: true / false
+constexpr int SCRIPT_END = -1;
 enum { S_OFF, S_START, S_OBJ_FIRST, S_KEY, S_AFTER_KEY, S_VALUE, S_STR, S_NUM, S_AFTER_VALUE, S_OBJ_NEXT, S_ARR_FIRST, S_DONE, S_END };
 constexpr int MAX_DEPTH = 16;
 constexpr int TPB = 1024;
@@ -57,7 +67,7 @@ __device__ inline St transition(St a, int c, bool& ok) {
       if (c == C_LBRACE && a.depth < MAX_DEPTH) { n.s = S_OBJ_FIRST; n.depth = a.depth + 1; return n; }
       if (c == C_LBRACK && a.depth < MAX_DEPTH) { n.s = S_ARR_FIRST; n.depth = a.depth + 1; n.stack = a.stack | (1 << a.depth); return n; }
       if (c == C_DIGIT_NZ) { n.s = S_NUM; return n; }
-      if (c == C_LIT) { n.s = S_AFTER_VALUE; return n; }
+      if (c == C_LIT || c == C_NULL) { n.s = S_AFTER_VALUE; return n; }
       if (a.s == S_ARR_FIRST && c == C_RBRACK) return pop(a);
       break;
     case S_STR:
@@ -126,18 +136,59 @@ __device__ inline unsigned allowed_classes(St a, int left, int vc) {
   return fits ? fits : grammar;
 }
 
+// a value has just been completed at the top level (or a literal is being written): the
+// script's next literal token comes next
+__device__ inline bool forcing(int s, int depth) { return depth == 1 && (s == S_AFTER_VALUE || s == S_NUM || s == S_OBJ_NEXT); }
+
+// scripted sequences: class mask + the one token that is allowed whatever its class (-1: none)
+__device__ inline unsigned allowed_scripted(St a, int left, int vc, const int* __restrict__ ent, const int* __restrict__ rest, int cur, int L, int& forced) {
+  forced = -1;
+  if (ent == nullptr || cur < 0 || cur >= L || ent[cur] == SCRIPT_END || a.s == S_OFF || a.s == S_END) return allowed_classes(a, left, vc);
+  const int e = ent[cur];
+  a.stack &= (1 << FIRST_SHIFT) - 1;
+  if (e >= 0 && forcing(a.s, a.depth)) {
+    forced = e;
+    const bool more_digits = a.s == S_NUM && left - 1 >= rest[cur];
+    return more_digits ? ((1u << C_DIGIT) | (1u << C_DIGIT_NZ)) : 0u;
+  }
+  const int after = e < 0 ? (cur + 1 < L ? rest[cur + 1] : 1) : rest[cur];
+  const unsigned first = (e < 0 && a.s == S_VALUE && a.depth == 1) ? (unsigned)(-2 - e) : 0u;
+  unsigned fits = 0, grammar = 0;
+#pragma unroll
+  for (int c = 1; c < N_CLASSES; ++c) {
+    bool ok;
+    const St n = transition(a, c, ok);
+    if (!ok || n.depth < 1) continue;  // closing the top-level object is the script's business
+    if (a.depth == 1 && (a.s == S_AFTER_VALUE || a.s == S_NUM) && (c == C_COMMA || c == C_RBRACE)) continue;
+    grammar |= 1u << c;
+    if (close_cost(n.s, n.depth, vc) - 2 + after <= left - 1) fits |= 1u << c;
+  }
+  if (first & grammar) {
+    grammar &= first;
+    fits &= first;
+  }
+  return fits ? fits : grammar;
+}
+
 typedef __attribute__((ext_vector_type(8))) unsigned short us8;
 
 __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __restrict__ logits, long long row_stride, int V, int n_cls, const long long* __restrict__ rows,
                                                            const int* __restrict__ slots, const int* __restrict__ init, int* __restrict__ state,
-                                                           const unsigned char* __restrict__ cls, int vc) {
+                                                           const unsigned char* __restrict__ cls, int vc, const int* __restrict__ script,
+                                                           int* __restrict__ cursor, const int* __restrict__ cur_init, int L) {
   const int r = blockIdx.x, tid = threadIdx.x;
   const int slot = slots[r];
-  const int* src = init[4 * r] >= 0 ? init + 4 * r : state + 4 * slot;
+  const bool fresh = init[4 * r] >= 0;
+  const int* src = fresh ? init + 4 * r : state + 4 * slot;
   const St a = {src[0], src[1], src[2]};
   const int left = src[3];
-  if (init[4 * r] >= 0 && tid < 4) state[4 * slot + tid] = init[4 * r + tid];  // nobody reads state[] of this slot in this launch
-  const unsigned allow = allowed_classes(a, left, vc);
+  int cur = -1;
+  if (script != nullptr) cur = fresh ? cur_init[r] : cursor[slot];
+  if (fresh && tid < 4) state[4 * slot + tid] = init[4 * r + tid];  // nobody reads state[] / cursor[] of this slot in this launch
+  if (fresh && tid == 4 && script != nullptr) cursor[slot] = cur;
+  int forced;
+  const int* ent = script != nullptr ? script + (long long)slot * 2 * L : nullptr;
+  const unsigned allow = allowed_scripted(a, left, vc, ent, ent != nullptr ? ent + L : nullptr, cur, L, forced);
   if (allow == (1u << N_CLASSES) - 1u) return;
   unsigned short* row = logits + rows[r] * row_stride;
   constexpr unsigned short NEG_INF = 0xFF80;
@@ -151,7 +202,7 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned c = (unsigned)(c8 >> (8 * j)) & 0xffu;
-        if (!((allow >> c) & 1u)) { x[j] = NEG_INF; any = true; }
+        if (!((allow >> c) & 1u) && i * 8 + j != forced) { x[j] = NEG_INF; any = true; }
       }
       if (any) reinterpret_cast<us8*>(row)[i] = x;
     }
@@ -159,19 +210,39 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
   }
   for (int i = done + tid; i < V; i += TPB) {
     const unsigned c = i < n_cls ? cls[i] : (unsigned)C_OTHER;  // ids past the tokenizer's vocabulary (padding columns) are never allowed
-    if (!((allow >> c) & 1u)) row[i] = NEG_INF;
+    if (!((allow >> c) & 1u) && i != forced) row[i] = NEG_INF;
   }
 }
 
 __global__ void guided_advance_kernel(const long long* __restrict__ out_ids, const long long* __restrict__ rows, const int* __restrict__ slots, int R,
-                                      int* __restrict__ state, const unsigned char* __restrict__ cls, int n_cls) {
+                                      int* __restrict__ state, const unsigned char* __restrict__ cls, int n_cls, const int* __restrict__ script,
+                                      int* __restrict__ cursor, int L) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
-  int* st = state + 4 * slots[r];
+  const int slot = slots[r];
+  int* st = state + 4 * slot;
   St a = {st[0], st[1], st[2] & ((1 << FIRST_SHIFT) - 1)};
   if (a.s == S_OFF || a.s == S_END) return;
   const long long tok = out_ids[rows[r]];
   const int c = (tok >= 0 && tok < n_cls) ? cls[tok] : (int)C_OTHER;
+  if (script != nullptr) {
+    const int cur = cursor[slot];
+    const int* ent = script + (long long)slot * 2 * L;
+    if (cur >= 0 && cur < L && ent[cur] != SCRIPT_END) {
+      const int e = ent[cur];
+      if (e >= 0 && forcing(a.s, a.depth) && tok == (long long)e) {
+        // a literal token was written: the automaton is set by what the script holds next
+        const int nx = cur + 1 < L ? ent[cur + 1] : SCRIPT_END;
+        cursor[slot] = cur + 1;
+        st[0] = nx == SCRIPT_END ? S_DONE : (nx < 0 ? S_VALUE : S_OBJ_NEXT);
+        st[1] = nx == SCRIPT_END ? 0 : 1;
+        st[2] = 0;
+        st[3] = st[3] - 1;
+        return;
+      }
+      if (e < 0 && a.s == S_VALUE && a.depth == 1) cursor[slot] = cur + 1;  // the slot's value has begun
+    }
+  }
   bool ok;
   const St n = transition(a, c, ok);
   st[0] = n.s; st[1] = n.depth; st[2] = n.stack; st[3] = st[3] - 1;
@@ -179,16 +250,22 @@ __global__ void guided_advance_kernel(const long long* __restrict__ out_ids, con
 
 }  // namespace
 
+// script: int32 [slots][2][L] (entries, rest) or nullptr (no sequence is scripted); cursor: int32 [slots];
+// cur_init: int32 [R], the cursor a row's slot starts from when init (re)sets it (-1: no script)
 extern "C" int kv_guided_mask(void* logits, long long row_stride, int V, int n_cls, const long long* rows, const int* slots, const int* init, int R, int* state,
-                              const unsigned char* cls, int vc, hipStream_t stream) {
+                              const unsigned char* cls, int vc, const int* script, int* cursor, const int* cur_init, int L, hipStream_t stream) {
   if (R <= 0) return 0;
   if (V <= 0 || n_cls > V) return -1;
-  hipLaunchKernelGGL(guided_mask_kernel, dim3(R), dim3(TPB), 0, stream, (unsigned short*)logits, row_stride, V, n_cls, rows, slots, init, state, cls, vc);
+  if (script != nullptr && (cursor == nullptr || cur_init == nullptr || L < 1)) return -1;
+  hipLaunchKernelGGL(guided_mask_kernel, dim3(R), dim3(TPB), 0, stream, (unsigned short*)logits, row_stride, V, n_cls, rows, slots, init, state, cls, vc, script, cursor,
+                     cur_init, L);
   return (int)hipGetLastError();
 }
 
-extern "C" int kv_guided_advance(const long long* out_ids, const long long* rows, const int* slots, int R, int* state, const unsigned char* cls, int n_cls, hipStream_t stream) {
+extern "C" int kv_guided_advance(const long long* out_ids, const long long* rows, const int* slots, int R, int* state, const unsigned char* cls, int n_cls,
+                                 const int* script, int* cursor, int L, hipStream_t stream) {
   if (R <= 0) return 0;
-  hipLaunchKernelGGL(guided_advance_kernel, dim3((R + 63) / 64), dim3(64), 0, stream, out_ids, rows, slots, R, state, cls, n_cls);
+  if (script != nullptr && (cursor == nullptr || L < 1)) return -1;
+  hipLaunchKernelGGL(guided_advance_kernel, dim3((R + 63) / 64), dim3(64), 0, stream, out_ids, rows, slots, R, state, cls, n_cls, script, cursor, L);
   return (int)hipGetLastError();
 }

@@ -228,6 +228,11 @@ class LLMEngine:
         self._guided_vc = 1
         self._guided_state = torch.zeros((ecfg.max_num_seqs, 4), dtype=torch.int32, device=self.device)
         self._guided_owner: List[Any] = [None] * ecfg.max_num_seqs
+        # schema-guided sequences: the skeleton script of each slot (entries, rest) and its cursor
+        from .guided import SCRIPT_MAX
+
+        self._guided_script = torch.zeros((ecfg.max_num_seqs, 2, SCRIPT_MAX), dtype=torch.int32, device=self.device)
+        self._guided_cursor = torch.full((ecfg.max_num_seqs,), -1, dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------
     def warmup(self) -> float:
@@ -362,13 +367,15 @@ class LLMEngine:
         g_rows: List[int] = []
         g_slots: List[int] = []
         g_init: List[int] = []
+        g_cur: List[int] = []
+        g_scripts: List[Tuple[int, List[List[int]]]] = []  # (slot, [entries, rest]) to upload before the mask runs
         g_greedy: List[int] = []
         r = 0
         for ch in batch.chunks:
             if ch.sample:
                 p = ch.seq.params
                 if p.guided:
-                    self._stage_guided(ch.seq, r, g_rows, g_slots, g_init)
+                    self._stage_guided(ch.seq, r, g_rows, g_slots, g_init, g_cur, g_scripts)
                     if p.temperature <= 0:
                         g_greedy.append(r)
                 if p.temperature > 0 and (p.guided or not guided_only):
@@ -382,21 +389,26 @@ class LLMEngine:
             ops, dev = self.runner.ops, logits.device
             if g_rows:
                 gr, gs = _host_to_device(g_rows, torch.int64, dev), _host_to_device(g_slots, torch.int32, dev)
-                ops.guided_mask(logits, gr, gs, _host_to_device(g_init, torch.int32, dev), self._guided_state, self._guided_cls, self._guided_vc)
+                for slot, rows2 in g_scripts:  # (stream-ordered: lands before the mask kernel reads it)
+                    self._guided_script[slot].copy_(_host_to_device(rows2, torch.int32, dev), non_blocking=True)
+                ops.guided_mask(logits, gr, gs, _host_to_device(g_init, torch.int32, dev), self._guided_state, self._guided_cls, self._guided_vc,
+                                self._guided_script, self._guided_cursor, _host_to_device(g_cur, torch.int32, dev))
                 if g_greedy:
                     idx = gr if len(g_greedy) == len(g_rows) else _host_to_device(g_greedy, torch.int64, dev)
                     out_ids.index_copy_(0, idx, ops.greedy_sample(logits.index_select(0, idx)))
             if rows:
                 self._sample_into(logits, rows, plist, out_ids)
             if g_rows:
-                ops.guided_advance(out_ids, gr, gs, self._guided_state, self._guided_cls)
+                ops.guided_advance(out_ids, gr, gs, self._guided_state, self._guided_cls, self._guided_script, self._guided_cursor)
 
         return run
 
-    def _stage_guided(self, seq: Sequence, row: int, g_rows: List[int], g_slots: List[int], g_init: List[int]) -> None:
+    def _stage_guided(self, seq: Sequence, row: int, g_rows: List[int], g_slots: List[int], g_init: List[int], g_cur: List[int],
+                      g_scripts: List[Tuple[int, List[List[int]]]]) -> None:
         """One guided row of the step being launched.  The automaton of the sequence's slot is
         (re)initialised by the kernel when this sequence has not used the slot before (first
-        sample, or taken up again after a preemption: replayed over the tokens it already has)."""
+        sample, or taken up again after a preemption: replayed over the tokens it already has);
+        a schema-guided sequence's skeleton script goes to the slot's device buffer then."""
         from . import guided
         from .scheduler import PLACEHOLDER
 
@@ -408,9 +420,16 @@ class LLMEngine:
         if self._guided_owner[seq.slot] != key:
             self._guided_owner[seq.slot] = key
             known = [t for t in seq.output_ids if t != PLACEHOLDER]
-            g_init += list(guided.replay(self._guided_cls_np, seq.params.guided_start, seq.params.max_tokens, known))
+            script = list(seq.params.guided_script) if seq.params.guided_script else None
+            st, cur = guided.replay(self._guided_cls_np, seq.params.guided_start, seq.params.max_tokens, known, script)
+            g_init += list(st)
+            g_cur.append(cur)
+            if script:
+                pad = guided.SCRIPT_MAX - len(script)
+                g_scripts.append((seq.slot, [script + [guided.SCRIPT_END] * pad, guided.script_rest(script, self._guided_vc) + [1] * pad]))
         else:
             g_init += [-1, 0, 0, 0]
+            g_cur.append(-1)
 
     def _sample_into(self, logits: torch.Tensor, rows: List[int], plist: List[SamplingParams], out_ids: torch.Tensor) -> torch.Tensor:
         """Sample rows ``rows`` of ``logits`` (one SamplingParams each, unseeded) into

@@ -47,6 +47,9 @@ class SamplingParams:
     # that pre-writes part of the document into the prompt starts it further in)
     guided: Optional[str] = None
     guided_start: Tuple[int, int, int] = (1, 0, 0)
+    # skeleton script of a schema-guided sequence (kvmini.engine.guided.schema_script): forced
+    # literal tokens (>= 0), typed value slots (<= -2), -1 at the end
+    guided_script: Optional[Tuple[int, ...]] = None
 
 
 @dataclass(eq=False)  # identity semantics: sequences live in lists / sets and are compared per step
@@ -160,6 +163,12 @@ class Scheduler:
                 return f"{name} must be a finite non-negative number, got {v!r}"
         if p.guided not in (None, "json"):
             return f"unknown guided decoding mode {p.guided!r}"
+        if p.guided_script is not None:
+            from .guided import SCRIPT_END, SCRIPT_MAX
+
+            sc = p.guided_script
+            if p.guided != "json" or not 0 < len(sc) <= SCRIPT_MAX or sc[-1] != SCRIPT_END or any(isinstance(e, bool) or not isinstance(e, int) for e in sc):
+                return f"bad guided script (integers, at most {SCRIPT_MAX} entries, the last one {SCRIPT_END})"
         if not isinstance(p.max_tokens, int) or p.max_tokens < 1:
             return f"max_tokens must be a positive integer, got {p.max_tokens!r}"
         bs = self.bm.block_size

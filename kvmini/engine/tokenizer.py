@@ -57,6 +57,12 @@ class SyntheticTokenizer:
         ids = [self._piece_id(p) for p in _PIECE.findall(text)]
         return ([self.bos_id] + ids) if add_bos else ids
 
+    def encode_pieces(self, text: str) -> List[Any]:
+        """``[(token id, the text it stands for)]`` — word ids are hashes, so a token does not
+        decode back to its word; callers that must reproduce ``text`` exactly (forced skeleton
+        tokens of guided decoding) keep the pieces."""
+        return [(self._piece_id(m.group(1)), m.group(0)) for m in re.finditer(r"\s*(\w+|[^\w\s])", text)]
+
     def apply_chat_template(self, messages: List[Dict[str, Any]]) -> List[int]:
         """BOS, then per message <|start_header|> role <|end_header|> \\n\\n content <|eot|>,
         then the assistant header — the token budget of the Llama-3 template."""
@@ -96,6 +102,11 @@ class HFTokenizer:
     def encode(self, text: str, add_bos: bool = False) -> List[int]:
         ids = self.tk.encode(text, add_special_tokens=False).ids
         return ([self.bos_id] + ids) if add_bos else ids
+
+    def encode_pieces(self, text: str) -> List[Any]:
+        """``[(token id, text)]`` whose texts concatenate to ``text`` (by the encoding's offsets)."""
+        enc = self.tk.encode(text, add_special_tokens=False)
+        return [(i, text[a:b]) for i, (a, b) in zip(enc.ids, enc.offsets)]
 
     def apply_chat_template(self, messages: List[Dict[str, Any]]) -> List[int]:
         parts = ["<|begin_of_text|>"]

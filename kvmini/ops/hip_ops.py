@@ -813,16 +813,19 @@ def sample_rows(logits: torch.Tensor, rows: torch.Tensor, temperature: torch.Ten
     native().sample_rows(logits, rows, temperature, top_k, top_p, u, out)
 
 
-def guided_mask(logits: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, init: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, vc: int) -> None:
+def guided_mask(logits: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, init: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, vc: int,
+                script: Optional[torch.Tensor] = None, cursor: Optional[torch.Tensor] = None, cur_init: Optional[torch.Tensor] = None) -> None:
     """Guided JSON decoding, step 1 (``csrc/guided.hip``): every token of ``logits[rows[r]]`` whose
     class the automaton of ``state[slots[r]]`` does not allow becomes -inf; ``init[r][0] >= 0``
-    (re)sets that automaton first."""
-    native().guided_mask(logits, rows, slots, init, state, cls, vc)
+    (re)sets that automaton first.  ``script`` int32 ``[S, 2, L]`` / ``cursor`` int32 ``[S]`` /
+    ``cur_init`` int32 ``[R]``: skeleton scripts of schema-guided sequences (forced literal tokens)."""
+    native().guided_mask(logits, rows, slots, init, state, cls, vc, script, cursor, cur_init)
 
 
-def guided_advance(out_ids: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, state: torch.Tensor, cls: torch.Tensor) -> None:
-    """Guided JSON decoding, step 2: feed ``out_ids[rows[r]]`` to the automaton of ``state[slots[r]]``."""
-    native().guided_advance(out_ids, rows, slots, state, cls)
+def guided_advance(out_ids: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, script: Optional[torch.Tensor] = None,
+                   cursor: Optional[torch.Tensor] = None) -> None:
+    """Guided JSON decoding, step 2: feed ``out_ids[rows[r]]`` to the automaton (and script cursor) of ``state[slots[r]]``."""
+    native().guided_advance(out_ids, rows, slots, state, cls, script, cursor)
 
 
 def greedy_sample(logits: torch.Tensor) -> torch.Tensor:

@@ -157,14 +157,16 @@ def greedy_sample(logits: torch.Tensor) -> torch.Tensor:
     return logits.argmax(dim=-1)
 
 
-def guided_mask(logits: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, init: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, vc: int) -> None:
+def guided_mask(logits: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, init: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, vc: int,
+                script: Optional[torch.Tensor] = None, cursor: Optional[torch.Tensor] = None, cur_init: Optional[torch.Tensor] = None) -> None:
     """Reference of the guided-decoding mask: the Python automaton, row by row."""
     from kvmini.engine.guided import mask_rows_reference
 
-    mask_rows_reference(logits, rows.tolist(), slots.tolist(), init.view(-1, 4).tolist(), state, cls.cpu().numpy(), vc)
+    mask_rows_reference(logits, rows.tolist(), slots.tolist(), init.view(-1, 4).tolist(), state, cls.cpu().numpy(), vc, script, cursor, None if cur_init is None else cur_init.tolist())
 
 
-def guided_advance(out_ids: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, state: torch.Tensor, cls: torch.Tensor) -> None:
+def guided_advance(out_ids: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, script: Optional[torch.Tensor] = None,
+                   cursor: Optional[torch.Tensor] = None) -> None:
     from kvmini.engine.guided import advance_rows_reference
 
-    advance_rows_reference(out_ids, rows.tolist(), slots.tolist(), state, cls.cpu().numpy())
+    advance_rows_reference(out_ids, rows.tolist(), slots.tolist(), state, cls.cpu().numpy(), script, cursor)

@@ -104,22 +104,15 @@ class NativeServer:
         return Response.json({"error": {"message": why, "type": "invalid_request_error"}}, 400)
 
     # guided decoding ------------------------------------------------------
-    def _schema_start(self, schema: Any) -> Tuple[str, Tuple[int, int, int]]:
-        """(text the server writes itself, automaton start) for a JSON schema: the opening brace
-        and the first required (else first) property key are written by the server and the value
-        that follows is restricted to the property's type; everything after that is free JSON."""
+    def _schema_start(self, schema: Any) -> Tuple[str, Tuple[int, int, int], Optional[List[int]], Optional[List[str]]]:
+        """(text the server writes itself, automaton start, skeleton script, text of its entries)
+        for a JSON schema: the opening brace and the first required key go in front of the
+        generation, every further required key (with its punctuation, and the closing brace) is a
+        run of forced tokens, and each value is restricted to the property's type
+        (``kvmini.engine.guided.schema_script``)."""
         from kvmini.engine import guided as G
 
-        props = schema.get("properties") if isinstance(schema, dict) else None
-        if not isinstance(props, dict) or not props:
-            return "", (G.S_START, 0, 0)
-        req_keys = [k for k in (schema.get("required") or []) if k in props]
-        key = req_keys[0] if req_keys else next(iter(props))
-        prefix = "{" + json.dumps(str(key)) + ":"
-        st, depth, stack = G.state_after_text(prefix)
-        ptype = props[key].get("type") if isinstance(props[key], dict) else None
-        first = G.TYPE_CLASSES.get(ptype if isinstance(ptype, str) else "", 0)
-        return prefix, (st, depth, stack | (first << G.FIRST_SHIFT))
+        return G.schema_script(schema if isinstance(schema, dict) else {}, self.tok.encode_pieces)
 
     def _guided_plan(self, body: Dict[str, Any], chat: bool) -> Tuple[Optional[List[Dict[str, Any]]], bool]:
         """What a request asks the automaton for.  Returns (sub-requests, they are tool calls):
@@ -145,8 +138,8 @@ class NativeServer:
                 raise ValueError(f"tool_choice must be none, auto, required or a function, got {choice!r}")
             subs = []
             for t in called[:16]:
-                prefix, start = self._schema_start(t["function"].get("parameters") or {})
-                subs.append({"name": str(t["function"]["name"]), "prefix": prefix, "start": start, "lead": f"call {t['function']['name']} {prefix}"})
+                prefix, start, script, texts = self._schema_start(t["function"].get("parameters") or {})
+                subs.append({"name": str(t["function"]["name"]), "prefix": prefix, "start": start, "lead": f"call {t['function']['name']} {prefix}", "script": script, "texts": texts})
             return subs, True
         schema = None
         if isinstance(rf, dict) and rf.get("type") == "json_schema":
@@ -155,8 +148,8 @@ class NativeServer:
             schema = body["guided_json"] if isinstance(body["guided_json"], dict) else json.loads(str(body["guided_json"]))
         elif not (isinstance(rf, dict) and rf.get("type") == "json_object"):
             return None, False
-        prefix, start = self._schema_start(schema or {})
-        return [{"name": None, "prefix": prefix, "start": start, "lead": prefix}], False
+        prefix, start, script, texts = self._schema_start(schema or {})
+        return [{"name": None, "prefix": prefix, "start": start, "lead": prefix, "script": script, "texts": texts}], False
 
     def _ensure_guided(self) -> None:
         if not self.engine.guided_ready:
@@ -245,6 +238,7 @@ class NativeServer:
         q: asyncio.Queue = asyncio.Queue()
         rids: List[int] = []
         lead_of = [""] * n  # text the server wrote in front of a choice's generated tokens
+        detok: List[Any] = [None] * n  # schema-guided choices: forced skeleton tokens stand for the schema's own text
         if subs is None:
             for i in range(n):
                 p_i = params if i == 0 else SamplingParams(**{**vars(params), "stop_token_ids": list(params.stop_token_ids), "seed": None if params.seed is None else params.seed + i})
@@ -258,9 +252,15 @@ class NativeServer:
             plan = subs if as_tools else subs * n
             budget = max(8, params.max_tokens // len(plan)) if as_tools else params.max_tokens
             lead_of = [sb["prefix"] for sb in plan]
+            detok = [None] * len(plan)
             for i, sb in enumerate(plan):
                 p_i = SamplingParams(**{**vars(params), "stop_token_ids": list(params.stop_token_ids), "seed": None if params.seed is None else params.seed + i,
-                                        "max_tokens": budget, "ignore_eos": False, "guided": "json", "guided_start": tuple(sb["start"])})
+                                        "max_tokens": budget, "ignore_eos": False, "guided": "json", "guided_start": tuple(sb["start"]),
+                                        "guided_script": tuple(sb["script"]) if sb.get("script") else None})
+                if sb.get("script"):
+                    from kvmini.engine.guided import ScriptedText
+
+                    detok[i] = ScriptedText(self.engine._guided_cls_np, tuple(sb["start"]), budget, sb["script"], sb["texts"], self.tok.decode_token)
                 ids_i = prompt_ids + (self.tok.encode(sb["lead"]) if sb["lead"] else [])
                 bad = self._reject(ids_i, p_i)
                 if bad:
@@ -278,6 +278,10 @@ class NativeServer:
         lp_of: List[List[Dict[str, Any]]] = [[] for _ in range(n)]
         open_choices = set(range(n))
 
+        def piece_of(idx: int, t: int, blank: str = " ") -> str:
+            d = detok[idx]
+            return d.piece(t) if d is not None else (self.tok.decode_token(t) or blank)
+
         def take(idx: int, toks: List[int], done: bool, reason: Optional[str], seq: Any) -> Tuple[str, List[Dict[str, Any]], bool]:
             """Fold one token event into choice ``idx``.  Returns (new text, logprob entries,
             finished now) after applying the stop strings (the text is cut in front of the match
@@ -286,9 +290,10 @@ class NativeServer:
                 return "", [], False
             first = len(toks_of[idx])
             toks_of[idx] += toks
-            piece = "".join(self.tok.decode_token(t) or " " for t in toks) if stream else ""
+            scripted = detok[idx] is not None
+            piece = "".join(piece_of(idx, t) for t in toks) if (stream or scripted) else ""
             lps = self._logprob_entries(seq, first, toks) if want_lp else []
-            full = text_of[idx] + piece if stream else lead_of[idx] + self.tok.decode(toks_of[idx])
+            full = text_of[idx] + piece if (stream or scripted) else lead_of[idx] + self.tok.decode(toks_of[idx])
             hit = min((full.find(sx) for sx in stops if sx in full), default=-1)
             if hit >= 0:
                 piece = full[len(text_of[idx]) : hit] if stream else ""
@@ -352,7 +357,7 @@ class NativeServer:
                     while open_choices:
                         idx, toks, done, reason, seq = await q.get()
                         toks_of[idx] += toks
-                        piece = "".join(self.tok.decode_token(t) for t in toks)
+                        piece = "".join(piece_of(idx, t, "") for t in toks)
                         if piece:
                             yield sse_event({**base, "choices": [{"index": 0, "delta": {"tool_calls": [{"index": idx, "function": {"arguments": piece}}]}, "finish_reason": None}]})
                         if done:
@@ -373,7 +378,7 @@ class NativeServer:
                         # the common case, one chunk per token
                         toks_of[idx] += toks
                         for t in toks:
-                            piece = self.tok.decode_token(t) or " "
+                            piece = piece_of(idx, t)
                             ch = {"index": idx, "delta": {"content": piece}, "finish_reason": None} if chat else {"index": idx, "text": piece, "finish_reason": None}
                             yield sse_event({**base, "choices": [ch]})
                         if done:

@@ -16,7 +16,7 @@ from kvmini.engine import guided as G
 
 def _text_of(cls_seq):
     piece = {G.C_LBRACE: "{", G.C_RBRACE: "}", G.C_LBRACK: "[", G.C_RBRACK: "]", G.C_COLON: ":", G.C_COMMA: ",", G.C_QUOTE: '"', G.C_STR: " w", G.C_DIGIT_NZ: "7",
-             G.C_DIGIT: "0", G.C_LIT: "true", G.C_EOS: ""}
+             G.C_DIGIT: "0", G.C_LIT: "true", G.C_NULL: "null", G.C_EOS: ""}
     return "".join(piece[c] for c in cls_seq)
 
 
@@ -29,7 +29,7 @@ def test_random_walks_inside_the_allowed_classes_are_complete_json_within_the_bu
         seq = []
         while st[0] != G.S_END:
             allow = G.allowed_classes(st, vc)
-            options = [c for c in range(1, G.N_CLASSES) if (allow >> c) & 1 and not (vc == 2 and c in (G.C_LIT, G.C_DIGIT_NZ) and st[0] in (G.S_VALUE, G.S_ARR_FIRST))]
+            options = [c for c in range(1, G.N_CLASSES) if (allow >> c) & 1 and not (vc == 2 and c in (G.C_LIT, G.C_NULL, G.C_DIGIT_NZ) and st[0] in (G.S_VALUE, G.S_ARR_FIRST))]
             assert options, (st, seq)
             c = rng.choice(options)
             seq.append(c)
@@ -52,7 +52,67 @@ def test_prefix_state_type_restriction_and_replay():
     with pytest.raises(ValueError):
         G.state_after_text('{"a"}')
     cls = np.array([G.C_OTHER, G.C_LBRACE, G.C_QUOTE, G.C_STR, G.C_COLON, G.C_LIT, G.C_RBRACE, G.C_EOS], dtype=np.uint8)
-    assert G.replay(cls, (G.S_START, 0, 0), 30, [1, 2, 3, 2, 4, 5]) == (G.S_AFTER_VALUE, 1, 0, 24)
+    assert G.replay(cls, (G.S_START, 0, 0), 30, [1, 2, 3, 2, 4, 5]) == ((G.S_AFTER_VALUE, 1, 0, 24), -1)
+
+
+SCHEMA = {"type": "object", "required": ["name", "age", "tags", "ok", "kind", "address"],
+          "properties": {"name": {"type": "string"}, "age": {"type": "integer"}, "tags": {"type": "array"}, "ok": {"type": "boolean"},
+                         "kind": {"enum": ["a b", "c"]}, "address": {"type": "object"}, "nickname": {"type": "string"}}}
+PY_TYPES = {"name": str, "age": int, "tags": list, "ok": bool, "kind": str, "address": dict}
+
+
+def _check_schema_doc(doc):
+    assert list(doc)[: len(PY_TYPES)] == list(PY_TYPES), doc  # every required key, in order
+    for k, t in PY_TYPES.items():
+        assert type(doc[k]) is t, (k, doc[k])
+    assert doc["kind"] == "a b" and "nickname" not in doc
+
+
+def test_scripted_random_walks_give_every_required_key_with_its_type_within_the_budget():
+    """Token-level random walks through the scripted automaton (forced skeleton tokens + class
+    automaton inside the value slots): whatever the model picks, the document parses, has every
+    required key in order with a value of the declared type, and ends within max_tokens once the
+    shortest document fits."""
+    from kvmini.engine.tokenizer import get_tokenizer
+
+    tok = get_tokenizer(2048, 1, 2)
+    cls = G.token_classes(tok, 2048, 2)
+    vc = G.value_cost(cls)
+    prefix, start, script, texts = G.schema_script(SCHEMA, tok.encode_pieces)
+    assert prefix == '{"name":' and start == (G.S_VALUE, 1, 0) and script[-1] == G.SCRIPT_END and len(texts) == len(script)
+    assert "".join(texts) == ',"age":,"tags":,"ok":,"kind":"a b","address":}'
+    assert script[0] == G.script_value(G.TYPE_CLASSES["string"])
+    rest = G.script_rest(script, vc)
+    assert rest[0] == sum(1 for e in script if e >= 0) + 2 + 1 + 2 + 1 + 2 + 1  # literals + "" 7 [] true {} + EOS
+    by_class = {c: [t for t in range(16, 2048) if cls[t] == c] for c in range(G.N_CLASSES)}
+    by_class[G.C_EOS] = [2]
+    rng = random.Random(11)
+    for trial in range(300):
+        budget = rng.randint(rest[0], rest[0] + 60)
+        st, cur, out = (start[0], start[1], start[2], budget), 0, []
+        while st[0] != G.S_END:
+            allow, forced = G.allowed_scripted(st, cur, script, rest, vc)
+            options = [rng.choice(by_class[c]) for c in range(1, G.N_CLASSES) if (allow >> c) & 1 and by_class[c]]
+            if forced >= 0:
+                options.append(forced)
+            assert options, (st, cur, out)
+            t = rng.choice(options)
+            out.append(t)
+            st, cur = G.advance_scripted(st, cur, t, cls, script)
+            assert len(out) <= budget, (budget, tok.decode(out))
+        assert out[-1] == 2
+        text = G.ScriptedText(cls, start, budget, script, texts, tok.decode_token)
+        _check_schema_doc(json.loads(prefix + "".join(text.piece(t) for t in out)))
+        # replay (a preempted sequence) reproduces state and cursor at every cut
+        cut = rng.randrange(len(out))
+        st2, cur2 = (start[0], start[1], start[2], budget), 0
+        for t in out[:cut]:
+            st2, cur2 = G.advance_scripted(st2, cur2, t, cls, script)
+        assert G.replay(cls, start, budget, out[:cut], script) == (st2, cur2)
+    # a schema of constants only is one forced literal; a schema without properties has no script
+    p2, s2, sc2, tx2 = G.schema_script({"properties": {"v": {"const": 3}, "w": {"enum": ["x"]}}}, tok.encode_pieces)
+    assert p2 == "" and s2 == (G.S_OBJ_NEXT, 1, 0) and "".join(tx2) == '{"v":3,"w":"x"}' and sc2[-1] == G.SCRIPT_END
+    assert G.schema_script({"type": "object"}, tok.encode_pieces) == ("", (G.S_START, 0, 0), None, None)
 
 
 def test_token_classes_of_the_synthetic_tokenizer():
@@ -122,7 +182,28 @@ def test_native_server_json_mode_schema_tools_and_parity_matrix(in_tmp):
         assert r.status_code == 200 and len(r.json()["choices"]) == 2
         for ch in r.json()["choices"]:
             doc = json.loads(ch["message"]["content"])
-            assert isinstance(doc["age"], int)  # the first required key is written by the server, its value typed by the automaton
+            # every required key in the order of `required`, each value of the declared type
+            assert list(doc) == ["age", "name"] and type(doc["age"]) is int and type(doc["name"]) is str and ch["finish_reason"] == "stop"
+        # a richer schema (string, integer, array, boolean, enum, object; one optional property), streamed and not
+        rf = {"type": "json_schema", "json_schema": {"name": "r", "schema": SCHEMA}}
+        r = c.post(url + "/v1/chat/completions", json={"model": "tiny", "messages": msg, "max_tokens": 96, "temperature": 1.0, "response_format": rf})
+        _check_schema_doc(json.loads(r.json()["choices"][0]["message"]["content"]))
+        txt = ""
+        with c.stream("POST", url + "/v1/chat/completions", json={"model": "tiny", "messages": msg, "max_tokens": 96, "response_format": rf, "stream": True}) as rs:
+            for line in rs.iter_lines():
+                if line.startswith("data: ") and line != "data: [DONE]":
+                    d = json.loads(line[6:])["choices"]
+                    txt += (d[0]["delta"].get("content") or "") if d else ""
+        _check_schema_doc(json.loads(txt))
+        # vLLM's guided_json spelling on the completions endpoint
+        r = c.post(url + "/v1/completions", json={"model": "tiny", "prompt": "person:", "max_tokens": 96, "guided_json": SCHEMA})
+        _check_schema_doc(json.loads(r.json()["choices"][0]["text"]))
+        # tool arguments carry every required parameter
+        two = [{"type": "function", "function": {"name": "forecast", "parameters": {"type": "object", "required": ["city", "days"],
+                                                                                  "properties": {"city": {"type": "string"}, "days": {"type": "integer"}, "units": {"enum": ["c", "f"]}}}}}]
+        r = c.post(url + "/v1/chat/completions", json={"model": "tiny", "messages": msg, "tools": two, "tool_choice": "required", "max_tokens": 48})
+        a = json.loads(r.json()["choices"][0]["message"]["tool_calls"][0]["function"]["arguments"])
+        assert list(a) == ["city", "days"] and type(a["city"]) is str and type(a["days"]) is int
         tools = [{"type": "function", "function": {"name": f, "parameters": {"type": "object", "properties": {"city": {"type": "string"}}}}} for f in ("get_weather", "get_timezone")]
         r = c.post(url + "/v1/chat/completions", json={"model": "tiny", "messages": msg, "tools": tools, "tool_choice": "auto", "max_tokens": 40})
         ch = r.json()["choices"][0]
@@ -223,6 +304,103 @@ def test_guided_kernels_match_the_python_automaton():
         tok = int(out_ids[int(rows[s])])
         want = G.advance(states[s], int(cls[tok]) if tok < n_cls else G.C_OTHER)
         assert tuple(st_d[s].tolist()) == want, (s, states[s], tok)
+
+
+@pytest.mark.gpu
+def test_guided_script_kernels_walk_in_step_with_the_python_automaton():
+    """Scripted (schema-guided) sequences through the two kernels, one token at a time: at every
+    step the masked logits row, the automaton state and the script cursor equal the Python
+    reference; the tokens are drawn at random from what the mask left, so forced skeleton tokens,
+    typed value slots, numbers that end with the next literal and nested containers all occur."""
+    import torch
+
+    from kvmini.engine.tokenizer import get_tokenizer
+    from kvmini.ops import hip_ops
+
+    hip_ops.require()
+    dev = torch.device("cuda:0")
+    V = 2051  # wider than the class table: padding columns
+    tok = get_tokenizer(2048, 1, 2)
+    cls = G.token_classes(tok, 2048, 2)
+    vc = G.value_cost(cls)
+    cls_d = torch.from_numpy(cls).to(dev)
+    prefix, start, script, texts = G.schema_script(SCHEMA, tok.encode_pieces)
+    rest = G.script_rest(script, vc)
+    S, L = 6, G.SCRIPT_MAX
+    budgets = [rest[0], rest[0] + 3, rest[0] + 40, rest[0] + 11, 200, rest[0] + 25]
+    pad = L - len(script)
+    script_d = torch.zeros((S, 2, L), dtype=torch.int32, device=dev)
+    for s_ in range(S - 1):  # the last slot carries no script: plain JSON mode next to the scripted ones
+        script_d[s_] = torch.tensor([script + [G.SCRIPT_END] * pad, rest + [1] * pad], dtype=torch.int32, device=dev)
+    cursor_d = torch.full((S,), 7, dtype=torch.int32, device=dev)  # garbage until the init records land
+    state_d = torch.full((S, 4), 3, dtype=torch.int32, device=dev)
+    rows = torch.tensor([5, 0, 3, 1, 4, 2], dtype=torch.int64, device=dev)
+    slots = torch.arange(S, dtype=torch.int32, device=dev)
+    py = [((start[0], start[1], start[2], budgets[s_]), 0) for s_ in range(S - 1)] + [((G.S_START, 0, 0, budgets[S - 1]), -1)]
+    out = [[] for _ in range(S)]
+    gen = torch.Generator().manual_seed(3)
+    rng = random.Random(9)
+    step = 0
+    while any(st[0] != G.S_END for st, _ in py):
+        logits = torch.randn(S, V, generator=gen).to(torch.bfloat16).to(dev)
+        ref = logits.clone()
+        init = torch.tensor([list(st) for st, _ in py] if step == 0 else [[-1, 0, 0, 0]] * S, dtype=torch.int32, device=dev)
+        cur_init = torch.tensor([c for _, c in py] if step == 0 else [-1] * S, dtype=torch.int32, device=dev)
+        hip_ops.guided_mask(logits, rows, slots, init, state_d, cls_d, vc, script_d, cursor_d, cur_init)
+        picks = torch.zeros(S, dtype=torch.int64)
+        for s_ in range(S):
+            st, cur = py[s_]
+            allow, forced = G.allowed_scripted(st, cur, script if s_ < S - 1 else None, rest if s_ < S - 1 else None, vc)
+            ok = np.array([(allow >> int(c)) & 1 for c in cls] + [allow == (1 << G.N_CLASSES) - 1] * (V - len(cls)), dtype=bool)
+            if forced >= 0:
+                ok[forced] = True
+            r = int(rows[s_])
+            want = torch.where(torch.from_numpy(ok).to(dev), ref[r].float(), torch.full((V,), float("-inf"), device=dev))
+            assert torch.equal(logits[r].float(), want), (step, s_, st, cur)
+            options = np.flatnonzero(ok[: len(cls)])
+            picks[r] = int(rng.choice(list(options))) if st[0] != G.S_END else 2
+        out_ids = picks.to(dev)
+        hip_ops.guided_advance(out_ids, rows, slots, state_d, cls_d, script_d, cursor_d)
+        torch.cuda.synchronize()
+        for s_ in range(S):
+            st, cur = py[s_]
+            t = int(picks[int(rows[s_])])
+            if st[0] != G.S_END:
+                out[s_].append(t)
+            py[s_] = G.advance_scripted(st, cur, t, cls, script if s_ < S - 1 else None)
+            assert tuple(state_d[s_].tolist()) == py[s_][0] and int(cursor_d[s_]) == py[s_][1], (step, s_, st, cur, t)
+        step += 1
+        assert step < 400
+    for s_ in range(S - 1):
+        assert len(out[s_]) <= budgets[s_] and out[s_][-1] == 2
+        text = G.ScriptedText(cls, start, budgets[s_], script, texts, tok.decode_token)
+        _check_schema_doc(json.loads(prefix + "".join(text.piece(t) for t in out[s_])))
+    assert isinstance(json.loads(tok.decode(out[S - 1])), dict)
+
+
+@pytest.mark.gpu
+def test_engine_schema_guided_generation_on_the_hip_path():
+    """A schema-guided batch on the HIP engine (graphs, launch-ahead): every output has all
+    required keys with the declared types; greedy and sampled."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.engine.tokenizer import get_tokenizer
+
+    eng = LLMEngine(EngineConfig(model="llama-3.2-1b", device="cuda:0", max_num_seqs=16, max_batched_tokens=128, max_model_len=512, kernels="hip", kv_memory_fraction=0.1))
+    eng.warmup()
+    tok = get_tokenizer(eng.mcfg.vocab_size, eng.mcfg.bos_token_id, eng.mcfg.eos_token_id)
+    cls = G.token_classes(tok, eng.mcfg.vocab_size, eng.mcfg.eos_token_id)
+    eng.set_token_classes(cls)
+    prefix, start, script, texts = G.schema_script(SCHEMA, tok.encode_pieces)
+    prompts = [tok.encode(f"describe person {i} as json " + prefix, add_bos=True) for i in range(10)]
+    for temp in (0.0, 0.9):
+        sp = SamplingParams(max_tokens=80, temperature=temp, guided="json", guided_start=start, guided_script=tuple(script))
+        outs = eng.generate(prompts, sp)
+        for o in outs:
+            assert o[-1] == eng.mcfg.eos_token_id and len(o) <= 80
+            text = G.ScriptedText(cls, start, 80, script, texts, tok.decode_token)
+            _check_schema_doc(json.loads(prefix + "".join(text.piece(t) for t in o)))
+    assert eng.pipelined_steps > 0
 
 
 @pytest.mark.gpu
