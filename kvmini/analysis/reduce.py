@@ -378,6 +378,10 @@ def analyze_run(
 
     results = analyze_rows(rows, cold_times, util, io_probe, chr_val)
     results.update(inter_token_latency_metrics(run_dir, engine=quantile_engine))
+    # structured-output runs: how many answers satisfy the schema they were asked for (written by the load generator)
+    structured_path = os.path.join(run_dir, "structured.json")
+    if os.path.exists(structured_path):
+        results["structured_output"] = load_json(structured_path, default={})
 
     # classified CSV (adds is_cold_start)
     fieldnames = list(rows[0].keys())

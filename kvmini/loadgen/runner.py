@@ -77,6 +77,10 @@ class ReqResult:
     token_times_ms: List[float] = field(default_factory=list)
     text: str = ""
     tenant: Optional[str] = None
+    # structured output (requests that carried a JSON schema): the answer parses / satisfies it
+    json_ok: Optional[bool] = None
+    schema_ok: Optional[bool] = None
+    schema_why: Optional[str] = None
 
     def csv_row(self) -> List[Any]:
         f3 = lambda v: "" if v is None else f"{v:.3f}"  # noqa: E731
@@ -184,6 +188,8 @@ async def _one_request(
         token_times: List[float] = []
         chunks = 0
         text = ""
+        answer: Optional[str] = None  # kept only when the answer is checked against a schema
+        check_schema = spec.response_schema is not None
 
         if cfg.admit is not None and not cfg.admit(rid):
             # throttled client-side: recorded as HTTP 429, like a server-side shed
@@ -205,7 +211,7 @@ async def _one_request(
                 status = resp.status
                 ctype = resp.headers.get("content-type", "")
                 if spec.stream and status == 200 and ("event-stream" in ctype or "json" not in ctype):
-                    parser = SSEParser(proto.sse_dialect, keep_text=cfg.keep_text)
+                    parser = SSEParser(proto.sse_dialect, keep_text=cfg.keep_text or check_schema)
                     if cfg.live is not None:
                         base_ns, live = int(p_start * 1e9), cfg.live
                         parser.on_token = lambda idx, t_ms, _rid=rid: live.on_token(_rid, idx, base_ns + int(t_ms * 1e6))
@@ -225,6 +231,7 @@ async def _one_request(
                     token_times = parser.token_times_ms
                     usage = parser.usage
                     text = parser.text if cfg.keep_text else ""
+                    answer = parser.text if check_schema else None
                     if usage is None and parser.content_events:
                         usage = {"completion_tokens": parser.content_events}
                 else:
@@ -245,6 +252,7 @@ async def _one_request(
                     if status == 200:
                         usage, text_full = proto.parse_body(body)
                         text = text_full if cfg.keep_text else ""
+                        answer = text_full if check_schema else None
                     elif isinstance(body, dict):
                         e = body.get("error")
                         err = (e.get("message") if isinstance(e, dict) else str(e)) if e else None
@@ -307,6 +315,10 @@ async def _one_request(
             text=text,
             tenant=cfg.extra_headers.get("X-Tenant"),
         )
+        if check_schema and status == 200 and answer is not None:
+            from .schema_check import check_document
+
+            res.json_ok, res.schema_ok, res.schema_why = check_document(answer, spec.response_schema)
         results.append(res)
         if cfg.live is not None:
             cfg.live.finished(rid)
@@ -367,6 +379,16 @@ async def run_load(cfg: LoadConfig, tracer: Optional[TraceCollector] = None, cli
     return results
 
 
+def structured_summary(results: List[ReqResult]) -> Optional[Dict[str, Any]]:
+    """Compliance of the answers that were checked against a schema (None: no request carried one)."""
+    checked = [r for r in results if r.json_ok is not None]
+    if not checked:
+        return None
+    ok = sum(1 for r in checked if r.schema_ok)
+    return {"checked": len(checked), "valid_json": sum(1 for r in checked if r.json_ok), "schema_valid": ok, "schema_valid_rate": ok / len(checked),
+            "first_failures": [{"id": r.id, "why": r.schema_why} for r in checked if not r.schema_ok][:5]}
+
+
 def persist_run(cfg: LoadConfig, results: List[ReqResult], tracer: Optional[TraceCollector], duration: float, target_rps: float, t0_wall: float, conns: int = 0) -> None:
     run_dir = cfg.run_dir
     assert run_dir
@@ -396,6 +418,11 @@ def persist_run(cfg: LoadConfig, results: List[ReqResult], tracer: Optional[Trac
                 k += m
         np.save(os.path.join(run_dir, "token_events.npy"), ev)
     spec = cfg.spec
+    structured = structured_summary(results)
+    if structured is not None:
+        write_json(os.path.join(run_dir, "structured.json"), structured)
+        if not cfg.quiet:
+            print(f"Structured output: {structured['schema_valid']} / {structured['checked']} answers satisfy the schema ({structured['valid_json']} parse as JSON)")
     write_json(
         os.path.join(run_dir, "meta.json"),
         {

@@ -1,0 +1,66 @@
+"""Does a structured-output answer honour the JSON schema that was sent with the request?
+
+The reference's ``structured-output`` profile promises "100 % format compliance"
+(``runners/profiles/structured-output.yaml:26``) but nothing in it looks at the answers.  The load
+generator checks every answer of a request that carried a schema: the text parses as JSON, and the
+document satisfies the parts of JSON Schema that serving runtimes' guided decoding enforces —
+``type`` (also a list of types), ``required``, ``properties`` (recursively), ``items``, ``enum``,
+``const``.  Numeric ranges, string formats and the like are not generation constraints and are not
+checked.
+"""
+
+from __future__ import annotations
+
+import json
+from typing import Any, Optional, Tuple
+
+_TYPES = {"object": dict, "array": list, "string": str, "boolean": bool, "null": type(None)}
+
+
+def _is_type(v: Any, t: str) -> bool:
+    if t == "integer":
+        return isinstance(v, int) and not isinstance(v, bool) or (isinstance(v, float) and v.is_integer())
+    if t == "number":
+        return isinstance(v, (int, float)) and not isinstance(v, bool)
+    py = _TYPES.get(t)
+    return py is not None and isinstance(v, py)
+
+
+def violation(doc: Any, schema: Any, path: str = "$") -> Optional[str]:
+    """First way ``doc`` breaks ``schema`` (None: it does not)."""
+    if not isinstance(schema, dict):
+        return None
+    if "const" in schema and doc != schema["const"]:
+        return f"{path}: not the constant {schema['const']!r}"
+    if isinstance(schema.get("enum"), list) and doc not in schema["enum"]:
+        return f"{path}: {doc!r} is not one of {schema['enum']!r}"
+    t = schema.get("type")
+    if t is not None:
+        types = [t] if isinstance(t, str) else list(t)
+        if not any(_is_type(doc, x) for x in types):
+            return f"{path}: {type(doc).__name__} where {' / '.join(types)} is required"
+    if isinstance(doc, dict):
+        for k in schema.get("required") or []:
+            if k not in doc:
+                return f"{path}: required property {k!r} is missing"
+        for k, sub in (schema.get("properties") or {}).items():
+            if k in doc:
+                why = violation(doc[k], sub, f"{path}.{k}")
+                if why:
+                    return why
+    if isinstance(doc, list) and isinstance(schema.get("items"), dict):
+        for i, v in enumerate(doc):
+            why = violation(v, schema["items"], f"{path}[{i}]")
+            if why:
+                return why
+    return None
+
+
+def check_document(text: str, schema: Any) -> Tuple[bool, bool, Optional[str]]:
+    """(parses as JSON, satisfies the schema, what is wrong) for one answer."""
+    try:
+        doc = json.loads(text)
+    except (TypeError, ValueError) as e:
+        return False, False, f"not JSON: {e}"
+    why = violation(doc, schema)
+    return True, why is None, why

@@ -195,6 +195,17 @@ def test_native_server_json_mode_schema_tools_and_parity_matrix(in_tmp):
                     d = json.loads(line[6:])["choices"]
                     txt += (d[0]["delta"].get("content") or "") if d else ""
         _check_schema_doc(json.loads(txt))
+        # the load generator checks every answer of a schema-carrying run and the analyzer reports the rate
+        from kvmini.analysis.reduce import analyze_run
+        from kvmini.cluster.backends import FakeBackend
+        from kvmini.loadgen.protocols import RequestSpec
+        from kvmini.loadgen.runner import LoadConfig, run_load_sync
+
+        for streaming in (True, False):
+            res = run_load_sync(LoadConfig(url=url, run_dir="so_run", requests=6, concurrency=3, quiet=True, spec=RequestSpec(model="tiny", max_tokens=96, stream=streaming, response_schema=SCHEMA)))
+            assert all(r.status == 200 and r.json_ok and r.schema_ok for r in res), [(r.status, r.schema_why) for r in res]
+        so = analyze_run("so_run", backend=FakeBackend(), quiet=True)["structured_output"]
+        assert so["checked"] == so["valid_json"] == so["schema_valid"] == 6 and so["schema_valid_rate"] == 1.0 and so["first_failures"] == []
         # vLLM's guided_json spelling on the completions endpoint
         r = c.post(url + "/v1/completions", json={"model": "tiny", "prompt": "person:", "max_tokens": 96, "guided_json": SCHEMA})
         _check_schema_doc(json.loads(r.json()["choices"][0]["text"]))
@@ -423,3 +434,24 @@ def test_engine_guided_json_on_the_hip_path_is_pipelined_and_valid():
             assert isinstance(json.loads(tok.decode(o)), dict)
     assert eng.pipelined_steps > 0
     torch.cuda.synchronize()
+
+
+def test_schema_check_of_structured_answers():
+    """The load generator's compliance check: parse errors, missing required keys, wrong types
+    (a boolean is not an integer), enum / const, nested properties and array items."""
+    from kvmini.loadgen.schema_check import check_document
+
+    good = '{"name":"x","age":3,"tags":["a"],"ok":false,"kind":"c","address":{}}'
+    assert check_document(good, SCHEMA) == (True, True, None)
+    assert check_document('{"name":"x"', SCHEMA)[:2] == (False, False)
+    assert check_document('[1]', SCHEMA)[:2] == (True, False)
+    for bad, needle in (('{"name":"x","age":3,"tags":[],"ok":true,"kind":"c"}', "'address' is missing"),
+                        ('{"name":"x","age":true,"tags":[],"ok":true,"kind":"c","address":{}}', "$.age"),
+                        ('{"name":"x","age":3,"tags":[],"ok":null,"kind":"c","address":{}}', "$.ok"),
+                        ('{"name":"x","age":3,"tags":[],"ok":true,"kind":"zzz","address":{}}', "$.kind")):
+        ok_json, ok_schema, why = check_document(bad, SCHEMA)
+        assert ok_json and not ok_schema and needle in why, (bad, why)
+    nested = {"type": "object", "properties": {"a": {"type": "array", "items": {"type": "object", "required": ["b"], "properties": {"b": {"const": 1}}}}, "n": {"type": ["number", "null"]}}}
+    assert check_document('{"a":[{"b":1},{"b":1}],"n":null}', nested)[1] and check_document('{"n":2.5}', nested)[1]
+    assert "$.a[1].b" in check_document('{"a":[{"b":1},{"b":2}]}', nested)[2]
+    assert "$.a[0]" in check_document('{"a":[{}]}', nested)[2]
