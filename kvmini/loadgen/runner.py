@@ -122,6 +122,7 @@ class LoadConfig:
     prompts: Optional[List[str]] = None
     extra_headers: Dict[str, str] = field(default_factory=dict)
     trace: bool = True
+    otlp_endpoint: Optional[str] = None  # OpenTelemetry collector the spans are also POSTed to (OTLP/HTTP JSON)
     keep_text: bool = False
     token_events: bool = True
     quiet: bool = False
@@ -398,6 +399,13 @@ def persist_run(cfg: LoadConfig, results: List[ReqResult], tracer: Optional[Trac
         tracer.export_traces(trace_file)
         if not cfg.quiet:
             print(f"Exported {len(tracer.spans)} trace spans to {trace_file}")
+        if cfg.otlp_endpoint:
+            try:  # a collector that is down must not cost the run its artifacts
+                n = tracer.export_http(cfg.otlp_endpoint)
+                if not cfg.quiet:
+                    print(f"Sent {n} trace spans to {cfg.otlp_endpoint}")
+            except (OSError, ValueError) as e:
+                print(f"OTLP export to {cfg.otlp_endpoint} failed: {e}", file=sys.stderr)
     with open(os.path.join(run_dir, "requests.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(CSV_HEADER)
@@ -483,6 +491,8 @@ def build_arg_parser() -> argparse.ArgumentParser:
     ap.add_argument("--no-pool", action="store_true", help="New TCP/TLS connection per request (reference behaviour)")
     ap.add_argument("--connect-retry-s", type=float, default=0.0, help="Keep retrying a refused connection for this long (requests wait out a server cold start)")
     ap.add_argument("--no-trace", action="store_true")
+    ap.add_argument("--otlp-endpoint", default=os.environ.get("OTEL_EXPORTER_OTLP_ENDPOINT"),
+                    help="also POST the trace spans to this OpenTelemetry collector (OTLP/HTTP JSON, <endpoint>/v1/traces; default: $OTEL_EXPORTER_OTLP_ENDPOINT)")
     ap.add_argument("--timeout", type=float, default=60.0)
     ap.add_argument("--header", action="append", default=[], help="Extra header 'Name: value' (repeatable)")
     ap.add_argument("--quiet", action="store_true")
@@ -565,6 +575,7 @@ def config_from_args(args: argparse.Namespace) -> LoadConfig:
         prompts=prompts,
         extra_headers=headers,
         trace=not args.no_trace,
+        otlp_endpoint=getattr(args, "otlp_endpoint", None),
         quiet=args.quiet,
     )
 

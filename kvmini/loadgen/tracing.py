@@ -115,3 +115,25 @@ class TraceCollector:
         os.makedirs(os.path.dirname(output_file) or ".", exist_ok=True)
         with open(output_file, "w") as f:
             json.dump(self.to_otlp(), f)
+
+    def export_http(self, endpoint: str, timeout_s: float = 10.0, batch: int = 2000, headers: Optional[Dict[str, str]] = None) -> int:
+        """POST the spans to an OpenTelemetry collector over OTLP/HTTP with the JSON encoding
+        (``<endpoint>/v1/traces``; an endpoint that already ends in ``/v1/traces`` is used as it
+        is), ``batch`` spans per request.  Returns the number of spans the collector accepted
+        (HTTP 2xx); raises ``OSError`` when it cannot be reached.  (The reference only writes the
+        file and leaves "future OTLP integration" as a placeholder: ``tools/bundle_run.sh:235``.)"""
+        import urllib.request
+
+        url = endpoint.rstrip("/")
+        if not url.endswith("/v1/traces"):
+            url += "/v1/traces"
+        doc = self.to_otlp()
+        spans = doc["resourceSpans"][0]["scopeSpans"][0]["spans"]
+        sent = 0
+        for i in range(0, len(spans), max(1, batch)):
+            part = {"resourceSpans": [{**doc["resourceSpans"][0], "scopeSpans": [{**doc["resourceSpans"][0]["scopeSpans"][0], "spans": spans[i : i + batch]}]}]}
+            req = urllib.request.Request(url, data=json.dumps(part).encode(), headers={"Content-Type": "application/json", **(headers or {})}, method="POST")
+            with urllib.request.urlopen(req, timeout=timeout_s) as resp:
+                if 200 <= resp.status < 300:
+                    sent += len(part["resourceSpans"][0]["scopeSpans"][0]["spans"])
+        return sent

@@ -226,3 +226,46 @@ def test_live_inter_token_quantiles_final_flush_equals_offline(tmp_path):
     for i in range(20):
         ring.append(3, i, 300 + i)
     assert ring.take()[:, 2].tolist() == list(range(312, 320)) and ring.dropped == 12
+
+
+def test_traces_are_posted_to_an_otlp_collector(mock_server, tmp_path):
+    """--otlp-endpoint: the spans of a run arrive at <endpoint>/v1/traces as OTLP/JSON batches that
+    add up to the file export; a collector that is down does not fail the run."""
+    import http.server
+    import json
+    import threading
+
+    from kvmini.loadgen.protocols import RequestSpec
+    from kvmini.loadgen.runner import LoadConfig, run_load_sync
+
+    got = []
+
+    class Collector(http.server.BaseHTTPRequestHandler):
+        def do_POST(self):  # noqa: N802
+            body = self.rfile.read(int(self.headers["Content-Length"]))
+            got.append((self.path, self.headers["Content-Type"], json.loads(body)))
+            self.send_response(200)
+            self.end_headers()
+            self.wfile.write(b"{}")
+
+        def log_message(self, *a):
+            pass
+
+    srv = http.server.ThreadingHTTPServer(("127.0.0.1", 0), Collector)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    try:
+        _mock, url = mock_server
+        run = tmp_path / "r"
+        res = run_load_sync(LoadConfig(url=url, run_dir=str(run), requests=8, concurrency=4, quiet=True, spec=RequestSpec(model="m", max_tokens=4),
+                                       otlp_endpoint=f"http://127.0.0.1:{srv.server_address[1]}"))
+        assert all(r.status == 200 for r in res)
+        file_spans = json.load(open(run / "traces" / "traces.json"))["resourceSpans"][0]["scopeSpans"][0]["spans"]
+        assert got and all(p == "/v1/traces" and "json" in ct for p, ct, _ in got)
+        sent = [s for _, _, d in got for s in d["resourceSpans"][0]["scopeSpans"][0]["spans"]]
+        assert [s["spanId"] for s in sent] == [s["spanId"] for s in file_spans] and len(sent) >= 8 * 3
+        assert got[0][2]["resourceSpans"][0]["resource"]["attributes"][0]["key"] == "service.name"
+    finally:
+        srv.shutdown()
+    # nobody listening: the run still completes and keeps its artifacts
+    res = run_load_sync(LoadConfig(url=url, run_dir=str(tmp_path / "r2"), requests=2, concurrency=1, quiet=True, spec=RequestSpec(model="m", max_tokens=2), otlp_endpoint="http://127.0.0.1:9"))
+    assert all(r.status == 200 for r in res) and (tmp_path / "r2" / "requests.csv").exists()
