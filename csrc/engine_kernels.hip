@@ -61,6 +61,77 @@ __device__ inline bf16x4 kv_load4(const void* base, long long off) {
     return __builtin_bit_cast(bf16x4, o);
   }
 }
+// 8 e4m3 bytes (two dwords) -> 8 bf16, exact
+__device__ inline bf16x8 fp8x8_widen(unsigned int lo, unsigned int hi) {
+  bf16x2x4 o;
+  o.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false);
+  o.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+  o.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false);
+  o.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+  return __builtin_bit_cast(bf16x8, o);
+}
+// One K/V block (16 tokens) of a wave of the fused decode attention kernel, as the lanes hold it
+// between the load and the use.  Lane roles (head_dim 128): K — lane (key = lane >> 2, chunk =
+// lane & 3) owns 32 consecutive dims of a key; V — lane (tg = lane >> 4, dv = lane & 15) owns dims
+// [8 dv, 8 dv + 8) of the tokens tg + 4 i, i = 0..3.
+//   bf16 cache: four 16-byte loads each, kept as they are.
+//   e4m3 cache: the stage keeps the RAW bytes of four 16-byte loads (half the registers of the
+//   widened form, and half the load instructions of reading 8 bytes at a time — at long contexts
+//   the kernel is bound by the loads it issues, so an FP8 cache read 8 bytes at a time halved
+//   the memory held but not the time).  K: the lane's 32 bytes are two loads.  V: the lanes dv
+//   and dv ^ 1 (neighbours in a quad) need the two halves of the same 16 bytes of every token, so
+//   each loads 16 bytes of HALF the tokens (even lane: i = 0, 2; odd lane: i = 1, 3) and, when
+//   the block is used, keeps its half and hands the other to its neighbour with one DPP quad
+//   permute per dword.  Widening and exchange happen in unpack(), i.e. when the block becomes
+//   the current one: nothing waits for a load at the point where it is issued.
+template <bool KV8>
+struct KVStage;
+template <>
+struct KVStage<false> {
+  bf16x8 k[4], v[4];
+  __device__ inline void load(const void* k_cache, const void* v_cache, long long blk, int key, int chunk, int tg, int dv) {
+    constexpr int HD = 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = kv_load8<false>(k_cache, blk + key * HD + chunk * 32 + i * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = kv_load8<false>(v_cache, blk + dv * 8 + (tg + 4 * i) * HD);
+  }
+  __device__ inline void unpack(bf16x8 (&kk)[4], bf16x8 (&vv)[4], int dv) const {
+    (void)dv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { kk[i] = k[i]; vv[i] = v[i]; }
+  }
+};
+template <>
+struct KVStage<true> {
+  uint4 k0, k1, v0, v1;
+  __device__ inline void load(const void* k_cache, const void* v_cache, long long blk, int key, int chunk, int tg, int dv) {
+    constexpr int HD = 128;
+    const unsigned char* kp = reinterpret_cast<const unsigned char*>(k_cache) + blk + key * HD + chunk * 32;
+    k0 = *reinterpret_cast<const uint4*>(kp);
+    k1 = *reinterpret_cast<const uint4*>(kp + 16);
+    const unsigned char* vp = reinterpret_cast<const unsigned char*>(v_cache) + blk + (dv >> 1) * 16 + (tg + 4 * (dv & 1)) * HD;
+    v0 = *reinterpret_cast<const uint4*>(vp);           // token tg + 4 (0 + odd), dims [16 (dv >> 1), + 16)
+    v1 = *reinterpret_cast<const uint4*>(vp + 8 * HD);  // token tg + 4 (2 + odd)
+  }
+  __device__ inline void unpack(bf16x8 (&kk)[4], bf16x8 (&vv)[4], int dv) const {
+    kk[0] = fp8x8_widen(k0.x, k0.y); kk[1] = fp8x8_widen(k0.z, k0.w);
+    kk[2] = fp8x8_widen(k1.x, k1.y); kk[3] = fp8x8_widen(k1.z, k1.w);
+    const bool odd = dv & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint4 r = j ? v1 : v0;
+      // my token is i = 2 j + odd: I keep the half with my dims and give my neighbour the other
+      const unsigned int mine0 = odd ? r.z : r.x, mine1 = odd ? r.w : r.y;
+      const unsigned int give0 = odd ? r.x : r.z, give1 = odd ? r.y : r.w;
+      const unsigned int got0 = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)give0, 0xB1, 0xF, 0xF, true);
+      const unsigned int got1 = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)give1, 0xB1, 0xF, 0xF, true);
+      const bf16x8 own = fp8x8_widen(mine0, mine1), other = fp8x8_widen(got0, got1);
+      vv[2 * j] = odd ? other : own;
+      vv[2 * j + 1] = odd ? own : other;
+    }
+  }
+};
 template <bool KV8, int N>
 __device__ inline auto kv_loadn(const void* base, long long off) {
   if constexpr (N == 8) return kv_load8<KV8>(base, off);
@@ -1032,26 +1103,9 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   }
   const int qk_tok = lane >> 2, qk_c = lane & 3;
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
-  bf16x8 kv[4], vv[4];
-  if (b0 + wave < n_blocks) {
-    const long long base = ((long long)bt[b0 + wave] * nkv + g) * BS * HD;
-    const long long kp = base + qk_tok * HD + qk_c * 32;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) kv[v] = kv_load8<KV8>(k_cache, kp + v * 8);
-    const long long vp = base + pv_dv * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vv[i] = kv_load8<KV8>(v_cache, vp + (pv_tg + 4 * i) * HD);
-  }
-  bf16x8 kn[4], vn[4];  // the block after that: two blocks (16 KB) per wave in flight at any time
-  if (b0 + wave + NWAVE < n_blocks) {
-    const long long base = ((long long)bt[b0 + wave + NWAVE] * nkv + g) * BS * HD;
-    const long long kp = base + qk_tok * HD + qk_c * 32;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) kn[v] = kv_load8<KV8>(k_cache, kp + v * 8);
-    const long long vp = base + pv_dv * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vn[i] = kv_load8<KV8>(v_cache, vp + (pv_tg + 4 * i) * HD);
-  }
+  KVStage<KV8> st_cur, st_nxt;  // this wave's first block and the one after: two blocks (16 KB of bf16) per wave in flight at any time
+  if (b0 + wave < n_blocks) st_cur.load(k_cache, v_cache, ((long long)bt[b0 + wave] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
+  if (b0 + wave + NWAVE < n_blocks) st_nxt.load(k_cache, v_cache, ((long long)bt[b0 + wave + NWAVE] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
   // likewise the RoPE table row of this token (needed in A.2)
   constexpr int ROT = (REP + 1) * 8;  // (q heads + k) x 8 pieces of 8 dims and their partners
   const int pos = positions[t];
@@ -1153,16 +1207,10 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   for (int b = b0 + wave; b < n_blocks; b += NWAVE) {
     // this block's K / V and the next one's are in registers or on their way (loaded before
     // phase A, or by earlier iterations); start the loads of the block after those
-    bf16x8 kf[4], vf[4];
-    if (b + 2 * NWAVE < n_blocks) {
-      const long long nbase = ((long long)bt[b + 2 * NWAVE] * nkv + g) * BS * HD;
-      const long long kp = nbase + qk_tok * HD + qk_c * 32;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) kf[v] = kv_load8<KV8>(k_cache, kp + v * 8);
-      const long long vp = nbase + pv_dv * 8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) vf[i] = kv_load8<KV8>(v_cache, vp + (pv_tg + 4 * i) * HD);
-    }
+    KVStage<KV8> st_far;
+    if (b + 2 * NWAVE < n_blocks) st_far.load(k_cache, v_cache, ((long long)bt[b + 2 * NWAVE] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
+    bf16x8 kv[4], vv[4];
+    st_cur.unpack(kv, vv, pv_dv);
     float s[REP];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
@@ -1211,8 +1259,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       }
     }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int v = 0; v < 4; ++v) { kv[v] = kn[v]; vv[v] = vn[v]; kn[v] = kf[v]; vn[v] = vf[v]; }
+    st_cur = st_nxt;
+    st_nxt = st_far;
   }
   // ---- the token's own key / value (wave 0 of split 0; one token group adds the value)
   if (wave == 0 && z == 0) {
