@@ -309,6 +309,9 @@ def generate_single_report(results_path: str, output: str, cost_file: Optional[s
         ("GPU power", format_number(r.get("gpu_power_watts_avg"), 0, " W")),
         ("Cold starts", format_number(r.get("cold_start_count"), 0)),
     ]
+    so = r.get("structured_output") or {}
+    if so.get("checked"):  # structured-output runs: answers checked against the schema they were asked for
+        cards.append(("Schema-valid answers", f"{so.get('schema_valid', 0)} / {so['checked']}"))
     lat_chart = svg_bar_chart(
         ["p50", "p95", "p99"],
         {

@@ -237,6 +237,12 @@ def test_single_report_links_the_p95_trace_and_writes_the_viewer(in_tmp, mock_ur
     assert os.path.exists("runs/r/traces/view.html") and "traces.json" in open("runs/r/traces/view.html").read()
     for needle in ("P95 latency", "Recommendations", "<svg"):
         assert needle in html
+    assert "Schema-valid answers" not in html  # no request of this run carried a schema
+    from kvmini.utils import write_json
+
+    write_json("runs/r/results.json", {**load_json("runs/r/results.json"), "structured_output": {"checked": 20, "valid_json": 20, "schema_valid": 19, "schema_valid_rate": 0.95, "first_failures": []}})
+    html = open(generate_single_report("runs/r/results.json", "runs/r/report2.html", cost_file="cost.yaml")).read()
+    assert "Schema-valid answers" in html and "19 / 20" in html
 
 
 def test_grid_and_partition_reports_from_fixtures(tmp_path):
