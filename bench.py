@@ -142,7 +142,7 @@ def main() -> int:
     ap.add_argument("--target-rps", type=float, default=0.0, help="0 = saturate (closed loop at --concurrency)")
     ap.add_argument("--kernels", default="hip", choices=["hip", "torch"])
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--quantization", default=None, choices=["fp8"], help="weight-only FP8 (NOT the headline configuration: the headline is bf16)")
+    ap.add_argument("--quantization", default=None, choices=["fp8", "mxfp4"], help="weight-only FP8 (e4m3) or MXFP4 (NOT the headline configuration: the headline is bf16)")
     ap.add_argument("--speculative-model", default=None, help="draft preset for speculative decoding (not the headline configuration)")
     ap.add_argument("--num-speculative-tokens", type=int, default=2)
     ap.add_argument("--max-num-seqs", type=int, default=32)
