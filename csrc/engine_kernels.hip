@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace {
 
@@ -722,15 +723,22 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
 // prefix per token: fine for decode, quadratic L2 traffic for a prompt.  Here one workgroup
 // serves one or two tiles of 16 consecutive query tokens of ONE chunk for one kv head (all REP
 // query heads of the group: wave w owns heads w, w+4, ...), walking the keys 32 at a time with
-// mfma_f32_16x16x32_bf16; K rows are read straight from the paged cache (a lane's 8 dims of
-// one key are 16 contiguous bytes: no staging needed), the 32 value rows of a step are staged
-// once per workgroup into LDS TRANSPOSED ([dim][key slot]) and shared by all heads.  The
-// operand roles are described at prefill_attention_tiles.
+// mfma_f32_16x16x32_bf16.  The 32 key rows and 32 value rows of a step are read from the paged
+// cache once per workgroup (16 lanes per 256-byte row) and staged ROW-MAJOR into LDS with
+// 16-byte writes; the four waves read K fragments with ds_read_b128 and the transposed V
+// fragments with ds_read_b64_tr_b16, so V never needs a transposing write.  Both images are
+// XOR-swizzled so that every lane group of those reads and writes covers distinct banks:
+//   K  16-byte chunk c of row r sits at slot c ^ (r & 15) of the row's 16;
+//   V  32-byte piece n (dims 16n ..) of row r sits at piece n ^ (r & 7) of the row's 8.
+// The operand roles are described at prefill_attention_tiles.
 // Tiles are described by host-staged arrays (first token row, valid queries, first position,
 // block-table row); tile_n == 0 marks an unused tile.  K/V of the chunk's own tokens must be
 // in the cache already (rope_kv_write runs first).  head_dim 128, block_size 16.
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_ab;
 typedef __attribute__((ext_vector_type(4))) float mfma_cd;
+typedef __attribute__((ext_vector_type(4))) short tr_b64;  // result of one ds_read_b64_tr_b16
+typedef __attribute__((address_space(3))) tr_b64 lds_tr_b64;
+
 
 // One pass over the keys for QT consecutive 16-query tiles (rows row0 .., positions pos0 ..,
 // n_q valid queries in all) of one sequence: with QT = 2 every K fragment, every staged V^T
@@ -744,17 +752,19 @@ typedef __attribute__((ext_vector_type(4))) float mfma_cd;
 //                 query), one running maximum / sum / rescale factor per lane;
 //   O^T += V^T P^T  the exponentiated accumulators, packed to bf16, ARE the B operand
 //                 (lane: query lr, k-slots 8*lq ..+8) once the k dimension is read as the
-//                 permutation slot(8*q + 4*b + j) = key 16*b + 4*q + j; V^T is staged into LDS
-//                 with its columns in that slot order and read as the A operand.
+//                 permutation slot(8*q + 4*b + j) = key 16*b + 4*q + j; the A operand V^T comes
+//                 from the row-major V image by transposed reads: the 16 lanes lq of a read take
+//                 the 4 rows key 16*b + 4*lq .. +3 x 16 dims and lane lr receives its dim of
+//                 those 4 keys, i.e. elements 4*b .. 4*b+3 of its fragment.
 // The output accumulator lane holds O[query lr][dims 16*nt + 4*lq .. +4]: 8-byte stores.
 template <int REP, int QT, bool KV8>
 __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
                                                         const void* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
-                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* vt_lds,
+                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* v_lds,
                                                         unsigned short* k_lds) {
-  constexpr int HD = 128, BS = 16, KSTEP = 32, VT_STRIDE = 40;  // 80-byte rows: 16-byte aligned fragments
-  constexpr int K_STRIDE = HD + 8;                             // 272-byte key rows: the 16 key lanes of a fragment read spread over the banks
-  constexpr int HPW = (REP + 3) / 4;                           // query heads per wave
+  constexpr int HD = 128, BS = 16, KSTEP = 32;
+  constexpr int TILE = KSTEP * HD;    // elements of one K or V image (8 KiB)
+  constexpr int HPW = (REP + 3) / 4;  // query heads per wave
   const int g = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
@@ -787,97 +797,136 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) o[qt][hh][nt] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
     }
-  // Staging role, the same for K and V: key = tid & 31, 16 dims starting at (tid >> 5) * 16.
-  // The 32 key rows and 32 value rows of a step are read from the cache ONCE per workgroup
-  // (32 bytes of each per thread), one step ahead, and staged into LDS: K row-major (the four
-  // waves read their MFMA fragments from there instead of each fetching the tile from L2),
-  // V transposed with its columns in k-slot order.
-  const int sv_key = tid & 31, sv_d0 = (tid >> 5) << 4;
-  const int sv_col = ((sv_key & 15) >> 2) * 8 + (sv_key >> 4) * 4 + (sv_key & 3);
-  bf16x8 k0, k1, v0, v1, k0_n, k1_n, v0_n, v1_n;
-  // The block-table entry of a step's key is fetched one step earlier still, so the dependent
-  // lookup -> address -> cache read chain never stalls the loop.  Keys past the end clamp to
-  // the last key (a valid row; masked in the softmax).
-#define BT_LOAD(KB, B)                                 \
+  // Staging role, the same for K and V: 16-byte chunk sv_c of the rows of keys sv_kr and
+  // sv_kr + 16 of the step, so 16 consecutive lanes fetch one whole 256-byte row.  The rows
+  // are read from the cache ONCE per workgroup (32 bytes of each of K and V per thread), one
+  // step ahead, and written to the swizzled images (the two keys of a thread share r & 15).
+  const int sv_c = tid & 15, sv_kr = tid >> 4;
+  const int k_st = sv_kr * HD + ((sv_c ^ sv_kr) << 3);
+  const int v_st = sv_kr * HD + ((((sv_c >> 1) ^ (sv_kr & 7)) << 4) | ((sv_c & 1) << 3));
+  bf16x8 k0, k1, v0, v1;
+  // The block-table entries of a step's keys are fetched one step earlier still, so the
+  // dependent lookup -> address -> cache read chain never stalls the loop.  Keys past the end
+  // clamp to the last key (a valid row; masked in the softmax).
+#define BT_LOAD(KB, B0, B1)                            \
   do {                                                 \
-    int key = (KB) + sv_key;                           \
+    int key = (KB) + sv_kr;                            \
     if (key > last_key) key = last_key;                \
-    B = bt[key >> 4];                                  \
+    B0 = bt[key >> 4];                                 \
+    key = (KB) + sv_kr + 16;                           \
+    if (key > last_key) key = last_key;                \
+    B1 = bt[key >> 4];                                 \
   } while (0)
-#define KV_LOAD_STEP(KB, B, K0, K1, V0, V1)                                                   \
+#define KV_LOAD_STEP(KB, B0, B1, K0, K1, V0, V1)                                              \
   do {                                                                                        \
-    int key = (KB) + sv_key;                                                                  \
+    int key = (KB) + sv_kr;                                                                   \
     if (key > last_key) key = last_key;                                                       \
-    const long long off = (((long long)(B) * nkv + g) * BS + (key & 15)) * HD + sv_d0;        \
+    long long off = (((long long)(B0) * nkv + g) * BS + (key & 15)) * HD + sv_c * 8;          \
     K0 = kv_load8<KV8>(k_cache, off);                                                         \
-    K1 = kv_load8<KV8>(k_cache, off + 8);                                                     \
     V0 = kv_load8<KV8>(v_cache, off);                                                         \
-    V1 = kv_load8<KV8>(v_cache, off + 8);                                                     \
+    key = (KB) + sv_kr + 16;                                                                  \
+    if (key > last_key) key = last_key;                                                       \
+    off = (((long long)(B1) * nkv + g) * BS + (key & 15)) * HD + sv_c * 8;                    \
+    K1 = kv_load8<KV8>(k_cache, off);                                                         \
+    V1 = kv_load8<KV8>(v_cache, off);                                                         \
   } while (0)
-  // Two LDS buffers: the tiles of step i+1 are written while step i computes, so a step needs
-  // ONE workgroup barrier (tiles of i+1 staged, everyone done with those of i).
-  constexpr int VT_TILE = HD * VT_STRIDE, K_TILE = KSTEP * K_STRIDE;
-#define STAGE_TILES(BUF)                                                                         \
+  // Three LDS slots per image, software-pipelined by one step.  Iteration i
+  //   writes the rows of step i+2 (in registers since the last iteration) into slot (i+2) % 3 and
+  //   starts the cache reads of step i+3,
+  //   reads the V fragments of step i and the K fragments of step i+1 BEFORE the softmax, whose
+  //   VALU work then covers their LDS latency,
+  //   issues the S^T MFMAs of step i+1 next to the softmax of step i (independent work in one
+  //   basic block: the matrix pipe runs while the softmax occupies the vector ALU),
+  //   and ends with the P V MFMAs of step i and ONE workgroup barrier.
+  // Slot (i+2) % 3 was last read in iteration i-1, which that iteration's barrier closed.
+#define STAGE_TILES(SLOT)                                                                        \
   do {                                                                                           \
-    unsigned short* kd = k_lds + (BUF) * K_TILE + sv_key * K_STRIDE + sv_d0;                      \
+    unsigned short* kd = k_lds + (SLOT) * TILE + k_st;                                            \
     *reinterpret_cast<bf16x8*>(kd) = k0;                                                         \
-    *reinterpret_cast<bf16x8*>(kd + 8) = k1;                                                     \
-    unsigned short* vd = vt_lds + (BUF) * VT_TILE + sv_d0 * VT_STRIDE + sv_col;                   \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                              \
-      vd[j * VT_STRIDE] = v0[j];                                                                 \
-      vd[(8 + j) * VT_STRIDE] = v1[j];                                                           \
-    }                                                                                            \
+    *reinterpret_cast<bf16x8*>(kd + 16 * HD) = k1;                                               \
+    unsigned short* vd = v_lds + (SLOT) * TILE + v_st;                                            \
+    *reinterpret_cast<bf16x8*>(vd) = v0;                                                         \
+    *reinterpret_cast<bf16x8*>(vd + 16 * HD) = v1;                                               \
   } while (0)
-  int blk;
-  BT_LOAD(0, blk);
-  KV_LOAD_STEP(0, blk, k0, k1, v0, v1);
-  BT_LOAD(KSTEP, blk);
+  // fragment read offsets (elements) inside an image
+  const int kf_row = lr * HD;                                       // + 16*b rows; chunk (4*ks + lq) ^ lr
+  const int vf_base = (4 * lq + (lr >> 2)) * HD + ((lr & 3) << 2);  // + 16*b rows; piece nt ^ vf_sw
+  const int vf_sw = 4 * (lq & 1) + (lr >> 2);                       // (row & 7) of this lane's row
+  // K fragments: lane = K[key 16*b + lr][dims 32*ks + 8*lq .. +8]
+#define K_FRAGS(SLOT, KF)                                                                                                        \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                 \
+      KF[b][ks] = *reinterpret_cast<const mfma_ab*>(k_lds + (SLOT) * TILE + 16 * b * HD + kf_row + (((4 * ks + lq) ^ lr) << 3))
+  // wave w owns heads w, w + 4: with REP not a multiple of 4 some waves own fewer (or none) and
+  // skip that work (a wave-uniform test; constant-folded otherwise)
+#define HEAD_ON(HH) (REP % 4 == 0 || wave + 4 * (HH) < REP)
+  // S^T = K Q^T for 2 x 16 keys: ST[qt][hh][b][r] = score(key 16*b + 4*lq + r of the step, query 16*qt + lr)
+#define S_MFMAS(KF, ST)                                                                                                          \
+  _Pragma("unroll") for (int hh = 0; hh < HPW; ++hh) if (HEAD_ON(hh)) _Pragma("unroll") for (int qt = 0; qt < QT; ++qt)          \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                            \
+    ST[qt][hh][b] = (mfma_cd){0.f, 0.f, 0.f, 0.f};                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                             \
+        ST[qt][hh][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KF[b][ks], qa[qt][hh][ks], ST[qt][hh][b], 0, 0, 0);              \
+  }
+  int blk0, blk1;
+  mfma_cd st_cur[QT][HPW][2];
+  BT_LOAD(0, blk0, blk1);
+  KV_LOAD_STEP(0, blk0, blk1, k0, k1, v0, v1);
+  BT_LOAD(KSTEP, blk0, blk1);
   STAGE_TILES(0);
-  KV_LOAD_STEP(KSTEP, blk, k0, k1, v0, v1);
-  BT_LOAD(2 * KSTEP, blk);
+  KV_LOAD_STEP(KSTEP, blk0, blk1, k0, k1, v0, v1);
+  BT_LOAD(2 * KSTEP, blk0, blk1);
+  STAGE_TILES(1);
+  KV_LOAD_STEP(2 * KSTEP, blk0, blk1, k0, k1, v0, v1);
+  BT_LOAD(3 * KSTEP, blk0, blk1);
   __syncthreads();
-
-  int buf = 0;
-  for (int kb = 0; kb <= last_key; kb += KSTEP, buf ^= 1) {
-    // unconditional (past the end the keys clamp to the last one): a branch around the loads
-    // would leave the in-order load counter unknown at the join and force a full drain there
-    // registers hold the rows of step kb + KSTEP (loaded a step ago): into the other buffer,
-    // then start the loads of the step after that
-    STAGE_TILES(buf ^ 1);
-    KV_LOAD_STEP(kb + 2 * KSTEP, blk, k0_n, k1_n, v0_n, v1_n);
-    BT_LOAD(kb + 3 * KSTEP, blk);
-    const unsigned short* kt = k_lds + buf * K_TILE;
-    const unsigned short* vt = vt_lds + buf * VT_TILE;
-    // K fragments: lane = K[key 16*b + lr][dims 32*ks + 8*lq .. +8]
+  if (HEAD_ON(0)) {
     mfma_ab kf[2][4];
+    K_FRAGS(0, kf);
+    S_MFMAS(kf, st_cur);
+  }
+
+  // One step.  MASKED: the step reaches the diagonal of some query of the tile (the last one or
+  // two steps of a pass); the others run without any mask code.
+  auto step = [&](auto masked_c, int kb, int s_v, int s_k, int s_w) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_c)::value;
+    // unconditional loads (past the end the keys clamp to the last one): a branch around them
+    // would leave the in-order load counter unknown at the join and force a full drain there
+    STAGE_TILES(s_w);
+    KV_LOAD_STEP(kb + 3 * KSTEP, blk0, blk1, k0, k1, v0, v1);
+    BT_LOAD(kb + 4 * KSTEP, blk0, blk1);
+    if (HEAD_ON(0)) {
+    // V^T fragments of this step (A lane = V^T[dim 16*nt + lr][k-slots 8*lq .. +8]): one pair of
+    // transposed reads (keys 16*b + 4*lq .. +3, b = 0, 1) per 16 dims; shared by all heads and tiles
+    const unsigned short* vt = v_lds + s_v * TILE + vf_base;
+    mfma_ab va[8];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int nt = 0; nt < 8; ++nt) {
+      struct { tr_b64 lo, hi; } vf;
+      vf.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + ((nt ^ vf_sw) << 4)));
+      vf.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + 16 * HD + ((nt ^ vf_sw) << 4)));
+      va[nt] = __builtin_bit_cast(mfma_ab, vf);
+    }
+    mfma_ab kf[2][4];
+    K_FRAGS(s_k, kf);
+    mfma_cd st_nxt[QT][HPW][2];
+    S_MFMAS(kf, st_nxt);
+    mfma_ab pb[QT][HPW];
+    float corr[QT][HPW];
+    bool moved = false;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[b][ks] = *reinterpret_cast<const mfma_ab*>(kt + (16 * b + lr) * K_STRIDE + ks * 32 + lq * 8);
-#pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) {
-      const int h = wave + 4 * hh;
-      if (h >= REP) continue;
-      mfma_ab pb[QT];
+    for (int hh = 0; hh < HPW; ++hh)
+      if (HEAD_ON(hh))
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        // ---- S^T = K Q^T for 2 x 16 keys: st[b][r] = score(key kb + 16*b + 4*lq + r, query 16*qt + lr)
-        mfma_cd st[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          st[b] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) st[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[b][ks], qa[qt][hh][ks], st[b], 0, 0, 0);
-        }
-        // ---- causal mask (only on steps that reach the diagonal) + online softmax
-        // scores stay unscaled: scale * log2(e) > 0 commutes with the maximum and folds into
-        // the exponent's fma
+        // ---- online softmax in units of scale * log2(e): the multiply comes first on purpose
+        // (a product is known to be a quiet number, so the maxima below need no canonicalising
+        // v_max x, x, x per MFMA result)
         float sc[8];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[4 * b + r] = st[b][r];
-        if (kb + KSTEP - 1 > pos0 + 16 * qt) {
+          for (int r = 0; r < 4; ++r) sc[4 * b + r] = st_cur[qt][hh][b][r] * scale_log2e;
+        if constexpr (MASKED) {
           const int lim = pos0 + 16 * qt + lr - kb - 4 * lq;  // key offset 16*b + r is visible iff <= lim
 #pragma unroll
           for (int b = 0; b < 2; ++b)
@@ -890,41 +939,69 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
         const float m_new = fmaxf(m_old, mx);
         // v_exp_f32 as is (arguments <= 0; a result below the normal range flushes to 0, which
         // is what a softmax weight of 2^-126 is worth)
-        const float m_scaled = m_new * scale_log2e;
         float pr[8], psum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], scale_log2e, -m_scaled));
+          pr[j] = __builtin_amdgcn_exp2f(sc[j] - m_new);
           psum += pr[j];
         }
-        const float corr = __builtin_amdgcn_exp2f((m_old - m_new) * scale_log2e);
-        l_run[qt][hh] = l_run[qt][hh] * corr + psum;  // this lane's keys only; folded after the loop
+        corr[qt][hh] = __builtin_amdgcn_exp2f(m_old - m_new);
+        l_run[qt][hh] = l_run[qt][hh] * corr[qt][hh] + psum;  // this lane's keys only; folded after the loop
         m_run[qt][hh] = m_new;
+        moved |= m_new != m_old;
         // ---- P^T as the B operand, straight from the accumulator layout (hardware bf16 conversion)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pb[qt][j] = (__bf16)pr[j];
-        if (__builtin_amdgcn_ballot_w64(m_new != m_old) != 0) {  // rescale O only when some query's maximum moved
+        for (int j = 0; j < 8; ++j) pb[qt][hh][j] = (__bf16)pr[j];
+      }
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // rescale O only when some query's maximum moved
+#pragma unroll
+      for (int hh = 0; hh < HPW; ++hh)
+        if (HEAD_ON(hh))
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[qt][hh][nt][r] *= corr;
-        }
-      }
-      // ---- O^T += V^T P^T   (A lane = V^T[dim 16*nt + lr][k-slots 8*lq .. +8]): one V^T
-      // fragment read serves every query tile
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        const mfma_ab va = *reinterpret_cast<const mfma_ab*>(vt + (nt * 16 + lr) * VT_STRIDE + lq * 8);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) o[qt][hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qt], o[qt][hh][nt], 0, 0, 0);
-      }
+            for (int r = 0; r < 4; ++r) o[qt][hh][nt][r] *= corr[qt][hh];
     }
-    k0 = k0_n;
-    k1 = k1_n;
-    v0 = v0_n;
-    v1 = v1_n;
-    __syncthreads();  // the next step's tiles are staged, and every wave is done with this step's
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int hh = 0; hh < HPW; ++hh)
+        if (HEAD_ON(hh))
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[nt], pb[qt][hh], o[qt][hh][nt], 0, 0, 0);
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) st_cur[qt][hh][b] = st_nxt[qt][hh][b];
+    }
+    __syncthreads();  // the tiles of step i+2 are staged, and every wave is done with slot i % 3
+  };
+
+  int kb = 0, s_v = 0, s_k = 1, s_w = 2;
+#define ROTATE_SLOTS()       \
+  do {                       \
+    const int s_t = s_v;     \
+    s_v = s_k;               \
+    s_k = s_w;               \
+    s_w = s_t;               \
+  } while (0)
+  for (; kb + KSTEP - 1 <= pos0; kb += KSTEP) {
+    step(std::false_type{}, kb, s_v, s_k, s_w);
+    ROTATE_SLOTS();
   }
+  for (; kb <= last_key; kb += KSTEP) {
+    step(std::true_type{}, kb, s_v, s_k, s_w);
+    ROTATE_SLOTS();
+  }
+#undef ROTATE_SLOTS
+#undef S_MFMAS
+#undef HEAD_ON
+#undef K_FRAGS
 #undef STAGE_TILES
 #undef KV_LOAD_STEP
 #undef BT_LOAD
@@ -966,14 +1043,16 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
                                                                 const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq, int n_tiles,
                                                                 unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e,
                                                                 const float* __restrict__ kv_scale, int order) {
-  constexpr int HD = 128, VT_STRIDE = 40;
+  constexpr int HD = 128;
   float v_scale = 1.f;
   if constexpr (KV8) {
     scale_log2e *= kv_scale[blockIdx.x];
     v_scale = kv_scale[nkv + blockIdx.x];
   }
-  __shared__ __attribute__((aligned(16))) unsigned short vt_lds[2 * HD * VT_STRIDE];  // V^T [buffer][dim][k-slot]
-  __shared__ __attribute__((aligned(16))) unsigned short k_lds[2 * 32 * (HD + 8)];    // K [buffer][key][dim], padded rows
+  // [buffer][key][dim] images, swizzled inside each 256-byte row; the bank analysis of the swizzles
+  // assumes rows that start on a multiple of 256 bytes
+  __shared__ __attribute__((aligned(256))) unsigned short v_lds[3 * 32 * HD];
+  __shared__ __attribute__((aligned(256))) unsigned short k_lds[3 * 32 * HD];
   // Later tiles of a chunk see more keys.  order 0: longest first, so the longest passes do not
   // start last.  order 1 (grids of at most two workgroups per CU, all resident at once): the
   // first half of the ids takes the tiles from the longest down, the second half from the
@@ -987,22 +1066,22 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
     const int n0 = tile_n[t0], n1 = t1 < n_tiles ? tile_n[t1] : 0;
     if (n0 == 16 && n1 > 0 && tile_seq[t1] == tile_seq[t0] && tile_pos0[t1] == tile_pos0[t0] + 16 && tile_row0[t1] == tile_row0[t0] + 16) {
       prefill_attention_tiles<REP, 2, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
-                                      16 + n1, out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
+                                      16 + n1, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
       return;
     }
     if (n0 > 0)
       prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
-                                      out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
+                                      out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
     if (n1 > 0) {
       __syncthreads();  // the first pass is done with the LDS tiles
       prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t1] * max_blocks_per_seq, tile_row0[t1], tile_pos0[t1], n1,
-                                      out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
+                                      out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
     }
   } else {
     const int n0 = tile_n[t0];
     if (n0 > 0)
       prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
-                                      out, nh, nkv, scale_log2e, v_scale, vt_lds, k_lds);
+                                      out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
   }
 }
 
