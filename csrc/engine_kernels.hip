@@ -50,6 +50,22 @@ __device__ inline bf16x8 kv_load8(const void* base, long long off) {
     return __builtin_bit_cast(bf16x8, o);
   }
 }
+// the same 8 elements addressed as a wave-uniform base (scalar registers) plus a 32-bit byte
+// offset per lane: the load takes the base from SGPRs and needs no 64-bit vector arithmetic
+template <bool KV8>
+__device__ inline bf16x8 kv_load8_at(const char* base, unsigned byte_off) {
+  if constexpr (!KV8) {
+    return *reinterpret_cast<const bf16x8*>(base + byte_off);
+  } else {
+    const uint2 r = *reinterpret_cast<const uint2*>(base + byte_off);
+    bf16x2x4 o;
+    o.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.x, 1.0f, false);
+    o.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.x, 1.0f, true);
+    o.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.y, 1.0f, false);
+    o.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r.y, 1.0f, true);
+    return __builtin_bit_cast(bf16x8, o);
+  }
+}
 template <bool KV8>
 __device__ inline bf16x4 kv_load4(const void* base, long long off) {
   if constexpr (!KV8) {
@@ -805,30 +821,35 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
   const int k_st = sv_kr * HD + ((sv_c ^ sv_kr) << 3);
   const int v_st = sv_kr * HD + ((((sv_c >> 1) ^ (sv_kr & 7)) << 4) | ((sv_c & 1) << 3));
   bf16x8 k0, k1, v0, v1;
-  // The block-table entries of a step's keys are fetched one step earlier still, so the
-  // dependent lookup -> address -> cache read chain never stalls the loop.  Keys past the end
-  // clamp to the last key (a valid row; masked in the softmax).
-#define BT_LOAD(KB, B0, B1)                            \
-  do {                                                 \
-    int key = (KB) + sv_kr;                            \
-    if (key > last_key) key = last_key;                \
-    B0 = bt[key >> 4];                                 \
-    key = (KB) + sv_kr + 16;                           \
-    if (key > last_key) key = last_key;                \
-    B1 = bt[key >> 4];                                 \
+  // A step's 32 keys are the rows of TWO cache blocks (kb is a multiple of 32): a thread's keys
+  // sv_kr and sv_kr + 16 are row sv_kr of block kb/16 and of block kb/16 + 1.  The block-table
+  // entries and the blocks' base addresses are therefore wave-uniform (scalar loads, SGPR
+  // arithmetic) and a lane adds one of two precomputed 32-bit offsets: its row, or — in the last
+  // block of the pass and past it — its row clamped to the last key (a valid row; masked in the
+  // softmax).  The entries are fetched one step before the rows, the rows one step before the
+  // LDS write, so the dependent lookup -> address -> cache read chain never stalls the loop.
+  constexpr int ESZ = KV8 ? 1 : 2;
+  const int last_blk = last_key >> 4;
+  const unsigned voff_row = (unsigned)((sv_kr * HD + sv_c * 8) * ESZ);
+  const unsigned voff_end = (unsigned)(((sv_kr < (last_key & 15) ? sv_kr : (last_key & 15)) * HD + sv_c * 8) * ESZ);
+  const long long blk_bytes = (long long)nkv * BS * HD * ESZ, head_bytes = (long long)g * BS * HD * ESZ;
+#define BT_LOAD(KB, B0, B1)                                        \
+  do {                                                             \
+    const int bi = (KB) >> 4;                                      \
+    B0 = bt[bi < last_blk ? bi : last_blk];                        \
+    B1 = bt[bi + 1 < last_blk ? bi + 1 : last_blk];                \
   } while (0)
-#define KV_LOAD_STEP(KB, B0, B1, K0, K1, V0, V1)                                              \
+#define KV_LOAD_STEP(KB, B0, B1)                                                              \
   do {                                                                                        \
-    int key = (KB) + sv_kr;                                                                   \
-    if (key > last_key) key = last_key;                                                       \
-    long long off = (((long long)(B0) * nkv + g) * BS + (key & 15)) * HD + sv_c * 8;          \
-    K0 = kv_load8<KV8>(k_cache, off);                                                         \
-    V0 = kv_load8<KV8>(v_cache, off);                                                         \
-    key = (KB) + sv_kr + 16;                                                                  \
-    if (key > last_key) key = last_key;                                                       \
-    off = (((long long)(B1) * nkv + g) * BS + (key & 15)) * HD + sv_c * 8;                    \
-    K1 = kv_load8<KV8>(k_cache, off);                                                         \
-    V1 = kv_load8<KV8>(v_cache, off);                                                         \
+    const int bi = (KB) >> 4;                                                                 \
+    const long long base0 = (long long)(B0) * blk_bytes + head_bytes;                         \
+    const long long base1 = (long long)(B1) * blk_bytes + head_bytes;                         \
+    const unsigned off0 = bi < last_blk ? voff_row : voff_end;                                \
+    const unsigned off1 = bi + 1 < last_blk ? voff_row : voff_end;                            \
+    k0 = kv_load8_at<KV8>(reinterpret_cast<const char*>(k_cache) + base0, off0);              \
+    v0 = kv_load8_at<KV8>(reinterpret_cast<const char*>(v_cache) + base0, off0);              \
+    k1 = kv_load8_at<KV8>(reinterpret_cast<const char*>(k_cache) + base1, off1);              \
+    v1 = kv_load8_at<KV8>(reinterpret_cast<const char*>(v_cache) + base1, off1);              \
   } while (0)
   // Three LDS slots per image, software-pipelined by one step.  Iteration i
   //   writes the rows of step i+2 (in registers since the last iteration) into slot (i+2) % 3 and
@@ -870,13 +891,13 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
   int blk0, blk1;
   mfma_cd st_cur[QT][HPW][2];
   BT_LOAD(0, blk0, blk1);
-  KV_LOAD_STEP(0, blk0, blk1, k0, k1, v0, v1);
+  KV_LOAD_STEP(0, blk0, blk1);
   BT_LOAD(KSTEP, blk0, blk1);
   STAGE_TILES(0);
-  KV_LOAD_STEP(KSTEP, blk0, blk1, k0, k1, v0, v1);
+  KV_LOAD_STEP(KSTEP, blk0, blk1);
   BT_LOAD(2 * KSTEP, blk0, blk1);
   STAGE_TILES(1);
-  KV_LOAD_STEP(2 * KSTEP, blk0, blk1, k0, k1, v0, v1);
+  KV_LOAD_STEP(2 * KSTEP, blk0, blk1);
   BT_LOAD(3 * KSTEP, blk0, blk1);
   __syncthreads();
   if (HEAD_ON(0)) {
@@ -892,7 +913,7 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
     // unconditional loads (past the end the keys clamp to the last one): a branch around them
     // would leave the in-order load counter unknown at the join and force a full drain there
     STAGE_TILES(s_w);
-    KV_LOAD_STEP(kb + 3 * KSTEP, blk0, blk1, k0, k1, v0, v1);
+    KV_LOAD_STEP(kb + 3 * KSTEP, blk0, blk1);
     BT_LOAD(kb + 4 * KSTEP, blk0, blk1);
     if (HEAD_ON(0)) {
     // V^T fragments of this step (A lane = V^T[dim 16*nt + lr][k-slots 8*lq .. +8]): one pair of
@@ -1029,6 +1050,240 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
     }
 }
 
+// The same pass for 32 consecutive queries of one sequence (two whole tiles, the second possibly
+// partial) and head groups of at most 4 (one head per wave), on mfma_f32_32x32x16_bf16.
+// Why a second shape: a 16x16x32 MFMA holds its SIMD's vector issue for 8 of its 16 cycles, a
+// 32x32x16 for 8 of its 32, and the two waves of a SIMD share that issue bandwidth.  The softmax
+// needs about 24 issue cycles per score and lane (multiply, maximum, subtract, v_exp_f32 at 8,
+// add, half a conversion) against 32 cycles of matrix time: with the small shape's 16 cycles of
+// hold per score on top the loop is bound by vector issue whatever the schedule, with the large
+// shape's 4 it is not.  The cross-lane part of the row maximum also shrinks from 4 lanes to 2.
+//   S^T = K Q^T   A = K rows (lane l: key l & 31, dims 16*ks + 8*(l >> 5) ..), B = Q (lane: query
+//                 l & 31, same dims) -> accumulator lane (query l & 31, half hi = l >> 5), register
+//                 r = score(key (r & 3) + 8*(r >> 2) + 4*hi): a lane owns ONE query and 16 of the
+//                 step's 32 keys, the other 16 live in lane l ^ 32;
+//   O^T += V^T P^T  registers 8*s .. 8*s+7, packed to bf16, are the B operand of k-step s (keys
+//                 16*s ..+15) with element j <-> key 16*s + 8*(j >> 2) + 4*hi + (j & 3); the A operand
+//                 V^T[dim 32*nt + (l & 31)][those keys] is two transposed reads (j >> 2 = 0, 1) of
+//                 4 keys x 16 dims per 16-lane group.
+// LDS images of THIS path are padded, not swizzled: every lane group of its reads has one value of
+// hi, so 272-byte K rows (16 rows of a ds_read_b128 group land on 16 different 16-byte slots) and
+// 320-byte V rows (the 4 rows x 64 bytes of a transposed read's 32-lane half cover the 256-byte
+// bank window once) are conflict-free, and every fragment address is lane base + slot base +
+// immediate: one vector add per slot and step instead of one per read.
+constexpr int PA32_K_RS = 136, PA32_V_RS = 160;
+typedef __attribute__((ext_vector_type(16))) float mfma_cd16;
+__device__ inline float half_rows_max(float x) {  // over lanes l and l ^ 32
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ inline float half_rows_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+
+template <int REP, bool KV8>
+__device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
+                                                          const void* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
+                                                          unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* v_lds,
+                                                          unsigned short* k_lds) {
+  static_assert(REP <= 4, "one query head per wave");
+  constexpr int HD = 128, BS = 16, KSTEP = 32;
+  constexpr int K_RS = PA32_K_RS, V_RS = PA32_V_RS;         // row strides (elements) of the padded images
+  constexpr int K_TILE = KSTEP * K_RS, V_TILE = KSTEP * V_RS;  // elements of one K / V image
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 31, hi = lane >> 5;
+  const int last_key = pos0 + n_q - 1;           // highest key index any query of the tiles may see
+  const bool head_on = REP == 4 || wave < REP;  // wave-uniform: a wave without a head only stages
+
+  // Q fragments: lane = Q[query lr][dims 16*ks + 8*hi .. +8]
+  mfma_ab qa[8];
+  if (head_on) {
+    const int qrow = row0 + (lr < n_q ? lr : n_q - 1);
+    const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + wave) * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qa[ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 16);
+  }
+  mfma_cd16 o[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  // staging role and cache reads: as in prefill_attention_tiles (16 lanes per 256-byte row, keys
+  // sv_kr and sv_kr + 16 of a step, one step ahead of the LDS write, block-table entries one
+  // step earlier still, keys past the end clamped to the last key)
+  const int sv_c = tid & 15, sv_kr = tid >> 4;
+  const int k_st = sv_kr * K_RS + sv_c * 8;
+  const int v_st = sv_kr * V_RS + sv_c * 8;
+  bf16x8 k0, k1, v0, v1;
+  constexpr int ESZ = KV8 ? 1 : 2;
+  const int last_blk = last_key >> 4;
+  const unsigned voff_row = (unsigned)((sv_kr * HD + sv_c * 8) * ESZ);
+  const unsigned voff_end = (unsigned)(((sv_kr < (last_key & 15) ? sv_kr : (last_key & 15)) * HD + sv_c * 8) * ESZ);
+  const long long blk_bytes = (long long)nkv * BS * HD * ESZ, head_bytes = (long long)g * BS * HD * ESZ;
+#define BT_LOAD(KB, B0, B1)                                        \
+  do {                                                             \
+    const int bi = (KB) >> 4;                                      \
+    B0 = bt[bi < last_blk ? bi : last_blk];                        \
+    B1 = bt[bi + 1 < last_blk ? bi + 1 : last_blk];                \
+  } while (0)
+#define KV_LOAD_STEP(KB, B0, B1)                                                              \
+  do {                                                                                        \
+    const int bi = (KB) >> 4;                                                                 \
+    const long long base0 = (long long)(B0) * blk_bytes + head_bytes;                         \
+    const long long base1 = (long long)(B1) * blk_bytes + head_bytes;                         \
+    const unsigned off0 = bi < last_blk ? voff_row : voff_end;                                \
+    const unsigned off1 = bi + 1 < last_blk ? voff_row : voff_end;                            \
+    k0 = kv_load8_at<KV8>(reinterpret_cast<const char*>(k_cache) + base0, off0);              \
+    v0 = kv_load8_at<KV8>(reinterpret_cast<const char*>(v_cache) + base0, off0);              \
+    k1 = kv_load8_at<KV8>(reinterpret_cast<const char*>(k_cache) + base1, off1);              \
+    v1 = kv_load8_at<KV8>(reinterpret_cast<const char*>(v_cache) + base1, off1);              \
+  } while (0)
+#define STAGE_TILES(SLOT)                                                                        \
+  do {                                                                                           \
+    unsigned short* kd = k_lds + (SLOT) * K_TILE + k_st;                                          \
+    *reinterpret_cast<bf16x8*>(kd) = k0;                                                         \
+    *reinterpret_cast<bf16x8*>(kd + 16 * K_RS) = k1;                                             \
+    unsigned short* vd = v_lds + (SLOT) * V_TILE + v_st;                                          \
+    *reinterpret_cast<bf16x8*>(vd) = v0;                                                         \
+    *reinterpret_cast<bf16x8*>(vd + 16 * V_RS) = v1;                                             \
+  } while (0)
+  // fragment read offsets (elements) inside an image
+  const int kf_base = lr * K_RS + hi * 8;  // + 16*ks: the rest of every K fragment address is an immediate
+  const int vq = (lane >> 2) & 3, vp = lane & 3, vodd = (lane >> 4) & 1;
+  const int vf_base = (4 * hi + vq) * V_RS + vodd * 16 + vp * 4;  // + (16*s + 8*jj) rows + 32*nt: immediates
+  // K fragments of a slot and the S^T MFMAs on them
+#define S_MFMAS(SLOT, ST)                                                                                             \
+  do {                                                                                                                \
+    mfma_ab kf[8];                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) kf[ks] =                                                         \
+        *reinterpret_cast<const mfma_ab*>(k_lds + (SLOT) * K_TILE + kf_base + 16 * ks);                               \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) ST[r] = 0.f;                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) ST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qa[ks], ST, 0, 0, 0); \
+  } while (0)
+  int blk0, blk1;
+  mfma_cd16 st_cur;
+  BT_LOAD(0, blk0, blk1);
+  KV_LOAD_STEP(0, blk0, blk1);
+  BT_LOAD(KSTEP, blk0, blk1);
+  STAGE_TILES(0);
+  KV_LOAD_STEP(KSTEP, blk0, blk1);
+  BT_LOAD(2 * KSTEP, blk0, blk1);
+  STAGE_TILES(1);
+  KV_LOAD_STEP(2 * KSTEP, blk0, blk1);
+  BT_LOAD(3 * KSTEP, blk0, blk1);
+  __syncthreads();
+  if (head_on) S_MFMAS(0, st_cur);
+
+  // One step, software-pipelined like the 16-query path: tiles of step i+2 into slot (i+2) % 3,
+  // cache reads of step i+3, V fragments of step i and S^T of step i+1 around the softmax of
+  // step i, then P V of step i and one barrier.
+  auto step = [&](auto masked_c, int kb, int s_v, int s_k, int s_w) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_c)::value;
+    STAGE_TILES(s_w);
+    KV_LOAD_STEP(kb + 3 * KSTEP, blk0, blk1);
+    BT_LOAD(kb + 4 * KSTEP, blk0, blk1);
+    if (head_on) {
+      const unsigned short* vt = v_lds + s_v * V_TILE + vf_base;
+      mfma_ab va[4][2];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          struct { tr_b64 lo, hi; } vf;
+          vf.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + (16 * s2) * V_RS + 32 * nt));
+          vf.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + (16 * s2 + 8) * V_RS + 32 * nt));
+          va[nt][s2] = __builtin_bit_cast(mfma_ab, vf);
+        }
+      mfma_cd16 st_nxt;
+      S_MFMAS(s_k, st_nxt);
+      // ---- online softmax in units of scale * log2(e) (the multiply first: a product is a
+      // quiet number, so the maxima need no canonicalising v_max x, x, x per MFMA result)
+      float sc[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = st_cur[r] * scale_log2e;
+      if constexpr (MASKED) {
+        const int lim = pos0 + lr - kb - 4 * hi;  // key offset (r & 3) + 8*(r >> 2) [+ 4*hi] is visible iff <= lim
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = ((r & 3) + 8 * (r >> 2) <= lim) ? sc[r] : -1e30f;
+      }
+      float mx = fmaxf(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))),
+                       fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
+      mx = half_rows_max(mx);  // the 2 lanes of a query
+      const float m_old = m_run;
+      const float m_new = fmaxf(m_old, mx);
+      float pr[16], psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = __builtin_amdgcn_exp2f(sc[r] - m_new);
+        psum += pr[r];
+      }
+      const float corr = __builtin_amdgcn_exp2f(m_old - m_new);
+      l_run = l_run * corr + psum;  // this lane's keys only; folded after the loop
+      m_run = m_new;
+      mfma_ab pb[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)pr[8 * s2 + j];
+      if (__builtin_amdgcn_ballot_w64(m_new != m_old) != 0) {  // rescale O only when some query's maximum moved
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
+      }
+      // ---- O^T += V^T P^T
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[nt][s2], pb[s2], o[nt], 0, 0, 0);
+      st_cur = st_nxt;
+    }
+    __syncthreads();  // the tiles of step i+2 are staged, and every wave is done with slot i % 3
+  };
+
+  int kb = 0, s_v = 0, s_k = 1, s_w = 2;
+#define ROTATE_SLOTS()       \
+  do {                       \
+    const int s_t = s_v;     \
+    s_v = s_k;               \
+    s_k = s_w;               \
+    s_w = s_t;               \
+  } while (0)
+  for (; kb + KSTEP - 1 <= pos0; kb += KSTEP) {
+    step(std::false_type{}, kb, s_v, s_k, s_w);
+    ROTATE_SLOTS();
+  }
+  for (; kb <= last_key; kb += KSTEP) {
+    step(std::true_type{}, kb, s_v, s_k, s_w);
+    ROTATE_SLOTS();
+  }
+#undef ROTATE_SLOTS
+#undef S_MFMAS
+#undef STAGE_TILES
+#undef KV_LOAD_STEP
+#undef BT_LOAD
+  // ---- normalise and store: lane holds O[query lr][dims 32*nt + 8*rq + 4*hi + (0..3)]
+  const float l = half_rows_sum(l_run);  // before any lane leaves: the exchange wants both lanes of a query
+  if (!head_on || lr >= n_q) return;
+  const float inv = l > 0.f ? v_scale / l : 0.f;
+  unsigned short* op = out + (long long)(row0 + lr) * nh * HD + (long long)(g * REP + wave) * HD + 4 * hi;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+      us4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = f2bf(o[nt][4 * rq + r] * inv);
+      *reinterpret_cast<us4*>(op + 32 * nt + 8 * rq) = w;
+    }
+}
+
 // grid = (kv heads, tile groups): consecutive workgroup ids differ in the kv head, so with the
 // round-robin placement of workgroups on the 8 XCDs every tile of kv head g (when nkv is a
 // multiple of 8) runs on XCD g % 8 and that head's K/V stay in ONE XCD's L2.  A workgroup owns
@@ -1051,8 +1306,8 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
   }
   // [buffer][key][dim] images, swizzled inside each 256-byte row; the bank analysis of the swizzles
   // assumes rows that start on a multiple of 256 bytes
-  __shared__ __attribute__((aligned(256))) unsigned short v_lds[3 * 32 * HD];
-  __shared__ __attribute__((aligned(256))) unsigned short k_lds[3 * 32 * HD];
+  __shared__ __attribute__((aligned(256))) unsigned short v_lds[3 * 32 * PA32_V_RS];  // sized for the padded images of the 32-query path
+  __shared__ __attribute__((aligned(256))) unsigned short k_lds[3 * 32 * PA32_K_RS];
   // Later tiles of a chunk see more keys.  order 0: longest first, so the longest passes do not
   // start last.  order 1 (grids of at most two workgroups per CU, all resident at once): the
   // first half of the ids takes the tiles from the longest down, the second half from the
@@ -1065,8 +1320,8 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
     const int t1 = t0 + 1;
     const int n0 = tile_n[t0], n1 = t1 < n_tiles ? tile_n[t1] : 0;
     if (n0 == 16 && n1 > 0 && tile_seq[t1] == tile_seq[t0] && tile_pos0[t1] == tile_pos0[t0] + 16 && tile_row0[t1] == tile_row0[t0] + 16) {
-      prefill_attention_tiles<REP, 2, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
-                                      16 + n1, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
+      prefill_attention_tiles32<REP, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
+                                          16 + n1, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
       return;
     }
     if (n0 > 0)

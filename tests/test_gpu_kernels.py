@@ -722,13 +722,14 @@ def _tp_one_rank_body(graphs, custom):
 
 
 @pytest.mark.parametrize("rep,nkv,chunks", [(r, 2, [(0, 0, 40), (1, 37, 23), (2, 0, 5), (3, 300, 33)]) for r in (1, 2, 3, 4, 7, 8)]
-                         + [(r, 8, [(0, 0, 600), (1, 37, 250), (2, 0, 5), (3, 300, 200)]) for r in (1, 4, 8)])
+                         + [(r, 8, [(0, 0, 600), (1, 37, 250), (2, 0, 5), (3, 300, 200)]) for r in (1, 2, 3, 4, 8)])
 def test_prefill_attention_tiles_match_reference(rep, nkv, chunks):
     """The tiled MFMA prompt-attention kernel against the per-token reference: chunks that
     start at position 0, mid-block continuations of an earlier chunk, short chunks, and rows
     that belong to no tile (left untouched).  The larger case (8 kv heads, 68 tiles) reaches
-    the two-tiles-per-workgroup path, with pairs that straddle chunk boundaries, a partial
-    second tile and an odd tile count."""
+    the 32-queries-per-workgroup path (32x32x16 MFMA; head groups of 1-4, so also waves that own
+    no head), with pairs that straddle chunk boundaries, a partial second tile and an odd tile
+    count."""
     from kvmini.ops import hip_ops, torch_ops
 
     torch.manual_seed(11)
