@@ -1050,8 +1050,10 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
     }
 }
 
-// The same pass for 32 consecutive queries of one sequence (two whole tiles, the second possibly
-// partial) and head groups of at most 4 (one head per wave), on mfma_f32_32x32x16_bf16.
+// The same pass on mfma_f32_32x32x16_bf16, a wave's 32 columns being either 32 consecutive queries
+// of one sequence for ONE head (HPW = 1: head groups of at most 4; two whole tiles, the second
+// possibly partial) or one 16-query tile for the wave's TWO heads (HPW = 2: head groups of 5-8,
+// column = 16 * (which head) + query) — the K / V fragment traffic is the same.
 // Why a second shape: a 16x16x32 MFMA holds its SIMD's vector issue for 8 of its 16 cycles, a
 // 32x32x16 for 8 of its 32, and the two waves of a SIMD share that issue bandwidth.  The softmax
 // needs about 24 issue cycles per score and lane (multiply, maximum, subtract, v_exp_f32 at 8,
@@ -1084,26 +1086,30 @@ __device__ inline float half_rows_sum(float x) {
   return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
 
-template <int REP, bool KV8>
+template <int REP, int HPW, bool KV8>
 __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
                                                           const void* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
                                                           unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* v_lds,
                                                           unsigned short* k_lds) {
-  static_assert(REP <= 4, "one query head per wave");
+  static_assert((HPW == 1 || HPW == 2) && REP <= 4 * HPW && REP > 4 * (HPW - 1), "32 columns = HPW heads x 32 / HPW queries");
   constexpr int HD = 128, BS = 16, KSTEP = 32;
   constexpr int K_RS = PA32_K_RS, V_RS = PA32_V_RS;         // row strides (elements) of the padded images
   constexpr int K_TILE = KSTEP * K_RS, V_TILE = KSTEP * V_RS;  // elements of one K / V image
   const int g = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 31, hi = lane >> 5;
-  const int last_key = pos0 + n_q - 1;           // highest key index any query of the tiles may see
-  const bool head_on = REP == 4 || wave < REP;  // wave-uniform: a wave without a head only stages
+  // column lr of the 32-column tile: query qi of head wave + 4*hh
+  const int qi = HPW == 2 ? (lr & 15) : lr, hh = HPW == 2 ? (lr >> 4) : 0;
+  const int h = wave + 4 * hh;
+  const int last_key = pos0 + n_q - 1;                // highest key index any query of the tiles may see
+  const bool head_on = REP % 4 == 0 || wave < REP;   // wave-uniform: a wave without any head only stages
+  const bool col_on = REP % 4 == 0 || h < REP;       // head groups of 5-7: some waves own one head, their other 16 columns idle
 
   // Q fragments: lane = Q[query lr][dims 16*ks + 8*hi .. +8]
   mfma_ab qa[8];
   if (head_on) {
-    const int qrow = row0 + (lr < n_q ? lr : n_q - 1);
-    const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + wave) * HD + hi * 8;
+    const int qrow = row0 + (qi < n_q ? qi : n_q - 1);
+    const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + (col_on ? h : wave)) * HD + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qa[ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 16);
   }
@@ -1182,8 +1188,17 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
   // One step, software-pipelined like the 16-query path: tiles of step i+2 into slot (i+2) % 3,
   // cache reads of step i+3, V fragments of step i and S^T of step i+1 around the softmax of
   // step i, then P V of step i and one barrier.
-  auto step = [&](auto masked_c, int kb, int s_v, int s_k, int s_w) __attribute__((always_inline)) {
-    constexpr bool MASKED = decltype(masked_c)::value;
+  // EXACT (the first step and the steps that reach the diagonal): causal mask, and the textbook
+  // online softmax whose reference m_run is the running maximum.  The other steps let the
+  // reference LAG: exponents are taken against the reference as it is, s * c - m_run in ONE fma
+  // (no separate scaling, subtraction or correction factor), and only when some query's scores
+  // exceed it by more than 2^LAG_LOG2 does the wave re-reference (m_run, l_run and O move
+  // together, BEFORE this step's exponentials are taken, so nothing is ever at two scales).
+  // P <= 2^LAG_LOG2 then instead of <= 1: the same relative precision in bf16, and the largest
+  // term of every row sum is still >= 1.
+  constexpr float LAG_LOG2 = 6.f;
+  auto step = [&](auto exact_c, int kb, int s_v, int s_k, int s_w) __attribute__((always_inline)) {
+    constexpr bool EXACT = decltype(exact_c)::value;
     STAGE_TILES(s_w);
     KV_LOAD_STEP(kb + 3 * KSTEP, blk0, blk1);
     BT_LOAD(kb + 4 * KSTEP, blk0, blk1);
@@ -1201,41 +1216,64 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
         }
       mfma_cd16 st_nxt;
       S_MFMAS(s_k, st_nxt);
-      // ---- online softmax in units of scale * log2(e) (the multiply first: a product is a
-      // quiet number, so the maxima need no canonicalising v_max x, x, x per MFMA result)
+      // sc = s * c - reference, in units of log2.  (A product or fma result is known to be a
+      // quiet number, so the maxima below need no canonicalising v_max x, x, x per MFMA result.)
       float sc[16];
+      if constexpr (EXACT) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[r] = st_cur[r] * scale_log2e;
-      if constexpr (MASKED) {
-        const int lim = pos0 + lr - kb - 4 * hi;  // key offset (r & 3) + 8*(r >> 2) [+ 4*hi] is visible iff <= lim
+        for (int r = 0; r < 16; ++r) sc[r] = st_cur[r] * scale_log2e;
+        const int lim = pos0 + qi - kb - 4 * hi;  // key offset (r & 3) + 8*(r >> 2) [+ 4*hi] is visible iff <= lim
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = ((r & 3) + 8 * (r >> 2) <= lim) ? sc[r] : -1e30f;
+      } else {
+        const float neg_ref = -m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_fmaf(st_cur[r], scale_log2e, neg_ref);
       }
       float mx = fmaxf(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))),
                        fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
       mx = half_rows_max(mx);  // the 2 lanes of a query
-      const float m_old = m_run;
-      const float m_new = fmaxf(m_old, mx);
-      float pr[16], psum = 0.f;
+      // how far the reference moves up (0: not at all), and by what factor l_run and O shrink
+      float up = 0.f;
+      bool move;
+      if constexpr (EXACT) {
+        const float m_new = fmaxf(m_run, mx);
+        up = m_new - m_run;  // m_run = -1e30 before the first step: up is huge, the factor 0, and O and l_run are 0 anyway
+        move = __builtin_amdgcn_ballot_w64(up != 0.f) != 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pr[r] = __builtin_amdgcn_exp2f(sc[r] - m_new);
-        psum += pr[r];
+        for (int r = 0; r < 16; ++r) sc[r] -= m_new;
+        m_run = m_new;
+      } else {
+        move = __builtin_amdgcn_ballot_w64(mx > LAG_LOG2) != 0;
       }
-      const float corr = __builtin_amdgcn_exp2f(m_old - m_new);
-      l_run = l_run * corr + psum;  // this lane's keys only; folded after the loop
-      m_run = m_new;
-      mfma_ab pb[2];
+      if (move) {
+        if constexpr (!EXACT) {
+          up = fmaxf(mx, 0.f);
+          m_run += up;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)pr[8 * s2 + j];
-      if (__builtin_amdgcn_ballot_w64(m_new != m_old) != 0) {  // rescale O only when some query's maximum moved
+          for (int r = 0; r < 16; ++r) sc[r] -= up;
+        }
+        const float corr = __builtin_amdgcn_exp2f(-up);
+        l_run *= corr;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
       }
+      // v_exp_f32 as is (a result below the normal range flushes to 0, which is what a softmax
+      // weight of 2^-126 is worth)
+      float pr[16], psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = __builtin_amdgcn_exp2f(sc[r]);
+        psum += pr[r];
+      }
+      l_run += psum;  // this lane's keys only; folded after the loop
+      mfma_ab pb[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)pr[8 * s2 + j];
       // ---- O^T += V^T P^T
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -1254,6 +1292,11 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
     s_k = s_w;               \
     s_w = s_t;               \
   } while (0)
+  if (KSTEP - 1 <= pos0) {  // the first step sets the reference: exact (its mask hides nothing)
+    step(std::true_type{}, kb, s_v, s_k, s_w);
+    ROTATE_SLOTS();
+    kb += KSTEP;
+  }
   for (; kb + KSTEP - 1 <= pos0; kb += KSTEP) {
     step(std::false_type{}, kb, s_v, s_k, s_w);
     ROTATE_SLOTS();
@@ -1267,11 +1310,11 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
 #undef STAGE_TILES
 #undef KV_LOAD_STEP
 #undef BT_LOAD
-  // ---- normalise and store: lane holds O[query lr][dims 32*nt + 8*rq + 4*hi + (0..3)]
+  // ---- normalise and store: lane holds O[its column's query and head][dims 32*nt + 8*rq + 4*hi + (0..3)]
   const float l = half_rows_sum(l_run);  // before any lane leaves: the exchange wants both lanes of a query
-  if (!head_on || lr >= n_q) return;
+  if (!head_on || !col_on || qi >= n_q) return;
   const float inv = l > 0.f ? v_scale / l : 0.f;
-  unsigned short* op = out + (long long)(row0 + lr) * nh * HD + (long long)(g * REP + wave) * HD + 4 * hi;
+  unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + 4 * hi;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -1320,7 +1363,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
     const int t1 = t0 + 1;
     const int n0 = tile_n[t0], n1 = t1 < n_tiles ? tile_n[t1] : 0;
     if (n0 == 16 && n1 > 0 && tile_seq[t1] == tile_seq[t0] && tile_pos0[t1] == tile_pos0[t0] + 16 && tile_row0[t1] == tile_row0[t0] + 16) {
-      prefill_attention_tiles32<REP, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
+      prefill_attention_tiles32<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
                                           16 + n1, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
       return;
     }
@@ -1334,9 +1377,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
     }
   } else {
     const int n0 = tile_n[t0];
-    if (n0 > 0)
-      prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
-                                      out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
+    if (n0 > 0) {
+      if constexpr (REP > 4)
+        prefill_attention_tiles32<REP, 2, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
+                                               n0, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
+      else
+        prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
+                                             n0, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
+    }
   }
 }
 
@@ -1969,10 +2017,10 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   if (hd != 128 || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
-  // two tiles per workgroup where one wave owns one query head (its registers hold both tiles)
-  // and the halved grid still fills the chip several times over.  Head groups of 6-8 already
-  // share every K / V^T fragment between the two heads of a wave; two tiles on top of that need
-  // one wave per SIMD and lose (8 heads per group, 2048 queries x 4096 keys: 691 vs 496 TFLOP/s)
+  // A wave's MFMA tile has 32 columns.  Head groups of at most 4 (one head per wave) fill them with
+  // two 16-query tiles per workgroup where the halved grid still fills the chip several times
+  // over, and otherwise run one tile per workgroup on the 16-column path; head groups of 5-8 fill
+  // them with the two heads of a wave x one tile.
   // (KVMINI_PREFILL_TILES=1|2 pins the choice, for measurements)
   static const int pinned = [] { const char* e = getenv("KVMINI_PREFILL_TILES"); return e ? atoi(e) : 0; }();
   const int qt = rep > 4 ? 1 : (pinned == 1 || pinned == 2 ? pinned : ((long long)nkv * n_tiles >= 512 ? 2 : 1));

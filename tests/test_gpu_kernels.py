@@ -721,7 +721,7 @@ def _tp_one_rank_body(graphs, custom):
         assert eng.metrics()["tp_allreduce"] == "xgmi-peer-memory"
 
 
-@pytest.mark.parametrize("rep,nkv,chunks", [(r, 2, [(0, 0, 40), (1, 37, 23), (2, 0, 5), (3, 300, 33)]) for r in (1, 2, 3, 4, 7, 8)]
+@pytest.mark.parametrize("rep,nkv,chunks", [(r, 2, [(0, 0, 40), (1, 37, 23), (2, 0, 5), (3, 300, 33)]) for r in (1, 2, 3, 4, 6, 7, 8)]
                          + [(r, 8, [(0, 0, 600), (1, 37, 250), (2, 0, 5), (3, 300, 200)]) for r in (1, 2, 3, 4, 8)])
 def test_prefill_attention_tiles_match_reference(rep, nkv, chunks):
     """The tiled MFMA prompt-attention kernel against the per-token reference: chunks that
@@ -762,6 +762,54 @@ def test_prefill_attention_tiles_match_reference(rep, nkv, chunks):
     owned = ctx_t > 0
     assert (out[owned].float() - ref[owned].float()).abs().max().item() <= 2.5e-2
     assert (out[~owned] == 7.0).all()
+
+
+@pytest.mark.parametrize("kv8", [False, True])
+def test_prefill_attention_follows_a_maximum_that_jumps_mid_pass(kv8):
+    """The 32-query path exponentiates against a reference that may lag the running maximum and
+    re-references only when a query's scores exceed it by more than 2^6.  On bounded random data
+    that branch never fires after the first step, so this case makes it fire: the keys of later
+    blocks are several times larger (scores jump by tens of log2 units at blocks 8, 20 and 33 of a
+    700-token prompt), for a chunk from position 0 and for a continuation chunk whose pass starts
+    below the jumps."""
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(5)
+    rep, nkv, hd, bs, nb = 4, 8, 128, 16, 120
+    nh = nkv * rep
+    n_seqs, max_blocks = 2, 48
+    bt = torch.randperm(nb, device=_dev())[: n_seqs * max_blocks].view(n_seqs, max_blocks).int()
+    kf = torch.randn(nb, nkv, bs, hd, device=_dev()) * 0.5
+    vf = torch.randn(nb, nkv, bs, hd, device=_dev()) * 0.5
+    for seq in range(n_seqs):
+        for j, gain in ((8, 3.0), (20, 2.0), (33, 2.0)):  # cumulative: x3, x6, x12 from those blocks on
+            kf[bt[seq, j:].long()] *= gain
+    sc = None
+    if kv8:
+        sc = torch.stack([kf.abs().amax(dim=(0, 2, 3)) / 400.0, vf.abs().amax(dim=(0, 2, 3)) / 400.0]).float().contiguous()
+        kc = (kf / sc[0].view(1, nkv, 1, 1)).to(torch.float8_e4m3fn)
+        vc = (vf / sc[1].view(1, nkv, 1, 1)).to(torch.float8_e4m3fn)
+    else:
+        kc, vc = kf.bfloat16(), vf.bfloat16()
+    chunks = [(0, 0, 700), (1, 100, 600)]
+    rows, tok_seq, ctx, tiles = 0, [], [], []
+    for seq, p0, n in chunks:
+        for off in range(0, n, 16):
+            tiles.append((rows + off, min(16, n - off), p0 + off, seq))
+        tok_seq += [seq] * n
+        ctx += [p0 + j + 1 for j in range(n)]
+        rows += n
+    q = torch.randn(rows, nh, hd, device=_dev()).bfloat16()
+    tok_seq_t = torch.tensor(tok_seq, device=_dev(), dtype=torch.int32)
+    ctx_t = torch.tensor(ctx, device=_dev(), dtype=torch.int32)
+    scale = 1 / math.sqrt(hd)
+    kw = {"kv_scale": sc} if kv8 else {}
+    ref = torch_ops.paged_attention(q, kc, vc, bt, tok_seq_t, ctx_t, scale, **kw)
+    out = torch.zeros((rows, nh * hd), device=_dev(), dtype=torch.bfloat16)
+    assert nkv * len(tiles) >= 512  # the 32-query path
+    hip_ops.prefill_attention(q, kc, vc, bt, torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous(), out, scale, **kw)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref.float()).abs().max().item() <= (4e-2 if kv8 else 2.5e-2)
 
 
 def test_engine_pads_unsupported_head_widths_to_128():
