@@ -737,16 +737,17 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
 // Tiled (flash-style) causal attention for prompt chunks on the paged cache, on MFMA.
 // paged_attention_kernel gives every query token its own workgroup and re-reads the whole
 // prefix per token: fine for decode, quadratic L2 traffic for a prompt.  Here one workgroup
-// serves one or two tiles of 16 consecutive query tokens of ONE chunk for one kv head (all REP
-// query heads of the group: wave w owns heads w, w+4, ...), walking the keys 32 at a time with
-// mfma_f32_16x16x32_bf16.  The 32 key rows and 32 value rows of a step are read from the paged
-// cache once per workgroup (16 lanes per 256-byte row) and staged ROW-MAJOR into LDS with
-// 16-byte writes; the four waves read K fragments with ds_read_b128 and the transposed V
-// fragments with ds_read_b64_tr_b16, so V never needs a transposing write.  Both images are
-// XOR-swizzled so that every lane group of those reads and writes covers distinct banks:
-//   K  16-byte chunk c of row r sits at slot c ^ (r & 15) of the row's 16;
-//   V  32-byte piece n (dims 16n ..) of row r sits at piece n ^ (r & 7) of the row's 8.
-// The operand roles are described at prefill_attention_tiles.
+// serves tiles of 16 consecutive query tokens of ONE chunk for one kv head (all REP query heads
+// of the group: wave w owns heads w, w + 4), walking the keys 32 at a time.  The 32 key rows and
+// 32 value rows of a step are read from the paged cache once per workgroup (16 lanes per 256-byte
+// row) and staged ROW-MAJOR into LDS with 16-byte writes; the four waves read K fragments with
+// ds_read_b128 and the transposed V fragments with ds_read_b64_tr_b16, so V never needs a
+// transposing write.  Two MFMA shapes:
+//   prefill_attention_tiles16   one 16-query tile, one head per wave (head groups of at most 4),
+//                               mfma_f32_16x16x32_bf16: prompts too short to fill the chip with
+//                               pairs of tiles, and tile pairs that are not neighbours of one chunk;
+//   prefill_attention_tiles32   32 columns per wave on mfma_f32_32x32x16_bf16: two neighbouring
+//                               tiles for one head, or one tile for the two heads of a wave.
 // Tiles are described by host-staged arrays (first token row, valid queries, first position,
 // block-table row); tile_n == 0 marks an unused tile.  K/V of the chunk's own tokens must be
 // in the cache already (rope_kv_write runs first).  head_dim 128, block_size 16.
@@ -755,10 +756,8 @@ typedef __attribute__((ext_vector_type(4))) float mfma_cd;
 typedef __attribute__((ext_vector_type(4))) short tr_b64;  // result of one ds_read_b64_tr_b16
 typedef __attribute__((address_space(3))) tr_b64 lds_tr_b64;
 
-
-// One pass over the keys for QT consecutive 16-query tiles (rows row0 .., positions pos0 ..,
-// n_q valid queries in all) of one sequence: with QT = 2 every K fragment, every staged V^T
-// row and every workgroup barrier serves twice the MFMA work.
+// One pass over the keys for ONE 16-query tile (rows row0 .., positions pos0 .., n_q valid
+// queries) of one sequence; wave w serves head w of the group (waves past REP only stage).
 //
 // Everything is computed TRANSPOSED, so that P never leaves the registers:
 //   S^T = K Q^T   A = K rows (lane: key lr, dims 32*ks + 8*lq ..), B = Q (lane: query lr, same
@@ -773,46 +772,36 @@ typedef __attribute__((address_space(3))) tr_b64 lds_tr_b64;
 //                 the 4 rows key 16*b + 4*lq .. +3 x 16 dims and lane lr receives its dim of
 //                 those 4 keys, i.e. elements 4*b .. 4*b+3 of its fragment.
 // The output accumulator lane holds O[query lr][dims 16*nt + 4*lq .. +4]: 8-byte stores.
-template <int REP, int QT, bool KV8>
-__device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
-                                                        const void* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
-                                                        unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* v_lds,
-                                                        unsigned short* k_lds) {
+// Both LDS images are XOR-swizzled so that every lane group of the reads and writes covers
+// distinct banks (a ds_read_b128 group mixes two values of lq here, so padding alone does not):
+//   K  16-byte chunk c of row r sits at slot c ^ (r & 15) of the row's 16;
+//   V  32-byte piece n (dims 16n ..) of row r sits at piece n ^ (r & 7) of the row's 8.
+template <int REP, bool KV8>
+__device__ __forceinline__ void prefill_attention_tiles16(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
+                                                          const void* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
+                                                          unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* v_lds,
+                                                          unsigned short* k_lds) {
+  static_assert(REP <= 4, "one query head per wave");
   constexpr int HD = 128, BS = 16, KSTEP = 32;
-  constexpr int TILE = KSTEP * HD;    // elements of one K or V image (8 KiB)
-  constexpr int HPW = (REP + 3) / 4;  // query heads per wave
+  constexpr int TILE = KSTEP * HD;  // elements of one K or V image (8 KiB)
   const int g = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
-  const int last_key = pos0 + n_q - 1;  // highest key index any query of the tile may see
+  const int last_key = pos0 + n_q - 1;          // highest key index any query of the tile may see
+  const bool head_on = REP == 4 || wave < REP;  // wave-uniform
 
   // Q fragments: lane = Q[query lr][dims 32*ks + 8*lq .. +8]
-  mfma_ab qa[QT][HPW][4];
+  mfma_ab qa[4];
+  if (head_on) {
+    const int qrow = row0 + (lr < n_q ? lr : n_q - 1);
+    const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + wave) * HD + lq * 8;
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int qi = 16 * qt + lr;
-    const int qrow = row0 + (qi < n_q ? qi : n_q - 1);
-#pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) {
-      const int h = wave + 4 * hh;
-      if (h < REP) {
-        const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + h) * HD + lq * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qa[qt][hh][ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 32);
-      }
-    }
+    for (int ks = 0; ks < 4; ++ks) qa[ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 32);
   }
-  mfma_cd o[QT][HPW][8];
-  float m_run[QT][HPW], l_run[QT][HPW];
+  mfma_cd o[8];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) {
-      m_run[qt][hh] = -1e30f;
-      l_run[qt][hh] = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) o[qt][hh][nt] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
-    }
+  for (int nt = 0; nt < 8; ++nt) o[nt] = (mfma_cd){0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
   // Staging role, the same for K and V: 16-byte chunk sv_c of the rows of keys sv_kr and
   // sv_kr + 16 of the step, so 16 consecutive lanes fetch one whole 256-byte row.  The rows
   // are read from the cache ONCE per workgroup (32 bytes of each of K and V per thread), one
@@ -828,6 +817,8 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
   // block of the pass and past it — its row clamped to the last key (a valid row; masked in the
   // softmax).  The entries are fetched one step before the rows, the rows one step before the
   // LDS write, so the dependent lookup -> address -> cache read chain never stalls the loop.
+  // The loads are unconditional: a branch around them would leave the in-order load counter
+  // unknown at the join and force a full drain there.
   constexpr int ESZ = KV8 ? 1 : 2;
   const int last_blk = last_key >> 4;
   const unsigned voff_row = (unsigned)((sv_kr * HD + sv_c * 8) * ESZ);
@@ -873,23 +864,20 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
   const int kf_row = lr * HD;                                       // + 16*b rows; chunk (4*ks + lq) ^ lr
   const int vf_base = (4 * lq + (lr >> 2)) * HD + ((lr & 3) << 2);  // + 16*b rows; piece nt ^ vf_sw
   const int vf_sw = 4 * (lq & 1) + (lr >> 2);                       // (row & 7) of this lane's row
-  // K fragments: lane = K[key 16*b + lr][dims 32*ks + 8*lq .. +8]
-#define K_FRAGS(SLOT, KF)                                                                                                        \
-  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                 \
-      KF[b][ks] = *reinterpret_cast<const mfma_ab*>(k_lds + (SLOT) * TILE + 16 * b * HD + kf_row + (((4 * ks + lq) ^ lr) << 3))
-  // wave w owns heads w, w + 4: with REP not a multiple of 4 some waves own fewer (or none) and
-  // skip that work (a wave-uniform test; constant-folded otherwise)
-#define HEAD_ON(HH) (REP % 4 == 0 || wave + 4 * (HH) < REP)
-  // S^T = K Q^T for 2 x 16 keys: ST[qt][hh][b][r] = score(key 16*b + 4*lq + r of the step, query 16*qt + lr)
-#define S_MFMAS(KF, ST)                                                                                                          \
-  _Pragma("unroll") for (int hh = 0; hh < HPW; ++hh) if (HEAD_ON(hh)) _Pragma("unroll") for (int qt = 0; qt < QT; ++qt)          \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                            \
-    ST[qt][hh][b] = (mfma_cd){0.f, 0.f, 0.f, 0.f};                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                             \
-        ST[qt][hh][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KF[b][ks], qa[qt][hh][ks], ST[qt][hh][b], 0, 0, 0);              \
-  }
+  // K fragments (lane = K[key 16*b + lr][dims 32*ks + 8*lq .. +8]) of a slot and S^T = K Q^T on
+  // them: ST[b][r] = score(key 16*b + 4*lq + r of the step, query lr)
+#define S_MFMAS(SLOT, ST)                                                                                                        \
+  do {                                                                                                                           \
+    mfma_ab kf[2][4];                                                                                                            \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                               \
+        kf[b][ks] = *reinterpret_cast<const mfma_ab*>(k_lds + (SLOT) * TILE + 16 * b * HD + kf_row + (((4 * ks + lq) ^ lr) << 3)); \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                              \
+      ST[b] = (mfma_cd){0.f, 0.f, 0.f, 0.f};                                                                                     \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) ST[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[b][ks], qa[ks], ST[b], 0, 0, 0); \
+    }                                                                                                                            \
+  } while (0)
   int blk0, blk1;
-  mfma_cd st_cur[QT][HPW][2];
+  mfma_cd st_cur[2];
   BT_LOAD(0, blk0, blk1);
   KV_LOAD_STEP(0, blk0, blk1);
   BT_LOAD(KSTEP, blk0, blk1);
@@ -900,105 +888,74 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
   KV_LOAD_STEP(2 * KSTEP, blk0, blk1);
   BT_LOAD(3 * KSTEP, blk0, blk1);
   __syncthreads();
-  if (HEAD_ON(0)) {
-    mfma_ab kf[2][4];
-    K_FRAGS(0, kf);
-    S_MFMAS(kf, st_cur);
-  }
+  if (head_on) S_MFMAS(0, st_cur);
 
   // One step.  MASKED: the step reaches the diagonal of some query of the tile (the last one or
   // two steps of a pass); the others run without any mask code.
   auto step = [&](auto masked_c, int kb, int s_v, int s_k, int s_w) __attribute__((always_inline)) {
     constexpr bool MASKED = decltype(masked_c)::value;
-    // unconditional loads (past the end the keys clamp to the last one): a branch around them
-    // would leave the in-order load counter unknown at the join and force a full drain there
     STAGE_TILES(s_w);
     KV_LOAD_STEP(kb + 3 * KSTEP, blk0, blk1);
     BT_LOAD(kb + 4 * KSTEP, blk0, blk1);
-    if (HEAD_ON(0)) {
-    // V^T fragments of this step (A lane = V^T[dim 16*nt + lr][k-slots 8*lq .. +8]): one pair of
-    // transposed reads (keys 16*b + 4*lq .. +3, b = 0, 1) per 16 dims; shared by all heads and tiles
-    const unsigned short* vt = v_lds + s_v * TILE + vf_base;
-    mfma_ab va[8];
+    if (head_on) {
+      // V^T fragments of this step (A lane = V^T[dim 16*nt + lr][k-slots 8*lq .. +8]): one pair of
+      // transposed reads (keys 16*b + 4*lq .. +3, b = 0, 1) per 16 dims
+      const unsigned short* vt = v_lds + s_v * TILE + vf_base;
+      mfma_ab va[8];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-      struct { tr_b64 lo, hi; } vf;
-      vf.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + ((nt ^ vf_sw) << 4)));
-      vf.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + 16 * HD + ((nt ^ vf_sw) << 4)));
-      va[nt] = __builtin_bit_cast(mfma_ab, vf);
-    }
-    mfma_ab kf[2][4];
-    K_FRAGS(s_k, kf);
-    mfma_cd st_nxt[QT][HPW][2];
-    S_MFMAS(kf, st_nxt);
-    mfma_ab pb[QT][HPW];
-    float corr[QT][HPW];
-    bool moved = false;
+      for (int nt = 0; nt < 8; ++nt) {
+        struct { tr_b64 lo, hi; } vf;
+        vf.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + ((nt ^ vf_sw) << 4)));
+        vf.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + 16 * HD + ((nt ^ vf_sw) << 4)));
+        va[nt] = __builtin_bit_cast(mfma_ab, vf);
+      }
+      mfma_cd st_nxt[2];
+      S_MFMAS(s_k, st_nxt);
+      // ---- online softmax in units of scale * log2(e): the multiply comes first on purpose (a
+      // product is known to be a quiet number, so the maxima below need no canonicalising
+      // v_max x, x, x per MFMA result)
+      float sc[8];
 #pragma unroll
-    for (int hh = 0; hh < HPW; ++hh)
-      if (HEAD_ON(hh))
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        // ---- online softmax in units of scale * log2(e): the multiply comes first on purpose
-        // (a product is known to be a quiet number, so the maxima below need no canonicalising
-        // v_max x, x, x per MFMA result)
-        float sc[8];
+        for (int r = 0; r < 4; ++r) sc[4 * b + r] = st_cur[b][r] * scale_log2e;
+      if constexpr (MASKED) {
+        const int lim = pos0 + lr - kb - 4 * lq;  // key offset 16*b + r is visible iff <= lim
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[4 * b + r] = st_cur[qt][hh][b][r] * scale_log2e;
-        if constexpr (MASKED) {
-          const int lim = pos0 + 16 * qt + lr - kb - 4 * lq;  // key offset 16*b + r is visible iff <= lim
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[4 * b + r] = (16 * b + r <= lim) ? sc[4 * b + r] : -1e30f;
-        }
-        float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
-        mx = quad_rows_max(mx);  // the 4 lanes of a query
-        const float m_old = m_run[qt][hh];
-        const float m_new = fmaxf(m_old, mx);
-        // v_exp_f32 as is (arguments <= 0; a result below the normal range flushes to 0, which
-        // is what a softmax weight of 2^-126 is worth)
-        float pr[8], psum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          pr[j] = __builtin_amdgcn_exp2f(sc[j] - m_new);
-          psum += pr[j];
-        }
-        corr[qt][hh] = __builtin_amdgcn_exp2f(m_old - m_new);
-        l_run[qt][hh] = l_run[qt][hh] * corr[qt][hh] + psum;  // this lane's keys only; folded after the loop
-        m_run[qt][hh] = m_new;
-        moved |= m_new != m_old;
-        // ---- P^T as the B operand, straight from the accumulator layout (hardware bf16 conversion)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pb[qt][hh][j] = (__bf16)pr[j];
+          for (int r = 0; r < 4; ++r) sc[4 * b + r] = (16 * b + r <= lim) ? sc[4 * b + r] : -1e30f;
       }
-    if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // rescale O only when some query's maximum moved
+      float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+      mx = quad_rows_max(mx);  // the 4 lanes of a query
+      const float m_old = m_run;
+      const float m_new = fmaxf(m_old, mx);
+      // v_exp_f32 as is (arguments <= 0; a result below the normal range flushes to 0, which
+      // is what a softmax weight of 2^-126 is worth)
+      float pr[8], psum = 0.f;
 #pragma unroll
-      for (int hh = 0; hh < HPW; ++hh)
-        if (HEAD_ON(hh))
+      for (int j = 0; j < 8; ++j) {
+        pr[j] = __builtin_amdgcn_exp2f(sc[j] - m_new);
+        psum += pr[j];
+      }
+      const float corr = __builtin_amdgcn_exp2f(m_old - m_new);
+      l_run = l_run * corr + psum;  // this lane's keys only; folded after the loop
+      m_run = m_new;
+      // ---- P^T as the B operand, straight from the accumulator layout (hardware bf16 conversion)
+      mfma_ab pb;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+      for (int j = 0; j < 8; ++j) pb[j] = (__bf16)pr[j];
+      if (__builtin_amdgcn_ballot_w64(m_new != m_old) != 0) {  // rescale O only when some query's maximum moved
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt)
+        for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[qt][hh][nt][r] *= corr[qt][hh];
-    }
-    // ---- O^T += V^T P^T
+          for (int r = 0; r < 4; ++r) o[nt][r] *= corr;
+      }
+      // ---- O^T += V^T P^T
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-      for (int hh = 0; hh < HPW; ++hh)
-        if (HEAD_ON(hh))
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) o[qt][hh][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[nt], pb[qt][hh], o[qt][hh][nt], 0, 0, 0);
-#pragma unroll
-    for (int hh = 0; hh < HPW; ++hh)
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) st_cur[qt][hh][b] = st_nxt[qt][hh][b];
+      for (int nt = 0; nt < 8; ++nt) o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[nt], pb, o[nt], 0, 0, 0);
+      st_cur[0] = st_nxt[0];
+      st_cur[1] = st_nxt[1];
     }
     __syncthreads();  // the tiles of step i+2 are staged, and every wave is done with slot i % 3
   };
@@ -1021,33 +978,22 @@ __device__ __forceinline__ void prefill_attention_tiles(const unsigned short* __
   }
 #undef ROTATE_SLOTS
 #undef S_MFMAS
-#undef HEAD_ON
-#undef K_FRAGS
 #undef STAGE_TILES
 #undef KV_LOAD_STEP
 #undef BT_LOAD
-  // ---- normalise and store: lane holds O[query 16*qt + lr][dims 16*nt + 4*lq + r]
+  // ---- normalise and store: lane holds O[query lr][dims 16*nt + 4*lq + r]
+  const float l = quad_rows_sum(l_run);  // per-lane partial sums: fold the 4 lanes of the query (before any lane leaves)
+  if (!head_on || lr >= n_q) return;
+  const float inv = l > 0.f ? v_scale / l : 0.f;
+  unsigned short* op = out + (long long)(row0 + lr) * nh * HD + (long long)(g * REP + wave) * HD + 4 * lq;
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt)
+  for (int nt = 0; nt < 8; ++nt) {
+    typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+    us4 w;
 #pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) {
-      const int h = wave + 4 * hh;
-      if (h >= REP) continue;
-      float l = l_run[qt][hh];  // per-lane partial sums: fold the 4 lanes of the query
-      l = quad_rows_sum(l);
-      const int qi = 16 * qt + lr;
-      if (qi >= n_q) continue;
-      const float inv = l > 0.f ? v_scale / l : 0.f;
-      unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + 4 * lq;
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        typedef __attribute__((ext_vector_type(4))) unsigned short us4;
-        us4 w;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = f2bf(o[qt][hh][nt][r] * inv);
-        *reinterpret_cast<us4*>(op + nt * 16) = w;
-      }
-    }
+    for (int r = 0; r < 4; ++r) w[r] = f2bf(o[nt][r] * inv);
+    *reinterpret_cast<us4*>(op + nt * 16) = w;
+  }
 }
 
 // The same pass on mfma_f32_32x32x16_bf16, a wave's 32 columns being either 32 consecutive queries
@@ -1119,7 +1065,7 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
-  // staging role and cache reads: as in prefill_attention_tiles (16 lanes per 256-byte row, keys
+  // staging role and cache reads: as in prefill_attention_tiles16 (16 lanes per 256-byte row, keys
   // sv_kr and sv_kr + 16 of a step, one step ahead of the LDS write, block-table entries one
   // step earlier still, keys past the end clamped to the last key)
   const int sv_c = tid & 15, sv_kr = tid >> 4;
@@ -1368,11 +1314,11 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
       return;
     }
     if (n0 > 0)
-      prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
+      prefill_attention_tiles16<REP, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0], n0,
                                       out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
     if (n1 > 0) {
       __syncthreads();  // the first pass is done with the LDS tiles
-      prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t1] * max_blocks_per_seq, tile_row0[t1], tile_pos0[t1], n1,
+      prefill_attention_tiles16<REP, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t1] * max_blocks_per_seq, tile_row0[t1], tile_pos0[t1], n1,
                                       out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
     }
   } else {
@@ -1382,7 +1328,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
         prefill_attention_tiles32<REP, 2, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
                                                n0, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
       else
-        prefill_attention_tiles<REP, 1, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
+        prefill_attention_tiles16<REP, KV8>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t0] * max_blocks_per_seq, tile_row0[t0], tile_pos0[t0],
                                              n0, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
     }
   }
