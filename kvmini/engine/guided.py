@@ -305,55 +305,87 @@ def advance_scripted(state: State, cursor: int, tok: int, cls: np.ndarray, scrip
 def schema_script(schema: Any, encode_pieces: Any) -> Tuple[str, Tuple[int, int, int], Optional[List[int]], Optional[List[str]]]:
     """(text the server writes in front, automaton start, script, text of every script entry) for
     a JSON schema of an object.  ``encode_pieces(text) -> [(token id, text piece)]`` (no BOS; the
-    pieces concatenate to ``text``).  Every ``required`` property (all properties when nothing
-    is required) is written in order; ``enum`` / ``const`` values are written literally (the
-    first enum entry), other values are slots restricted to the declared ``type``.  Nested objects
-    and arrays are free JSON of that container type.  Without properties: no script, the document
-    is free JSON.  The texts are what a forced token stands for in the response (a tokenizer
-    need not decode a token back to the piece it encoded)."""
+    pieces concatenate to ``text``).  The schema is flattened into ONE line of literals and value
+    slots, at any depth:
+
+    * an object with ``properties`` writes every ``required`` property (all of them when nothing
+      is required) in order, recursively;
+    * an array whose ``items`` is a schema writes ``max(minItems, 1)`` items (none when
+      ``maxItems`` is 0), each flattened like any other value;
+    * ``enum`` / ``const`` values are written literally (the first enum entry);
+    * every other value is a slot restricted to the declared ``type`` — scalars, and objects /
+      arrays that declare nothing about their content (free JSON of that container type).
+
+    The automaton is SET at the end of every literal and a slot always runs at its own depth 1,
+    so the brackets inside the literals need no tracking.  Without properties at the top: no
+    script, the document is free JSON.  The texts are what a forced token stands for in the
+    response (a tokenizer need not decode a token back to the piece it encoded)."""
     import json as _json
 
     props = schema.get("properties") if isinstance(schema, dict) else None
     if not isinstance(props, dict) or not props:
         return "", (S_START, 0, 0), None, None
-    keys = [k for k in (schema.get("required") or []) if k in props] or list(props)
     script: List[int] = []
     texts: List[str] = []
+    out = {"prefix": None, "pending": ""}  # pending: literal text waiting in front of the next slot / the end
 
     def literal(text: str) -> None:
         for tid, piece in encode_pieces(text):
             script.append(int(tid))
             texts.append(piece)
 
-    prefix = ""
-    pending = "{"  # literal text waiting to be written in front of the next value slot / the end
-    for i, key in enumerate(keys):
-        spec = props[key] if isinstance(props[key], dict) else {}
-        pending += ("," if i else "") + _json.dumps(str(key)) + ":"
-        fixed = spec["const"] if "const" in spec else (spec["enum"][0] if isinstance(spec.get("enum"), list) and spec["enum"] else None)
-        if fixed is not None or "const" in spec:
-            pending += _json.dumps(fixed, separators=(",", ":"))
-            continue
-        types = spec.get("type")
-        mask = 0
-        for t in ([types] if isinstance(types, str) else (types if isinstance(types, list) else [])):
-            mask |= TYPE_CLASSES.get(t, 0)
-        if not script and not prefix:
-            prefix = pending  # the first literal goes into the prompt: the model sees it, nothing to force
+    def slot(mask: int) -> None:
+        if out["prefix"] is None:
+            out["prefix"] = out["pending"]  # the first literal goes into the prompt: the model sees it, nothing to force
         else:
-            literal(pending)
-        pending = ""
+            literal(out["pending"])
+        out["pending"] = ""
         script.append(script_value(mask))
         texts.append("")
-    literal(pending + "}")
+
+    def value(spec: Any, depth: int) -> None:
+        spec = spec if isinstance(spec, dict) else {}
+        if "const" in spec or (isinstance(spec.get("enum"), list) and spec["enum"]):
+            out["pending"] += _json.dumps(spec["const"] if "const" in spec else spec["enum"][0], separators=(",", ":"))
+            return
+        types = spec.get("type")
+        tl = [types] if isinstance(types, str) else (list(types) if isinstance(types, list) else [])
+        sub = spec.get("properties")
+        if isinstance(sub, dict) and sub and (not tl or "object" in tl) and depth < 16:
+            keys = [k for k in (spec.get("required") or []) if k in sub] or list(sub)
+            out["pending"] += "{"
+            for i, key in enumerate(keys):
+                out["pending"] += ("," if i else "") + _json.dumps(str(key)) + ":"
+                value(sub[key], depth + 1)
+            out["pending"] += "}"
+            return
+        items = spec.get("items")
+        if isinstance(items, dict) and items and (not tl or "array" in tl) and depth < 16:
+            lo = spec.get("minItems") if isinstance(spec.get("minItems"), int) else 0
+            hi = spec.get("maxItems") if isinstance(spec.get("maxItems"), int) else None
+            n = max(lo, 1) if hi is None else min(max(lo, 1), max(hi, 0))
+            out["pending"] += "["
+            for i in range(n):
+                out["pending"] += "," if i else ""
+                value(items, depth + 1)
+            out["pending"] += "]"
+            return
+        mask = 0
+        for t in tl:
+            mask |= TYPE_CLASSES.get(t, 0)
+        slot(mask)
+
+    value({"type": "object", "properties": props, "required": schema.get("required")}, 0)
+    literal(out["pending"])
     script.append(SCRIPT_END)
     texts.append("")
     if len(script) > SCRIPT_MAX:
         raise ValueError(f"schema skeleton of {len(script)} tokens exceeds the {SCRIPT_MAX} the guided-decoding script holds")
-    if not prefix:  # every property was a constant: the whole document is one literal
+    prefix = out["prefix"]
+    if prefix is None:  # every value was a constant: the whole document is one literal
         return "", (S_OBJ_NEXT, 1, 0), script, texts
-    st, depth, stack = state_after_text(prefix)
-    return prefix, (st, depth, stack), script, texts
+    state_after_text(prefix)  # raises on a prefix that is not JSON
+    return prefix, (S_VALUE, 1, 0), script, texts  # the first slot: the state every literal ends in
 
 
 class ScriptedText:

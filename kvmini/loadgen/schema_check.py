@@ -4,9 +4,9 @@ The reference's ``structured-output`` profile promises "100 % format compliance"
 (``runners/profiles/structured-output.yaml:26``) but nothing in it looks at the answers.  The load
 generator checks every answer of a request that carried a schema: the text parses as JSON, and the
 document satisfies the parts of JSON Schema that serving runtimes' guided decoding enforces —
-``type`` (also a list of types), ``required``, ``properties`` (recursively), ``items``, ``enum``,
-``const``.  Numeric ranges, string formats and the like are not generation constraints and are not
-checked.
+``type`` (also a list of types), ``required``, ``properties`` (recursively), ``items``,
+``minItems`` / ``maxItems``, ``enum``, ``const``.  Numeric ranges, string formats and the like are
+not generation constraints and are not checked.
 """
 
 from __future__ import annotations
@@ -48,6 +48,12 @@ def violation(doc: Any, schema: Any, path: str = "$") -> Optional[str]:
                 why = violation(doc[k], sub, f"{path}.{k}")
                 if why:
                     return why
+    if isinstance(doc, list):
+        lo, hi = schema.get("minItems"), schema.get("maxItems")
+        if isinstance(lo, int) and len(doc) < lo:
+            return f"{path}: {len(doc)} items where at least {lo} are required"
+        if isinstance(hi, int) and len(doc) > hi:
+            return f"{path}: {len(doc)} items where at most {hi} are allowed"
     if isinstance(doc, list) and isinstance(schema.get("items"), dict):
         for i, v in enumerate(doc):
             why = violation(v, schema["items"], f"{path}[{i}]")

@@ -115,6 +115,65 @@ def test_scripted_random_walks_give_every_required_key_with_its_type_within_the_
     assert G.schema_script({"type": "object"}, tok.encode_pieces) == ("", (G.S_START, 0, 0), None, None)
 
 
+NESTED = {"type": "object", "required": ["user", "items", "total"],
+          "properties": {
+              "user": {"type": "object", "required": ["id", "name", "geo"],
+                       "properties": {"id": {"type": "integer"}, "name": {"type": "string"}, "email": {"type": "string"},
+                                      "geo": {"type": "object", "properties": {"lat": {"type": "number"}, "lon": {"type": "number"}}}}},
+              "items": {"type": "array", "minItems": 2,
+                        "items": {"type": "object", "required": ["sku", "qty", "flags"],
+                                  "properties": {"sku": {"type": "string"}, "qty": {"type": "integer"},
+                                                 "flags": {"type": "array", "items": {"type": "boolean"}}, "note": {"type": "string"}}}},
+              "total": {"type": ["number", "null"]},
+              "comment": {"type": "string"}}}
+
+
+def test_scripted_random_walks_through_a_nested_schema():
+    """Nested objects and arrays of objects are flattened into the same line of literals and value
+    slots: whatever the model picks inside the slots, the document satisfies the schema at every
+    depth (checked by the load generator's schema checker), arrays have at least ``minItems``
+    items, and optional properties are left out."""
+    from kvmini.engine.tokenizer import get_tokenizer
+    from kvmini.loadgen.schema_check import violation
+
+    tok = get_tokenizer(2048, 1, 2)
+    cls = G.token_classes(tok, 2048, 2)
+    vc = G.value_cost(cls)
+    prefix, start, script, texts = G.schema_script(NESTED, tok.encode_pieces)
+    assert prefix == '{"user":{"id":' and start == (G.S_VALUE, 1, 0)
+    assert "".join(texts) == (',"name":,"geo":{"lat":,"lon":}},"items":[{"sku":,"qty":,"flags":[]},{"sku":,"qty":,"flags":[]}],"total":}')
+    slots = [-2 - e for e in script if e <= -2]
+    T = G.TYPE_CLASSES
+    assert slots == [T["integer"], T["string"], T["number"], T["number"], T["string"], T["integer"], T["boolean"],
+                     T["string"], T["integer"], T["boolean"], T["number"] | T["null"]]
+    rest = G.script_rest(script, vc)
+    by_class = {c: [t for t in range(16, 2048) if cls[t] == c] for c in range(G.N_CLASSES)}
+    by_class[G.C_EOS] = [2]
+    rng = random.Random(5)
+    for trial in range(200):
+        budget = rng.randint(rest[0], rest[0] + 80)
+        st, cur, out = (start[0], start[1], start[2], budget), 0, []
+        while st[0] != G.S_END:
+            allow, forced = G.allowed_scripted(st, cur, script, rest, vc)
+            options = [rng.choice(by_class[c]) for c in range(1, G.N_CLASSES) if (allow >> c) & 1 and by_class[c]]
+            if forced >= 0:
+                options.append(forced)
+            assert options, (st, cur, out)
+            t = rng.choice(options)
+            out.append(t)
+            st, cur = G.advance_scripted(st, cur, t, cls, script)
+            assert len(out) <= budget
+        text = G.ScriptedText(cls, start, budget, script, texts, tok.decode_token)
+        doc = json.loads(prefix + "".join(text.piece(t) for t in out))
+        assert violation(doc, NESTED) is None, (violation(doc, NESTED), doc)
+        assert list(doc) == ["user", "items", "total"] and list(doc["user"]) == ["id", "name", "geo"] and list(doc["user"]["geo"]) == ["lat", "lon"]
+        assert len(doc["items"]) == 2 and all(list(it) == ["sku", "qty", "flags"] and len(it["flags"]) == 1 for it in doc["items"])
+    # maxItems 0 writes an empty array; an array or object that says nothing about its content stays a free slot
+    p3, _, sc3, tx3 = G.schema_script({"properties": {"a": {"type": "array", "maxItems": 0, "items": {"type": "integer"}}, "b": {"type": "array"},
+                                                      "c": {"type": "object"}}}, tok.encode_pieces)
+    assert p3 == '{"a":[],"b":' and "".join(tx3) == ',"c":}' and [-2 - e for e in sc3 if e <= -2] == [T["array"], T["object"]]
+
+
 def test_token_classes_of_the_synthetic_tokenizer():
     from kvmini.engine.tokenizer import get_tokenizer
 
@@ -412,6 +471,18 @@ def test_engine_schema_guided_generation_on_the_hip_path():
             text = G.ScriptedText(cls, start, 80, script, texts, tok.decode_token)
             _check_schema_doc(json.loads(prefix + "".join(text.piece(t) for t in o)))
     assert eng.pipelined_steps > 0
+    # a nested schema (objects in objects, an array of objects): the same kernels, a longer script
+    from kvmini.loadgen.schema_check import violation
+
+    prefix, start, script, texts = G.schema_script(NESTED, tok.encode_pieces)
+    prompts = [tok.encode(f"order {i} as json " + prefix, add_bos=True) for i in range(10)]
+    for temp in (0.0, 0.9):
+        sp = SamplingParams(max_tokens=160, temperature=temp, guided="json", guided_start=start, guided_script=tuple(script))
+        for o in eng.generate(prompts, sp):
+            assert o[-1] == eng.mcfg.eos_token_id and len(o) <= 160
+            text = G.ScriptedText(cls, start, 160, script, texts, tok.decode_token)
+            doc = json.loads(prefix + "".join(text.piece(t) for t in o))
+            assert violation(doc, NESTED) is None and len(doc["items"]) == 2, doc
 
 
 @pytest.mark.gpu
