@@ -206,7 +206,10 @@ def attn_bench(out):
     kc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
     vc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
     bt = torch.randperm(nb, device=dev)[: 4096 // bs].view(1, -1).int().contiguous()
-    for p0, n in ((0, 1024), (1024, 1024), (0, 2048), (2048, 2048)):
+    shapes = ((0, 1024), (1024, 1024), (0, 2048), (2048, 2048))
+    if os.environ.get("ATTN_SHAPES"):  # "pos0:queries,..." (a counter run wants one shape only)
+        shapes = tuple(tuple(int(v) for v in sh.split(":")) for sh in os.environ["ATTN_SHAPES"].split(","))
+    for p0, n in shapes:
         q = torch.randn(n, nh, hd, device=dev).bfloat16()
         o = torch.empty(n, nh * hd, device=dev, dtype=torch.bfloat16)
         tiles = torch.tensor([(off, 16, p0 + off, 0) for off in range(0, n, 16)], device=dev, dtype=torch.int32).T.contiguous()
