@@ -1095,12 +1095,12 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
     k1 = kv_load8_at<KV8>(reinterpret_cast<const char*>(k_cache) + base1, off1);              \
     v1 = kv_load8_at<KV8>(reinterpret_cast<const char*>(v_cache) + base1, off1);              \
   } while (0)
-#define STAGE_TILES(SLOT)                                                                        \
+#define STAGE_TILES(KSLOT, VSLOT)                                                                \
   do {                                                                                           \
-    unsigned short* kd = k_lds + (SLOT) * K_TILE + k_st;                                          \
+    unsigned short* kd = k_lds + (KSLOT) * K_TILE + k_st;                                         \
     *reinterpret_cast<bf16x8*>(kd) = k0;                                                         \
     *reinterpret_cast<bf16x8*>(kd + 16 * K_RS) = k1;                                             \
-    unsigned short* vd = v_lds + (SLOT) * V_TILE + v_st;                                          \
+    unsigned short* vd = v_lds + (VSLOT) * V_TILE + v_st;                                         \
     *reinterpret_cast<bf16x8*>(vd) = v0;                                                         \
     *reinterpret_cast<bf16x8*>(vd + 16 * V_RS) = v1;                                             \
   } while (0)
@@ -1119,21 +1119,42 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
   } while (0)
   int blk0, blk1;
   mfma_cd16 st_cur;
+  // P of the previous step (bf16, as the B operand of its P V MFMAs, which run one iteration late);
+  // before the first step: zero, against a zeroed V slot
+  mfma_ab p_prev[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p_prev[s2][j] = (__bf16)0.f;
+  k0 = k1 = v0 = v1 = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    unsigned short* vd = v_lds + 3 * V_TILE + v_st;
+    *reinterpret_cast<bf16x8*>(vd) = v0;
+    *reinterpret_cast<bf16x8*>(vd + 16 * V_RS) = v1;
+  }
   BT_LOAD(0, blk0, blk1);
   KV_LOAD_STEP(0, blk0, blk1);
   BT_LOAD(KSTEP, blk0, blk1);
-  STAGE_TILES(0);
+  STAGE_TILES(0, 0);
   KV_LOAD_STEP(KSTEP, blk0, blk1);
   BT_LOAD(2 * KSTEP, blk0, blk1);
-  STAGE_TILES(1);
+  STAGE_TILES(1, 1);
   KV_LOAD_STEP(2 * KSTEP, blk0, blk1);
   BT_LOAD(3 * KSTEP, blk0, blk1);
   __syncthreads();
   if (head_on) S_MFMAS(0, st_cur);
 
-  // One step, software-pipelined like the 16-query path: tiles of step i+2 into slot (i+2) % 3,
-  // cache reads of step i+3, V fragments of step i and S^T of step i+1 around the softmax of
-  // step i, then P V of step i and one barrier.
+  // One step, software-pipelined over THREE steps so that both halves of it carry matrix and vector
+  // work (a wave whose P V MFMAs follow its own exponentials leaves the matrix pipe idle meanwhile,
+  // and two such waves on a SIMD fall into the same phase rather than filling each other's gaps).
+  // Iteration i
+  //   writes the rows of step i+2 into K slot (i+2) % 3 and V slot (i+2) % 4, starts the cache reads
+  //   of step i+3, reads the K fragments of step i+1 and the V fragments of step i-1;
+  //   first half:  S^T MFMAs of step i+1   beside   s*c - reference and the row maximum of step i;
+  //   (rare re-reference branch)
+  //   second half: P V MFMAs of step i-1   beside   the exponentials, row sum and bf16 packing of step i;
+  //   one barrier.  V of step i-1 is still read while step i+2 is staged: four V slots.
+  // The P V of the last step follows the loops.
   // EXACT (the first step and the steps that reach the diagonal): causal mask, and the textbook
   // online softmax whose reference m_run is the running maximum.  The other steps let the
   // reference LAG: exponents are taken against the reference as it is, s * c - m_run in ONE fma
@@ -1143,13 +1164,13 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
   // P <= 2^LAG_LOG2 then instead of <= 1: the same relative precision in bf16, and the largest
   // term of every row sum is still >= 1.
   constexpr float LAG_LOG2 = 6.f;
-  auto step = [&](auto exact_c, int kb, int s_v, int s_k, int s_w) __attribute__((always_inline)) {
+  auto step = [&](auto exact_c, int kb, int it, int s_k, int s_w) __attribute__((always_inline)) {
     constexpr bool EXACT = decltype(exact_c)::value;
-    STAGE_TILES(s_w);
+    STAGE_TILES(s_w, (it + 2) & 3);
     KV_LOAD_STEP(kb + 3 * KSTEP, blk0, blk1);
     BT_LOAD(kb + 4 * KSTEP, blk0, blk1);
     if (head_on) {
-      const unsigned short* vt = v_lds + s_v * V_TILE + vf_base;
+      const unsigned short* vt = v_lds + ((it + 3) & 3) * V_TILE + vf_base;  // step i-1
       mfma_ab va[4][2];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -1201,6 +1222,11 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
         }
         const float corr = __builtin_amdgcn_exp2f(-up);
         l_run *= corr;
+        // the previous step's P is still on its way into O: it moves with O
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p_prev[s2][j] = (__bf16)((float)p_prev[s2][j] * corr);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -1215,41 +1241,53 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
         psum += pr[r];
       }
       l_run += psum;  // this lane's keys only; folded after the loop
-      mfma_ab pb[2];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)pr[8 * s2 + j];
-      // ---- O^T += V^T P^T
+      // ---- O^T += V^T P^T of the previous step
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[nt][s2], pb[s2], o[nt], 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[nt][s2], p_prev[s2], o[nt], 0, 0, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p_prev[s2][j] = (__bf16)pr[8 * s2 + j];
       st_cur = st_nxt;
     }
-    __syncthreads();  // the tiles of step i+2 are staged, and every wave is done with slot i % 3
+    __syncthreads();  // the tiles of step i+2 are staged, and every wave is done with K slot (i+1) % 3 and V slot (i-1) % 4
   };
 
-  int kb = 0, s_v = 0, s_k = 1, s_w = 2;
+  int kb = 0, it = 0, s_i = 0, s_k = 1, s_w = 2;  // K slots: idle, read (step i+1), written (step i+2)
 #define ROTATE_SLOTS()       \
   do {                       \
-    const int s_t = s_v;     \
-    s_v = s_k;               \
+    const int s_t = s_i;     \
+    s_i = s_k;               \
     s_k = s_w;               \
     s_w = s_t;               \
+    ++it;                    \
   } while (0)
   if (KSTEP - 1 <= pos0) {  // the first step sets the reference: exact (its mask hides nothing)
-    step(std::true_type{}, kb, s_v, s_k, s_w);
+    step(std::true_type{}, kb, it, s_k, s_w);
     ROTATE_SLOTS();
     kb += KSTEP;
   }
   for (; kb + KSTEP - 1 <= pos0; kb += KSTEP) {
-    step(std::false_type{}, kb, s_v, s_k, s_w);
+    step(std::false_type{}, kb, it, s_k, s_w);
     ROTATE_SLOTS();
   }
   for (; kb <= last_key; kb += KSTEP) {
-    step(std::true_type{}, kb, s_v, s_k, s_w);
+    step(std::true_type{}, kb, it, s_k, s_w);
     ROTATE_SLOTS();
+  }
+  if (head_on) {  // P V of the last step (its V slot was staged three iterations ago; nothing overwrote it)
+    const unsigned short* vt = v_lds + ((it + 3) & 3) * V_TILE + vf_base;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        struct { tr_b64 lo, hi; } vf;
+        vf.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + (16 * s2) * V_RS + 32 * nt));
+        vf.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + (16 * s2 + 8) * V_RS + 32 * nt));
+        o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_ab, vf), p_prev[s2], o[nt], 0, 0, 0);
+      }
   }
 #undef ROTATE_SLOTS
 #undef S_MFMAS
@@ -1295,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
   }
   // [buffer][key][dim] images, swizzled inside each 256-byte row; the bank analysis of the swizzles
   // assumes rows that start on a multiple of 256 bytes
-  __shared__ __attribute__((aligned(256))) unsigned short v_lds[3 * 32 * PA32_V_RS];  // sized for the padded images of the 32-query path
+  __shared__ __attribute__((aligned(256))) unsigned short v_lds[4 * 32 * PA32_V_RS];  // sized for the 32-column path: padded images, four V slots
   __shared__ __attribute__((aligned(256))) unsigned short k_lds[3 * 32 * PA32_K_RS];
   // Later tiles of a chunk see more keys.  order 0: longest first, so the longest passes do not
   // start last.  order 1 (grids of at most two workgroups per CU, all resident at once): the
