@@ -27,7 +27,7 @@ reference the kernels are tested against, and the implementation of the CPU path
 from __future__ import annotations
 
 import re
-from typing import Any, List, Optional, Sequence, Tuple
+from typing import Dict, Any, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -313,6 +313,8 @@ def schema_script(schema: Any, encode_pieces: Any) -> Tuple[str, Tuple[int, int,
     * an array whose ``items`` is a schema writes ``max(minItems, 1)`` items (none when
       ``maxItems`` is 0), each flattened like any other value;
     * ``enum`` / ``const`` values are written literally (the first enum entry);
+    * ``$ref`` (into ``$defs`` / ``definitions``) and ``allOf`` are resolved; of ``anyOf`` /
+      ``oneOf`` the first alternative that is not ``null`` is written (``Optional[X]``: an X);
     * every other value is a slot restricted to the declared ``type`` — scalars, and objects /
       arrays that declare nothing about their content (free JSON of that container type).
 
@@ -322,7 +324,10 @@ def schema_script(schema: Any, encode_pieces: Any) -> Tuple[str, Tuple[int, int,
     response (a tokenizer need not decode a token back to the piece it encoded)."""
     import json as _json
 
-    props = schema.get("properties") if isinstance(schema, dict) else None
+    from ..utils.jsonschema_lite import preferred
+
+    top = preferred(schema, schema)
+    props = top.get("properties")
     if not isinstance(props, dict) or not props:
         return "", (S_START, 0, 0), None, None
     script: List[int] = []
@@ -343,8 +348,23 @@ def schema_script(schema: Any, encode_pieces: Any) -> Tuple[str, Tuple[int, int,
         script.append(script_value(mask))
         texts.append("")
 
+    on_path: List[str] = []  # references being expanded: a recursive schema stops at its first repeat
+
     def value(spec: Any, depth: int) -> None:
-        spec = spec if isinstance(spec, dict) else {}
+        ref = spec.get("$ref") if isinstance(spec, dict) else None
+        spec = preferred(spec, schema)  # $ref / allOf resolved; of anyOf / oneOf the first alternative that is not null
+        if isinstance(ref, str):
+            if ref in on_path:  # a node of its own kind below itself: free JSON of that type from here on
+                spec = {"type": spec.get("type")} if "type" in spec else {}
+            on_path.append(ref)
+            try:
+                emit(spec, depth)
+            finally:
+                on_path.pop()
+            return
+        emit(spec, depth)
+
+    def emit(spec: Dict[str, Any], depth: int) -> None:
         if "const" in spec or (isinstance(spec.get("enum"), list) and spec["enum"]):
             out["pending"] += _json.dumps(spec["const"] if "const" in spec else spec["enum"][0], separators=(",", ":"))
             return
@@ -375,7 +395,7 @@ def schema_script(schema: Any, encode_pieces: Any) -> Tuple[str, Tuple[int, int,
             mask |= TYPE_CLASSES.get(t, 0)
         slot(mask)
 
-    value({"type": "object", "properties": props, "required": schema.get("required")}, 0)
+    value({"type": "object", "properties": props, "required": top.get("required")}, 0)
     literal(out["pending"])
     script.append(SCRIPT_END)
     texts.append("")

@@ -5,7 +5,8 @@ The reference's ``structured-output`` profile promises "100 % format compliance"
 generator checks every answer of a request that carried a schema: the text parses as JSON, and the
 document satisfies the parts of JSON Schema that serving runtimes' guided decoding enforces —
 ``type`` (also a list of types), ``required``, ``properties`` (recursively), ``items``,
-``minItems`` / ``maxItems``, ``enum``, ``const``.  Numeric ranges, string formats and the like are
+``minItems`` / ``maxItems``, ``enum``, ``const``, with ``$ref`` / ``allOf`` resolved and any
+alternative of ``anyOf`` / ``oneOf`` accepted.  Numeric ranges, string formats and the like are
 not generation constraints and are not checked.
 """
 
@@ -13,6 +14,8 @@ from __future__ import annotations
 
 import json
 from typing import Any, Optional, Tuple
+
+from ..utils.jsonschema_lite import alternatives, deref
 
 _TYPES = {"object": dict, "array": list, "string": str, "boolean": bool, "null": type(None)}
 
@@ -26,10 +29,18 @@ def _is_type(v: Any, t: str) -> bool:
     return py is not None and isinstance(v, py)
 
 
-def violation(doc: Any, schema: Any, path: str = "$") -> Optional[str]:
-    """First way ``doc`` breaks ``schema`` (None: it does not)."""
+def violation(doc: Any, schema: Any, path: str = "$", root: Any = None) -> Optional[str]:
+    """First way ``doc`` breaks ``schema`` (None: it does not).  ``root`` is the document that
+    ``$ref`` pointers refer to (the schema itself at the top)."""
+    root = schema if root is None else root
     if not isinstance(schema, dict):
         return None
+    schema = deref(schema, root)
+    alts = alternatives(schema, root)
+    if alts:
+        whys = [violation(doc, a, path, root) for a in alts]
+        if all(whys):
+            return f"{path}: no alternative of anyOf / oneOf fits ({whys[0]})"
     if "const" in schema and doc != schema["const"]:
         return f"{path}: not the constant {schema['const']!r}"
     if isinstance(schema.get("enum"), list) and doc not in schema["enum"]:
@@ -45,7 +56,7 @@ def violation(doc: Any, schema: Any, path: str = "$") -> Optional[str]:
                 return f"{path}: required property {k!r} is missing"
         for k, sub in (schema.get("properties") or {}).items():
             if k in doc:
-                why = violation(doc[k], sub, f"{path}.{k}")
+                why = violation(doc[k], sub, f"{path}.{k}", root)
                 if why:
                     return why
     if isinstance(doc, list):
@@ -56,7 +67,7 @@ def violation(doc: Any, schema: Any, path: str = "$") -> Optional[str]:
             return f"{path}: {len(doc)} items where at most {hi} are allowed"
     if isinstance(doc, list) and isinstance(schema.get("items"), dict):
         for i, v in enumerate(doc):
-            why = violation(v, schema["items"], f"{path}[{i}]")
+            why = violation(v, schema["items"], f"{path}[{i}]", root)
             if why:
                 return why
     return None

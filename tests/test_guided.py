@@ -168,6 +168,19 @@ def test_scripted_random_walks_through_a_nested_schema():
         assert violation(doc, NESTED) is None, (violation(doc, NESTED), doc)
         assert list(doc) == ["user", "items", "total"] and list(doc["user"]) == ["id", "name", "geo"] and list(doc["user"]["geo"]) == ["lat", "lon"]
         assert len(doc["items"]) == 2 and all(list(it) == ["sku", "qty", "flags"] and len(it["flags"]) == 1 for it in doc["items"])
+    # what pydantic emits: nested models behind $ref, Optional[X] as anyOf [X, null]; a recursive model stops at its first repeat
+    pyd = {"$defs": {"Geo": {"type": "object", "properties": {"lat": {"type": "number"}, "lon": {"type": "number"}}, "required": ["lat", "lon"]},
+                     "Node": {"type": "object", "properties": {"v": {"type": "integer"}, "kids": {"type": "array", "items": {"$ref": "#/$defs/Node"}}}, "required": ["v", "kids"]}},
+           "type": "object", "required": ["id", "geo", "note", "tree"],
+           "properties": {"id": {"type": "integer"}, "geo": {"allOf": [{"$ref": "#/$defs/Geo"}]}, "note": {"anyOf": [{"type": "string"}, {"type": "null"}], "default": None},
+                          "tree": {"$ref": "#/$defs/Node"}}}
+    p4, _, sc4, tx4 = G.schema_script(pyd, tok.encode_pieces)
+    assert p4 == '{"id":' and "".join(tx4) == ',"geo":{"lat":,"lon":},"note":,"tree":{"v":,"kids":[]}}'
+    assert [-2 - e for e in sc4 if e <= -2] == [T["integer"], T["number"], T["number"], T["string"], T["integer"], T["object"]]
+    assert violation({"id": 1, "geo": {"lat": 1.5, "lon": 2}, "note": None, "tree": {"v": 1, "kids": [{"v": 2, "kids": []}]}}, pyd) is None
+    assert "geo.lat" in violation({"id": 1, "geo": {"lat": "x", "lon": 2}, "note": "n", "tree": {"v": 1, "kids": []}}, pyd)
+    assert "kids[0].v" in violation({"id": 1, "geo": {"lat": 1, "lon": 2}, "note": "n", "tree": {"v": 1, "kids": [{"v": "x", "kids": []}]}}, pyd)
+    assert "anyOf" in violation({"id": 1, "geo": {"lat": 1, "lon": 2}, "note": 3, "tree": {"v": 1, "kids": []}}, pyd)
     # maxItems 0 writes an empty array; an array or object that says nothing about its content stays a free slot
     p3, _, sc3, tx3 = G.schema_script({"properties": {"a": {"type": "array", "maxItems": 0, "items": {"type": "integer"}}, "b": {"type": "array"},
                                                       "c": {"type": "object"}}}, tok.encode_pieces)
