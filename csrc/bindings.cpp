@@ -72,6 +72,7 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
                     float* ss_out, int* counters, int ft, hipStream_t stream);
 int kv_prefetch(const void* p, long long bytes, int workgroups, unsigned int* sink, hipStream_t stream);
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
+int kv_unpack_mxfp4(const void* Wp4, const void* scales, void* Wp, int N, int K, hipStream_t stream);
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
                        const void* pf_base, const long long* pf, unsigned int* pf_sink, hipStream_t stream);
 int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride, void* residual, const void* w, void* y, int T, int H, float eps,
@@ -448,6 +449,17 @@ at::Tensor pack_weight(at::Tensor W) {
   return Wp;
 }
 
+// MXFP4 packed weights + E8M0 scale words -> `out`, bf16 in the fragment order of pack_weight
+// (the first N * K elements of `out`, a scratch buffer that may be larger).
+void unpack_mxfp4(at::Tensor Wp4, at::Tensor scales, at::Tensor out, int64_t N, int64_t K) {
+  TORCH_CHECK(Wp4.is_cuda() && scales.is_cuda() && out.is_cuda(), "unpack_mxfp4: GPU tensors");
+  TORCH_CHECK(Wp4.scalar_type() == at::kByte && scales.scalar_type() == at::kInt && out.scalar_type() == at::kBFloat16, "unpack_mxfp4: uint8 weights, int32 scales, bf16 output");
+  TORCH_CHECK(Wp4.is_contiguous() && scales.is_contiguous() && out.is_contiguous(), "unpack_mxfp4: contiguous tensors");
+  TORCH_CHECK(N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0, "unpack_mxfp4: N % 16 == 0, K % 128 == 0");
+  TORCH_CHECK(Wp4.numel() == N * K / 2 && scales.numel() == N * K / 32 / 4 && out.numel() >= N * K, "unpack_mxfp4: sizes do not match N x K");
+  check(kv_unpack_mxfp4(Wp4.data_ptr(), scales.data_ptr(), out.data_ptr(), (int)N, (int)K, cur_stream()), "kv_unpack_mxfp4");
+}
+
 at::Tensor pack_weight_fp8(at::Tensor W) {
   CHECK_DEV(W); CHECK_CONTIG(W);
   TORCH_CHECK(W.dim() == 2 && W.scalar_type() == at::kByte, "W must be uint8 [N, K] (e4m3 bytes)");
@@ -767,6 +779,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_gemm", &stream_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("ks_per_chunk"), py::arg("splits"),
         py::arg("chunks_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none());
   m.def("pack_weight_fp8", &pack_weight_fp8);
+  m.def("unpack_mxfp4", &unpack_mxfp4);
   m.def("stream_gemm3_plan", &stream_gemm3_plan, py::arg("N"), py::arg("K"), py::arg("nb"), py::arg("max_splits"), py::arg("target_wgs") = 512, py::arg("nw") = 4);
   m.def("stream_gemm3", &stream_gemm3, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("nb"), py::arg("splits"),
         py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4, py::arg("weight_bits") = 0,

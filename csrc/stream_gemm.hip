@@ -91,6 +91,21 @@ __device__ inline frag_ab a_frag4(const raw16 raw, unsigned int sc, int u) {
   return a;
 }
 
+// One thread per (16-feature tile, 128-column group, lane): its 16 bytes are four k-steps of 8
+// values; each becomes the lane's 16-byte bf16 fragment of that k-step (1 KiB per wave and store).
+__global__ __launch_bounds__(256) void unpack_mxfp4_kernel(const raw16* __restrict__ wp4, const unsigned int* __restrict__ scales, raw16* __restrict__ wp,
+                                                           long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const long long tg = i >> 6;  // tile * groups + group
+  const raw16 raw = wp4[i];
+  const unsigned int sc = scales[tg * 16 + (lane & 15)];
+  raw16* dst = wp + (tg * 4) * 64 + lane;  // k-step 4 * group + u of the same tile: 64 fragments further per u
+#pragma unroll
+  for (int u = 0; u < 4; ++u) dst[u * 64] = __builtin_bit_cast(raw16, a_frag4(raw, sc, u));
+}
+
 // Shared epilogue.  Lane holds y[token j*16 + r][feature tile*16 + 4q + e], e = 0..3, in acc[j][e].
 template <int MT, int EPI, bool W8>
 __device__ inline void gemm_epilogue(frag_cd (&acc)[MT], unsigned char* lds_raw, void* __restrict__ out, long long tile, int wave, int lane, long long ldy,
@@ -666,6 +681,18 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
     case 16: return wb == 4 ? -1 : (wb == 8 ? dispatch3_wide<16, 8>(epi, nw, a) : dispatch3_wide<16, 16>(epi, nw, a));  // (256-row tiles are not built for MXFP4: callers use 128-row passes)
   }
   return -1;
+}
+
+// MXFP4 packed weights (pack_mxfp4 order: [N/16][K/128][64 lanes][16 B] + E8M0 scale words
+// [N/16][K/128][16 rows]) -> the bf16 fragment order of kv_pack_weight ([N/16][K/32][64][8]),
+// exact (e2m1 times a power of two fits in bf16).  Wide steps expand a matrix into a scratch
+// buffer with this and run the bf16 tiled GEMM on it: 0.5 bytes read and 2 written per weight,
+// once per use, instead of one 128-row pass of the streaming kernel per 128 token rows.
+int kv_unpack_mxfp4(const void* Wp4, const void* scales, void* Wp, int N, int K, hipStream_t stream) {
+  if (N <= 0 || K <= 0 || (N & 15) || (K & 127)) return -1;
+  const long long total = (long long)(N >> 4) * (K >> 7) * 64;
+  hipLaunchKernelGGL(unpack_mxfp4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const raw16*)Wp4, (const unsigned int*)scales, (raw16*)Wp, total);
+  return (int)hipGetLastError();
 }
 
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream) {

@@ -80,6 +80,7 @@ class PackedLinear:
             if k % 256:
                 raise ValueError(f"in_features {k} must be a multiple of 256 for MXFP4 weights")
             self.wp, self.wscale = pack_mxfp4(*quantize_mxfp4(w))
+            _reserve_w4_scratch(w.device, n_pad * k)
         elif fp8:
             from kvmini.models.llama import quantize_fp8_rows
 
@@ -114,6 +115,38 @@ def pack_mxfp4(codes: torch.Tensor, scales: torch.Tensor) -> Tuple[torch.Tensor,
     sc = scales.view(n // 16, 16, k // 128, 4).permute(0, 2, 1, 3).contiguous().to(torch.int32)  # tile, group, row, u
     words = sc[..., 0] | (sc[..., 1] << 8) | (sc[..., 2] << 16) | (sc[..., 3] << 24)
     return packed, words.contiguous()
+
+
+# Wide steps (more than 128 token rows) with MXFP4 weights: the matrix is expanded, exactly, into a
+# bf16 scratch buffer in the packed fragment order and the bf16 tiled GEMM runs on that — one
+# streaming pass (0.5 bytes read, 2 written per weight) instead of one 128-row pass of the
+# streaming kernel per 128 token rows (2048-token prompt, Llama-3-8B: 180 ms that way).  One buffer
+# per device, sized for the largest matrix at packing time (nothing is allocated during a step);
+# matrices above the cap (an LM head: wide steps need logits for a few rows only) keep the passes.
+_W4_SCRATCH_MAX_ELEMS = 256 * 1024 * 1024  # 512 MiB of bf16
+_w4_scratch: Dict[torch.device, torch.Tensor] = {}
+
+
+def _reserve_w4_scratch(device: torch.device, elems: int) -> None:
+    if elems > _W4_SCRATCH_MAX_ELEMS:
+        return
+    cur = _w4_scratch.get(device)
+    if cur is None or cur.numel() < elems:
+        _w4_scratch[device] = torch.empty(elems, dtype=torch.bfloat16, device=device)
+
+
+class _ExpandedView:
+    """What the tiled GEMM needs to know of a weight: a PackedLinear's MXFP4 matrix expanded to bf16."""
+
+    __slots__ = ("wp", "n", "k", "n_pad", "wscale", "bits")
+
+    def __init__(self, w: "PackedLinear"):
+        buf = _w4_scratch.get(w.wp.device)
+        elems = w.n_pad * w.k
+        if buf is None or buf.numel() < elems:
+            raise RuntimeError("no MXFP4 expansion buffer was reserved for this matrix")
+        native().unpack_mxfp4(w.wp, w.wscale, buf, w.n_pad, w.k)
+        self.wp, self.n, self.k, self.n_pad, self.wscale, self.bits = buf[:elems], w.n, w.k, w.n_pad, None, 16
 
 
 Weight = Union[torch.Tensor, PackedLinear]
@@ -279,7 +312,7 @@ def _plan_wide(m: int, n_pad: int, k: int, fp8: bool, may_split: bool) -> Tuple[
     return best[1]
 
 
-def _wide(w: PackedLinear, h: Union[torch.Tensor, "Normed"], epi: int, allow_slabs: bool) -> Union[torch.Tensor, "Partial"]:
+def _wide(w: Union[PackedLinear, "_ExpandedView"], h: Union[torch.Tensor, "Normed"], epi: int, allow_slabs: bool) -> Union[torch.Tensor, "Partial"]:
     """More than 128 token rows: the tiled MFMA kernel on the packed weights."""
     C = native()
     ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
@@ -426,8 +459,9 @@ def _plan_slabs_w4(n_pad: int, k: int, rows: int) -> Optional[Tuple[int, int, in
 
 def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_slabs: bool) -> Union[torch.Tensor, Partial]:
     """MXFP4 weights: the deep-pipeline streaming kernel for every row count — up to 64 rows as
-    the bf16 / FP8 path (split-K slabs where that pays), 65..128 rows in one 8-tile pass, more in
-    128-row passes (the tiled GEMM does not read 4-bit weights)."""
+    the bf16 / FP8 path (split-K slabs where that pays), 65..128 rows in one 8-tile pass; more rows
+    run the bf16 tiled GEMM on an exact bf16 expansion of the matrix (``_ExpandedView``), or — for
+    a matrix above the expansion buffer's cap — 128-row passes."""
     C = native()
     ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
     x = h.x if isinstance(h, Normed) else h
@@ -436,6 +470,8 @@ def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow
     m = x.shape[0]
     n_out = w.n_pad // 2 if epi == 2 else w.n_pad
     n_true = w.n // 2 if epi == 2 else w.n
+    if m > 128 and w.k % 64 == 0 and w.n_pad * w.k <= _W4_SCRATCH_MAX_ELEMS:
+        return _wide(_ExpandedView(w), h, epi, allow_slabs)
     if m > 128:
         out = torch.empty((m, n_true), dtype=torch.bfloat16, device=x.device)
         for r0 in range(0, m, 128):

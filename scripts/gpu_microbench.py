@@ -341,7 +341,10 @@ def prefill_bench(out, model):
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
 
-    for mode, budget in ((None, 256), (None, 1024), (None, 2048), ("fp8", 1024), ("fp8", 2048)):
+    modes = ((None, 256), (None, 1024), (None, 2048), ("fp8", 1024), ("fp8", 2048), ("mxfp4", 2048))
+    if os.environ.get("PREFILL_MODES"):  # "mode:budget,..." with mode in bf16 / fp8 / mxfp4
+        modes = tuple((None if m == "bf16" else m, int(b)) for m, b in (x.split(":") for x in os.environ["PREFILL_MODES"].split(",")))
+    for mode, budget in modes:
         eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=budget, max_model_len=4096, kernels="hip", kv_memory_fraction=0.2, quantization=mode))
         eng.warmup()
         res = {}

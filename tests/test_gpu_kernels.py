@@ -1588,6 +1588,37 @@ def test_stream_gemm3_two_feature_tiles_per_wave(C, M, bits, nw, nb):
 
 
 @pytest.mark.gpu
+def test_mxfp4_expansion_is_the_packed_bf16_weight_bit_for_bit(C):
+    """Wide steps run the bf16 tiled GEMM on an expansion of the MXFP4 matrix: the expansion equals,
+    bit for bit, the dequantised weight packed as a bf16 weight would be (e2m1 x 2^e is exact in
+    bf16), also when the scratch buffer is larger than the matrix; and the 254- and 2048-row
+    shapes of a prompt step match the fp32 reference on the same quantised weights."""
+    from kvmini.models.llama import dequantize_mxfp4, quantize_mxfp4
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(9)
+    N, K = 1000, 1024  # N is padded to 1024 rows of zeros
+    W = (torch.randn(N, K, device=_dev()) * 0.05).bfloat16()
+    W[7] *= 51.0
+    W[:, 96:128] *= 1e-4
+    pw = hip_ops.PackedLinear(W, mxfp4=True)
+    codes, scales = quantize_mxfp4(W)
+    Wdq = dequantize_mxfp4(codes, scales, torch.bfloat16)
+    Wdq = torch.cat((Wdq, torch.zeros(pw.n_pad - N, K, dtype=Wdq.dtype, device=Wdq.device)), 0)
+    want = C.pack_weight(Wdq.contiguous()).view(-1).view(torch.int16)
+    buf = torch.full((pw.n_pad * K + 4096,), 3.0, dtype=torch.bfloat16, device=_dev())
+    C.unpack_mxfp4(pw.wp, pw.wscale, buf, pw.n_pad, K)
+    assert torch.equal(buf[: pw.n_pad * K].view(torch.int16), want)
+    assert (buf[pw.n_pad * K:] == 3.0).all()
+    Wf = dequantize_mxfp4(codes, scales, torch.float32)
+    for M in (254, 2048):
+        x = torch.randn(M, K, device=_dev()).bfloat16()
+        ref = x.float() @ Wf.T
+        y = hip_ops.linear(x, pw)
+        assert y.shape == (M, N) and (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 48, 200])
 def test_stream_gemm_mxfp4_swiglu_and_folded_norm(M):
     from kvmini.models.llama import GU_GROUP, dequantize_mxfp4, quantize_mxfp4
