@@ -1,6 +1,7 @@
 """Numerics of the gfx950 HIP kernels against plain PyTorch / numpy fp32-fp64 references."""
 
 import math
+import random
 import os
 
 import numpy as np
@@ -762,6 +763,53 @@ def test_prefill_attention_tiles_match_reference(rep, nkv, chunks):
     owned = ctx_t > 0
     assert (out[owned].float() - ref[owned].float()).abs().max().item() <= 2.5e-2
     assert (out[~owned] == 7.0).all()
+
+
+@pytest.mark.parametrize("seed,rep,kv8", [(1, 4, False), (2, 4, True), (3, 1, False), (4, 2, False), (5, 8, False), (6, 6, True), (7, 3, True)])
+def test_prefill_attention_random_chunk_layouts(seed, rep, kv8):
+    """Random chunk layouts (starts anywhere, lengths 1..300, continuation chunks of earlier ones,
+    enough tiles that head groups of at most 4 take the 32-query path) against the per-token
+    reference: partial tiles, pairs that are and are not neighbours, passes that end inside a
+    cache block, first steps that already reach the diagonal."""
+    from kvmini.ops import hip_ops, torch_ops
+
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    nkv, hd, bs = 8, 128, 16
+    nh = nkv * rep
+    n_seqs, max_blocks = 6, 40
+    nb = n_seqs * max_blocks + 8
+    bt = torch.randperm(nb, device=_dev())[: n_seqs * max_blocks].view(n_seqs, max_blocks).int()
+    sc = None
+    if kv8:
+        kc, vc = _fp8_cache(nb, nkv, bs, hd, 1), _fp8_cache(nb, nkv, bs, hd, 2)
+        sc = (torch.rand(2, nkv, device=_dev()) + 0.5).contiguous()
+    else:
+        kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
+    rows, tok_seq, ctx, tiles = 0, [], [], []
+    pos = [0] * n_seqs  # a sequence's chunks continue where its last one ended (or skip ahead: a prefix-cache hit)
+    while len(tiles) < 70:
+        seq = rng.randrange(n_seqs)
+        p0 = pos[seq] + rng.choice((0, 0, 0, rng.randrange(0, 50)))
+        n = min(rng.choice((rng.randint(1, 15), rng.randint(16, 48), rng.randint(49, 300))), max_blocks * bs - p0)
+        if n <= 0:
+            continue
+        for off in range(0, n, 16):
+            tiles.append((rows + off, min(16, n - off), p0 + off, seq))
+        tok_seq += [seq] * n
+        ctx += [p0 + j + 1 for j in range(n)]
+        rows += n
+        pos[seq] = p0 + n
+    q = torch.randn(rows, nh, hd, device=_dev()).bfloat16()
+    tok_seq_t = torch.tensor(tok_seq, device=_dev(), dtype=torch.int32)
+    ctx_t = torch.tensor(ctx, device=_dev(), dtype=torch.int32)
+    scale = 1 / math.sqrt(hd)
+    kw = {"kv_scale": sc} if kv8 else {}
+    ref = torch_ops.paged_attention(q, kc, vc, bt, tok_seq_t, ctx_t, scale, **kw)
+    out = torch.zeros((rows, nh * hd), device=_dev(), dtype=torch.bfloat16)
+    hip_ops.prefill_attention(q, kc, vc, bt, torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous(), out, scale, **kw)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref.float()).abs().max().item() <= (4e-2 if kv8 else 2.5e-2)
 
 
 @pytest.mark.parametrize("kv8", [False, True])
