@@ -1325,14 +1325,13 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
                                                                 const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq, int n_tiles,
                                                                 unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e,
                                                                 const float* __restrict__ kv_scale, int order) {
-  constexpr int HD = 128;
   float v_scale = 1.f;
   if constexpr (KV8) {
     scale_log2e *= kv_scale[blockIdx.x];
     v_scale = kv_scale[nkv + blockIdx.x];
   }
-  // [buffer][key][dim] images, swizzled inside each 256-byte row; the bank analysis of the swizzles
-  // assumes rows that start on a multiple of 256 bytes
+  // [slot][key][dim] images (swizzled 256-byte rows on the 16-column path, padded rows on the
+  // 32-column path); the bank analysis of both assumes images that start on a multiple of 256 bytes
   __shared__ __attribute__((aligned(256))) unsigned short v_lds[4 * 32 * PA32_V_RS];  // sized for the 32-column path: padded images, four V slots
   __shared__ __attribute__((aligned(256))) unsigned short k_lds[3 * 32 * PA32_K_RS];
   // Later tiles of a chunk see more keys.  order 0: longest first, so the longest passes do not
