@@ -267,6 +267,21 @@ def test_native_server_json_mode_schema_tools_and_parity_matrix(in_tmp):
                     d = json.loads(line[6:])["choices"]
                     txt += (d[0]["delta"].get("content") or "") if d else ""
         _check_schema_doc(json.loads(txt))
+        # nested: objects in objects, an array of objects, streamed and not — the schema holds at every depth
+        from kvmini.loadgen.schema_check import violation
+
+        rf = {"type": "json_schema", "json_schema": {"name": "order", "schema": NESTED}}
+        r = c.post(url + "/v1/chat/completions", json={"model": "tiny", "messages": msg, "max_tokens": 200, "temperature": 0.8, "response_format": rf})
+        assert r.status_code == 200 and r.json()["choices"][0]["finish_reason"] == "stop"
+        doc = json.loads(r.json()["choices"][0]["message"]["content"])
+        assert violation(doc, NESTED) is None and len(doc["items"]) == 2 and "comment" not in doc, doc
+        txt = ""
+        with c.stream("POST", url + "/v1/chat/completions", json={"model": "tiny", "messages": msg, "max_tokens": 200, "response_format": rf, "stream": True}) as rs:
+            for line in rs.iter_lines():
+                if line.startswith("data: ") and line != "data: [DONE]":
+                    d = json.loads(line[6:])["choices"]
+                    txt += (d[0]["delta"].get("content") or "") if d else ""
+        assert violation(json.loads(txt), NESTED) is None
         # the load generator checks every answer of a schema-carrying run and the analyzer reports the rate
         from kvmini.analysis.reduce import analyze_run
         from kvmini.cluster.backends import FakeBackend
