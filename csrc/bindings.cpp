@@ -25,7 +25,7 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
                        hipStream_t stream);
 int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                          const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
-                         int block_size, float scale, const float* kv_scale, hipStream_t stream);
+                         int block_size, float scale, const float* kv_scale, int quads, hipStream_t stream);
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
@@ -223,8 +223,10 @@ void paged_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::T
 }
 
 // Tiled MFMA attention for prompt chunks; `tiles` is int32 [4, n_tiles]: row0, n, pos0, block-table row
+// quads: the tile list is padded per chunk to a multiple of four tiles, so every aligned group of
+// four is consecutive tiles of one chunk (unused ones last): the 8-wave kernel takes a group each.
 void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tiles, at::Tensor out, double scale,
-                       c10::optional<at::Tensor> kv_scale) {
+                       c10::optional<at::Tensor> kv_scale, bool quads) {
   CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tiles);
   const float* ksc = check_cache(k_cache, v_cache, kv_scale);
   CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tiles);
@@ -234,10 +236,11 @@ void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at:
   TORCH_CHECK(tiles.dim() == 2 && tiles.size(0) == 4, "tiles must be int32 [4, n_tiles]");
   TORCH_CHECK(block_tables.dim() == 2 && out.dim() == 2 && out.size(0) == T && out.size(1) == nh * hd, "bad block_tables/out shape");
   const int64_t n_tiles = tiles.size(1);
+  TORCH_CHECK(!quads || (n_tiles % 4 == 0 && nh / k_cache.size(1) <= 4), "quads: a multiple of four tiles and head groups of at most 4");
   const int* tp = (const int*)tiles.data_ptr();
   check(kv_prefill_attention(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1), tp,
                              tp + n_tiles, tp + 2 * n_tiles, tp + 3 * n_tiles, out.data_ptr(), (int)n_tiles, (int)nh, (int)k_cache.size(1), (int)hd,
-                             (int)k_cache.size(2), (float)scale, ksc, cur_stream()),
+                             (int)k_cache.size(2), (float)scale, ksc, quads ? 1 : 0, cur_stream()),
         "kv_prefill_attention");
 }
 
@@ -759,7 +762,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("paged_attention", &paged_attention, py::arg("q"), py::arg("k_cache"), py::arg("v_cache"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"),
         py::arg("out"), py::arg("scale"), py::arg("kv_scale") = py::none());
   m.def("prefill_attention", &prefill_attention, py::arg("q"), py::arg("k_cache"), py::arg("v_cache"), py::arg("block_tables"), py::arg("tiles"), py::arg("out"),
-        py::arg("scale"), py::arg("kv_scale") = py::none());
+        py::arg("scale"), py::arg("kv_scale") = py::none(), py::arg("quads") = false);
   m.def("decode_attention_fused", &decode_attention_fused, py::arg("slabs"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
         py::arg("v_cache"), py::arg("slot_mapping"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"), py::arg("out"), py::arg("nh"),
         py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4, py::arg("kv_scale") = py::none(), py::arg("n_split") = 1,

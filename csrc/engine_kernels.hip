@@ -1311,6 +1311,260 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
     }
 }
 
+// ---------------------------------------------------------------------------------
+// The 32-column pass in an 8-wave workgroup: two halves (waves 0-3 and 4-7; a SIMD hosts one wave
+// of each) serve two NEIGHBOURING 32-query blocks of one chunk on the SAME K / V images and
+// alternate by construction — while one half is in its matrix phase (S^T of step i+1 and P V of
+// step i-1: 16 MFMAs, the fragment reads, the staging) the other is in its vector phase (the
+// softmax of step i), two workgroup barriers per step, the second half one phase behind the
+// first.  Two independent 4-wave workgroups per CU drift into the SAME phase instead (measured:
+// matrix pipe 39.5 % busy, vector ALU 34.5 %, hardly overlapping); here the phases are
+// complementary whatever the timing, and 512 threads share the staging of a step (one row each).
+// The host hands out groups of four neighbouring tiles of one chunk (tile lists padded per chunk
+// to a multiple of four: `quads`), so a group is up to 64 consecutive queries of one sequence.
+template <int REP, bool KV8>
+__global__ __launch_bounds__(512) void prefill_attention_quads_kernel(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
+                                                                      const void* __restrict__ v_cache, const int* __restrict__ block_tables, int max_blocks_per_seq,
+                                                                      const int* __restrict__ tile_row0, const int* __restrict__ tile_n,
+                                                                      const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq,
+                                                                      unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e,
+                                                                      const float* __restrict__ kv_scale) {
+  static_assert(REP <= 4, "one query head per wave");
+  constexpr int HD = 128, BS = 16, KSTEP = 32;
+  constexpr int K_RS = PA32_K_RS, V_RS = PA32_V_RS;
+  constexpr int K_TILE = KSTEP * K_RS, V_TILE = KSTEP * V_RS;
+  __shared__ __attribute__((aligned(256))) unsigned short v_lds[4 * V_TILE];
+  __shared__ __attribute__((aligned(256))) unsigned short k_lds[3 * K_TILE];
+  const int t0 = 4 * (gridDim.y - 1 - blockIdx.y);  // later groups of a chunk see more keys: longest first
+  const int n_total = tile_n[t0] + tile_n[t0 + 1] + tile_n[t0 + 2] + tile_n[t0 + 3];
+  if (n_total == 0) return;
+  const int row0_wg = tile_row0[t0], pos0_wg = tile_pos0[t0];
+  const int* __restrict__ bt = block_tables + (long long)tile_seq[t0] * max_blocks_per_seq;
+  float v_scale = 1.f;
+  if constexpr (KV8) {
+    scale_log2e *= kv_scale[blockIdx.x];
+    v_scale = kv_scale[nkv + blockIdx.x];
+  }
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, hw = wave & 3;  // which 32-query block, which head of the group
+  const int lr = lane & 31, hi = lane >> 5;
+  const int row0 = row0_wg + 32 * half, pos0 = pos0_wg + 32 * half;
+  const int n_q = n_total - 32 * half < 32 ? n_total - 32 * half : 32;  // <= 0: this half has no queries
+  const int last_key = pos0_wg + n_total - 1;  // of the WORKGROUP: both halves walk the same steps
+  const bool head_on = (REP == 4 || hw < REP) && n_q > 0;
+
+  mfma_ab qa[8];
+  if (head_on) {
+    const int qrow = row0 + (lr < n_q ? lr : n_q - 1);
+    const unsigned short* qp = q + (long long)qrow * q_row_stride + (long long)(g * REP + hw) * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qa[ks] = *reinterpret_cast<const mfma_ab*>(qp + ks * 16);
+  }
+  mfma_cd16 o[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  // staging: thread = 16-byte chunk sv_c of row sv_kr (0..31) of the step; rows 0-15 (first half's
+  // waves) are cache block kb/16, rows 16-31 (second half's) block kb/16 + 1: wave-uniform lookups
+  const int sv_c = tid & 15, sv_kr = tid >> 4;
+  const int k_st = sv_kr * K_RS + sv_c * 8, v_st = sv_kr * V_RS + sv_c * 8;
+  bf16x8 k0, v0;
+  constexpr int ESZ = KV8 ? 1 : 2;
+  const int last_blk = last_key >> 4;
+  const unsigned voff_row = (unsigned)(((sv_kr & 15) * HD + sv_c * 8) * ESZ);
+  const unsigned voff_end = (unsigned)((((sv_kr & 15) < (last_key & 15) ? (sv_kr & 15) : (last_key & 15)) * HD + sv_c * 8) * ESZ);
+  const long long blk_bytes = (long long)nkv * BS * HD * ESZ, head_bytes = (long long)g * BS * HD * ESZ;
+#define BT_LOAD(KB, B)                                   \
+  do {                                                   \
+    const int bi = ((KB) >> 4) + half;                   \
+    B = bt[bi < last_blk ? bi : last_blk];               \
+  } while (0)
+#define KV_LOAD_STEP(KB, B)                                                                   \
+  do {                                                                                        \
+    const int bi = ((KB) >> 4) + half;                                                        \
+    const long long base = (long long)(B) * blk_bytes + head_bytes;                           \
+    const unsigned off = bi < last_blk ? voff_row : voff_end;                                 \
+    k0 = kv_load8_at<KV8>(reinterpret_cast<const char*>(k_cache) + base, off);                \
+    v0 = kv_load8_at<KV8>(reinterpret_cast<const char*>(v_cache) + base, off);                \
+  } while (0)
+#define STAGE_TILES(KSLOT, VSLOT)                                                  \
+  do {                                                                             \
+    *reinterpret_cast<bf16x8*>(k_lds + (KSLOT) * K_TILE + k_st) = k0;               \
+    *reinterpret_cast<bf16x8*>(v_lds + (VSLOT) * V_TILE + v_st) = v0;               \
+  } while (0)
+  const int kf_base = lr * K_RS + hi * 8;
+  const int vq = (lane >> 2) & 3, vp = lane & 3, vodd = (lane >> 4) & 1;
+  const int vf_base = (4 * hi + vq) * V_RS + vodd * 16 + vp * 4;
+  // K fragments are read at the end of a vector phase (the LDS is idle then) for the matrix phase
+  // that follows; V fragments at the start of the matrix phase, landing behind its S^T MFMAs
+#define READ_K_FRAGS(KSLOT)                                                                                           \
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) kf[ks] =                                                           \
+      *reinterpret_cast<const mfma_ab*>(k_lds + (KSLOT) * K_TILE + kf_base + 16 * ks)
+#define READ_V_FRAGS(VSLOT)                                                                                           \
+  do {                                                                                                                \
+    const unsigned short* vt = v_lds + (VSLOT) * V_TILE + vf_base;                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {               \
+      struct { tr_b64 lo, hi; } vf;                                                                                   \
+      vf.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + (16 * s2) * V_RS + 32 * nt));                \
+      vf.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_b64*)(vt + (16 * s2 + 8) * V_RS + 32 * nt));            \
+      va[nt][s2] = __builtin_bit_cast(mfma_ab, vf);                                                                   \
+    }                                                                                                                 \
+  } while (0)
+#define S_MFMAS(ST)                                                                                                   \
+  do {                                                                                                                \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) ST[r] = 0.f;                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) ST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qa[ks], ST, 0, 0, 0); \
+  } while (0)
+#define PV_MFMAS()                                                                                                    \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                   \
+      o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[nt][s2], pb[s2], o[nt], 0, 0, 0)
+  int blk;
+  mfma_cd16 st;        // S^T of the step whose softmax comes next
+  mfma_ab kf[8], pb[2];
+  BT_LOAD(0, blk);
+  KV_LOAD_STEP(0, blk);
+  BT_LOAD(KSTEP, blk);
+  STAGE_TILES(0, 0);
+  KV_LOAD_STEP(KSTEP, blk);
+  BT_LOAD(2 * KSTEP, blk);
+  STAGE_TILES(1, 1);
+  KV_LOAD_STEP(2 * KSTEP, blk);
+  BT_LOAD(3 * KSTEP, blk);
+  STAGE_TILES(2, 2);
+  KV_LOAD_STEP(3 * KSTEP, blk);
+  BT_LOAD(4 * KSTEP, blk);
+  __syncthreads();
+  if (head_on) {
+    READ_K_FRAGS(0);
+    S_MFMAS(st);  // S^T of step 0
+  }
+
+  // vector phase of step kb: the softmax of prefill_attention_tiles32 (EXACT: mask + textbook
+  // form; otherwise the lagging reference) on `st`, leaving P (bf16) in `pb`.  The P V of the
+  // previous step is complete by now, so a re-reference rescales O and l only.
+  constexpr float LAG_LOG2 = 6.f;
+  auto softmax = [&](auto exact_c, int kb) __attribute__((always_inline)) {
+    constexpr bool EXACT = decltype(exact_c)::value;
+    float sc[16];
+    if constexpr (EXACT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = st[r] * scale_log2e;
+      const int lim = pos0 + lr - kb - 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = ((r & 3) + 8 * (r >> 2) <= lim) ? sc[r] : -1e30f;
+    } else {
+      const float neg_ref = -m_run;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = __builtin_fmaf(st[r], scale_log2e, neg_ref);
+    }
+    float mx = fmaxf(fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))),
+                     fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
+    mx = half_rows_max(mx);
+    float up = 0.f;
+    bool move;
+    if constexpr (EXACT) {
+      const float m_new = fmaxf(m_run, mx);
+      up = m_new - m_run;
+      move = __builtin_amdgcn_ballot_w64(up != 0.f) != 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] -= m_new;
+      m_run = m_new;
+    } else {
+      move = __builtin_amdgcn_ballot_w64(mx > LAG_LOG2) != 0;
+    }
+    if (move) {
+      if constexpr (!EXACT) {
+        up = fmaxf(mx, 0.f);
+        m_run += up;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] -= up;
+      }
+      const float corr = __builtin_amdgcn_exp2f(-up);
+      l_run *= corr;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
+    }
+    float pr[16], psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pr[r] = __builtin_amdgcn_exp2f(sc[r]);
+      psum += pr[r];
+    }
+    l_run += psum;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)pr[8 * s2 + j];
+  };
+
+  // A wave alternates: vector phase of step i (softmax on S^T of step i, then the K fragment reads of
+  // step i+1 for its matrix phase — the LDS is idle in this phase, so their latency costs nothing),
+  // barrier, matrix phase of step i (writes the rows of step i+3 into K slot i % 3 and V slot
+  // (i+3) % 4, starts the cache reads of step i+4; reads the V fragments of step i behind S^T of
+  // step i+1, then P V of step i), barrier.  The second half runs one phase behind the first, so
+  // one half's matrix phase always runs beside the other's vector phase.  A K image lives from the
+  // matrix phase that writes it (step - 3) to the vector phases that read it (step - 1): three
+  // slots; a V image until the second half's vector phase of its own step, which runs beside the
+  // first half's matrix phase of that step: four slots.
+  if (half == 1) __syncthreads();
+  int kb = 0, it = 0, ks3 = 0;  // ks3 = it % 3
+  auto step = [&](auto exact_c) __attribute__((always_inline)) {
+    // ---- vector phase
+    if (head_on) {
+      softmax(exact_c, kb);
+      READ_K_FRAGS(ks3 + 1 < 3 ? ks3 + 1 : 0);
+    }
+    __syncthreads();
+    // ---- matrix phase
+    STAGE_TILES(ks3, (it + 3) & 3);
+    KV_LOAD_STEP(kb + 4 * KSTEP, blk);
+    BT_LOAD(kb + 5 * KSTEP, blk);
+    if (head_on) {
+      mfma_ab va[4][2];
+      READ_V_FRAGS(it & 3);
+      S_MFMAS(st);
+      PV_MFMAS();
+    }
+    __syncthreads();
+    ks3 = ks3 + 1 < 3 ? ks3 + 1 : 0;
+    kb += KSTEP;
+    ++it;
+  };
+  // the two forms of the softmax run in loops of their own (one loop with both would pay register
+  // copies where the forms join); every half takes the same number of steps in all
+  if (KSTEP - 1 <= pos0) step(std::true_type{});  // the first step sets the reference: exact
+  while (kb + KSTEP - 1 <= pos0 && kb <= last_key) step(std::false_type{});
+  while (kb <= last_key) step(std::true_type{});
+  if (half == 0) __syncthreads();
+#undef READ_V_FRAGS
+#undef READ_K_FRAGS
+#undef PV_MFMAS
+#undef S_MFMAS
+#undef STAGE_TILES
+#undef KV_LOAD_STEP
+#undef BT_LOAD
+  const float l = half_rows_sum(l_run);
+  if (!head_on || lr >= n_q) return;
+  const float inv = l > 0.f ? v_scale / l : 0.f;
+  unsigned short* op = out + (long long)(row0 + lr) * nh * HD + (long long)(g * REP + hw) * HD + 4 * hi;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+      us4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = f2bf(o[nt][4 * rq + r] * inv);
+      *reinterpret_cast<us4*>(op + 32 * nt + 8 * rq) = w;
+    }
+}
+
 // grid = (kv heads, tile groups): consecutive workgroup ids differ in the kv head, so with the
 // round-robin placement of workgroups on the 8 XCDs every tile of kv head g (when nkv is a
 // multiple of 8) runs on XCD g % 8 and that head's K/V stay in ONE XCD's L2.  A workgroup owns
@@ -1995,11 +2249,33 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
 // n_tiles entries; rows of `out` not covered by a tile are left untouched.
 int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                          const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
-                         int block_size, float scale, const float* kv_scale, hipStream_t stream) {
+                         int block_size, float scale, const float* kv_scale, int quads, hipStream_t stream) {
   if (n_tiles <= 0) return 0;
   if (hd != 128 || block_size != 16 || nh % nkv) return -1;
   const int rep = nh / nkv;
   const float sl = scale * 1.4426950408889634f;
+  if (quads) {
+    // every aligned group of four tiles is consecutive tiles of ONE chunk (the caller pads each
+    // chunk's tiles to a multiple of four with unused ones): the 8-wave kernel, head groups of at most 4
+    if (rep > 4 || (n_tiles & 3)) return -1;
+    dim3 grid(nkv, n_tiles / 4), block(512);
+#define KV_LAUNCH_QUADS(R)                                                                                                                           \
+  if (kv_scale)                                                                                                                                      \
+    hipLaunchKernelGGL((prefill_attention_quads_kernel<R, true>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, k_cache, v_cache,   \
+                       block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, (unsigned short*)out, nh, nkv, sl, kv_scale);        \
+  else                                                                                                                                               \
+    hipLaunchKernelGGL((prefill_attention_quads_kernel<R, false>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, k_cache, v_cache,  \
+                       block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, (unsigned short*)out, nh, nkv, sl, kv_scale)
+    switch (rep) {
+      case 1: KV_LAUNCH_QUADS(1); break;
+      case 2: KV_LAUNCH_QUADS(2); break;
+      case 3: KV_LAUNCH_QUADS(3); break;
+      case 4: KV_LAUNCH_QUADS(4); break;
+      default: return -1;
+    }
+#undef KV_LAUNCH_QUADS
+    return (int)hipGetLastError();
+  }
   // A wave's MFMA tile has 32 columns.  Head groups of at most 4 (one head per wave) fill them with
   // two 16-query tiles per workgroup where the halved grid still fills the chip several times
   // over, and otherwise run one tile per workgroup on the 16-column path; head groups of 5-8 fill

@@ -22,6 +22,7 @@ never wait for their GPU to learn what to run next and steps can be launched ahe
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -190,7 +191,19 @@ class ModelRunner:
         # attention kernel: 16-query tiles (first row, valid queries, first position, block-table
         # row), and a context-length array that is zero for those tokens so that the per-token
         # kernel skips them
+        # With a step budget that can fill the CUs with groups of four tiles (and head groups of at
+        # most 4), every chunk's tiles start at a multiple of four (unused tiles in between), so that
+        # a step deep inside long prompts can run the 8-wave attention kernel, which takes such a
+        # group per workgroup (measured: +5 % at 14 k tokens of context, +10 % at 129 k; behind the
+        # 4-wave kernels near position 0 and on grids that leave CUs idle).  The padded list serves
+        # the other kernels as well: their tile pairs stay aligned.
+        self.quads_min_groups = int(os.environ.get("KVMINI_QUADS_MIN_GROUPS", "256"))  # groups x kv heads a step needs
+        self.quads_min_pos = int(os.environ.get("KVMINI_QUADS_MIN_POS", "8192"))       # first position of every multi-tile chunk
+        self.tile_quads = bool(hasattr(self.ops, "pad_tiles_to_quads") and self.device.type == "cuda" and self.hd == 128 and self.nh // self.nkv <= 4
+                               and (tmax // 64) * self.nkv >= self.quads_min_groups)
         self.max_tiles = tmax // 16 + smax
+        if self.tile_quads:
+            self.max_tiles = (tmax // 16 + 4 * smax + 3) // 4 * 4
         self._off["ctx_decode"] = (off, tmax)
         off += tmax
         self._off["tiles"] = (off, 4 * self.max_tiles)
@@ -287,11 +300,12 @@ class ModelRunner:
         splits = getattr(self.ops, "decode_attention_splits", None)
         return 2 if splits is not None and max_ctx >= self.SPLIT_KV_MIN_CTX and splits(t_pad, self.nkv) > 1 else 1
 
-    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: int = 0) -> torch.Tensor:
+    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: int = 0, quads: bool = False) -> torch.Tensor:
         """The ragged forward pass over the first ``t_pad`` staged tokens; writes
         sampled ids into ``out_ids[:t_pad]`` and returns the logits ``[t_pad, V]``.
         ``decode_only`` (a step kind, see ``self.graphs``): every staged token is the only new token of its sequence, which
-        allows RoPE + KV write + attention to run as one kernel."""
+        allows RoPE + KV write + attention to run as one kernel.  ``quads``: the step's prompt chunks go to
+        the 8-wave attention kernel (see ``tile_quads``)."""
         ops, cfg, w = self.ops, self.cfg, self.w
         tokens = self._dev("tokens", t_pad)
         positions = self._dev("positions", t_pad)
@@ -328,7 +342,7 @@ class ModelRunner:
                 # decode tokens: one workgroup per token; prompt chunks: 16-query MFMA tiles
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self.scale, max_blocks, **kw)
-                ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale, **kw)
+                ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale, **kw, **({"quads": True} if quads else {}))
             else:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks, **kw)
@@ -465,14 +479,15 @@ class ModelRunner:
                 self._graph_pool = g.pool()
             self.graphs[key] = (g, logits)
 
-    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: int = 0) -> torch.Tensor:
-        entry = self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, 0))
+    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: int = 0, quads: bool = False) -> torch.Tensor:
+        # (a step for the 8-wave attention kernel runs eagerly: captured graphs hold the other kernels)
+        entry = None if quads else self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, 0))
         if entry is not None:
             g, logits = entry
             g.replay()
         else:
             with torch.no_grad():
-                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size, decode_only=decode_only)
+                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size, decode_only=decode_only, quads=quads)
         self.steps += 1
         return logits
 
@@ -496,11 +511,11 @@ class ModelRunner:
             if sb.event is not None:
                 sb.event.synchronize()  # the copy that last read this pinned buffer is done
             self.channel.receive(sb.np)
-            t_pad, _n_samples, max_ctx, cmd, dec = (int(v) for v in sb.np[o_h : o_h + 5])
+            t_pad, _n_samples, max_ctx, cmd, dec, quads = (int(v) for v in sb.np[o_h : o_h + 6])
             if cmd == 1:
                 return n
             self.stage_dev.copy_(sb.cpu, non_blocking=True)
-            self._run_staged(t_pad, max_ctx, dec)
+            self._run_staged(t_pad, max_ctx, dec, bool(quads))
             if self.device.type == "cuda":
                 if sb.event is None:
                     sb.event = torch.cuda.Event()
@@ -559,6 +574,7 @@ class ModelRunner:
         o_tok, o_pos, o_slot, o_seq, o_ctx, o_smp = (self._off[k][0] for k in ("tokens", "positions", "slots", "tok_seq", "ctx", "sample_idx"))
         o_cd, o_tl, mt = self._off["ctx_decode"][0], self._off["tiles"][0], self.max_tiles
         n_tiles = 0
+        quad_groups, quad_min_pos = 0, 1 << 30  # groups of four tiles in multi-tile chunks, their shallowest start
         bs = self.block_size
         i = 0
         n_samples = 0
@@ -610,6 +626,13 @@ class ModelRunner:
                 st[o_ctx + i : o_ctx + i + n] = pos + 1
                 st[o_cd + i : o_cd + i + n] = -1  # rows of a prompt chunk: left to the tiled kernel (0 = padding row, zeroed)
                 st[o_fd + i : o_fd + i + n] = 0
+                if self.tile_quads:
+                    while n_tiles % 4:  # the chunk's tiles start a group of four
+                        st[o_tl + mt + n_tiles] = 0
+                        n_tiles += 1
+                    if n > 16:
+                        quad_groups += (n + 63) // 64
+                        quad_min_pos = min(quad_min_pos, p0)
                 for off in range(0, n, 16):
                     st[o_tl + n_tiles], st[o_tl + mt + n_tiles], st[o_tl + 2 * mt + n_tiles], st[o_tl + 3 * mt + n_tiles] = i + off, min(16, n - off), p0 + off, seq.slot
                     n_tiles += 1
@@ -634,13 +657,14 @@ class ModelRunner:
         # plain decoding step: every chunk is one token (no prompt chunk, no drafts to verify)
         decode_only = self.step_kind(t_pad, all(ch.n_tokens == 1 for ch in batch.chunks), max_ctx)
         o_h = self._off["header"][0]
-        st[o_h : o_h + 5] = (t_pad, n_samples, max_ctx, 0, decode_only)
+        quads = int(self.tile_quads and not decode_only and quad_groups * self.nkv >= self.quads_min_groups and quad_min_pos >= self.quads_min_pos)
+        st[o_h : o_h + 6] = (t_pad, n_samples, max_ctx, 0, decode_only, quads)
         if self.channel is not None:
             # every rank runs the same step: hand the staged image to the followers first (host
             # shared memory, see follow()), so that they enqueue it while this rank does
             self.channel.publish(st)
         self.stage_dev.copy_(sb.cpu, non_blocking=True)
-        logits = self._run_staged(t_pad, max_ctx, decode_only)
+        logits = self._run_staged(t_pad, max_ctx, decode_only, bool(quads))
         if sampler is not None:
             sampler(logits, self.out_ids)
         # the ids leave the device right behind the step, before a later launch overwrites them

@@ -25,7 +25,7 @@ from __future__ import annotations
 import functools
 import os
 
-from typing import Any, Dict, Optional, Tuple, Union
+from typing import Any, Dict, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.nn.functional as F
@@ -831,12 +831,31 @@ def supports_prefill_attention(n_heads: int, k_cache: torch.Tensor) -> bool:
 
 
 def prefill_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor, tiles: torch.Tensor, out: torch.Tensor, scale: float,
-                      kv_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      kv_scale: Optional[torch.Tensor] = None, quads: bool = False) -> torch.Tensor:
     """Tiled MFMA causal attention for prompt chunks, written into ``out`` ``[T, nh*hd]``
     in place (rows not covered by a tile keep their content).  ``tiles``: int32
     ``[4, n_tiles]`` = first token row, valid queries (0 = unused), first position,
-    block-table row of each 16-query tile; K/V of the chunk must be in the cache already."""
-    native().prefill_attention(q, k_cache, v_cache, block_tables, tiles, out, scale, kv_scale)
+    block-table row of each 16-query tile; K/V of the chunk must be in the cache already.
+    ``quads``: the list is padded per chunk to a multiple of four tiles (``pad_tiles_to_quads``),
+    so every aligned group of four is consecutive tiles of one chunk: the 8-wave kernel then
+    serves a group (up to 64 queries) per workgroup (head groups of at most 4)."""
+    native().prefill_attention(q, k_cache, v_cache, block_tables, tiles, out, scale, kv_scale, quads)
+    return out
+
+
+def pad_tiles_to_quads(tiles: Sequence[Tuple[int, int, int, int]]) -> list:
+    """``tiles`` (first row, valid queries, first position, block-table row; a chunk's tiles in
+    order) with unused tiles inserted so that every chunk starts at a multiple of four."""
+    out: list = []
+    for k, t in enumerate(tiles):
+        prev = tiles[k - 1] if k else None
+        same_chunk = prev is not None and prev[1] == 16 and t[1] > 0 and t[3] == prev[3] and t[0] == prev[0] + 16 and t[2] == prev[2] + 16
+        if not same_chunk:
+            while len(out) % 4:
+                out.append((0, 0, 0, 0))
+        out.append(tuple(t))
+    while len(out) % 4:
+        out.append((0, 0, 0, 0))
     return out
 
 

@@ -202,10 +202,11 @@ def attn_bench(out):
 
     dev = torch.device("cuda:0")
     nh, nkv, hd, bs = int(os.environ.get("ATTN_HEADS", "32")), 8, 128, 16
-    nb = 4096 // bs + 8
+    ctx = int(os.environ.get("ATTN_CTX", "4096"))  # longest position any shape reaches
+    nb = ctx // bs + 8
     kc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
     vc = (torch.randn(nb, nkv, bs, hd, device=dev) * 0.5).bfloat16()
-    bt = torch.randperm(nb, device=dev)[: 4096 // bs].view(1, -1).int().contiguous()
+    bt = torch.randperm(nb, device=dev)[: ctx // bs].view(1, -1).int().contiguous()
     shapes = ((0, 1024), (1024, 1024), (0, 2048), (2048, 2048))
     if os.environ.get("ATTN_SHAPES"):  # "pos0:queries,..." (a counter run wants one shape only)
         shapes = tuple(tuple(int(v) for v in sh.split(":")) for sh in os.environ["ATTN_SHAPES"].split(","))
@@ -213,9 +214,10 @@ def attn_bench(out):
         q = torch.randn(n, nh, hd, device=dev).bfloat16()
         o = torch.empty(n, nh * hd, device=dev, dtype=torch.bfloat16)
         tiles = torch.tensor([(off, 16, p0 + off, 0) for off in range(0, n, 16)], device=dev, dtype=torch.int32).T.contiguous()
-        t = time_fns({"tiled": lambda: hip_ops.prefill_attention(q, kc, vc, bt, tiles, o, 1 / math.sqrt(hd))}, rounds=10, inner=5)["tiled"]
+        quads = os.environ.get("ATTN_QUADS", "0") == "1"  # the 8-wave kernel (groups of four tiles)
+        t = time_fns({"tiled": lambda: hip_ops.prefill_attention(q, kc, vc, bt, tiles, o, 1 / math.sqrt(hd), quads=quads)}, rounds=10, inner=5)["tiled"]
         flops = 4.0 * hd * nh * sum(p0 + i + 1 for i in range(n))
-        row = {"bench": "prefill_attention", "heads": nh, "pos0": p0, "queries": n, "us": round(t, 1), "TFLOPs": round(flops / t / 1e6, 1)}
+        row = {"bench": "prefill_attention", "quads": quads, "heads": nh, "pos0": p0, "queries": n, "us": round(t, 1), "TFLOPs": round(flops / t / 1e6, 1)}
         print(json.dumps(row), flush=True)
         out.append(row)
 

@@ -585,6 +585,44 @@ def test_engine_wide_prefill_paths_match_oracle(budget):
         ids.append(tok)
 
 
+def test_engine_prompt_steps_on_the_eight_wave_attention_kernel(monkeypatch):
+    """The runner pads every chunk's tiles to groups of four and sends a step to the 8-wave attention
+    kernel when its groups fill the CUs and its chunks start deep enough; with both thresholds
+    lowered a small model takes that path for every multi-tile chunk (a 300-token prompt in 128-token
+    chunks beside a short one and running decodes) and must still follow the dense oracle."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.models.reference import dense_logits
+
+    monkeypatch.setenv("KVMINI_QUADS_MIN_GROUPS", "1")
+    monkeypatch.setenv("KVMINI_QUADS_MIN_POS", "0")
+    cfg = get_config("small-hd128")
+    w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
+    oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
+    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=128, max_model_len=512, num_blocks=256, kernels="hip"), weights=w)
+    eng.warmup()
+    assert eng.runner.tile_quads and eng.runner.max_tiles % 4 == 0
+    calls = {"quads": 0, "other": 0}
+    real = eng.runner.ops.prefill_attention
+
+    def counted(*a, **kw):
+        calls["quads" if kw.get("quads") else "other"] += 1
+        return real(*a, **kw)
+
+    monkeypatch.setattr(eng.runner.ops, "prefill_attention", counted)
+    prompts = [[1] + [(13 * i) % 900 + 20 for i in range(299)], [1, 2, 3], [1] + [(5 * i) % 700 + 30 for i in range(40)]]
+    outs = eng.generate(prompts, SamplingParams(max_tokens=4, ignore_eos=True))
+    assert calls["quads"] > 0
+    for p, out in zip(prompts, outs):
+        ids = list(p)
+        for tok in out:
+            lg = dense_logits(oracle, ids)[-1]
+            top = lg.max().item()
+            assert lg[tok].item() >= top - 0.05 * abs(top) - 0.05
+            ids.append(tok)
+
+
 def test_native_sampler_and_rccl_gather_on_gpu():
     import time
 
@@ -765,8 +803,9 @@ def test_prefill_attention_tiles_match_reference(rep, nkv, chunks):
     assert (out[~owned] == 7.0).all()
 
 
-@pytest.mark.parametrize("seed,rep,kv8", [(1, 4, False), (2, 4, True), (3, 1, False), (4, 2, False), (5, 8, False), (6, 6, True), (7, 3, True)])
-def test_prefill_attention_random_chunk_layouts(seed, rep, kv8):
+@pytest.mark.parametrize("seed,rep,kv8,quads", [(1, 4, False, False), (2, 4, True, False), (3, 1, False, False), (4, 2, False, False), (5, 8, False, False), (6, 6, True, False),
+                                               (7, 3, True, False), (8, 4, False, True), (9, 4, True, True), (10, 1, False, True), (11, 3, True, True), (12, 2, False, True)])
+def test_prefill_attention_random_chunk_layouts(seed, rep, kv8, quads):
     """Random chunk layouts (starts anywhere, lengths 1..300, continuation chunks of earlier ones,
     enough tiles that head groups of at most 4 take the 32-query path) against the per-token
     reference: partial tiles, pairs that are and are not neighbours, passes that end inside a
@@ -807,13 +846,17 @@ def test_prefill_attention_random_chunk_layouts(seed, rep, kv8):
     kw = {"kv_scale": sc} if kv8 else {}
     ref = torch_ops.paged_attention(q, kc, vc, bt, tok_seq_t, ctx_t, scale, **kw)
     out = torch.zeros((rows, nh * hd), device=_dev(), dtype=torch.bfloat16)
-    hip_ops.prefill_attention(q, kc, vc, bt, torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous(), out, scale, **kw)
+    if quads:  # the 8-wave kernel: groups of four neighbouring tiles, chunks padded to a multiple of four
+        tiles = hip_ops.pad_tiles_to_quads(tiles)
+        assert len(tiles) % 4 == 0 and all(t[1] == 0 or t[3] == tiles[4 * (i // 4)][3] for i, t in enumerate(tiles))
+    hip_ops.prefill_attention(q, kc, vc, bt, torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous(), out, scale, quads=quads, **kw)
     assert torch.isfinite(out.float()).all()
     assert (out.float() - ref.float()).abs().max().item() <= (4e-2 if kv8 else 2.5e-2)
 
 
+@pytest.mark.parametrize("quads", [False, True])
 @pytest.mark.parametrize("kv8", [False, True])
-def test_prefill_attention_follows_a_maximum_that_jumps_mid_pass(kv8):
+def test_prefill_attention_follows_a_maximum_that_jumps_mid_pass(kv8, quads):
     """The 32-query path exponentiates against a reference that may lag the running maximum and
     re-references only when a query's scores exceed it by more than 2^6.  On bounded random data
     that branch never fires after the first step, so this case makes it fire: the keys of later
@@ -855,7 +898,9 @@ def test_prefill_attention_follows_a_maximum_that_jumps_mid_pass(kv8):
     ref = torch_ops.paged_attention(q, kc, vc, bt, tok_seq_t, ctx_t, scale, **kw)
     out = torch.zeros((rows, nh * hd), device=_dev(), dtype=torch.bfloat16)
     assert nkv * len(tiles) >= 512  # the 32-query path
-    hip_ops.prefill_attention(q, kc, vc, bt, torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous(), out, scale, **kw)
+    if quads:
+        tiles = hip_ops.pad_tiles_to_quads(tiles)
+    hip_ops.prefill_attention(q, kc, vc, bt, torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous(), out, scale, quads=quads, **kw)
     assert torch.isfinite(out.float()).all()
     assert (out.float() - ref.float()).abs().max().item() <= (4e-2 if kv8 else 2.5e-2)
 
