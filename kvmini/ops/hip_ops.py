@@ -215,7 +215,18 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
 # formats; with random-init or bf16 weights quantised at load there is one 4-bit weight format here
 FOUR_BIT_ALIASES = {"int4": "mxfp4", "awq": "mxfp4", "autoawq": "mxfp4", "gptq": "mxfp4", "fp4": "mxfp4"}
 
-_NUM_CUS = 256
+@functools.lru_cache(maxsize=1)
+def _num_cus() -> int:
+    """Compute units of the device the process runs on: 256 on a whole MI355X, 128 / 64 / 32 inside a
+    DPX / QPX / CPX partition (the GEMM planners count rounds of workgroups over them)."""
+    try:
+        if torch.cuda.is_available():
+            return max(1, int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count))
+    except Exception:  # noqa: BLE001 - a planner must not fail over a device query
+        pass
+    return 256
+
+
 
 
 @functools.lru_cache(maxsize=None)
@@ -229,7 +240,7 @@ def _waves_per_workgroup(n_pad: int) -> int:
         if n_pad % (16 * nw):
             continue
         wgs = n_pad // (16 * nw)
-        eff = wgs / (-(-wgs // _NUM_CUS) * _NUM_CUS)
+        eff = wgs / (-(-wgs // _num_cus()) * _num_cus())
         if eff >= best_eff - 1e-9:
             best, best_eff = nw, max(eff, best_eff)
     return best
@@ -258,7 +269,7 @@ def _plan_slabs(n_pad: int, k: int, m: int = 32, group_cols: int = 256) -> Tuple
                 continue
             seen.add((splits, gps))
             wgs = tiles * splits
-            fill = wgs / (-(-wgs // _NUM_CUS) * _NUM_CUS)
+            fill = wgs / (-(-wgs // _num_cus()) * _num_cus())
             even = ngroups / (splits * gps)  # the longest split sets the time
             cost = 1.0 / (fill * even) + 2.0 * m * splits / k + m / (32.0 * nw)
             if best is None or cost < best[0] - 1e-9:
@@ -302,7 +313,7 @@ def _plan_wide(m: int, n_pad: int, k: int, fp8: bool, may_split: bool) -> Tuple[
             sps = -(-nst // splits)
             if (splits - 1) * sps >= nst:
                 continue
-            rounds = -(-tiles * splits // _NUM_CUS)
+            rounds = -(-tiles * splits // _num_cus())
             t = rounds * (sps * per_stage / 64.0) * (step_us + _WIDE_ROUND_SLOPE.get((bm, bn), 0.0) * rounds) + (2.0 * splits * m * n_pad * 4 / 2.5e6 if splits > 1 else 0.0)
             # token rows of the last tile that are padding still cost MFMAs
             if best is None or t < best[0] - 1e-9:
@@ -447,7 +458,7 @@ def _plan_slabs_w4(n_pad: int, k: int, rows: int) -> Optional[Tuple[int, int, in
         for splits in range(min(ngroups, MAX_SPLITS), 0, -1):
             if ngroups % splits or (wide and ngroups // splits < 2):
                 continue
-            if tiles * splits <= (_NUM_CUS if wide else 384):
+            if tiles * splits <= (_num_cus() if wide else 384):
                 cand = (nw, nb, splits, ngroups // splits, ft)
                 if best is None or (wide and best[0] == 8 and (n_pad // (16 * 8 * ft)) * best[2] < 192 and tiles * splits > (n_pad // (16 * 8 * ft)) * best[2]):
                     best = cand  # 128 rows: 8-wave workgroups unless they leave a quarter of the CUs idle
@@ -505,7 +516,7 @@ def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow
     nw, ft = _waves_per_workgroup(w.n_pad), 1
     if mp == 128 and w.n_pad % 128 == 0:
         wgs1, wgs2 = w.n_pad // (16 * nw), w.n_pad // 128
-        fill = lambda g: g / (-(-g // _NUM_CUS) * _NUM_CUS)  # noqa: E731
+        fill = lambda g: g / (-(-g // _num_cus()) * _num_cus())  # noqa: E731
         if fill(wgs2) >= fill(wgs1) - 1e-9:
             nw, ft = 4, 2
     out = torch.empty((mp, n_out), dtype=torch.bfloat16, device=x.device)
@@ -752,7 +763,7 @@ DECODE_ATTENTION_WAVES = int(os.environ.get("KVMINI_DECODE_WAVES", "0"))
 def _decode_attention_waves(tokens: int, n_kv_heads: int) -> int:
     if DECODE_ATTENTION_WAVES in (4, 8):
         return DECODE_ATTENTION_WAVES
-    return 8 if tokens * n_kv_heads <= _NUM_CUS else 4
+    return 8 if tokens * n_kv_heads <= _num_cus() else 4
 
 
 # Split-KV decode attention: with few (token, kv head) pairs in a step the grid cannot fill the
@@ -774,7 +785,7 @@ def decode_attention_splits(tokens: int, n_kv_heads: int) -> int:
     pairs = tokens * n_kv_heads
     if pairs > SPLIT_KV_MAX_PAIRS:
         return 1
-    return max(1, min(SPLIT_KV_MAX, 8 * _NUM_CUS // pairs))
+    return max(1, min(SPLIT_KV_MAX, 8 * _num_cus() // pairs))
 
 
 _SPLIT_WS_FLOATS = 4 << 20  # 16 MiB: 4096 counters + partials of up to ~4000 (pair, split) combinations of an 8-head group
