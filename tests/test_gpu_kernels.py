@@ -585,18 +585,21 @@ def test_engine_wide_prefill_paths_match_oracle(budget):
         ids.append(tok)
 
 
-def test_engine_prompt_steps_on_the_eight_wave_attention_kernel(monkeypatch):
+@pytest.mark.parametrize("min_pos", ["0", "1000000"])
+def test_engine_prompt_steps_on_the_eight_wave_attention_kernel(monkeypatch, min_pos):
     """The runner pads every chunk's tiles to groups of four and sends a step to the 8-wave attention
     kernel when its groups fill the CUs and its chunks start deep enough; with both thresholds
     lowered a small model takes that path for every multi-tile chunk (a 300-token prompt in 128-token
-    chunks beside a short one and running decodes) and must still follow the dense oracle."""
+    chunks beside a short one and running decodes) and must still follow the dense oracle.  With the
+    position threshold out of reach the tile list is still padded but the other kernels serve it
+    (pairs stay aligned, unused tiles are skipped): the same answers."""
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
     from kvmini.models.llama import get_config, random_weights
     from kvmini.models.reference import dense_logits
 
     monkeypatch.setenv("KVMINI_QUADS_MIN_GROUPS", "1")
-    monkeypatch.setenv("KVMINI_QUADS_MIN_POS", "0")
+    monkeypatch.setenv("KVMINI_QUADS_MIN_POS", min_pos)
     cfg = get_config("small-hd128")
     w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
     oracle = random_weights(cfg, "cuda:0", torch.bfloat16, seed=7)
@@ -613,7 +616,7 @@ def test_engine_prompt_steps_on_the_eight_wave_attention_kernel(monkeypatch):
     monkeypatch.setattr(eng.runner.ops, "prefill_attention", counted)
     prompts = [[1] + [(13 * i) % 900 + 20 for i in range(299)], [1, 2, 3], [1] + [(5 * i) % 700 + 30 for i in range(40)]]
     outs = eng.generate(prompts, SamplingParams(max_tokens=4, ignore_eos=True))
-    assert calls["quads"] > 0
+    assert (calls["quads"] > 0) == (min_pos == "0")  # (steps for the other kernels replay captured graphs: not counted here)
     for p, out in zip(prompts, outs):
         ids = list(p)
         for tok in out:
