@@ -6,8 +6,9 @@ generator checks every answer of a request that carried a schema: the text parse
 document satisfies the parts of JSON Schema that serving runtimes' guided decoding enforces —
 ``type`` (also a list of types), ``required``, ``properties`` (recursively), ``items``,
 ``minItems`` / ``maxItems``, ``enum``, ``const``, with ``$ref`` / ``allOf`` resolved and any
-alternative of ``anyOf`` / ``oneOf`` accepted.  Numeric ranges, string formats and the like are
-not generation constraints and are not checked.
+alternative of ``anyOf`` / ``oneOf`` accepted, and numeric bounds (``minimum`` / ``maximum`` and
+the exclusive forms; the native engine writes unsigned integers, so a lower bound of 0 holds by
+construction and an upper bound is up to the model).  String formats and patterns are not checked.
 """
 
 from __future__ import annotations
@@ -50,6 +51,11 @@ def violation(doc: Any, schema: Any, path: str = "$", root: Any = None) -> Optio
         types = [t] if isinstance(t, str) else list(t)
         if not any(_is_type(doc, x) for x in types):
             return f"{path}: {type(doc).__name__} where {' / '.join(types)} is required"
+    if isinstance(doc, (int, float)) and not isinstance(doc, bool):
+        for key, bad in (("minimum", lambda b: doc < b), ("maximum", lambda b: doc > b), ("exclusiveMinimum", lambda b: doc <= b), ("exclusiveMaximum", lambda b: doc >= b)):
+            bound = schema.get(key)
+            if isinstance(bound, (int, float)) and not isinstance(bound, bool) and bad(bound):
+                return f"{path}: {doc!r} violates {key} {bound!r}"
     if isinstance(doc, dict):
         for k in schema.get("required") or []:
             if k not in doc:

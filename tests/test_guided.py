@@ -554,3 +554,8 @@ def test_schema_check_of_structured_answers():
     assert check_document('{"a":[{"b":1},{"b":1}],"n":null}', nested)[1] and check_document('{"n":2.5}', nested)[1]
     assert "$.a[1].b" in check_document('{"a":[{"b":1},{"b":2}]}', nested)[2]
     assert "$.a[0]" in check_document('{"a":[{}]}', nested)[2]
+    # numeric bounds are checked (a lower bound of 0 holds by construction on the native engine; an upper one may not)
+    bounded = {"type": "object", "properties": {"age": {"type": "integer", "minimum": 0, "maximum": 150}, "p": {"type": "number", "exclusiveMinimum": 0}}}
+    assert check_document('{"age":5,"p":0.5}', bounded)[1]
+    for bad, needle in (('{"age":-1}', "minimum"), ('{"age":200}', "maximum"), ('{"p":0}', "exclusiveMinimum")):
+        assert needle in check_document(bad, bounded)[2]
