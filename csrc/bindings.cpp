@@ -26,6 +26,9 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
 int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                          const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
                          int block_size, float scale, const float* kv_scale, int quads, hipStream_t stream);
+int kv_split_decode_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                              const int* tok_seq, const int* ctx_lens, const int* row_list, int n_rows, void* out, int nh, int nkv, int hd, int block_size, float scale,
+                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, hipStream_t stream);
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
                               void* v_cache, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens,
                               void* out, int T, int nh, int nkv, int hd, int block_size, const float* row_ss, int ss_parts, int h_in, float eps, float scale,
@@ -313,6 +316,34 @@ void decode_attention_fused(at::Tensor slabs, at::Tensor positions, at::Tensor c
                                   out.data_ptr(), (int)T, (int)nh, (int)nkv, (int)hd, (int)k_cache.size(2), ssp, parts, (int)h_in, (float)eps, (float)scale,
                                   (int)waves, ksc, (int)n_split, part_o, part_ml, counters, pfb, pfb ? pfv : nullptr, pfs, cur_stream()),
         "kv_decode_attention_fused");
+}
+
+// Split-KV attention for listed decode rows of a step that also carries prompt chunks (q rotated,
+// keys / values of the step already in the cache).  `rows`: int32 token rows, -1 = unused entry.
+void split_decode_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, at::Tensor rows,
+                            at::Tensor out, double scale, int64_t waves, c10::optional<at::Tensor> kv_scale, int64_t n_split, at::Tensor split_ws) {
+  TORCH_CHECK(waves == 4 || waves == 8, "waves per workgroup must be 4 or 8");
+  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(out); CHECK_CONTIG(out); CHECK_I32(block_tables); CHECK_CONTIG(block_tables);
+  CHECK_I32(tok_seq); CHECK_CONTIG(tok_seq); CHECK_I32(ctx_lens); CHECK_CONTIG(ctx_lens); CHECK_I32(rows); CHECK_CONTIG(rows);
+  const float* ksc = check_cache(k_cache, v_cache, kv_scale);
+  TORCH_CHECK(q.dim() == 3 && q.stride(2) == 1 && q.stride(1) == q.size(2) && q.stride(0) % 8 == 0, "q must be [T, nh, hd] with contiguous heads and 16-byte aligned rows");
+  const int64_t T = q.size(0), nh = q.size(1), hd = q.size(2);
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  const int64_t nkv = k_cache.size(1), n_rows = rows.numel();
+  TORCH_CHECK(block_tables.dim() == 2 && out.dim() == 2 && out.size(0) == T && out.size(1) == nh * hd, "bad block_tables/out shape");
+  TORCH_CHECK(tok_seq.numel() >= T && ctx_lens.numel() >= T, "per-token index tensors shorter than T");
+  TORCH_CHECK(n_split >= 1 && n_split <= 64, "n_split must be in [1, 64]");
+  TORCH_CHECK(n_rows * nkv <= 4096, "split-KV decode attention: at most 4096 (row, kv head) pairs");
+  CHECK_DEV(split_ws); CHECK_CONTIG(split_ws);
+  const int64_t rep = nh / nkv, n_o = n_rows * nkv * n_split * rep * hd, n_ml = n_rows * nkv * n_split * rep * 2;
+  TORCH_CHECK(split_ws.scalar_type() == at::kFloat && split_ws.numel() >= 4096 + n_o + n_ml, "split_ws too small");
+  int* counters = (int*)split_ws.data_ptr();
+  float* part_ml = (float*)split_ws.data_ptr() + 4096;
+  float* part_o = part_ml + n_ml;
+  check(kv_split_decode_attention(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1),
+                                  (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(), (const int*)rows.data_ptr(), (int)n_rows, out.data_ptr(), (int)nh,
+                                  (int)nkv, (int)hd, (int)k_cache.size(2), (float)scale, (int)waves, ksc, (int)n_split, part_o, part_ml, counters, cur_stream()),
+        "kv_split_decode_attention");
 }
 
 void embed_fed(at::Tensor table, at::Tensor tokens, at::Tensor feed, at::Tensor prev_ids, at::Tensor out) {
@@ -763,6 +794,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("out"), py::arg("scale"), py::arg("kv_scale") = py::none());
   m.def("prefill_attention", &prefill_attention, py::arg("q"), py::arg("k_cache"), py::arg("v_cache"), py::arg("block_tables"), py::arg("tiles"), py::arg("out"),
         py::arg("scale"), py::arg("kv_scale") = py::none(), py::arg("quads") = false);
+  m.def("split_decode_attention", &split_decode_attention);
   m.def("decode_attention_fused", &decode_attention_fused, py::arg("slabs"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
         py::arg("v_cache"), py::arg("slot_mapping"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"), py::arg("out"), py::arg("nh"),
         py::arg("row_ss"), py::arg("h_in"), py::arg("eps"), py::arg("scale"), py::arg("waves") = 4, py::arg("kv_scale") = py::none(), py::arg("n_split") = 1,

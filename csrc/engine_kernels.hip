@@ -1650,7 +1650,12 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
 // (a few KB of slabs); only split 0 writes the cache and folds in the token's own key / value.
 constexpr int SPLIT_MIN_BLOCKS = 16;
 
-template <int REP, int NWAVE, bool KV8, bool SPLIT>
+//
+// ATTN (with SPLIT; decode tokens of a step that also carries prompt chunks): phase A is another
+// kernel's work — q arrives rotated (`q_in`, bf16 rows of `q_row_stride` elements) and the token's
+// own key / value are in the cache already, so the walk covers all `ctx` positions and nothing is
+// folded in from LDS.  `row_list` names the token rows to serve (grid.z entries; -1 = none).
+template <int REP, int NWAVE, bool KV8, bool SPLIT, bool ATTN = false>
 __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                                      const int* __restrict__ positions, const float* __restrict__ cos_t,
                                                                      const float* __restrict__ sin_t, void* __restrict__ k_cache,
@@ -1661,8 +1666,10 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
                                                                      const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
                                                                      float scale_log2e, const float* __restrict__ kv_scale,
                                                                      float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ counters,
-                                                                     PrefetchPlan pf) {
+                                                                     PrefetchPlan pf, const unsigned short* __restrict__ q_in = nullptr,
+                                                                     long long q_row_stride = 0, const int* __restrict__ row_list = nullptr) {
   constexpr int HD = 128, BS = 16, HALF = 64, NT = 64 * NWAVE;
+  static_assert(!ATTN || SPLIT, "the attention-only form exists in the split layout");
   if constexpr (!SPLIT) {
     // grid rows past the kv heads: weight prefetch for the output projection (see prefetch_role).
     // A workgroup of this kernel fills a CU's registers, so these run where the step's (token, kv
@@ -1692,8 +1699,11 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   // deals round-robin to the 8 XCDs) are the splits of one pair, so that a lone long sequence
   // is streamed by every XCD; with the token index fastest, a 16-row step whose only live row
   // is row 0 would put all its workgroups on one XCD.
-  const int t = SPLIT ? blockIdx.z : blockIdx.x, g = blockIdx.y;
+  const int t = ATTN ? row_list[blockIdx.z] : SPLIT ? (int)blockIdx.z : (int)blockIdx.x, g = blockIdx.y;
   const int n_z = SPLIT ? (int)gridDim.x : 1;
+  if constexpr (ATTN) {
+    if (t < 0) return;
+  }
   // wave index in a scalar register: block-table reads become scalar loads (see paged_attention_kernel)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int ctx = ctx_lens[t];
@@ -1708,7 +1718,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   }
   // The keys / values of earlier positions do not depend on phase A: each wave loads its
   // first KV block now, so that round trip overlaps the slab loads and the RoPE phase.
-  const int prev = ctx - 1;
+  const int prev = ATTN ? ctx : ctx - 1;
   const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
   const int all_blocks = (prev + BS - 1) / BS;
   int eff = 1, b0 = 0, n_blocks = all_blocks;  // this workgroup walks blocks [b0, n_blocks)
@@ -1725,6 +1735,12 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   KVStage<KV8> st_cur, st_nxt;  // this wave's first block and the one after: two blocks (16 KB of bf16) per wave in flight at any time
   if (b0 + wave < n_blocks) st_cur.load(k_cache, v_cache, ((long long)bt[b0 + wave] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
   if (b0 + wave + NWAVE < n_blocks) st_nxt.load(k_cache, v_cache, ((long long)bt[b0 + wave + NWAVE] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
+  if constexpr (ATTN) {
+    for (int pc = tid; pc < REP * (HD / 8); pc += NT) {
+      const int h = pc >> 4, d0 = (pc & 15) << 3;
+      *reinterpret_cast<bf16x8*>(&xb_lds[h][d0]) = *reinterpret_cast<const bf16x8*>(q_in + (long long)t * q_row_stride + (long long)(g * REP + h) * HD + d0);
+    }
+  } else {
   // likewise the RoPE table row of this token (needed in A.2)
   constexpr int ROT = (REP + 1) * 8;  // (q heads + k) x 8 pieces of 8 dims and their partners
   const int pos = positions[t];
@@ -1801,6 +1817,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       }
     }
   }
+  }  // !ATTN
   __syncthreads();
   // ---- phase B: earlier positions from the cache
   // q stays packed as bf16 pairs (16 registers per head instead of 32) and meets the keys in
@@ -1882,7 +1899,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     st_nxt = st_far;
   }
   // ---- the token's own key / value (wave 0 of split 0; one token group adds the value)
-  if (wave == 0 && z == 0) {
+  if (!ATTN && wave == 0 && z == 0) {
     bf16x2 kp2[16];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -1920,7 +1937,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   }
   __syncthreads();
   const bool direct = !SPLIT || eff == 1;
-  const long long pbase = SPLIT ? ((long long)(t * nkv + g) * n_z) : 0;  // this (token, kv head)'s first partial
+  const int wt = ATTN ? (int)blockIdx.z : t;  // workspace entries go by grid row (listed rows may be any token rows of a wide step)
+  const long long pbase = SPLIT ? ((long long)(wt * nkv + g) * n_z) : 0;  // this (token, kv head)'s first partial
   for (int i = tid; i < REP * HD; i += NT) {
     const int h = i / HD, d = i % HD;
     float m = m_lds[0][h];
@@ -1952,9 +1970,9 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the write-through stores of this wave have completed ...
     __syncthreads();                                        // ... of every wave, before the arrival is counted
     if (tid == 0) {
-      const int arrived = __hip_atomic_fetch_add(counters + t * nkv + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int arrived = __hip_atomic_fetch_add(counters + wt * nkv + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       is_last = arrived == eff - 1;
-      if (is_last) __hip_atomic_store(counters + t * nkv + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      if (is_last) __hip_atomic_store(counters + wt * nkv + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
     __syncthreads();
     if (!is_last) return;
@@ -2373,6 +2391,53 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
 #undef KV_LAUNCH
 #undef KV_LAUNCH_W
 #undef KV_LAUNCH_K
+#undef KV_LAUNCH_S
+  return (int)hipGetLastError();
+}
+
+// Split-KV attention for the decode tokens of a step that also carries prompt chunks: q is rotated
+// and the step's keys / values are in the cache (rope_kv_write ran).  `row_list` (n_rows entries,
+// -1 = unused) names the rows; rows outside the list are not written.
+int kv_split_decode_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                              const int* tok_seq, const int* ctx_lens, const int* row_list, int n_rows, void* out, int nh, int nkv, int hd, int block_size, float scale,
+                              int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, hipStream_t stream) {
+  if (n_rows <= 0) return 0;
+  if (hd != 128 || block_size != 16 || nh % nkv || (waves != 4 && waves != 8) || !row_list) return -1;
+  if (n_split < 1 || n_split > 64 || !part_o || !part_ml || !counters) return -1;
+  const int rep = nh / nkv;
+  const float sl = scale * 1.4426950408889634f;
+  if (rep > 4) waves = 4;
+  const dim3 grid(n_split, nkv, n_rows), block(64 * waves);
+  const PrefetchPlan plan{};
+#define KV_LAUNCH_S(R, W, K8)                                                                                                                                  \
+  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8, true, true>), grid, block, 0, stream, (const float*)nullptr, 0, 0LL, (const int*)nullptr,        \
+                     (const float*)nullptr, (const float*)nullptr, const_cast<void*>(k_cache), const_cast<void*>(v_cache), (const int*)nullptr, block_tables, \
+                     max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, (const float*)nullptr, 0, 0.f, 0.f, sl, kv_scale, part_o, part_ml,   \
+                     counters, plan, (const unsigned short*)q, q_row_stride, row_list)
+#define KV_LAUNCH_W(R, W)     \
+  if (kv_scale) {             \
+    KV_LAUNCH_S(R, W, true);  \
+  } else {                    \
+    KV_LAUNCH_S(R, W, false); \
+  }
+#define KV_LAUNCH(R)                        \
+  if (waves == 8) {                         \
+    KV_LAUNCH_W(R, ((R) <= 4 ? 8 : 4));     \
+  } else {                                  \
+    KV_LAUNCH_W(R, 4);                      \
+  }
+  switch (rep) {
+    case 1: KV_LAUNCH(1); break;
+    case 2: KV_LAUNCH(2); break;
+    case 3: KV_LAUNCH(3); break;
+    case 4: KV_LAUNCH(4); break;
+    case 6: KV_LAUNCH(6); break;
+    case 7: KV_LAUNCH(7); break;
+    case 8: KV_LAUNCH(8); break;
+    default: return -1;
+  }
+#undef KV_LAUNCH
+#undef KV_LAUNCH_W
 #undef KV_LAUNCH_S
   return (int)hipGetLastError();
 }

@@ -208,6 +208,13 @@ class ModelRunner:
         off += tmax
         self._off["tiles"] = (off, 4 * self.max_tiles)
         off += 4 * self.max_tiles
+        # decode tokens with long contexts riding along in a step that also carries prompt chunks:
+        # up to DEC_SPLIT_ROWS of them are listed here (-1 = unused) and served by the split-KV
+        # attention kernel, which spreads each context over many workgroups — the per-token kernel
+        # walks a context with one workgroup per kv head (a 128k-token context: 1.9 ms per layer)
+        self.dec_split_ok = bool(hasattr(self.ops, "split_decode_attention") and self.device.type == "cuda" and self.hd == 128 and self.block_size == 16)
+        self._off["dec_rows"] = (off, self.DEC_SPLIT_ROWS)
+        off += self.DEC_SPLIT_ROWS
         # step header (tensor parallelism: rank 0 broadcasts the whole staging buffer, followers
         # read the step shape from here): t_pad, n_samples, max_ctx, command (0 = run, 1 = stop)
         self._off["header"] = (off, 8)
@@ -293,6 +300,10 @@ class ModelRunner:
     # contexts from this many tokens on take the split-KV variant of a decode-only step (when the
     # step's shape has one: few rows); below it the extra workgroups only cost launch time
     SPLIT_KV_MIN_CTX = 2048
+    # steps that also carry prompt chunks: at most this many decode tokens, the longest context
+    # from DEC_SPLIT_MIN_CTX tokens on (such steps run without a graph)
+    DEC_SPLIT_ROWS = 16  # from ~64 consecutive decode rows on the per-token kernel fills the chip as well (measured equal)
+    DEC_SPLIT_MIN_CTX = int(os.environ.get("KVMINI_DEC_SPLIT_MIN_CTX", "4096"))
 
     def step_kind(self, t_pad: int, decode_only: bool, max_ctx: int) -> int:
         if not decode_only:
@@ -300,7 +311,7 @@ class ModelRunner:
         splits = getattr(self.ops, "decode_attention_splits", None)
         return 2 if splits is not None and max_ctx >= self.SPLIT_KV_MIN_CTX and splits(t_pad, self.nkv) > 1 else 1
 
-    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: int = 0, quads: bool = False) -> torch.Tensor:
+    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: int = 0, quads: bool = False, dec_split: int = 0) -> torch.Tensor:
         """The ragged forward pass over the first ``t_pad`` staged tokens; writes
         sampled ids into ``out_ids[:t_pad]`` and returns the logits ``[t_pad, V]``.
         ``decode_only`` (a step kind, see ``self.graphs``): every staged token is the only new token of its sequence, which
@@ -341,7 +352,11 @@ class ModelRunner:
             elif not decode_only and self._tiled_ok(kc):
                 # decode tokens: one workgroup per token; prompt chunks: 16-query MFMA tiles
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
-                a = ops.paged_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self.scale, max_blocks, **kw)
+                if dec_split:  # few decode tokens, long contexts: split-KV over the listed rows (padding rows stay zero)
+                    a = ops.split_decode_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self._dev("dec_rows", dec_split),
+                                                   torch.zeros((t_pad, self.nh * self.hd), dtype=q.dtype, device=q.device), self.scale, **kw)
+                else:
+                    a = ops.paged_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self.scale, max_blocks, **kw)
                 ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale, **kw, **({"quads": True} if quads else {}))
             else:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
@@ -479,15 +494,15 @@ class ModelRunner:
                 self._graph_pool = g.pool()
             self.graphs[key] = (g, logits)
 
-    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: int = 0, quads: bool = False) -> torch.Tensor:
-        # (a step for the 8-wave attention kernel runs eagerly: captured graphs hold the other kernels)
-        entry = None if quads else self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, 0))
+    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: int = 0, quads: bool = False, dec_split: int = 0) -> torch.Tensor:
+        # (a step for the 8-wave attention kernel or the listed-rows split-KV kernel runs eagerly: captured graphs hold the other kernels)
+        entry = None if quads or dec_split else self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, 0))
         if entry is not None:
             g, logits = entry
             g.replay()
         else:
             with torch.no_grad():
-                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size, decode_only=decode_only, quads=quads)
+                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size, decode_only=decode_only, quads=quads, dec_split=dec_split)
         self.steps += 1
         return logits
 
@@ -511,11 +526,11 @@ class ModelRunner:
             if sb.event is not None:
                 sb.event.synchronize()  # the copy that last read this pinned buffer is done
             self.channel.receive(sb.np)
-            t_pad, _n_samples, max_ctx, cmd, dec, quads = (int(v) for v in sb.np[o_h : o_h + 6])
+            t_pad, _n_samples, max_ctx, cmd, dec, quads, dec_split = (int(v) for v in sb.np[o_h : o_h + 7])
             if cmd == 1:
                 return n
             self.stage_dev.copy_(sb.cpu, non_blocking=True)
-            self._run_staged(t_pad, max_ctx, dec, bool(quads))
+            self._run_staged(t_pad, max_ctx, dec, bool(quads), dec_split)
             if self.device.type == "cuda":
                 if sb.event is None:
                     sb.event = torch.cuda.Event()
@@ -573,6 +588,7 @@ class ModelRunner:
         o_fd = self._off["feed"][0]
         o_tok, o_pos, o_slot, o_seq, o_ctx, o_smp = (self._off[k][0] for k in ("tokens", "positions", "slots", "tok_seq", "ctx", "sample_idx"))
         o_cd, o_tl, mt = self._off["ctx_decode"][0], self._off["tiles"][0], self.max_tiles
+        o_dr, n_dec, dec_max_ctx = self._off["dec_rows"][0], 0, 0
         n_tiles = 0
         quad_groups, quad_min_pos = 0, 1 << 30  # groups of four tiles in multi-tile chunks, their shallowest start
         bs = self.block_size
@@ -605,6 +621,10 @@ class ModelRunner:
                 st[o_seq + i] = seq.slot
                 st[o_ctx + i] = p0 + 1
                 st[o_cd + i] = p0 + 1
+                if n_dec < self.DEC_SPLIT_ROWS:
+                    st[o_dr + n_dec] = i
+                n_dec += 1
+                dec_max_ctx = max(dec_max_ctx, p0 + 1)
                 if ch.sample:
                     st[o_smp + n_samples] = i
                     n_samples += 1
@@ -658,13 +678,18 @@ class ModelRunner:
         decode_only = self.step_kind(t_pad, all(ch.n_tokens == 1 for ch in batch.chunks), max_ctx)
         o_h = self._off["header"][0]
         quads = int(self.tile_quads and not decode_only and quad_groups * self.nkv >= self.quads_min_groups and quad_min_pos >= self.quads_min_pos)
-        st[o_h : o_h + 6] = (t_pad, n_samples, max_ctx, 0, decode_only, quads)
+        # (the header carries the listed rows rounded up to a power of two: fewer rows, more workgroups per context)
+        dec_split = 0
+        if self.dec_split_ok and not decode_only and 0 < n_dec <= self.DEC_SPLIT_ROWS and dec_max_ctx >= self.DEC_SPLIT_MIN_CTX and n_tiles > 0:
+            dec_split = 1 << (n_dec - 1).bit_length()
+        st[o_dr + min(n_dec, self.DEC_SPLIT_ROWS) : o_dr + self.DEC_SPLIT_ROWS] = -1
+        st[o_h : o_h + 7] = (t_pad, n_samples, max_ctx, 0, decode_only, quads, dec_split)
         if self.channel is not None:
             # every rank runs the same step: hand the staged image to the followers first (host
             # shared memory, see follow()), so that they enqueue it while this rank does
             self.channel.publish(st)
         self.stage_dev.copy_(sb.cpu, non_blocking=True)
-        logits = self._run_staged(t_pad, max_ctx, decode_only, bool(quads))
+        logits = self._run_staged(t_pad, max_ctx, decode_only, bool(quads), dec_split)
         if sampler is not None:
             sampler(logits, self.out_ids)
         # the ids leave the device right behind the step, before a later launch overwrites them

@@ -836,6 +836,34 @@ def rope_attention_fused(
     return out
 
 
+def split_decode_attention(
+    q: torch.Tensor,
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    block_tables: torch.Tensor,
+    tok_seq: torch.Tensor,
+    ctx_lens: torch.Tensor,
+    rows: torch.Tensor,
+    out: torch.Tensor,
+    scale: float,
+    kv_scale: Optional[torch.Tensor] = None,
+    n_split: Optional[int] = None,
+) -> torch.Tensor:
+    """Split-KV attention for the decode tokens of a step that also carries prompt chunks:
+    ``rows`` (int32, -1 = unused entry) lists the token rows to serve, ``q`` ``[T, nh, hd]`` is
+    rotated and the step's keys / values are in the cache (:func:`rope_kv_write` ran).  Writes
+    the listed rows of ``out`` ``[T, nh*hd]``; the context of a listed row is spread over up to
+    ``n_split`` workgroups per kv head (None: by the number of listed rows), where
+    :func:`paged_attention` would walk it with one."""
+    n_rows = rows.numel()
+    nh, hd = q.shape[1], q.shape[2]
+    nkv = k_cache.shape[1]
+    ns = decode_attention_splits(n_rows, nkv) if n_split is None else n_split
+    ws = _split_workspace(out.device, 4096 + n_rows * nh * ns * (hd + 2))
+    native().split_decode_attention(q, k_cache, v_cache, block_tables, tok_seq, ctx_lens, rows, out, scale, _decode_attention_waves(n_rows, nkv), kv_scale, ns, ws)
+    return out
+
+
 def supports_prefill_attention(n_heads: int, k_cache: torch.Tensor) -> bool:
     nkv, bs, hd = k_cache.shape[1], k_cache.shape[2], k_cache.shape[3]
     return hd == 128 and bs == 16 and n_heads % nkv == 0 and n_heads // nkv in GQA_RATIOS

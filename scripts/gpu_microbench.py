@@ -410,6 +410,46 @@ def longctx_bench(out, model, lens=(8192, 32768, 131072), kv_dtypes=("auto", "fp
             torch.cuda.empty_cache()
 
 
+def ridealong_bench(out, model, lens=(32768, 131072), kv_dtypes=("auto",)):
+    """A sequence of N tokens keeps decoding while a second N-token prompt is fed in 2048-token
+    chunks: time of the steps that carry both (the first sequence's inter-token time during the
+    other's prefill) and the second prompt's prefill rate — with the decode rows on the split-KV
+    kernel, and (threshold out of reach) on the per-token kernel."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    for kv in kv_dtypes:
+        for plen in lens:
+            for split in (True, False):
+                eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=2, max_batched_tokens=2048, max_model_len=plen + 4096, kernels="hip", kv_memory_fraction=0.6,
+                                             kv_cache_dtype=kv, enable_prefix_caching=False))
+                if not split:
+                    eng.runner.DEC_SPLIT_MIN_CTX = 1 << 30
+                eng.warmup()
+                s1 = eng.make_sequence([1] + [(7 * i) % 5000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=2048, ignore_eos=True))
+                assert eng.scheduler.add(s1) is None
+                while s1.first_token_time is None:
+                    eng.step()
+                for _ in range(4):
+                    eng.step()
+                s2 = eng.make_sequence([1] + [(11 * i) % 5000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=2, ignore_eos=True))
+                assert eng.scheduler.add(s2) is None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = 0
+                while s2.first_token_time is None:
+                    eng.step()
+                    n += 1
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                row = {"bench": "decode_rides_along_with_prefill", "model": model, "kv_cache_dtype": kv, "context_tokens": plen, "decode_rows_on_split_kv": split, "steps": n,
+                       "ms_per_step": round(dt / max(1, n) * 1e3, 2), "second_prompt_prefill_s": round(dt, 3), "second_prompt_tok_per_s": round(plen / dt)}
+                print(json.dumps(row), flush=True)
+                out.append(row)
+                del eng, s1, s2
+                torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="gemm,step")
@@ -438,6 +478,8 @@ def main():
         nw_bench(out, rows=(128, 256))
     if "prefill" in a.what.split(","):
         prefill_bench(out, a.model)
+    if "ridealong" in a.what.split(","):
+        ridealong_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")))
     if "longctx" in a.what.split(","):
         longctx_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")), batch=a.batch if a.batch < 20 else 1)
     if "step" in a.what:

@@ -1602,6 +1602,95 @@ def test_engine_long_context_decode_takes_the_split_kv_graph_and_matches_eager(k
     assert len(short[0]) == 8
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rep,kv8", [(4, False), (8, False), (2, False), (4, True)])
+def test_split_kv_attention_over_listed_rows_matches_the_fp32_reference(rep, kv8):
+    """Decode tokens of a step that also carries prompt chunks: listed rows (any rows of a wide
+    step, -1 entries unused) against fp32 paged attention over the same cache; contexts from one
+    token to 5000; rows outside the list keep their content; repeated launches on one workspace."""
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(13)
+    nkv, hd, bs = 2, 128, 16
+    nh = nkv * rep
+    T = 300
+    live = [0, 7, 64, 129, 255, 299, 33]
+    ctx_of = [1, 17, 5000, 256, 2049, 700, 4097]
+    ctx = torch.full((T,), -1, device=_dev(), dtype=torch.int32)  # prompt rows: not this kernel's
+    ctx[torch.tensor(live, device=_dev())] = torch.tensor(ctx_of, device=_dev(), dtype=torch.int32)
+    n_seq = len(live)
+    max_blocks = 5008 // bs
+    nb = n_seq * max_blocks + 8
+    tok_seq = torch.zeros(T, device=_dev(), dtype=torch.int32)
+    tok_seq[torch.tensor(live, device=_dev())] = torch.arange(n_seq, device=_dev(), dtype=torch.int32)
+    bt = torch.randperm(nb, device=_dev())[: n_seq * max_blocks].view(n_seq, max_blocks).int()
+    sc = torch.tensor([[0.5, 1.5], [1.25, 0.75]], device=_dev()) if kv8 else None
+    if kv8:
+        kc, vc = _fp8_cache(nb, nkv, bs, hd, 1), _fp8_cache(nb, nkv, bs, hd, 2)
+    else:
+        kc, vc = torch.randn(nb, nkv, bs, hd, device=_dev()).bfloat16(), torch.randn(nb, nkv, bs, hd, device=_dev()).bfloat16()
+    qkv = torch.randn(T, (nh + 2 * nkv) * hd, device=_dev()).bfloat16()
+    q = qkv[:, : nh * hd].view(T, nh, hd)  # strided rows, as rope_kv_write returns them
+    scale = 1 / math.sqrt(hd)
+    ref = torch_ops.paged_attention(q.float(), kc, vc, bt, tok_seq, ctx.clamp(min=0), scale, max_blocks, sc)
+    rows = torch.full((16,), -1, device=_dev(), dtype=torch.int32)
+    order = [4, 0, 2, 6, 1, 5, 3]
+    rows[torch.tensor([0, 1, 2, 5, 6, 9, 15], device=_dev())] = torch.tensor([live[i] for i in order], device=_dev(), dtype=torch.int32)
+    for n_split in (None, 1, 5, 32):
+        for _ in range(2):
+            out = torch.full((T, nh * hd), 3.0, device=_dev(), dtype=torch.bfloat16)
+            hip_ops.split_decode_attention(q, kc, vc, bt, tok_seq, ctx, rows, out, scale, kv_scale=sc, n_split=n_split)
+            lv = torch.tensor(live, device=_dev())
+            err = (out[lv].float() - ref[lv].float()).abs().max().item()
+            assert err <= (3e-2 if kv8 else 1.2e-2), (n_split, err)
+            rest = torch.ones(T, dtype=torch.bool, device=_dev()); rest[lv] = False
+            assert bool((out[rest] == 3.0).all())
+    torch.cuda.synchronize()
+    assert int(hip_ops._split_ws[_dev()][:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_engine_decodes_ride_along_with_a_prompt_on_the_split_kv_kernel(kv, monkeypatch):
+    """A 3000-token sequence keeps decoding while another long prompt is fed in chunks: those
+    steps list the decode row for the split-KV kernel (threshold lowered to 2048 tokens here) and
+    the tokens equal those of the per-token kernel (threshold out of reach)."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.ops import hip_ops
+
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=4, max_batched_tokens=256, max_model_len=4096, kernels="hip", kv_cache_dtype=kv, kv_memory_fraction=0.02)
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # noqa: E731
+    first = [1] + [(7 * i) % 900 + 10 for i in range(2999)]
+    second = [1] + [(11 * i) % 900 + 10 for i in range(1499)]
+
+    def run(min_ctx):
+        eng = LLMEngine(EngineConfig(**common), weights=w())
+        eng.runner.DEC_SPLIT_MIN_CTX = min_ctx
+        eng.warmup()
+        calls = []
+        real = hip_ops.split_decode_attention
+        monkeypatch.setattr(hip_ops, "split_decode_attention", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        s1 = eng.make_sequence(first, SamplingParams(max_tokens=40, ignore_eos=True))
+        eng.scheduler.add(s1)
+        while len(s1.output_ids) < 4:
+            eng.step()
+        s2 = eng.make_sequence(second, SamplingParams(max_tokens=8, ignore_eos=True))
+        eng.scheduler.add(s2)  # 1500 tokens at 256 per step: six steps that also carry s1's decode token
+        while eng.scheduler.has_work():
+            eng.step()
+        monkeypatch.setattr(hip_ops, "split_decode_attention", real)
+        return list(s1.output_ids), list(s2.output_ids), len(calls)
+
+    a1, a2, n_a = run(2048)
+    b1, b2, n_b = run(1 << 30)
+    assert n_a >= 5 * get_config("small-hd128").num_layers and n_b == 0, (n_a, n_b)
+    agree = sum(x == y for x, y in zip(a1, b1)) / len(b1)
+    assert agree >= 0.9 and a1[:8] == b1[:8], (agree, a1, b1)
+    assert a2 == b2 or sum(x == y for x, y in zip(a2, b2)) >= 7
+
+
 # ---------------------------------------------------------------- MXFP4 (4-bit) weights
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 32, 64, 20, 100, 128, 300])
