@@ -644,16 +644,26 @@ class ModelRunner:
                 st[o_slot + i : o_slot + i + n] = blk * bs + pos % bs
                 st[o_seq + i : o_seq + i + n] = seq.slot
                 st[o_ctx + i : o_ctx + i + n] = pos + 1
-                st[o_cd + i : o_cd + i + n] = -1  # rows of a prompt chunk: left to the tiled kernel (0 = padding row, zeroed)
                 st[o_fd + i : o_fd + i + n] = 0
-                if self.tile_quads:
+                # A short chunk deep inside a long context (drafts to verify, the tail of a prompt) would be ONE
+                # tile whose workgroup walks the whole context per kv head; as listed rows (each with its own
+                # causal length) the split-KV kernel spreads every row's walk over the chip instead.
+                as_rows = self.dec_split_ok and n <= self.DEC_SPLIT_ROWS and p0 >= self.DEC_SPLIT_MIN_CTX and n_dec + n <= self.DEC_SPLIT_ROWS
+                if as_rows:
+                    st[o_cd + i : o_cd + i + n] = pos + 1
+                    st[o_dr + n_dec : o_dr + n_dec + n] = np.arange(i, i + n, dtype=np.int32)
+                    n_dec += n
+                    dec_max_ctx = max(dec_max_ctx, p0 + n)
+                else:
+                    st[o_cd + i : o_cd + i + n] = -1  # rows of a prompt chunk: left to the tiled kernel (0 = padding row, zeroed)
+                if self.tile_quads and not as_rows:
                     while n_tiles % 4:  # the chunk's tiles start a group of four
                         st[o_tl + mt + n_tiles] = 0
                         n_tiles += 1
                     if n > 16:
                         quad_groups += (n + 63) // 64
                         quad_min_pos = min(quad_min_pos, p0)
-                for off in range(0, n, 16):
+                for off in range(0, 0 if as_rows else n, 16):
                     st[o_tl + n_tiles], st[o_tl + mt + n_tiles], st[o_tl + 2 * mt + n_tiles], st[o_tl + 3 * mt + n_tiles] = i + off, min(16, n - off), p0 + off, seq.slot
                     n_tiles += 1
                 if ch.sample:
@@ -680,7 +690,7 @@ class ModelRunner:
         quads = int(self.tile_quads and not decode_only and quad_groups * self.nkv >= self.quads_min_groups and quad_min_pos >= self.quads_min_pos)
         # (the header carries the listed rows rounded up to a power of two: fewer rows, more workgroups per context)
         dec_split = 0
-        if self.dec_split_ok and not decode_only and 0 < n_dec <= self.DEC_SPLIT_ROWS and dec_max_ctx >= self.DEC_SPLIT_MIN_CTX and n_tiles > 0:
+        if self.dec_split_ok and not decode_only and 0 < n_dec <= self.DEC_SPLIT_ROWS and dec_max_ctx >= self.DEC_SPLIT_MIN_CTX:
             dec_split = 1 << (n_dec - 1).bit_length()
         st[o_dr + min(n_dec, self.DEC_SPLIT_ROWS) : o_dr + self.DEC_SPLIT_ROWS] = -1
         st[o_h : o_h + 7] = (t_pad, n_samples, max_ctx, 0, decode_only, quads, dec_split)

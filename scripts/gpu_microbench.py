@@ -450,6 +450,41 @@ def ridealong_bench(out, model, lens=(32768, 131072), kv_dtypes=("auto",)):
                 torch.cuda.empty_cache()
 
 
+def deepspec_bench(out, model, lens=(32768,), kv_dtypes=("auto",)):
+    """Speculative decoding (self-drafting, 4 layers, 3 proposals) N tokens into a sequence: ms per
+    verification step with the chunk's rows on the split-KV kernel and, threshold out of reach,
+    as one tile of the prompt attention kernel."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    for kv in kv_dtypes:
+        for plen in lens:
+            for split in (True, False):
+                eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=2, max_batched_tokens=2048, max_model_len=plen + 4096, kernels="hip", kv_memory_fraction=0.5,
+                                             kv_cache_dtype=kv, enable_prefix_caching=False, draft_model="self:4", num_speculative_tokens=3))
+                if not split:
+                    eng.runner.DEC_SPLIT_MIN_CTX = 1 << 30
+                eng.warmup()
+                s1 = eng.make_sequence([1] + [(7 * i) % 5000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=64, ignore_eos=True))
+                assert eng.scheduler.add(s1) is None
+                while s1.first_token_time is None:
+                    eng.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = 0
+                while eng.scheduler.has_work():
+                    eng.step()
+                    n += 1
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                row = {"bench": "speculative_verification_deep_in_context", "model": model, "kv_cache_dtype": kv, "context_tokens": plen, "rows_on_split_kv": split, "steps": n,
+                       "ms_per_step": round(dt / max(1, n) * 1e3, 2), "tokens": len(s1.output_ids), "ms_per_token": round(dt / max(1, len(s1.output_ids) - 1) * 1e3, 2)}
+                print(json.dumps(row), flush=True)
+                out.append(row)
+                del eng, s1
+                torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="gemm,step")
@@ -478,6 +513,8 @@ def main():
         nw_bench(out, rows=(128, 256))
     if "prefill" in a.what.split(","):
         prefill_bench(out, a.model)
+    if "deepspec" in a.what.split(","):
+        deepspec_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")))
     if "ridealong" in a.what.split(","):
         ridealong_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")))
     if "longctx" in a.what.split(","):

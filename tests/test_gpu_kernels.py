@@ -1691,6 +1691,41 @@ def test_engine_decodes_ride_along_with_a_prompt_on_the_split_kv_kernel(kv, monk
     assert a2 == b2 or sum(x == y for x, y in zip(a2, b2)) >= 7
 
 
+@pytest.mark.gpu
+def test_short_chunks_deep_in_a_context_are_served_as_listed_rows(monkeypatch):
+    """Speculative verification (three positions per step) 3000 tokens into a sequence: the chunk is
+    listed row by row for the split-KV kernel (each row with its own causal length) instead of one
+    tile whose workgroup walks the context alone; tokens equal those of the tiled path."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.ops import hip_ops
+
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=4, max_batched_tokens=512, max_model_len=4096, kernels="hip", kv_memory_fraction=0.02,
+                  draft_model="small-hd128-draft", num_speculative_tokens=2)
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # noqa: E731
+    prompts = [[1] + [(7 * i) % 900 + 10 for i in range(2999)]]
+    params = SamplingParams(max_tokens=24, ignore_eos=True)
+
+    def run(min_ctx):
+        eng = LLMEngine(EngineConfig(**common), weights=w())
+        eng.runner.DEC_SPLIT_MIN_CTX = min_ctx
+        eng.warmup()
+        calls = []
+        real = hip_ops.split_decode_attention
+        monkeypatch.setattr(hip_ops, "split_decode_attention", lambda *a, **k: (calls.append(int(a[6].numel())), real(*a, **k))[1])
+        out = eng.generate(prompts, params)
+        monkeypatch.setattr(hip_ops, "split_decode_attention", real)
+        return out[0], calls, eng.stats.spec_proposed
+
+    a, calls_a, prop = run(2048)
+    b, calls_b, _ = run(1 << 30)
+    assert prop > 0 and calls_a and not calls_b
+    assert set(calls_a) <= {1, 2, 4}, set(calls_a)  # three rows per verification, rounded up to four
+    agree = sum(x == y for x, y in zip(a, b)) / len(b)
+    assert len(a) == len(b) and agree >= 0.9 and a[:8] == b[:8], (agree, a, b)
+
+
 # ---------------------------------------------------------------- MXFP4 (4-bit) weights
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 32, 64, 20, 100, 128, 300])
