@@ -771,7 +771,7 @@ def _decode_attention_waves(tokens: int, n_kv_heads: int) -> int:
 # alone: 8 workgroups, 0.28 TB/s).  Such steps run several workgroups per pair, each over a
 # contiguous part of the context (the kernel uses fewer for short contexts), merged by the last
 # one to finish.  The choice depends only on the step's shape, so a captured graph keeps it.
-SPLIT_KV_MAX_PAIRS = 128  # the smallest token bucket (16 rows, padding included) of an 8-kv-head model
+SPLIT_KV_MAX_PAIRS = int(os.environ.get("KVMINI_SPLIT_KV_MAX_PAIRS", "128"))  # 128: the smallest token bucket (16 rows, padding included) of an 8-kv-head model
 SPLIT_KV_MAX = 32
 _split_ws: Dict[Any, torch.Tensor] = {}
 

@@ -378,10 +378,13 @@ def longctx_bench(out, model, lens=(8192, 32768, 131072), kv_dtypes=("auto", "fp
 
     for kv in kv_dtypes:
         for plen in lens:
-            eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=max(2, batch), max_batched_tokens=2048, max_model_len=plen + 64, kernels="hip", kv_memory_fraction=0.6,
+            # (several prompts: the first ones decode while the later ones are fed, so every sequence gets enough
+            # tokens to still be running when the last prompt is in; the decode phase is then timed over 32 steps)
+            extra = 0 if batch == 1 else batch * (plen // 2048 + 2)
+            eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=max(2, batch), max_batched_tokens=2048, max_model_len=plen + 64 + extra, kernels="hip", kv_memory_fraction=0.6,
                                          kv_cache_dtype=kv, enable_prefix_caching=False))
             eng.warmup()
-            seqs = [eng.make_sequence([1] + [(7 * i + 13 * b) % 5000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=33, ignore_eos=True)) for b in range(batch)]
+            seqs = [eng.make_sequence([1] + [(7 * i + 13 * b) % 5000 + 10 for i in range(plen - 1)], SamplingParams(max_tokens=33 + extra, ignore_eos=True)) for b in range(batch)]
             for s_ in seqs:
                 assert eng.scheduler.add(s_) is None
             torch.cuda.synchronize()
@@ -392,17 +395,18 @@ def longctx_bench(out, model, lens=(8192, 32768, 131072), kv_dtypes=("auto", "fp
             t_prefill = time.perf_counter() - t0
             n = 0
             t0 = time.perf_counter()
-            while eng.scheduler.has_work():
+            while eng.scheduler.has_work() and n < 32:
                 eng.step()
                 n += 1
             torch.cuda.synchronize()
             t_dec = (time.perf_counter() - t0) / max(1, n)
+            running = len(eng.scheduler.running)
             r = eng.runner
             per_tok = r.cfg.num_layers * 2 * r.nkv * r.hd * r.kv_cache.element_size()
             # host side of one decode step: staging the image (block tables included) without running it
             batch_obj = None
             row = {"bench": "long_context", "model": model, "kv_cache_dtype": kv, "prompt_tokens": plen, "batch": batch, "prefill_s": round(t_prefill, 3), "prefill_tok_per_s": round(batch * plen / t_prefill),
-                   "decode_ms_per_step": round(t_dec * 1e3, 3), "decode_steps": n, "kv_GB_held": round(batch * plen * per_tok / 1e9, 3), "kv_bytes_per_token": per_tok,
+                   "decode_ms_per_step": round(t_dec * 1e3, 3), "decode_steps": n, "sequences_decoding": running, "kv_GB_held": round(batch * plen * per_tok / 1e9, 3), "kv_bytes_per_token": per_tok,
                    "kv_blocks_total": r.num_blocks, "stage_ints": int(r.stage_dev.numel()), "mem_GB": round(torch.cuda.memory_allocated() / 1e9, 1)}
             print(json.dumps(row), flush=True)
             out.append(row)
@@ -518,7 +522,7 @@ def main():
     if "ridealong" in a.what.split(","):
         ridealong_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")))
     if "longctx" in a.what.split(","):
-        longctx_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")), batch=a.batch if a.batch < 20 else 1)
+        longctx_bench(out, a.model, lens=tuple(int(x) for x in a.lens.split(",")), kv_dtypes=tuple(a.kv_dtypes.split(",")), batch=a.batch if a.batch != 20 else 1)
     if "step" in a.what:
         step_bench(out, a.model, a.batch, a.kernels.split(","), a.quantization)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
