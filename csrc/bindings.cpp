@@ -76,6 +76,14 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
 int kv_prefetch(const void* p, long long bytes, int workgroups, unsigned int* sink, hipStream_t stream);
 int kv_pack_weight_fp8(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_unpack_mxfp4(const void* Wp4, const void* scales, void* Wp, int N, int K, hipStream_t stream);
+int kv_stream_gemm_rowsum(const void* Wp, const void* x, int M, int N, int K, long long ldx, int nb, void* residual, int has_residual, float* ss_out,
+                          const float* w_scale, hipStream_t stream);
+long long kv_decode_layers_workspace_bytes(int H, int nh, int nkv, int I, int s_qkv, int s_proj);
+void kv_decode_layers_layout(int H, int nh, int nkv, int I, int s_qkv, int s_proj, long long* out9);
+long long kv_decode_layers_state_offset(int H, int nh, int nkv, int I, int s_qkv, int s_proj);
+int kv_decode_layers(const void* layers, int n_layers, int T, int H, int nh, int nkv, int I, const int* plans, const int* positions, const float* cos_t,
+                     const float* sin_t, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens, float eps,
+                     float scale, const float* kv_scale, void* residual, float* ss, void* ws, int grid, int timeline, hipStream_t stream);
 int kv_residual_reduce(const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T, int H,
                        const void* pf_base, const long long* pf, unsigned int* pf_sink, hipStream_t stream);
 int kv_add_rmsnorm_slabs(const float* slabs, int n_slabs, long long slab_stride, void* residual, const void* w, void* y, int T, int H, float eps,
@@ -624,6 +632,91 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
         "kv_stream_gemm3");
 }
 
+// residual[M, N] += x[M, K] @ W^T in place (bf16), without slabs: one workgroup per 16-feature tile, K split over
+// its waves.  Returns the per-row sums of squares of the new residual, one per tile: fp32 [M, N / 16].
+at::Tensor stream_gemm_rowsum(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor residual, bool has_residual, c10::optional<at::Tensor> w_scale, int64_t nb) {
+  CHECK_DEV(Wp); CHECK_CONTIG(Wp); CHECK_BF16(x); CHECK_BF16(residual); CHECK_CONTIG(residual);
+  const float* wsp = nullptr;
+  if (w_scale.has_value()) {
+    const at::Tensor& ws = *w_scale;
+    TORCH_CHECK(Wp.scalar_type() == at::kByte, "FP8 weights are passed as uint8 bytes");
+    TORCH_CHECK(ws.is_cuda() && ws.scalar_type() == at::kFloat && ws.is_contiguous() && ws.numel() == N, "w_scale must be contiguous fp32 [N]");
+    wsp = (const float*)ws.data_ptr();
+  } else {
+    CHECK_BF16(Wp);
+  }
+  TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
+  const int64_t M = x.size(0);
+  TORCH_CHECK(M > 0 && M <= 64 && M % 16 == 0, "rows must be 16, 32, 48 or 64");
+  TORCH_CHECK(N % 16 == 0 && K % 1024 == 0, "N must be a multiple of 16 and K of 1024");
+  TORCH_CHECK(residual.dim() == 2 && residual.size(0) == M && residual.size(1) == N, "residual must be bf16 [M, N]");
+  auto ss = at::empty({M, N / 16}, residual.options().dtype(at::kFloat));
+  check(kv_stream_gemm_rowsum(Wp.data_ptr(), x.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), (int)nb, residual.data_ptr(), has_residual ? 1 : 0, (float*)ss.data_ptr(),
+                              wsp, cur_stream()),
+        "kv_stream_gemm_rowsum");
+  return ss;
+}
+
+// ---- persistent decode-layers kernel (csrc/engine_kernels.hip: decode_layers_kernel)
+// Device memory the caches do not hold (hipDeviceMallocUncached), zeroed, as a uint8 tensor: what workgroups of ONE launch
+// exchange across XCDs (each XCD has an L2 of its own) without cache write-backs or invalidates.
+at::Tensor alloc_uncached(int64_t nbytes) {
+  TORCH_CHECK(nbytes > 0, "alloc_uncached: size must be positive");
+  void* p = nullptr;
+  TORCH_CHECK(hipExtMallocWithFlags(&p, (size_t)nbytes, hipDeviceMallocUncached) == hipSuccess && p != nullptr, "hipExtMallocWithFlags(uncached) failed");
+  TORCH_CHECK(hipMemset(p, 0, (size_t)nbytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess, "zeroing the uncached buffer failed");
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return at::from_blob(p, {nbytes}, [](void* q) { (void)hipFree(q); }, at::TensorOptions().dtype(at::kByte).device(at::kCUDA, dev));
+}
+
+int64_t decode_layers_workspace_bytes(int64_t H, int64_t nh, int64_t nkv, int64_t I, int64_t s_qkv, int64_t s_proj) {
+  return kv_decode_layers_workspace_bytes((int)H, (int)nh, (int)nkv, (int)I, (int)s_qkv, (int)s_proj);
+}
+std::vector<int64_t> decode_layers_layout(int64_t H, int64_t nh, int64_t nkv, int64_t I, int64_t s_qkv, int64_t s_proj) {
+  long long v[10];
+  kv_decode_layers_layout((int)H, (int)nh, (int)nkv, (int)I, (int)s_qkv, (int)s_proj, v);
+  return std::vector<int64_t>(v, v + 10);
+}
+int64_t decode_layers_state_offset(int64_t H, int64_t nh, int64_t nkv, int64_t I, int64_t s_qkv, int64_t s_proj) {
+  return kv_decode_layers_state_offset((int)H, (int)nh, (int)nkv, (int)I, (int)s_qkv, (int)s_proj);
+}
+
+// layers: int64 [L, 6] device tensor of pointers (wqkv, wo, wgu, wdown, K cache, V cache per layer); plans: 20 ints (4 x N, K, waves,
+// splits, chunks per split); residual bf16 [T, H] and ss fp32 [T, ceil(H / 512)] are updated in place; ws: alloc_uncached tensor.
+void decode_layers(at::Tensor layers, std::vector<int64_t> plans, int64_t nh, int64_t nkv, int64_t I, at::Tensor positions, at::Tensor cos_t, at::Tensor sin_t,
+                   at::Tensor slot_mapping, at::Tensor block_tables, at::Tensor tok_seq, at::Tensor ctx_lens, double eps, double scale, c10::optional<at::Tensor> kv_scale,
+                   at::Tensor residual, at::Tensor ss, at::Tensor ws, int64_t grid, bool timeline) {
+  CHECK_DEV(layers); CHECK_CONTIG(layers); CHECK_BF16(residual); CHECK_CONTIG(residual); CHECK_DEV(ss); CHECK_CONTIG(ss); CHECK_DEV(ws);
+  CHECK_I32(positions); CHECK_I32(slot_mapping); CHECK_I32(block_tables); CHECK_I32(tok_seq); CHECK_I32(ctx_lens);
+  CHECK_CONTIG(positions); CHECK_CONTIG(slot_mapping); CHECK_CONTIG(block_tables); CHECK_CONTIG(tok_seq); CHECK_CONTIG(ctx_lens); CHECK_CONTIG(cos_t); CHECK_CONTIG(sin_t);
+  TORCH_CHECK(layers.scalar_type() == at::kLong && layers.dim() == 2 && layers.size(1) == 6, "layers must be int64 [L, 6]");
+  TORCH_CHECK(plans.size() == 20, "plans must hold 4 x (N, K, waves, splits, chunks per split)");
+  TORCH_CHECK(residual.dim() == 2 && ss.scalar_type() == at::kFloat, "residual must be [T, H], ss fp32");
+  const int64_t T = residual.size(0), H = residual.size(1);
+  TORCH_CHECK(ss.numel() == T * ((H + 511) / 512), "ss must be [T, ceil(H / 512)]");
+  TORCH_CHECK(positions.numel() >= T && slot_mapping.numel() >= T && tok_seq.numel() >= T && ctx_lens.numel() >= T, "step inputs shorter than T");
+  TORCH_CHECK(cos_t.scalar_type() == at::kFloat && sin_t.scalar_type() == at::kFloat && cos_t.dim() == 2 && cos_t.size(1) == 64 && sin_t.sizes() == cos_t.sizes(),
+              "cos/sin must be float32 [max_pos, 64]");
+  TORCH_CHECK(block_tables.dim() == 2, "block_tables must be [seqs, max_blocks]");
+  int pl[20];
+  for (int i = 0; i < 20; ++i) pl[i] = (int)plans[i];
+  const int s_proj = pl[8] > pl[18] ? pl[8] : pl[18];
+  TORCH_CHECK(ws.scalar_type() == at::kByte && ws.numel() >= kv_decode_layers_workspace_bytes((int)H, (int)nh, (int)nkv, (int)I, pl[3], s_proj), "workspace too small");
+  const float* ksc = nullptr;
+  if (kv_scale.has_value()) {
+    const at::Tensor& k = *kv_scale;
+    TORCH_CHECK(k.is_cuda() && k.scalar_type() == at::kFloat && k.is_contiguous() && k.numel() == layers.size(0) * 2 * nkv, "kv_scale must be fp32 [L, 2, nkv]");
+    ksc = (const float*)k.data_ptr();
+  }
+  check(kv_decode_layers(layers.data_ptr(), (int)layers.size(0), (int)T, (int)H, (int)nh, (int)nkv, (int)I, pl, (const int*)positions.data_ptr(), (const float*)cos_t.data_ptr(),
+                         (const float*)sin_t.data_ptr(), (const int*)slot_mapping.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1),
+                         (const int*)tok_seq.data_ptr(), (const int*)ctx_lens.data_ptr(), (float)eps, (float)scale, ksc, residual.data_ptr(), (float*)ss.data_ptr(),
+                         ws.data_ptr(), (int)grid, timeline ? 1 : 0, cur_stream()),
+        "kv_decode_layers");
+}
+
 // ---- tiled MFMA GEMM for wide token batches (csrc/wide_gemm.hip); same packed weights as the streaming kernels
 int64_t wide_gemm_stage_ksteps(int64_t bm, int64_t bn, int64_t variant) { return kv_wide_gemm_stage_ksteps((int)bm, (int)bn, (int)variant); }
 
@@ -819,6 +912,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_gemm3", &stream_gemm3, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("nb"), py::arg("splits"),
         py::arg("groups_per_split"), py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("nw") = 4, py::arg("weight_bits") = 0,
         py::arg("residual") = py::none(), py::arg("has_residual") = true, py::arg("ss_out") = py::none(), py::arg("counters") = py::none(), py::arg("ft") = 1);
+  m.def("stream_gemm_rowsum", &stream_gemm_rowsum, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("residual"), py::arg("has_residual"),
+        py::arg("w_scale") = py::none(), py::arg("nb") = 2);
+  m.def("alloc_uncached", &alloc_uncached);
+  m.def("decode_layers_workspace_bytes", &decode_layers_workspace_bytes);
+  m.def("decode_layers_state_offset", &decode_layers_state_offset);
+  m.def("decode_layers_layout", &decode_layers_layout);
+  m.def("decode_layers", &decode_layers);
   m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);

@@ -189,6 +189,15 @@ __device__ inline float wave_sum(float v) {
   return v;
 }
 
+// Sum of the `parts` partial sums of squares of one token row, by a whole wave (lane-strided loads
+// + butterfly; every lane gets the total).  Rows carry 8 parts from the residual kernel and
+// hidden/16 from the row-parallel projections that update the residual in their own epilogue.
+__device__ inline float row_ss_total(const float* __restrict__ p, int parts, int lane) {
+  float v = 0.f;
+  for (int i = lane; i < parts; i += 64) v += p[i];
+  return wave_sum(v);
+}
+
 // ---------------------------------------------------------------------------------
 // Weight prefetch beside a latency-bound kernel.  The residual / RMSNorm-statistics kernel and
 // the decode attention kernel at short contexts are chains of dependent loads: HBM idles while
@@ -426,11 +435,7 @@ __global__ __launch_bounds__(64) void rope_kv_write_kernel(unsigned short* __res
   // several CUs instead of one 256-thread loop.
   const int t = blockIdx.x, tid = blockIdx.y * 64 + threadIdx.x;
   float rs = 1.f;  // 1/rms of the row when the preceding RMSNorm was folded into the projection
-  if (row_ss != nullptr) {
-    float ssum = 0.f;
-    for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)t * ss_parts + p];
-    rs = rsqrtf(ssum * inv_h + eps);
-  }
+  if (row_ss != nullptr) rs = rsqrtf(row_ss_total(row_ss + (long long)t * ss_parts, ss_parts, threadIdx.x & 63) * inv_h + eps);
   const int half = hd >> 1;
   const int tasks_per_head = half >> 3;
   const int width = (nh + 2 * nkv) * hd;
@@ -1656,7 +1661,7 @@ constexpr int SPLIT_MIN_BLOCKS = 16;
 // own key / value are in the cache already, so the walk covers all `ctx` positions and nothing is
 // folded in from LDS.  `row_list` names the token rows to serve (grid.z entries; -1 = none).
 template <int REP, int NWAVE, bool KV8, bool SPLIT, bool ATTN = false>
-__global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+__device__ __forceinline__ void decode_attention_body(const int bx, const int by, const int bz, const int gdx, const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                                      const int* __restrict__ positions, const float* __restrict__ cos_t,
                                                                      const float* __restrict__ sin_t, void* __restrict__ k_cache,
                                                                      void* __restrict__ v_cache, const int* __restrict__ slot_mapping,
@@ -1666,24 +1671,14 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
                                                                      const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
                                                                      float scale_log2e, const float* __restrict__ kv_scale,
                                                                      float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ counters,
-                                                                     PrefetchPlan pf, const unsigned short* __restrict__ q_in = nullptr,
-                                                                     long long q_row_stride = 0, const int* __restrict__ row_list = nullptr) {
+                                                                     const unsigned short* __restrict__ q_in,
+                                                                     long long q_row_stride, const int* __restrict__ row_list) {
   constexpr int HD = 128, BS = 16, HALF = 64, NT = 64 * NWAVE;
   static_assert(!ATTN || SPLIT, "the attention-only form exists in the split layout");
-  if constexpr (!SPLIT) {
-    // grid rows past the kv heads: weight prefetch for the output projection (see prefetch_role).
-    // A workgroup of this kernel fills a CU's registers, so these run where the step's (token, kv
-    // head) pairs leave CUs free and queue behind them otherwise.
-    if ((int)blockIdx.y >= nkv) {
-      prefetch_role(pf, ((int)blockIdx.y - nkv) * (int)gridDim.x + (int)blockIdx.x, (int)(blockIdx.y * gridDim.x + blockIdx.x),
-                    __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), NWAVE, (int)threadIdx.x & 63);
-      return;
-    }
-  }
   float inv_ks = 1.f, inv_vs = 1.f, v_scale = 1.f;
   if constexpr (KV8) {
-    const float ks = kv_scale[blockIdx.y];
-    v_scale = kv_scale[nkv + blockIdx.y];
+    const float ks = kv_scale[by];
+    v_scale = kv_scale[nkv + by];
     inv_ks = 1.f / ks;
     inv_vs = 1.f / v_scale;
     scale_log2e *= ks;
@@ -1699,8 +1694,8 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   // deals round-robin to the 8 XCDs) are the splits of one pair, so that a lone long sequence
   // is streamed by every XCD; with the token index fastest, a 16-row step whose only live row
   // is row 0 would put all its workgroups on one XCD.
-  const int t = ATTN ? row_list[blockIdx.z] : SPLIT ? (int)blockIdx.z : (int)blockIdx.x, g = blockIdx.y;
-  const int n_z = SPLIT ? (int)gridDim.x : 1;
+  const int t = ATTN ? row_list[bz] : SPLIT ? bz : bx, g = by;
+  const int n_z = SPLIT ? gdx : 1;
   if constexpr (ATTN) {
     if (t < 0) return;
   }
@@ -1710,7 +1705,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   unsigned short* orow = out + (long long)t * nh * HD + (long long)g * REP * HD;
   // the split index is rotated by the pair index: when short contexts leave only split 0 at work,
   // the working workgroups of consecutive pairs still sit on different XCDs
-  const int z = SPLIT ? (int)((blockIdx.x + (unsigned)(t * nkv + g)) % (unsigned)n_z) : 0;
+  const int z = SPLIT ? (int)((bx + (unsigned)(t * nkv + g)) % (unsigned)n_z) : 0;
   if (ctx <= 0) {  // padding token: no KV write (slot -1), zero output
     if (z == 0)
       for (int i = tid; i < REP * HD; i += NT) orow[i] = 0;
@@ -1757,11 +1752,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   // trip instead of n_slabs), and summed in slab order — the order of the two-kernel path.
   {
     float rs = 1.f;
-    if (row_ss != nullptr) {
-      float ssum = 0.f;
-      for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)t * ss_parts + p];
-      rs = rsqrtf(ssum * inv_h + eps);
-    }
+    if (row_ss != nullptr) rs = rsqrtf(row_ss_total(row_ss + (long long)t * ss_parts, ss_parts, lane) * inv_h + eps);
     const int width = (nh + 2 * nkv) * HD;
     const float* row0 = slabs + (long long)t * width;
     constexpr int PIECES = (REP + 2) * (HD / 4);  // q heads, then k, then v; 32 pieces per row
@@ -1937,7 +1928,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   }
   __syncthreads();
   const bool direct = !SPLIT || eff == 1;
-  const int wt = ATTN ? (int)blockIdx.z : t;  // workspace entries go by grid row (listed rows may be any token rows of a wide step)
+  const int wt = ATTN ? bz : t;  // workspace entries go by grid row (listed rows may be any token rows of a wide step)
   const long long pbase = SPLIT ? ((long long)(wt * nkv + g) * n_z) : 0;  // this (token, kv head)'s first partial
   for (int i = tid; i < REP * HD; i += NT) {
     const int h = i / HD, d = i % HD;
@@ -1967,8 +1958,14 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
   if constexpr (SPLIT) {
     if (direct) return;
     __shared__ int is_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the write-through stores of this wave have completed ...
-    __syncthreads();                                        // ... of every wave, before the arrival is counted
+    // The partial stores are write-through (device scope) but asynchronous: a workgroup-scope release
+    // does not wait for them on this target (it only drains the LDS / scalar counter).  Every wave
+    // therefore waits until its vector-memory counter is zero — the stores have reached memory —
+    // before the barrier, and only then is the arrival counted; the merging workgroup, possibly
+    // on another XCD, can no longer see the full count while a partial is still in flight.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also a compiler barrier: no store may sink below it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
     if (tid == 0) {
       const int arrived = __hip_atomic_fetch_add(counters + wt * nkv + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       is_last = arrived == eff - 1;
@@ -2008,6 +2005,37 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       orow[i] = f2bf(num * v_scale);
     }
   }
+}
+
+// The kernel: one workgroup per (token, kv head[, split]) of the launch grid; grid rows past the kv
+// heads of an unsplit launch are weight-prefetch workgroups (see prefetch_role).  The same body runs
+// as the attention phase of the persistent decode kernel below, one (token, kv head) at a time.
+template <int REP, int NWAVE, bool KV8, bool SPLIT, bool ATTN = false>
+__global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
+                                                                     const int* __restrict__ positions, const float* __restrict__ cos_t,
+                                                                     const float* __restrict__ sin_t, void* __restrict__ k_cache,
+                                                                     void* __restrict__ v_cache, const int* __restrict__ slot_mapping,
+                                                                     const int* __restrict__ block_tables, int max_blocks_per_seq,
+                                                                     const int* __restrict__ tok_seq, const int* __restrict__ ctx_lens,
+                                                                     unsigned short* __restrict__ out, int nh, int nkv,
+                                                                     const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
+                                                                     float scale_log2e, const float* __restrict__ kv_scale,
+                                                                     float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ counters,
+                                                                     PrefetchPlan pf, const unsigned short* __restrict__ q_in = nullptr,
+                                                                     long long q_row_stride = 0, const int* __restrict__ row_list = nullptr) {
+  if constexpr (!SPLIT) {
+    // grid rows past the kv heads: weight prefetch for the output projection (see prefetch_role).
+    // A workgroup of this kernel fills a CU's registers, so these run where the step's (token, kv
+    // head) pairs leave CUs free and queue behind them otherwise.
+    if ((int)blockIdx.y >= nkv) {
+      prefetch_role(pf, ((int)blockIdx.y - nkv) * (int)gridDim.x + (int)blockIdx.x, (int)(blockIdx.y * gridDim.x + blockIdx.x),
+                    __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), NWAVE, (int)threadIdx.x & 63);
+      return;
+    }
+  }
+  decode_attention_body<REP, NWAVE, KV8, SPLIT, ATTN>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, slabs, n_slabs, slab_stride, positions, cos_t, sin_t,
+                                                      k_cache, v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, out, nh, nkv, row_ss,
+                                                      ss_parts, inv_h, eps, scale_log2e, kv_scale, part_o, part_ml, counters, q_in, q_row_stride, row_list);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2072,9 +2100,7 @@ __global__ __launch_bounds__(256) void embed_fed_kernel(const unsigned short* __
 __global__ __launch_bounds__(256) void scale_rows_kernel(const unsigned short* __restrict__ x, const float* __restrict__ row_ss, int ss_parts, float inv_h, float eps,
                                                          unsigned short* __restrict__ y, int H) {
   const int t = blockIdx.x;
-  float ssum = 0.f;
-  for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)t * ss_parts + p];
-  const float rs = rsqrtf(ssum * inv_h + eps);
+  const float rs = rsqrtf(row_ss_total(row_ss + (long long)t * ss_parts, ss_parts, threadIdx.x & 63) * inv_h + eps);
   const bf16x8* src = reinterpret_cast<const bf16x8*>(x + (long long)t * H);
   bf16x8* dst = reinterpret_cast<bf16x8*>(y + (long long)t * H);
   for (int c = threadIdx.x; c < (H >> 3); c += 256) {
@@ -2114,6 +2140,365 @@ int make_prefetch_plan(const void* base, const long long* v, unsigned int* sink,
   if ((gx * nw - 1) * tile_bytes + (gy - 1) * split_bytes + kib * 1024 > bytes) return -1;
   *out = PrefetchPlan{(const unsigned char*)base, (int)gx, (int)gy, (int)nw, (int)kib, tile_bytes, split_bytes, (int)wgs, sink};
   return 0;
+}
+
+
+// =================================================================================================
+// Persistent decode-layers kernel: all decoder layers of a plain decoding step in ONE launch.
+//
+// A decode step of a dense model is one long weight stream (Llama-3-8B: 436 MB per layer) cut into
+// seven dependent kernels per layer; at every cut HBM drains, the next kernel ramps up again, and
+// the latency-bound kernels in between (residual update, decode attention at short contexts) leave
+// it idle altogether — 98 us per layer against 69 us of weight bytes at 6.3 TB/s.  Weights do not
+// depend on activations, so here the cuts become device-wide barriers INSIDE one kernel and every
+// GEMM phase issues the first chunks of its weight ring BEFORE it waits at the barrier in front of
+// it: the bytes are in flight while the flags travel and while the residual phase runs.
+//
+//   * grid = one workgroup of 8 waves per CU (co-resident by LDS size), phases per layer:
+//       QKV GEMM | RoPE + KV write + attention | output GEMM | residual | gate/up GEMM (SwiGLU)
+//       | down GEMM | residual        — 7 barriers per layer.
+//   * GEMM phases are the weight-streaming kernel's loop (csrc/stream_gemm.hip): packed weights
+//     global -> registers in a ring of NB chunks per wave, the x chunk shared through LDS, the
+//     same (waves, K splits) plans, the same fp32 slabs — so every number equals what the
+//     kernel-per-phase path computes, bit for bit.  Work units (feature group, K split) are dealt
+//     round-robin to the workgroups.
+//   * The attention phase is decode_attention_body, one (token, kv head) per workgroup at a time.
+//   * Barrier: workgroup g stores the epoch into flags[g]; thread i of every workgroup polls
+//     flags[i].  No read-modify-write, 2.6 us for 256 workgroups (csrc/tests/grid_barrier_bench.hip).
+//     A poll is bounded by the real-time counter: a workgroup that never arrives makes the launch
+//     finish with an error word set, not hang.
+//   * Coherence: the XCDs' L2 caches are not coherent with each other and a kernel boundary's
+//     write-back / invalidate is gone, so everything one workgroup writes and another reads inside
+//     the launch (slabs, residual stream, attention output, activations, flags) lives in an
+//     UNCACHED allocation: plain loads and stores, complete when vmcnt says so.  The residual stream
+//     enters and leaves through ordinary memory (read by layer 0 only, written by the last layer
+//     only); the KV cache is ordinary memory too (a step's own key / value are used by the
+//     workgroup that wrote them).
+typedef __attribute__((ext_vector_type(8))) __bf16 dl_frag_ab;
+typedef __attribute__((ext_vector_type(4))) float dl_frag_cd;
+typedef __attribute__((ext_vector_type(4))) unsigned int dl_raw16;
+
+struct DlLayer { const void* wqkv; const void* wo; const void* wgu; const void* wdown; void* k_cache; void* v_cache; };
+struct DlGemm { int N, K, nw, splits, cps; };  // cps: chunks of 128 columns per K split
+
+struct DlParams {
+  const DlLayer* layers;
+  int n_layers, T, H, nh, nkv, I;
+  DlGemm qkv, o, gu, down;
+  const int* positions; const float* cos_t; const float* sin_t; const int* slot_mapping; const int* block_tables; int max_blocks_per_seq;
+  const int* tok_seq; const int* ctx_lens;
+  float eps, scale_log2e;
+  const float* kv_scale; int kv_scale_stride;  // FP8 cache: [layers][2][nkv]
+  unsigned short* residual; float* ss;         // ordinary memory: [T][H] bf16, [T][ceil(H/512)] fp32 (in: layer 0 reads; out: last layer writes)
+  // uncached workspace
+  unsigned short* xres; float* ssb; float* qkv_slabs; unsigned short* attn_out; float* proj_slabs; unsigned short* act;
+  unsigned int* flags; unsigned int* state;    // state[0]: epoch reached by the previous launch, state[1]: error word
+  unsigned long long* timeline;                // [layers][16] real-time counter stamps of workgroup 0 (100 MHz), or nullptr
+};
+
+// phase timeline of workgroup 0 (profiling aid: where a layer's time goes, barrier by barrier)
+__device__ __forceinline__ void dl_stamp(const DlParams& p, int li, int idx, int wg, int tid) {
+  if (p.timeline != nullptr && wg == 0 && tid == 0) p.timeline[li * 16 + idx] = __builtin_amdgcn_s_memrealtime();
+}
+
+constexpr unsigned long long DL_SPIN_TICKS = 200000000ull;  // 2 s of the 100 MHz real-time counter
+
+struct DlBarrier {
+  unsigned int* flags; unsigned int* state; unsigned int epoch; int G, wg;
+};
+
+// arrive: this workgroup's stores are complete (every wave waits for its vector-memory counter,
+// then the workgroup barrier), then its flag carries the new epoch
+__device__ __forceinline__ void dl_arrive(DlBarrier& b, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also a compiler barrier: no store may sink below it
+  __syncthreads();
+  b.epoch += 1;
+  if (tid == 0) __hip_atomic_store(b.flags + b.wg, b.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void dl_wait(const DlBarrier& b, int tid, int* dead) {
+  if (tid < b.G && !*dead) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(b.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b.epoch) < 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > DL_SPIN_TICKS) {
+        *dead = 1;
+        atomicOr(b.state + 1, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+}
+
+// residual' = bf16(res_in + bf16(sum of slabs)), sums of squares per 512-column segment: the math of
+// residual_reduce_kernel<true>, one (row, segment) per wave, dealt over the workgroups' waves
+__device__ __forceinline__ void dl_reduce(const float* __restrict__ slabs, int n_slabs, long long slab_stride, const unsigned short* __restrict__ res_in,
+                                          unsigned short* __restrict__ res_out, float* __restrict__ ss_out, int H, int T, int wg, int G, int wave, int lane) {
+  const int parts = (H + 511) / 512;
+  const int n_items = T * parts;
+  for (int item = wg + G * wave; item < n_items; item += G * 8) {
+    const int t = item / parts, p = item - t * parts;
+    const int col = (p * 64 + lane) * 8;
+    float ss = 0.f;
+    if (col < H) {
+      const long long off = (long long)t * H + col;
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      // slabs in groups of 8 (all loads of a group in flight together, summed in slab order): the
+      // weight ring of the next GEMM phase is live in registers while this runs
+      constexpr int GRP = 8;
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(res_in + off);
+      for (int s0 = 0; s0 < n_slabs; s0 += GRP) {
+        f32x4 lo[GRP], hi[GRP];
+#pragma unroll
+        for (int k = 0; k < GRP; ++k)
+          if (s0 + k < n_slabs) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(slabs + (long long)(s0 + k) * slab_stride + off);
+            lo[k] = q[0];
+            hi[k] = q[1];
+          }
+#pragma unroll
+        for (int k = 0; k < GRP; ++k)
+          if (s0 + k < n_slabs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] += lo[k][j]; a[4 + j] += hi[k][j]; }
+          }
+      }
+      bf16x8 c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c[j] = f2bf(bf2f(f2bf(a[j])) + bf2f(b[j]));
+        const float f = bf2f(c[j]);
+        ss += f * f;
+      }
+      *reinterpret_cast<bf16x8*>(res_out + off) = c;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) ss_out[(long long)t * parts + p] = ss;
+  }
+}
+
+// One GEMM phase.  `mid()` runs between the issue of the first unit's first weight chunks and the
+// first use of x: it holds the wait at the barrier in front of the phase (and, where a residual
+// phase sits in between, that phase and its barrier), so the weight bytes travel meanwhile.
+// EPI 1: fp32 slabs out[split][T][N]; EPI 2: SwiGLU, bf16 out[T][N/2] scaled by rs_lds[row].
+template <int MT, int NB, int EPI, typename Mid>
+__device__ __forceinline__ void dl_gemm(const void* __restrict__ Wp, const DlGemm g, const unsigned short* __restrict__ x, long long ldx, void* __restrict__ out,
+                                        const float* rs_lds, dl_frag_ab* xs, unsigned int& seq, int wg, int G, int wave, int lane, Mid&& mid) {
+  constexpr int KS = 4, PD = NB - 1, XF = KS * MT, XL = (XF + 7) / 8;
+  const int r = lane & 15, q = lane >> 4;
+  const int ksteps = g.K >> 5, nchunks = ksteps / KS;
+  const int groups = g.N / (16 * g.nw);
+  const int n_units = groups * g.splits;
+  const bool active = wave < g.nw;
+  const unsigned short* xsrc[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int f = wave + 8 * i;
+    const int ks = (f < XF ? f : 0) / MT, j = (f < XF ? f : 0) % MT;
+    xsrc[i] = x + (long long)(j * 16 + r) * ldx + ks * 32 + q * 8;
+  }
+  dl_raw16 a[NB][KS];
+  dl_frag_ab xr[NB][XL];
+  dl_frag_cd acc[MT];
+
+#define DL_ISSUE_W(slot, chunk)                                                                                                     \
+  do {                                                                                                                              \
+    if (active) {                                                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < KS; ++u) a[slot][u] = __builtin_nontemporal_load(wp + ((long long)(chunk) * KS + u) * 64); \
+    }                                                                                                                               \
+  } while (0)
+#define DL_ISSUE_X(slot, chunk)                                                                                                     \
+  do {                                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + 8 * i < XF)                                                           \
+        xr[slot][i] = *reinterpret_cast<const dl_frag_ab*>(xsrc[i] + (long long)(chunk) * KS * 32);                                 \
+  } while (0)
+#define DL_CONSUME(slot)                                                                                                            \
+  do {                                                                                                                              \
+    const int buf = (int)(seq & 1u);                                                                                                \
+    seq += 1;                                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + 8 * i < XF) xs[(buf * XF + wave + 8 * i) * 64 + lane] = xr[slot][i];  \
+    __syncthreads();                                                                                                                \
+    if (active) {                                                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                                              \
+        const dl_frag_ab af = __builtin_bit_cast(dl_frag_ab, a[slot][u]);                                                           \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                                              \
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xs[(buf * XF + u * MT + j) * 64 + lane], acc[j], 0, 0, 0);         \
+      }                                                                                                                             \
+    }                                                                                                                               \
+  } while (0)
+
+  int unit = wg;
+  bool has = unit < n_units;
+  int fg = has ? unit % groups : 0, sp = has ? unit / groups : 0;
+  long long tile = (long long)fg * g.nw + wave;
+  const dl_raw16* wp = reinterpret_cast<const dl_raw16*>(Wp) + tile * (long long)ksteps * 64 + lane;
+  int c0 = sp * g.cps, c1 = c0 + g.cps < nchunks ? c0 + g.cps : nchunks;
+  if (has) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+      if (c0 + s < c1) DL_ISSUE_W(s, c0 + s);
+  }
+  mid();
+  while (has) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[j] = (dl_frag_cd){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+      if (c0 + s < c1) DL_ISSUE_X(s, c0 + s);
+    int c = c0;
+    for (; c + NB + PD <= c1; c += NB) {
+#pragma unroll
+      for (int s = 0; s < NB; ++s) {
+        DL_ISSUE_X((s + PD) % NB, c + s + PD);
+        DL_ISSUE_W((s + PD) % NB, c + s + PD);
+        DL_CONSUME(s);
+      }
+    }
+    // drain (the macros' own loop variables are i, u, j: the step counter must not be one of them)
+#pragma unroll
+    for (int dstep = 0; dstep < NB + PD - 1; ++dstep) {
+      if (c + dstep < c1) {
+        if (c + dstep + PD < c1) {
+          DL_ISSUE_X((dstep + PD) % NB, c + dstep + PD);
+          DL_ISSUE_W((dstep + PD) % NB, c + dstep + PD);
+        }
+        DL_CONSUME(dstep % NB);
+      }
+    }
+    if (active) {
+      const long long n_base = tile * 16 + q * 4;
+      if constexpr (EPI == 1) {
+        float* o = reinterpret_cast<float*>(out) + (long long)sp * ((long long)(16 * MT) * g.N);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) *reinterpret_cast<dl_frag_cd*>(o + (long long)(j * 16 + r) * g.N + n_base) = acc[j];
+      } else {
+        unsigned short* o = reinterpret_cast<unsigned short*>(out);
+        const long long i_base = tile * 8 + q * 4;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const float rs = rs_lds[j * 16 + r];
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gt = acc[j][e] * rs, up = __shfl_xor(acc[j][e], 32, 64) * rs;
+            v[e] = f2bf(gt / (1.f + __expf(-gt)) * up);
+          }
+          if (q < 2) *reinterpret_cast<bf16x4*>(o + (long long)(j * 16 + r) * (g.N >> 1) + i_base) = v;
+        }
+      }
+    }
+    unit += G;
+    has = unit < n_units;
+    if (has) {  // further units of this workgroup (more units than workgroups): no barrier to hide behind
+      fg = unit % groups; sp = unit / groups;
+      tile = (long long)fg * g.nw + wave;
+      wp = reinterpret_cast<const dl_raw16*>(Wp) + tile * (long long)ksteps * 64 + lane;
+      c0 = sp * g.cps; c1 = c0 + g.cps < nchunks ? c0 + g.cps : nchunks;
+#pragma unroll
+      for (int s = 0; s < PD; ++s)
+        if (c0 + s < c1) DL_ISSUE_W(s, c0 + s);
+    }
+  }
+#undef DL_ISSUE_W
+#undef DL_ISSUE_X
+#undef DL_CONSUME
+}
+
+template <int MT, int REP, bool KV8>
+__global__ __launch_bounds__(512) void decode_layers_kernel(const DlParams p) {
+  constexpr int XF = 4 * MT;
+  __shared__ __attribute__((aligned(16))) dl_frag_ab xs[2 * XF * 64];
+  __shared__ float rs_lds[16 * MT];
+  __shared__ int dead;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wg = blockIdx.x, G = gridDim.x;
+  if (tid == 0) dead = 0;
+  DlBarrier bar{p.flags, p.state, __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), G, wg};
+  unsigned int seq = 0;
+  __syncthreads();
+  const int T = 16 * MT, H = p.H;
+  const int parts = (H + 511) / 512;
+  const int qkv_w = (p.nh + 2 * p.nkv) * 128;
+  const float inv_h = 1.f / (float)H;
+  const unsigned short* xin = p.residual;  // the residual stream a layer starts from
+  const float* ssin = p.ss;
+  for (int li = 0; li < p.n_layers; ++li) {
+    const DlLayer L = p.layers[li];
+    const bool last = li + 1 == p.n_layers;
+    dl_stamp(p, li, 0, wg, tid);
+    // ---- QKV projection: x = residual stream (the row scale 1/rms is applied by the attention phase)
+    dl_gemm<MT, 4, 1>(L.wqkv, p.qkv, xin, H, p.qkv_slabs, nullptr, xs, seq, wg, G, wave, lane, [&]() {
+      if (li > 0) {
+        // the previous layer's down projection has arrived at its barrier just before this phase
+        dl_wait(bar, tid, &dead);
+        dl_stamp(p, li, 1, wg, tid);  // down projection of the previous layer done everywhere
+        dl_reduce(p.proj_slabs, p.down.splits, (long long)T * H, p.xres, p.xres, p.ssb, H, T, wg, G, wave, lane);
+        dl_arrive(bar, tid);
+        dl_wait(bar, tid, &dead);
+        dl_stamp(p, li, 2, wg, tid);  // residual update done everywhere
+      }
+    });
+    dl_stamp(p, li, 3, wg, tid);      // own share of the QKV projection done
+    dl_arrive(bar, tid);
+    dl_wait(bar, tid, &dead);
+    dl_stamp(p, li, 4, wg, tid);      // QKV done everywhere
+    // ---- RoPE + KV write + attention: one (token, kv head) per workgroup at a time
+    {
+      const float* kvs = KV8 ? p.kv_scale + (long long)li * p.kv_scale_stride : nullptr;
+      const int n_items = T * p.nkv;
+      for (int item = wg; item < n_items; item += G) {
+        decode_attention_body<REP, 8, KV8, false, false>(item / p.nkv, item % p.nkv, 0, 1, p.qkv_slabs, p.qkv.splits, (long long)T * qkv_w, p.positions, p.cos_t, p.sin_t,
+                                                         L.k_cache, L.v_cache, p.slot_mapping, p.block_tables, p.max_blocks_per_seq, p.tok_seq, p.ctx_lens,
+                                                         p.attn_out, p.nh, p.nkv, ssin, parts, inv_h, p.eps, p.scale_log2e, kvs, nullptr, nullptr, nullptr, nullptr,
+                                                         0, nullptr);
+        __syncthreads();
+      }
+    }
+    dl_stamp(p, li, 5, wg, tid);      // own attention items done
+    dl_arrive(bar, tid);
+    // ---- output projection
+    dl_gemm<MT, 4, 1>(L.wo, p.o, p.attn_out, (long long)p.nh * 128, p.proj_slabs, nullptr, xs, seq, wg, G, wave, lane, [&]() {
+      dl_wait(bar, tid, &dead);
+      dl_stamp(p, li, 6, wg, tid);    // attention done everywhere
+    });
+    dl_stamp(p, li, 7, wg, tid);      // own share of the output projection done
+    dl_arrive(bar, tid);
+    // ---- gate/up projection + SwiGLU; the residual update of the output projection runs while its first weights travel
+    dl_gemm<MT, 6, 2>(L.wgu, p.gu, p.xres, H, p.act, rs_lds, xs, seq, wg, G, wave, lane, [&]() {
+      dl_wait(bar, tid, &dead);
+      dl_stamp(p, li, 8, wg, tid);    // output projection done everywhere
+      dl_reduce(p.proj_slabs, p.o.splits, (long long)T * H, xin, p.xres, p.ssb, H, T, wg, G, wave, lane);
+      dl_arrive(bar, tid);
+      dl_wait(bar, tid, &dead);
+      dl_stamp(p, li, 9, wg, tid);    // residual update done everywhere
+      for (int row = wave; row < T; row += 8) {
+        const float tot = row_ss_total(p.ssb + (long long)row * parts, parts, lane);
+        if (lane == 0) rs_lds[row] = rsqrtf(tot * inv_h + p.eps);
+      }
+    });
+    dl_stamp(p, li, 10, wg, tid);     // own share of the gate/up projection done
+    dl_arrive(bar, tid);
+    // ---- down projection
+    dl_gemm<MT, 4, 1>(L.wdown, p.down, p.act, p.I, p.proj_slabs, nullptr, xs, seq, wg, G, wave, lane, [&]() {
+      dl_wait(bar, tid, &dead);
+      dl_stamp(p, li, 11, wg, tid);   // gate/up done everywhere
+    });
+    dl_stamp(p, li, 12, wg, tid);     // own share of the down projection done
+    dl_arrive(bar, tid);
+    if (last) {
+      // the step's last residual update leaves through ordinary memory
+      dl_wait(bar, tid, &dead);
+      dl_reduce(p.proj_slabs, p.down.splits, (long long)T * H, p.xres, p.residual, p.ss, H, T, wg, G, wave, lane);
+      dl_arrive(bar, tid);
+      dl_wait(bar, tid, &dead);
+    }
+    xin = p.xres;
+    ssin = p.ssb;
+  }
+  if (wg == 0 && tid == 0) __hip_atomic_store(p.state, bar.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -2469,5 +2854,90 @@ int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t s
   hipLaunchKernelGGL(swiglu_interleaved_kernel, grid, dim3(256), 0, stream, (const unsigned short*)gu, (unsigned short*)act, I);
   return (int)hipGetLastError();
 }
+
+
+// Bytes of the uncached workspace of kv_decode_layers for a model (rows up to 64), and its layout.
+struct DlLayout { long long flags, state, xres, ssb, qkv_slabs, attn_out, proj_slabs, act, timeline, total; };
+static DlLayout dl_layout(int H, int nh, int nkv, int I, int s_qkv, int s_proj) {
+  auto up = [](long long v) { return (v + 255) / 256 * 256; };
+  DlLayout l{};
+  const long long R = 64, parts = (H + 511) / 512;
+  long long off = 0;
+  l.flags = off; off = up(off + 512 * 4);
+  l.state = off; off = up(off + 64);
+  l.xres = off; off = up(off + R * H * 2);
+  l.ssb = off; off = up(off + R * parts * 4);
+  l.qkv_slabs = off; off = up(off + (long long)s_qkv * R * (nh + 2 * nkv) * 128 * 4);
+  l.attn_out = off; off = up(off + R * nh * 128 * 2);
+  l.proj_slabs = off; off = up(off + (long long)s_proj * R * H * 4);
+  l.act = off; off = up(off + R * I * 2);
+  l.timeline = off; off = up(off + 128 * 16 * 8);  // up to 128 layers
+  l.total = off;
+  return l;
+}
+
+long long kv_decode_layers_workspace_bytes(int H, int nh, int nkv, int I, int s_qkv, int s_proj) { return dl_layout(H, nh, nkv, I, s_qkv, s_proj).total; }
+
+// All decoder layers of a plain decoding step (every token the only new one of its sequence) in one
+// persistent launch: see decode_layers_kernel.  layers: device array of n_layers x 6 pointers (packed
+// bf16 wqkv, wo, wgu, wdown, K cache, V cache of the layer); plans: 4 x {N, K, waves, splits, chunks
+// per split} for the QKV, output, gate/up and down projections; residual / ss: the residual stream
+// and its per-row sums of squares (in and out); ws: kv_decode_layers_workspace_bytes of UNCACHED,
+// initially zeroed device memory; grid: workgroups (at most one per CU, at most 512).
+// Returns 0, -1 for shapes outside the kernel's set.  ws word [state + 4] is non-zero after a launch
+// whose barrier timed out.
+int kv_decode_layers(const void* layers, int n_layers, int T, int H, int nh, int nkv, int I, const int* plans, const int* positions, const float* cos_t,
+                     const float* sin_t, const int* slot_mapping, const int* block_tables, int max_blocks_per_seq, const int* tok_seq, const int* ctx_lens, float eps,
+                     float scale, const float* kv_scale, void* residual, float* ss, void* ws, int grid, int timeline, hipStream_t stream) {
+  if (!layers || n_layers < 1 || !plans || !ws || !residual || !ss || grid < 1 || grid > 512) return -1;
+  if (T != 16 && T != 32 && T != 48 && T != 64) return -1;
+  if (nkv < 1 || nh % nkv || nh / nkv != 4 || (H & 127)) return -1;  // head groups of 4 (Llama-3-8B, Mistral-7B); others keep the kernel-per-phase path
+  DlParams p{};
+  DlGemm* gp[4] = {&p.qkv, &p.o, &p.gu, &p.down};
+  for (int i = 0; i < 4; ++i) {
+    DlGemm& g = *gp[i];
+    g.N = plans[5 * i]; g.K = plans[5 * i + 1]; g.nw = plans[5 * i + 2]; g.splits = plans[5 * i + 3]; g.cps = plans[5 * i + 4];
+    if (g.N <= 0 || g.K <= 0 || (g.K & 127) || g.nw < 1 || g.nw > 8 || g.N % (16 * g.nw) || g.splits < 1 || g.splits > 16 || g.cps < 1) return -1;
+    const int nchunks = g.K / 128;
+    if ((long long)g.splits * g.cps < nchunks || (long long)(g.splits - 1) * g.cps >= nchunks) return -1;
+  }
+  if (p.qkv.N != (nh + 2 * nkv) * 128 || p.qkv.K != H || p.o.N != H || p.o.K != nh * 128 || p.gu.N != 2 * I || p.gu.K != H || p.gu.splits != 1 || p.down.N != H ||
+      p.down.K != I)
+    return -1;
+  const DlLayout l = dl_layout(H, nh, nkv, I, p.qkv.splits, p.o.splits > p.down.splits ? p.o.splits : p.down.splits);
+  char* w = reinterpret_cast<char*>(ws);
+  p.layers = reinterpret_cast<const DlLayer*>(layers);
+  p.n_layers = n_layers; p.T = T; p.H = H; p.nh = nh; p.nkv = nkv; p.I = I;
+  p.positions = positions; p.cos_t = cos_t; p.sin_t = sin_t; p.slot_mapping = slot_mapping; p.block_tables = block_tables; p.max_blocks_per_seq = max_blocks_per_seq;
+  p.tok_seq = tok_seq; p.ctx_lens = ctx_lens;
+  p.eps = eps; p.scale_log2e = scale * 1.4426950408889634f;
+  p.kv_scale = kv_scale; p.kv_scale_stride = 2 * nkv;
+  p.residual = (unsigned short*)residual; p.ss = ss;
+  p.xres = (unsigned short*)(w + l.xres); p.ssb = (float*)(w + l.ssb); p.qkv_slabs = (float*)(w + l.qkv_slabs); p.attn_out = (unsigned short*)(w + l.attn_out);
+  p.proj_slabs = (float*)(w + l.proj_slabs); p.act = (unsigned short*)(w + l.act);
+  p.flags = (unsigned int*)(w + l.flags); p.state = (unsigned int*)(w + l.state);
+  p.timeline = (timeline && n_layers <= 128) ? (unsigned long long*)(w + l.timeline) : nullptr;
+#define KV_DL(MTv)                                                                                                    \
+  if (kv_scale) hipLaunchKernelGGL((decode_layers_kernel<MTv, 4, true>), dim3(grid), dim3(512), 0, stream, p);        \
+  else hipLaunchKernelGGL((decode_layers_kernel<MTv, 4, false>), dim3(grid), dim3(512), 0, stream, p)
+  switch (T >> 4) {
+    case 1: KV_DL(1); break;
+    case 2: KV_DL(2); break;
+    case 3: KV_DL(3); break;
+    case 4: KV_DL(4); break;
+  }
+#undef KV_DL
+  return (int)hipGetLastError();
+}
+
+// byte offsets of the workspace regions: flags, state, xres, ssb, qkv_slabs, attn_out, proj_slabs, act, total (tests and debugging)
+void kv_decode_layers_layout(int H, int nh, int nkv, int I, int s_qkv, int s_proj, long long* out9) {
+  const DlLayout l = dl_layout(H, nh, nkv, I, s_qkv, s_proj);
+  const long long v[10] = {l.flags, l.state, l.xres, l.ssb, l.qkv_slabs, l.attn_out, l.proj_slabs, l.act, l.total, l.timeline};
+  for (int i = 0; i < 10; ++i) out9[i] = v[i];
+}
+
+// byte offset of the two state words (epoch, error) inside the workspace
+long long kv_decode_layers_state_offset(int H, int nh, int nkv, int I, int s_qkv, int s_proj) { return dl_layout(H, nh, nkv, I, s_qkv, s_proj).state; }
 
 }  // extern "C"

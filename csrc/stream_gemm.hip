@@ -107,10 +107,26 @@ __global__ __launch_bounds__(256) void unpack_mxfp4_kernel(const raw16* __restri
 }
 
 // Shared epilogue.  Lane holds y[token j*16 + r][feature tile*16 + 4q + e], e = 0..3, in acc[j][e].
+// 1/rms of the token rows a workgroup's epilogue scales, left in LDS: row_ss holds `ss_parts` partial
+// sums of squares per row — 8 from the residual kernel (512-column segments), hidden/16 from the
+// row-parallel projections that update the residual themselves (one per feature tile) — so a row
+// is summed by a whole wave (lane-strided loads, butterfly), not by one lane in a serial loop.
+template <int ROWS, int NW>
+__device__ inline void row_scales_to_lds(float* rs_lds, const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps, int wave, int lane) {
+  for (int row = wave; row < ROWS; row += NW) {
+    const float* p = row_ss + (long long)row * ss_parts;
+    float ssum = 0.f;
+    for (int i = lane; i < ss_parts; i += 64) ssum += p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
+    if (lane == 0) rs_lds[row] = rsqrtf(ssum * inv_k + eps);
+  }
+}
+
 template <int MT, int EPI, bool W8>
 __device__ inline void gemm_epilogue(frag_cd (&acc)[MT], unsigned char* lds_raw, void* __restrict__ out, long long tile, int wave, int lane, long long ldy,
                                      long long slab_stride, const float* __restrict__ row_ss, int ss_parts, float inv_k, float eps,
-                                     const float* __restrict__ w_scale) {
+                                     const float* __restrict__ w_scale, const float* rs_lds = nullptr) {
   const int r = lane & 15, q = lane >> 4;
   const long long n_base = tile * 16 + q * 4;
   if constexpr (W8) {
@@ -126,9 +142,14 @@ __device__ inline void gemm_epilogue(frag_cd (&acc)[MT], unsigned char* lds_raw,
   if (EPI != EPI_SLAB && EPI != EPI_RESID && row_ss != nullptr) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-      float ssum = 0.f;
-      for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)(j * 16 + r) * ss_parts + p];
-      const float rs = rsqrtf(ssum * inv_k + eps);
+      float rs;
+      if (rs_lds != nullptr) {
+        rs = rs_lds[j * 16 + r];
+      } else {
+        float ssum = 0.f;
+        for (int p = 0; p < ss_parts; ++p) ssum += row_ss[(long long)(j * 16 + r) * ss_parts + p];
+        rs = rsqrtf(ssum * inv_k + eps);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[j][e] *= rs;
     }
@@ -359,6 +380,12 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
 #pragma unroll
   for (int s = 0; s < PD; ++s) KV_ISSUE(s, cbase + s);
 
+  // 1/rms of the token rows, for the epilogue: summed while the first weight chunks are on their
+  // way (the loads queue behind them; the barriers of the chunk loop publish the LDS writes)
+  __shared__ float rs_lds[16 * MT];
+  const bool scale_rows = EPI != EPI_SLAB && EPI != EPI_RESID && row_ss != nullptr;
+  if (scale_rows) row_scales_to_lds<16 * MT, NW>(rs_lds, row_ss, ss_parts, inv_k, eps, wave, lane);
+
   // steady state: every sub-step issues chunk c+PD and consumes chunk c
   for (int g = g0; g + 1 < g1; ++g) {
     const int c = g * NB;
@@ -379,15 +406,18 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
 #undef KV_CONSUME
 
 #pragma unroll
-  for (int f = 0; f < FT; ++f) gemm_epilogue<MT, EPI, W8>(acc[f], lds_raw, out, tile + f, wave, lane, ldy, slab_stride, row_ss, ss_parts, inv_k, eps, w_scale);
+  for (int f = 0; f < FT; ++f) gemm_epilogue<MT, EPI, W8>(acc[f], lds_raw, out, tile + f, wave, lane, ldy, slab_stride, row_ss, ss_parts, inv_k, eps, w_scale, scale_rows ? rs_lds : nullptr);
 
   if constexpr (EPI == EPI_RESID) {
     // ---- fix-up by the last split of this feature group (16 * NW features x 16 * MT rows)
     constexpr int GC = 16 * NW, ROWS = 16 * MT, NTH = 64 * NW;
     __shared__ int is_last;
     float* ss_lds = reinterpret_cast<float*>(lds_raw);  // the x staging area is free once every wave is past its last chunk
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every write-through store of this wave has completed ...
-    __syncthreads();                                        // ... of every wave, before the arrival is counted
+    // write-through stores are asynchronous: wait until this wave's have reached memory (vmcnt(0)) —
+    // a workgroup-scope release alone does not — then the barrier, then the arrival is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also a compiler barrier: no store may sink below it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
     if (tid == 0) {
       const int arrived = __hip_atomic_fetch_add(ra.counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       is_last = arrived == (int)gridDim.y - 1;
@@ -425,6 +455,134 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
     __syncthreads();
     if (tid < ROWS) ra.ss_out[(long long)tid * gridDim.x + blockIdx.x] = ss_lds[tid];
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row-parallel projection + residual update in ONE launch, without slabs (output and down
+// projections of a decode step):
+//     residual' = bf16(residual + bf16(x @ W^T)),   ss[t][tile] = sum over the tile's 16 features of residual'[t]^2
+// One workgroup owns ONE 16-feature tile over the whole of K; its NW waves split K among
+// themselves (wave w: columns [w K/NW, (w+1) K/NW)), meet in LDS and the first MT waves add the
+// residual.  With 256 tiles (hidden 4096) that is one workgroup per CU and no cross-workgroup
+// dependency at all: no fp32 slabs written and read back, no arrival counter, and the separate
+// residual kernel (a launch boundary plus a chain of dependent loads, ~5 us per call) disappears.
+// The price is x traffic: every wave fetches its own B fragments of x straight from L2 into
+// registers (no sharing through LDS: the waves of a workgroup read different columns), i.e. the
+// whole of x once per CU.  x is a few hundred KB that every CU reads — it lives in each XCD's L2.
+// The waves' partial sums are added in wave order, which is the slab order of the split-K path
+// with NW equal splits: the new residual is bit-identical to stream_gemm3 + residual_reduce.
+// The main loop has no barrier: a ring of NB register slots per wave (weights and x of a chunk of
+// 4 k-steps issued together), steady state unrolled by NB with exact s_waitcnt counts, then a
+// guarded drain (chunks per wave need not be a multiple of NB).
+template <int MT, int NB, bool W8, int NW>
+__global__ __launch_bounds__(NW * 64) void stream_gemm_rowsum_kernel(const void* __restrict__ Wp, const __bf16* __restrict__ x, int N, int K, long long ldx, int cpw,
+                                                                     unsigned short* __restrict__ residual, int has_residual, float* __restrict__ ss_out,
+                                                                     const float* __restrict__ w_scale) {
+  constexpr int KS = 4, AL = W8 ? KS / 2 : KS, PD = NB - 1;
+  __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int ksteps = K >> 5;
+  const long long tile = blockIdx.x;
+  const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * (long long)(ksteps * AL / KS) * 64 + (long long)wave * cpw * AL * 64 + lane;
+  const __bf16* xp = x + (long long)r * ldx + (long long)wave * cpw * (KS * 32) + q * 8;
+
+  frag_cd acc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) acc[j] = (frag_cd){0.f, 0.f, 0.f, 0.f};
+  raw16 a[NB][AL];
+  frag_ab xr[NB][KS][MT];
+
+#define KV_ISSUE(slot, chunk)                                                                                              \
+  do {                                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                                       \
+      _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                                       \
+          xr[slot][u][j] = *reinterpret_cast<const frag_ab*>(xp + (long long)j * 16 * ldx + ((long long)(chunk) * KS + u) * 32); \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < AL; ++u) a[slot][u] = ldw16<true>(wp + ((long long)(chunk) * AL + u) * 64);      \
+  } while (0)
+
+#define KV_CONSUME(slot)                                                                                                   \
+  do {                                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                                       \
+      const frag_ab af = a_frag<W8>(a[slot], u);                                                                           \
+      _Pragma("unroll") for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xr[slot][u][j], acc[j], 0, 0, 0); \
+    }                                                                                                                      \
+  } while (0)
+
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (s < cpw) KV_ISSUE(s, s);
+  int c = 0;
+  for (; c + NB + PD <= cpw; c += NB) {  // every issue of this group is inside the wave's range: branch-free
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      KV_ISSUE((s + PD) % NB, c + s + PD);
+      KV_CONSUME(s);
+    }
+  }
+  // drain: at most NB + PD - 1 chunks are left (c is a multiple of NB, so slot = step % NB)
+#pragma unroll
+  for (int i = 0; i < NB + PD - 1; ++i) {
+    if (c + i < cpw) {
+      if (c + i + PD < cpw) KV_ISSUE((i + PD) % NB, c + i + PD);
+      KV_CONSUME(i % NB);
+    }
+  }
+#undef KV_ISSUE
+#undef KV_CONSUME
+
+  if constexpr (W8) {  // one scale per output feature, applied per K slice as the split-K path does per slab
+    const frag_cd ws = *reinterpret_cast<const frag_cd*>(w_scale + tile * 16 + q * 4);
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[j][e] *= ws[e];
+  }
+#pragma unroll
+  for (int j = 0; j < MT; ++j) *reinterpret_cast<frag_cd*>(&red[wave][j][lane][0]) = acc[j];
+  __syncthreads();
+  if (wave < MT) {
+    // wave j finishes token rows 16j .. 16j+15: lane (q, r) holds features 4q .. 4q+3 of row 16j + r
+    const int j = wave;
+    frag_cd s = (frag_cd){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const frag_cd*>(&red[w][j][lane][0]);
+    const long long off = (long long)(j * 16 + r) * N + tile * 16 + q * 4;
+    us4 b = (us4){0, 0, 0, 0};
+    if (has_residual) b = *reinterpret_cast<const us4*>(residual + off);
+    us4 cv;
+    float ssq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = __uint_as_float(((unsigned int)f2bf(s[e])) << 16) + __uint_as_float(((unsigned int)b[e]) << 16);
+      cv[e] = f2bf(v);
+      const float f = __uint_as_float(((unsigned int)cv[e]) << 16);
+      ssq += f * f;
+    }
+    *reinterpret_cast<us4*>(residual + off) = cv;
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (q == 0) ss_out[(long long)(j * 16 + r) * (N >> 4) + tile] = ssq;
+  }
+}
+
+template <int MT, bool W8>
+int launch_rowsum(const void* Wp, const void* x, int N, int K, long long ldx, int nb, void* residual, int has_residual, float* ss_out, const float* w_scale,
+                  hipStream_t stream) {
+  constexpr int NW = 8;
+  const int cpw = K / (128 * NW);
+  dim3 grid(N / 16), block(NW * 64);
+#define KV_RS(NBv)                                                                                                                                         \
+  hipLaunchKernelGGL((stream_gemm_rowsum_kernel<MT, NBv, W8, NW>), grid, block, 0, stream, Wp, (const __bf16*)x, N, K, ldx, cpw, (unsigned short*)residual, \
+                     has_residual, ss_out, w_scale)
+  // ring depth: 16 MT + 16 registers per slot (x fragments + weights), so deep rings only for few rows
+  if (nb == 2) KV_RS(2);
+  else if (nb == 3 && MT <= 2) { if constexpr (MT <= 2) KV_RS(3); }
+  else if (nb == 4 && MT <= 2) { if constexpr (MT <= 2) KV_RS(4); }
+  else return -1;
+#undef KV_RS
+  return (int)hipGetLastError();
 }
 
 struct Args {
@@ -679,6 +837,24 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
     case 4: return dispatch3_wb<4>(epi, nb, nw, wb, a);
     case 8: return dispatch3_wide_wb<8>(epi, nw, wb, a);
     case 16: return wb == 4 ? -1 : (wb == 8 ? dispatch3_wide<16, 8>(epi, nw, a) : dispatch3_wide<16, 16>(epi, nw, a));  // (256-row tiles are not built for MXFP4: callers use 128-row passes)
+  }
+  return -1;
+}
+
+// residual[M, N] (bf16, in place; has_residual = 0: taken as zero) += x[M, K] @ W^T, and
+// ss_out[M][N/16] = per-row sums of squares of the new residual over each 16-feature tile, in one
+// launch without slabs (stream_gemm_rowsum_kernel).  M in {16, 32, 48, 64}, N % 16 == 0,
+// K % 1024 == 0 (8 waves x chunks of 128 columns), nb = ring depth (2; 3 or 4 up to 32 rows).
+// w_scale != nullptr: FP8 (e4m3) weights with one scale per output row.
+int kv_stream_gemm_rowsum(const void* Wp, const void* x, int M, int N, int K, long long ldx, int nb, void* residual, int has_residual, float* ss_out,
+                          const float* w_scale, hipStream_t stream) {
+  if (M <= 0 || M > 64 || (M & 15) || N <= 0 || (N & 15) || K <= 0 || (K % 1024) || !residual || !ss_out || !Wp || !x) return -1;
+  const bool w8 = w_scale != nullptr;
+  switch (M >> 4) {
+    case 1: return w8 ? launch_rowsum<1, true>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream) : launch_rowsum<1, false>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream);
+    case 2: return w8 ? launch_rowsum<2, true>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream) : launch_rowsum<2, false>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream);
+    case 3: return w8 ? launch_rowsum<3, true>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream) : launch_rowsum<3, false>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream);
+    case 4: return w8 ? launch_rowsum<4, true>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream) : launch_rowsum<4, false>(Wp, x, N, K, ldx, nb, residual, has_residual, ss_out, w_scale, stream);
   }
   return -1;
 }

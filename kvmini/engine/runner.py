@@ -178,6 +178,12 @@ class ModelRunner:
         # inside e4m3's +-448.
         self.kv_scale = torch.ones((cfg.num_layers, 2, self.nkv), dtype=torch.float32, device=self.device) if self.kv_fp8 else None
 
+        # the persistent decode-layers kernel (HIP ops, one rank, shapes it is built for)
+        self.decode_layers = None
+        dl = getattr(self.ops, "DecodeLayers", None)
+        if dl is not None and self.device.type == "cuda" and not self.tp_active and dl.supported(weights, self.kv_cache[0, 0], self.nh, self.nkv):
+            self.decode_layers = dl(weights, self.kv_cache, self.kv_scale, self.nh, self.nkv)
+
         self.buckets = tuple(b for b in DEFAULT_BUCKETS if b < rcfg.max_batched_tokens) + (rcfg.max_batched_tokens,)
         tmax = self.buckets[-1]
         self.tmax = tmax
@@ -340,6 +346,15 @@ class ModelRunner:
             return {"prefetch": p} if p is not None else {}
 
         x = ops.embed_tokens(w.embed, tokens, self._dev("feed", t_pad), self.out_ids)
+        if decode_only == 1 and self.decode_layers is not None and t_pad <= 64:
+            # plain decoding step: every layer in one persistent launch (phases separated by device-wide
+            # barriers instead of kernel boundaries, weight chunks in flight across them)
+            h, residual = self._add_rmsnorm(x, None, w.layers[0].attn_norm, False)
+            self.decode_layers.run(residual, h.ss, positions, self.cos, self.sin, slots, bt, tok_seq, ctx, cfg.rms_eps, self.scale)
+            hs = ops.select_rows(h, sample_idx[: self.sample_rows(t_pad)])
+            logits = ops.linear(hs, w.lm_head)
+            self.out_ids[: logits.shape[0]].copy_(ops.greedy_sample(logits))
+            return logits
         residual = None  # the first residual add is a copy
         pending_reduce = False  # x is a row-parallel projection's partial output that still has to be summed over the TP ranks
         h = None  # set when a projection already folded its output into the residual stream (fused epilogue)

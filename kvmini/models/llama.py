@@ -81,6 +81,8 @@ PRESETS: Dict[str, LlamaConfig] = {
     # smallest shape that exercises every HIP kernel specialisation (head_dim 128)
     "small-hd128": LlamaConfig("small-hd128", 1024, 256, 512, 2, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
     "small-hd128-draft": LlamaConfig("small-hd128-draft", 1024, 256, 512, 1, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
+    # smallest shape the persistent decode-layers kernel serves (head groups of 4, K multiples of 256)
+    "mid-hd128": LlamaConfig("mid-hd128", 1024, 1024, 2048, 3, 8, 2, 128, 500000.0, 1e-5, 4096, 1, 2),
     # Llama 3
     "llama-3-8b": LlamaConfig("llama-3-8b", 128256, 4096, 14336, 32, 32, 8, 128, 500000.0, 1e-5, 8192, 128000, 128001),
     "llama-3-70b": LlamaConfig("llama-3-70b", 128256, 8192, 28672, 80, 64, 8, 128, 500000.0, 1e-5, 8192, 128000, 128001),

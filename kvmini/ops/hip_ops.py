@@ -600,15 +600,48 @@ _resid_counters: Dict[Any, torch.Tensor] = {}
 FUSE_RESIDUAL = os.environ.get("KVMINI_FUSE_RESIDUAL", "0") == "1"  # measured slower than the two-kernel path (see linear_residual): off unless asked for
 
 
+# Row-parallel projections (output, down) of steps up to 64 rows: one workgroup per 16-feature tile
+# with K split over its 8 waves, residual add and sums of squares in the epilogue — no slabs, no
+# residual kernel (csrc/stream_gemm.hip: stream_gemm_rowsum_kernel).  OFF by default: measured on MI355X
+# (Llama-3-8B, batch 20) the decode step is 3.39 ms with it on the output projection and 3.78 ms with it
+# on both row-parallel projections, against 3.34 ms for the split-K GEMM + residual_reduce pair (the form
+# makes every CU read the whole of x).  KVMINI_ROWSUM_GEMM=1 turns it on; KVMINI_ROWSUM_NB pins the ring depth.
+ROWSUM_GEMM = os.environ.get("KVMINI_ROWSUM_GEMM", "0") == "1"
+ROWSUM_NB = int(os.environ.get("KVMINI_ROWSUM_NB", "0"))
+# Every CU reads the whole of x (rows x K) in this form, which is what bounds it: measured on MI355X at 32 rows,
+# K = 4096 (Llama-3-8B output projection) 12.4 us against 13.2 for the pair of kernels, K = 14336 (down
+# projection) 37 against 24.5; at 16 rows 9.2 / 12.7 and 25.0 / 24.2.  So: rows x K up to this bound.
+ROWSUM_MAX_ROWS_K = int(os.environ.get("KVMINI_ROWSUM_MAX_ROWS_K", str(32 * 4096)))
+
+
+def _linear_residual_rowsum(x: torch.Tensor, w: "PackedLinear", residual: torch.Tensor, eps: float) -> Optional[Tuple[Normed, torch.Tensor]]:
+    m = x.shape[0]
+    if m * w.k > ROWSUM_MAX_ROWS_K or w.bits == 4 or m > MAX_M or m % 16 or w.n != w.n_pad or w.k % 1024 or residual.shape != (m, w.n) or residual.dtype != torch.bfloat16 or not residual.is_contiguous():
+        return None
+    if x.stride(1) != 1 or x.stride(0) % 8:
+        x = x.contiguous()
+    nb = ROWSUM_NB or (3 if m <= 32 else 2)
+    ss = native().stream_gemm_rowsum(w.wp, w.n_pad, w.k, x, residual, True, w.wscale, nb)
+    return Normed(residual, ss, eps), residual
+
+
 def linear_residual(x: torch.Tensor, w: Weight, residual: torch.Tensor, eps: float) -> Optional[Tuple[Normed, torch.Tensor]]:
-    """``residual += x @ W^T`` plus the sums of squares of the new residual rows, in ONE launch:
-    the split-K streaming GEMM writes its slabs and the last workgroup of each feature group to
-    finish folds them into ``residual`` (bf16, in place) — the separate residual / RMSNorm-statistics
-    kernel between a row-parallel projection and the next one disappears.  Returns
+    """``residual += x @ W^T`` plus the sums of squares of the new residual rows, in ONE launch.
+    Default form: :func:`_linear_residual_rowsum` (K split inside the workgroup, no slabs).  The
+    older form (``KVMINI_FUSE_RESIDUAL=1`` with ``KVMINI_ROWSUM_GEMM=0``): the split-K streaming GEMM
+    writes its slabs and the last workgroup of each feature group to finish folds them into
+    ``residual`` (bf16, in place).  Either way the separate residual / RMSNorm-statistics kernel
+    between a row-parallel projection and the next one disappears.  Returns
     ``(Normed(residual, ss, eps), residual)``, or None when the step is outside what the fused
-    epilogue serves (more than 64 rows, rows not a multiple of 16, padded features, 4-bit weights):
+    epilogues serve (more than 64 rows, rows not a multiple of 16, padded features, 4-bit weights):
     the caller then runs the projection and the residual update separately."""
-    if not FUSE_RESIDUAL or not isinstance(w, PackedLinear) or isinstance(x, Normed) or w.bits == 4:
+    if not isinstance(w, PackedLinear) or isinstance(x, Normed) or residual is None:
+        return None
+    if ROWSUM_GEMM:
+        out = _linear_residual_rowsum(x, w, residual, eps)
+        if out is not None:
+            return out
+    if not FUSE_RESIDUAL or w.bits == 4:
         return None
     m = x.shape[0]
     if m > MAX_M or m % 16 or w.n != w.n_pad or w.k % 256 or residual is None or residual.shape != (m, w.n):
@@ -862,6 +895,82 @@ def split_decode_attention(
     ws = _split_workspace(out.device, 4096 + n_rows * nh * ns * (hd + 2))
     native().split_decode_attention(q, k_cache, v_cache, block_tables, tok_seq, ctx_lens, rows, out, scale, _decode_attention_waves(n_rows, nkv), kv_scale, ns, ws)
     return out
+
+
+# ---- all decoder layers of a plain decoding step in one persistent launch ------------------------
+# OFF by default (KVMINI_DECODE_LAYERS=1 turns it on; KVMINI_DECODE_LAYERS_GRID pins the workgroup count).
+# Measured on MI355X, Llama-3-8B, batch 20 (profiles/bench/decode_layers_persistent_r3.json): bit-equal to
+# the kernel-per-phase path, 4.48 ms per step against 3.32 ms.  Workgroup 0's timeline per layer: barriers
+# 3.3-6.9 us each in situ (a kernel boundary costs ~1.8 us), gate/up 46.8 us against 38.2 (every workgroup
+# reads x from the uncached exchange buffer), attention 13.4 against 9.1; the weight chunks issued before a
+# barrier do not shorten the GEMM phases.  What it would take to win is a loader that keeps HBM busy
+# independently of the phases (weights into an LDS ring by dedicated waves), not cheaper barriers.
+DECODE_LAYERS = os.environ.get("KVMINI_DECODE_LAYERS", "0") == "1"
+
+
+class DecodeLayers:
+    """State of the persistent decode-layers kernel for one model on one device
+    (``csrc/engine_kernels.hip``: ``decode_layers_kernel``): the per-layer pointer table, the
+    GEMM plans (the streaming GEMM's own: same waves, same K splits, hence the same numbers as
+    the kernel-per-phase path) and the uncached workspace the phases exchange their results
+    through.  Built once, before any graph capture; :meth:`run` is capturable."""
+
+    def __init__(self, weights: Any, kv_cache: torch.Tensor, kv_scale: Optional[torch.Tensor], n_heads: int, n_kv: int):
+        C = native()
+        cfg = weights.cfg
+        layers = weights.layers
+        self.nh, self.nkv, self.inter = n_heads, n_kv, layers[0].wdown.k
+        self.hidden = cfg.hidden_size
+        plans = []
+        for w, split in ((layers[0].wqkv, True), (layers[0].wo, True), (layers[0].wgu, False), (layers[0].wdown, True)):
+            if split:
+                nw, splits, gps = _plan_slabs(w.n_pad, w.k)
+                cps = 2 * gps
+            else:
+                nw, splits, cps = _waves_per_workgroup(w.n_pad), 1, w.k // 128
+            plans += [w.n_pad, w.k, nw, splits, cps]
+        self.plans = plans
+        self.s_qkv, self.s_proj = plans[3], max(plans[8], plans[18])
+        dev = kv_cache.device
+        rows = []
+        for li, lw in enumerate(layers):
+            rows.append([lw.wqkv.wp.data_ptr(), lw.wo.wp.data_ptr(), lw.wgu.wp.data_ptr(), lw.wdown.wp.data_ptr(), kv_cache[li, 0].data_ptr(), kv_cache[li, 1].data_ptr()])
+        self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.kv_scale = kv_scale
+        self.ws = C.alloc_uncached(C.decode_layers_workspace_bytes(self.hidden, n_heads, n_kv, self.inter, self.s_qkv, self.s_proj))
+        self.state_off = C.decode_layers_state_offset(self.hidden, n_heads, n_kv, self.inter, self.s_qkv, self.s_proj)
+        self.grid = int(os.environ.get("KVMINI_DECODE_LAYERS_GRID", "0")) or min(_num_cus(), 512)
+        self.keep = (weights, kv_cache)  # the table holds raw pointers into these
+        self.timeline = os.environ.get("KVMINI_DECODE_LAYERS_TIMELINE", "0") == "1"
+
+    @staticmethod
+    def supported(weights: Any, kv_cache: torch.Tensor, n_heads: int, n_kv: int) -> bool:
+        """bf16 packed weights, head_dim 128, KV blocks of 16, head groups of 4, shapes the streaming plans divide."""
+        if not DECODE_LAYERS or not gpu_available():
+            return False
+        lw = weights.layers[0]
+        ws = (lw.wqkv, lw.wo, lw.wgu, lw.wdown)
+        if not all(isinstance(w, PackedLinear) and w.bits == 16 and w.n == w.n_pad and w.k % 256 == 0 for w in ws):
+            return False
+        if kv_cache.shape[-1] != 128 or kv_cache.shape[-2] != 16 or n_kv < 1 or n_heads % n_kv or n_heads // n_kv != 4:
+            return False
+        return weights.cfg.hidden_size % 128 == 0 and lw.wgu.n_pad == 2 * lw.wdown.k
+
+    def run(self, residual: torch.Tensor, ss: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, slot_mapping: torch.Tensor, block_tables: torch.Tensor,
+            tok_seq: torch.Tensor, ctx_lens: torch.Tensor, eps: float, scale: float) -> None:
+        """``residual`` (bf16 ``[T, H]``, T in 16 / 32 / 48 / 64) and ``ss`` (its per-row sums of squares, ``[T, H/512]``)
+        enter as the first layer's input and leave as the last layer's output."""
+        native().decode_layers(self.table, self.plans, self.nh, self.nkv, self.inter, positions, cos, sin, slot_mapping, block_tables, tok_seq, ctx_lens, eps, scale,
+                               self.kv_scale, residual, ss, self.ws, self.grid, self.timeline)
+
+    def read_timeline(self, n_layers: int) -> "torch.Tensor":
+        """Workgroup 0's phase stamps of the last launch (``timeline = True``): int64 ``[layers, 16]`` ticks of the 100 MHz real-time counter."""
+        off = native().decode_layers_layout(self.hidden, self.nh, self.nkv, self.inter, self.s_qkv, self.s_proj)[9]
+        return self.ws[off : off + n_layers * 16 * 8].view(torch.int64).view(n_layers, 16).cpu()
+
+    def error_word(self) -> int:
+        """Non-zero after a launch in which a barrier timed out (a workgroup never arrived): results of that launch are garbage."""
+        return int(self.ws[self.state_off + 4 : self.state_off + 8].view(torch.int32).item())
 
 
 def supports_prefill_attention(n_heads: int, k_cache: torch.Tensor) -> bool:

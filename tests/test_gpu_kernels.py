@@ -1903,6 +1903,7 @@ def test_linear_residual_epilogue_is_bit_equal_to_the_two_kernel_path(M, N, K, f
     from kvmini.ops import hip_ops
 
     monkeypatch.setattr(hip_ops, "FUSE_RESIDUAL", True)
+    monkeypatch.setattr(hip_ops, "ROWSUM_GEMM", False)
 
     torch.manual_seed(12)
     W = (torch.randn(N, K, device=_dev()) * 0.03).bfloat16()
@@ -1928,3 +1929,108 @@ def test_linear_residual_epilogue_is_bit_equal_to_the_two_kernel_path(M, N, K, f
     torch.cuda.synchronize()
     assert int(hip_ops._resid_counters[_dev()].abs().sum()) == 0
     assert hip_ops.linear_residual(torch.randn(20, K, device=_dev()).bfloat16(), pw, torch.zeros(20, N, device=_dev(), dtype=torch.bfloat16), 1e-5) is None  # 20 rows: not served
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 32, 48, 64])
+@pytest.mark.parametrize("N,K,fp8", [(4096, 4096, False), (4096, 14336, False), (2048, 8192, False), (4096, 4096, True), (1024, 2048, False), (8192, 28672, False)])
+def test_rowsum_gemm_updates_the_residual_like_gemm_plus_residual_kernel(M, N, K, fp8, monkeypatch):
+    """One workgroup per 16-feature tile, K split over its 8 waves, residual add in the epilogue:
+    against the fp32 matmul of the same operands, and bit-equal to the split-K GEMM +
+    residual_reduce pair whenever that pair splits K into the same 8 equal ranges (the waves' sums
+    are added in slab order).  Sums of squares: one part per tile, totals equal the row's."""
+    from kvmini.ops import hip_ops
+
+    monkeypatch.setattr(hip_ops, "ROWSUM_GEMM", True)
+    monkeypatch.setattr(hip_ops, "ROWSUM_MAX_ROWS_K", 1 << 30)
+    torch.manual_seed(21)
+    W = (torch.randn(N, K, device=_dev()) * 0.03).bfloat16()
+    pw = hip_ops.PackedLinear(W, fp8=fp8)
+    Wd = W.float()
+    if fp8:
+        from kvmini.models.llama import quantize_fp8_rows
+
+        q, sc = quantize_fp8_rows(W)
+        Wd = q.float() * sc[:, None]
+    for nb in (2, 3, 4):
+        if nb > 2 and M > 32:
+            continue
+        monkeypatch.setattr(hip_ops, "ROWSUM_NB", nb)
+        x = torch.randn(M, K, device=_dev()).bfloat16()
+        res0 = torch.randn(M, N, device=_dev()).bfloat16()
+        got = res0.clone()
+        out = hip_ops.linear_residual(x, pw, got, 1e-5)
+        assert out is not None
+        normed, r2 = out
+        assert r2 is got and normed.x is got and normed.ss.shape == (M, N // 16)
+        ref = (x.float() @ Wd.T).bfloat16().float() + res0.float()
+        err = (got.float() - ref).abs().max().item()
+        assert err <= 2e-2 * ref.abs().max().item(), (nb, err)
+        assert torch.allclose(normed.ss.sum(-1), (got.float() ** 2).sum(-1), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(normed.ss, (got.float() ** 2).view(M, N // 16, 16).sum(-1), rtol=1e-4, atol=1e-4)
+        part = hip_ops.linear(x, pw, allow_slabs=True)
+        if isinstance(part, hip_ops.Partial) and part.slabs.shape[0] == 8 and hip_ops._plan_slabs(N, K)[2] * 256 * 8 == K:
+            want = res0.clone()
+            hip_ops.add_rmsnorm(part, want, torch.ones(N, device=_dev(), dtype=torch.bfloat16), 1e-5)
+            assert torch.equal(got, want), nb
+    assert hip_ops.linear_residual(torch.randn(20, K, device=_dev()).bfloat16(), pw, torch.zeros(20, N, device=_dev(), dtype=torch.bfloat16), 1e-5) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts", [8, 64, 256])
+def test_projections_take_row_scales_from_any_number_of_partial_sums(parts):
+    """The folded RMSNorm's 1/rms comes from per-row partial sums of squares — 8 from the residual
+    kernel, hidden/16 from the row-sum GEMMs; the consuming GEMM epilogues give the same result for
+    any split of the same total."""
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(5)
+    M, N, K = 32, 1024, 4096
+    W = (torch.randn(N, K, device=_dev()) * 0.03).bfloat16()
+    pw = hip_ops.PackedLinear(W)
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    sq = (x.float() ** 2).view(M, parts, K // parts).sum(-1).contiguous()
+    y = hip_ops.linear(hip_ops.Normed(x, sq, 1e-5), pw)
+    ref = (x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)) @ W.float().T
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+def _decode_layers_pair(model, n_seqs, kv_dtype, graphs, max_tokens=12, prompt_len=9):
+    """Two engines on the same random weights, one with the persistent decode-layers kernel, one with a
+    kernel per phase; returns (tokens, KV cache, runner) of each after the same greedy generation."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    from kvmini.ops import hip_ops
+
+    out = []
+    for persistent in (True, False):
+        hip_ops.DECODE_LAYERS = persistent  # read when the runner is built
+        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=max(n_seqs, 4), max_batched_tokens=128, max_model_len=1024, kernels="hip", num_blocks=512,
+                                     kv_cache_dtype=kv_dtype, use_graphs=graphs, async_scheduling=False))
+        if persistent:
+            assert eng.runner.decode_layers is not None, "the persistent kernel does not apply to this model"
+        else:
+            eng.runner.decode_layers = None
+        eng.warmup()
+        prompts = [[1] + [(13 * i + 7 * j) % 900 + 20 for j in range(prompt_len + (i % 3))] for i in range(n_seqs)]
+        toks = eng.generate(prompts, SamplingParams(max_tokens=max_tokens, ignore_eos=True))
+        torch.cuda.synchronize()
+        out.append((toks, eng.runner.kv_cache.clone(), eng.runner))
+    hip_ops.DECODE_LAYERS = False
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_seqs,kv_dtype,graphs", [(3, "auto", False), (20, "auto", True), (40, "auto", True), (60, "auto", False), (20, "fp8", True)])
+def test_persistent_decode_layers_equal_the_kernel_per_phase_path(n_seqs, kv_dtype, graphs):
+    """All decoder layers in one persistent launch (phases separated by device-wide barriers): the
+    GEMM phases use the streaming kernel's plans and slab order, so tokens AND the KV cache are
+    bit-equal to the kernel-per-phase path — for 16 / 32 / 48 / 64-row steps, eagerly and through
+    HIP graphs, with a bf16 and an FP8 cache.  No barrier may have timed out."""
+    (tok_a, kv_a, run_a), (tok_b, kv_b, _run_b) = _decode_layers_pair("mid-hd128", n_seqs, kv_dtype, graphs)
+    assert run_a.decode_layers.error_word() == 0
+    assert tok_a == tok_b
+    assert kv_a.shape == kv_b.shape
+    diff = (kv_a.view(torch.uint8) != kv_b.view(torch.uint8))
+    assert not bool(diff.any()), f"{int(diff.sum())} KV bytes differ, first at {diff.nonzero()[0].tolist()}"
