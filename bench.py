@@ -292,11 +292,17 @@ def main() -> int:
     from kvmini.ops.hist_quantile import StreamingHistogram
 
     itl_hist = None
+    itl_exact = None
     if world > 1:
         itl_hist = StreamingHistogram(1, device=device)
         if itl.size:
             itl_hist.update(itl.astype(np.float32))
         itl_hist.all_reduce(dist)
+        # the reported quantiles are EXACT at every rank count (the same definition as one rank's radix
+        # select): the ranks sum the radix-digit histograms of each selection pass instead of their samples
+        from kvmini.ops.hist_quantile import distributed_quantiles
+
+        itl_exact = distributed_quantiles(itl, (0.5, 0.95, 0.99), dist, device=device)
 
     # lock-step telemetry table: C++ ncclAllGather on its own communicator and stream when the
     # ranks are GPU processes, the torch.distributed path over gloo in the CPU rehearsal
@@ -340,10 +346,13 @@ def main() -> int:
             m3 = torch.stack([lat, ttfb, ttft]).numpy()
             q = np.nanquantile(m3, (0.5, 0.95, 0.99), axis=1).T
             stats = [{"mean": float(np.nanmean(r))} for r in m3]
+        itl_hist_q = None
         if itl_hist is not None:
             snap = itl_hist.snapshot((0.5, 0.95, 0.99))[0]["quantiles"]
-            qi = [[snap.get(p, float("nan")) for p in (0.5, 0.95, 0.99)]]
-            itl_engine = ("hip:stream_hist" if on_gpu else "numpy histogram") + " + all-reduce of 2048 bins"
+            itl_hist_q = [snap.get(p, float("nan")) for p in (0.5, 0.95, 0.99)]  # the live view's 2048-bin estimate, merged over the ranks
+        if itl_exact is not None:
+            qi = [itl_exact]
+            itl_engine = ("hip:radix_hist/scan" if on_gpu else "numpy radix select") + " + all-reduce of the digit histograms per pass (exact)"
         elif on_gpu and itl.size:
             qi, _ = hq.batched_quantiles(torch.from_numpy(itl).to(device).reshape(1, -1), (0.5, 0.95, 0.99), return_stats=True)
             itl_engine = "hip:kv_radix_select"
@@ -434,6 +443,7 @@ def main() -> int:
             },
             "quantile_engine": "hip:kv_radix_select" if on_gpu else "numpy (cpu rehearsal)",
             "itl_quantile_engine": itl_engine,
+            "itl_histogram_p50_p95_p99_ms": itl_hist_q,
             "collective_backend": (dist.get_backend() if world > 1 else None),
             "telemetry": pj["source"] if watts else "unavailable",
             **({"telemetry_native_fallback": tg.native_error} if tg.native_error else {}),

@@ -14,6 +14,9 @@ int kv_stream_hist(const void* x, long long n, long long row_stride, int n_metri
                    hipStream_t stream);
 int kv_radix_init(const void* stream_state, void* st, const double* ps, int n_ps, int n_metrics, hipStream_t stream);
 int kv_radix_select(const void* x, long long n, long long row_stride, int n_metrics, int dtype, void* st, unsigned int* hist, hipStream_t stream);
+int kv_radix_num_passes(int dtype);
+int kv_radix_pass_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, const void* st, unsigned int* hist, int pass, hipStream_t stream);
+int kv_radix_pass_scan(void* st, unsigned int* hist, int n_metrics, int dtype, int pass, hipStream_t stream);
 int kv_equal_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, const void* state, unsigned long long* out, int n_bins,
                   hipStream_t stream);
 int kv_energy_trapz(const double* ts, const double* watts, const int* n, int n_series, int max_samples, double t0, double t1, double* out, hipStream_t stream);
@@ -148,6 +151,36 @@ void radix_select(at::Tensor x, int64_t n, at::Tensor stream_state, at::Tensor p
   auto s = cur_stream();
   check(kv_radix_init(stream_state.data_ptr(), rstate.data_ptr(), (const double*)ps.data_ptr(), (int)ps.numel(), (int)m, s), "kv_radix_init");
   check(kv_radix_select(x.data_ptr(), n, x.size(1), (int)m, sample_dtype(x), rstate.data_ptr(), (unsigned int*)hist.data_ptr(), s), "kv_radix_select");
+}
+
+// ---- the selection one pass at a time (samples spread over ranks: the digit histograms are summed between hist and scan)
+int64_t radix_num_passes(bool is_double) { return kv_radix_num_passes(is_double ? 1 : 0); }
+
+void radix_init(at::Tensor stream_state, at::Tensor ps, at::Tensor rstate) {
+  CHECK_DEV(stream_state); CHECK_DEV(ps); CHECK_DEV(rstate); CHECK_CONTIG(stream_state); CHECK_CONTIG(ps); CHECK_CONTIG(rstate);
+  TORCH_CHECK(ps.scalar_type() == at::kDouble && ps.numel() >= 1 && ps.numel() <= 4, "ps must be float64 with 1..4 quantile levels");
+  const int64_t m = stream_state.numel() / stream_state_bytes();
+  TORCH_CHECK(stream_state.scalar_type() == at::kByte && m >= 1 && stream_state.numel() == m * stream_state_bytes(), "bad stream state size");
+  TORCH_CHECK(rstate.scalar_type() == at::kByte && rstate.numel() == m * radix_state_bytes(), "bad radix state size");
+  check(kv_radix_init(stream_state.data_ptr(), rstate.data_ptr(), (const double*)ps.data_ptr(), (int)ps.numel(), (int)m, cur_stream()), "kv_radix_init");
+}
+
+void radix_pass_hist(at::Tensor x, int64_t n, at::Tensor rstate, at::Tensor hist, int64_t pass) {
+  CHECK_DEV(x); CHECK_DEV(rstate); CHECK_DEV(hist); CHECK_CONTIG(x); CHECK_CONTIG(rstate); CHECK_CONTIG(hist);
+  TORCH_CHECK(x.dim() == 2, "x must be [n_metrics, row_stride]");
+  const int64_t m = x.size(0);
+  TORCH_CHECK(n >= 0 && n <= x.size(1), "n exceeds the row length");
+  TORCH_CHECK(rstate.scalar_type() == at::kByte && rstate.numel() == m * radix_state_bytes(), "bad radix state size");
+  TORCH_CHECK(hist.scalar_type() == at::kInt && hist.numel() == m * 8 * 2048, "hist must be int32 [n_metrics, 8, 2048]");
+  check(kv_radix_pass_hist(x.data_ptr(), n, x.size(1), (int)m, sample_dtype(x), rstate.data_ptr(), (unsigned int*)hist.data_ptr(), (int)pass, cur_stream()), "kv_radix_pass_hist");
+}
+
+void radix_pass_scan(at::Tensor rstate, at::Tensor hist, bool is_double, int64_t pass) {
+  CHECK_DEV(rstate); CHECK_DEV(hist); CHECK_CONTIG(rstate); CHECK_CONTIG(hist);
+  const int64_t m = rstate.numel() / radix_state_bytes();
+  TORCH_CHECK(rstate.scalar_type() == at::kByte && m >= 1 && rstate.numel() == m * radix_state_bytes(), "bad radix state size");
+  TORCH_CHECK(hist.scalar_type() == at::kInt && hist.numel() == m * 8 * 2048, "hist must be int32 [n_metrics, 8, 2048]");
+  check(kv_radix_pass_scan(rstate.data_ptr(), (unsigned int*)hist.data_ptr(), (int)m, is_double ? 1 : 0, (int)pass, cur_stream()), "kv_radix_pass_scan");
 }
 
 void equal_hist(at::Tensor x, int64_t n, at::Tensor stream_state, at::Tensor out, int64_t n_bins) {
@@ -878,6 +911,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("radix_state_bytes", &radix_state_bytes);
   m.def("stream_hist", &stream_hist);
   m.def("radix_select", &radix_select);
+  m.def("radix_num_passes", &radix_num_passes);
+  m.def("radix_init", &radix_init);
+  m.def("radix_pass_hist", &radix_pass_hist);
+  m.def("radix_pass_scan", &radix_pass_scan);
   m.def("equal_hist", &equal_hist);
   m.def("energy_trapz", &energy_trapz);
   m.def("add_rmsnorm", &add_rmsnorm);

@@ -469,6 +469,44 @@ int kv_radix_select(const void* x, long long n, long long row_stride, int n_metr
   return (int)hipGetLastError();
 }
 
+// The same selection one pass at a time, for samples spread over several ranks: every rank runs
+// pass_hist on its own samples, the ranks SUM the digit histograms (one all-reduce of
+// [n_metrics][8][2048] counts per pass), and every rank runs pass_scan on the summed counts — the
+// selection state stays identical everywhere and ends at the exact order statistics of the union.
+// The state must have been initialised from the GLOBAL sample count.
+int kv_radix_num_passes(int dtype) { return dtype == 0 ? 3 : 6; }
+
+static void radix_pass_geometry(int dtype, int pass, int* shift, int* digit_bits) {
+  int top = dtype == 0 ? 32 : 64;
+  for (int i = 0;; ++i) {
+    const int db = top >= 11 ? 11 : top;
+    if (i == pass) { *shift = top - db; *digit_bits = db; return; }
+    top -= db;
+  }
+}
+
+int kv_radix_pass_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, const void* st, unsigned int* hist, int pass, hipStream_t stream) {
+  if (n_metrics <= 0 || pass < 0 || pass >= kv_radix_num_passes(dtype)) return -1;
+  if (n <= 0) return 0;  // a rank without samples contributes zeros
+  int shift = 0, digit_bits = 0;
+  radix_pass_geometry(dtype, pass, &shift, &digit_bits);
+  dim3 grid(grid_x(n, 16), n_metrics);
+  if (dtype == 0)
+    hipLaunchKernelGGL(radix_hist_kernel<float>, grid, dim3(KV_THREADS), 0, stream, (const float*)x, n, row_stride, (const RadixState*)st, hist, shift, digit_bits, pass == 0 ? 1 : 0);
+  else
+    hipLaunchKernelGGL(radix_hist_kernel<double>, grid, dim3(KV_THREADS), 0, stream, (const double*)x, n, row_stride, (const RadixState*)st, hist, shift, digit_bits, pass == 0 ? 1 : 0);
+  return (int)hipGetLastError();
+}
+
+int kv_radix_pass_scan(void* st, unsigned int* hist, int n_metrics, int dtype, int pass, hipStream_t stream) {
+  if (n_metrics <= 0 || pass < 0 || pass >= kv_radix_num_passes(dtype)) return -1;
+  int shift = 0, digit_bits = 0;
+  radix_pass_geometry(dtype, pass, &shift, &digit_bits);
+  const int key_bits = dtype == 0 ? 32 : 64;
+  hipLaunchKernelGGL(radix_scan_kernel, dim3(n_metrics), dim3(KV_THREADS), 0, stream, (RadixState*)st, hist, shift + (64 - key_bits), pass == 0 ? 1 : 0);
+  return (int)hipGetLastError();
+}
+
 int kv_equal_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, const void* state, unsigned long long* out, int n_bins,
                   hipStream_t stream) {
   if (n <= 0 || n_metrics <= 0) return 0;

@@ -20,6 +20,8 @@ from typing import Any, Dict, List, Optional
 
 ISVC_LABEL = "serving.kserve.io/inferenceservice"
 GPU_RESOURCE = "amd.com/gpu"
+# CUs of an MI355X compute partition (8 XCDs x 32 CUs), by the name a partition profile carries
+PARTITION_CUS = {"cpx": 32, "qpx": 64, "dpx": 128, "mi355x-cpx-nps4": 32, "mi355x-qpx-nps1": 64, "mi355x-dpx-nps1": 128}
 
 
 def iso_utc(ts: float) -> str:
@@ -428,6 +430,7 @@ class LocalBackend(ClusterBackend):
 
     def get_pods(self, namespace: str, service: str) -> List[Dict[str, Any]]:
         pods = []
+        dep = (self._load().get("isvc") or {}).get(f"{namespace}/{service}") or {}
         for i, s in enumerate(self._records(namespace, service)):
             pods.append(
                 make_pod(
@@ -441,6 +444,7 @@ class LocalBackend(ClusterBackend):
                     cpu=str(s.get("cpu", "8")),
                     memory=str(s.get("memory", "64Gi")),
                     image=s.get("image", "kvmini-native"),
+                    gpu_resource=s.get("gpu_resource") or dep.get("gpu_resource") or GPU_RESOURCE,
                 )
             )
         return pods
@@ -463,16 +467,163 @@ class LocalBackend(ClusterBackend):
         return {"kind": "Node", "metadata": {"name": node_name, "labels": labels}, "status": {"capacity": {}}}
 
     def get_isvc(self, namespace: str, service: str) -> Dict[str, Any]:
+        dep = (self._load().get("isvc") or {}).get(f"{namespace}/{service}")
+        if dep and self._alive(int(dep.get("pid", 0))):
+            m = dict(dep.get("manifest") or {"kind": "InferenceService", "metadata": {"name": service, "namespace": namespace}})
+            m["status"] = {"url": dep["url"], "replicas": dep.get("replicas", 1), "gpus_per_replica": dep.get("gpus_per_replica", 1)}
+            return m
         recs = [s for s in self._records(namespace, service) if s.get("finished_at") is None]
         if not recs:
             return {}
         return {"kind": "InferenceService", "metadata": {"name": service, "namespace": namespace}, "status": {"url": recs[-1]["url"]}}
+
+    # write side -------------------------------------------------------------
+    @staticmethod
+    def _alive(pid: int) -> bool:
+        if pid <= 0:
+            return False
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+        try:  # a child of this process that has exited but was not waited for still answers signal 0
+            with open(f"/proc/{pid}/stat") as f:
+                return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return True
+
+    @staticmethod
+    def local_spec(manifest: Dict[str, Any]) -> Dict[str, Any]:
+        """What an InferenceService manifest means on a bare node: which server to start with which
+        arguments, how many replicas, how many GPUs each.
+
+        * the native engine's manifests (``kvmini.deploy.manifests.native_isvc``: a container whose command
+          is ``kvmini serve``) run as they are: the container's args minus the in-cluster host / port;
+        * replicas: ``autoscaling.knative.dev/initialScale``, else ``minScale``, at least one (scale to
+          zero has no meaning for a process that is started on demand);
+        * GPUs per replica: the ``amd.com/*`` limit of the container (a whole GPU or a partition);
+          ``--tensor-parallel-size`` follows it unless the args already say;
+        * other runtimes' manifests (vLLM-ROCm, TGI-ROCm) cannot run here; with
+          ``KVMINI_LOCAL_EMULATE=mock`` they are stood in for by the protocol mock, else this raises."""
+        md = manifest.get("metadata") or {}
+        pred = ((manifest.get("spec") or {}).get("predictor")) or {}
+        wl = pred.get("model") or ((pred.get("containers") or [{}])[0])
+        limits = ((wl.get("resources") or {}).get("limits")) or {}
+        gpus, gpu_key = 0, GPU_RESOURCE
+        for k, v in limits.items():
+            if k.startswith("amd.com/"):
+                try:
+                    gpus, gpu_key = max(gpus, int(float(v))), k
+                except (TypeError, ValueError):
+                    pass
+        ann = md.get("annotations") or {}
+        replicas = 1
+        for key in ("autoscaling.knative.dev/initialScale", "autoscaling.knative.dev/minScale"):
+            if str(ann.get(key, "")).isdigit():
+                replicas = max(1, int(ann[key]))
+                break
+        cmd = list(wl.get("command") or [])
+        args = [str(x) for x in (wl.get("args") or [])]
+        kind = "native" if cmd[:2] == ["kvmini", "serve"] else "mock" if cmd[:2] == ["kvmini", "mock"] else None
+        if kind is None:
+            if os.environ.get("KVMINI_LOCAL_EMULATE") == "mock":
+                kind, args = "mock", []
+            else:
+                raise ValueError(f"the local backend runs this repository's servers only (manifest command {cmd or (wl.get('runtime') or wl.get('image'))!r}); "
+                                 "deploy --backend native, or set KVMINI_LOCAL_EMULATE=mock to stand the runtime in with the protocol mock")
+        keep: List[str] = []
+        i = 0
+        while i < len(args):  # the host / port of the in-cluster container are this backend's to choose
+            if args[i] in ("--host", "--port"):
+                i += 2
+                continue
+            keep.append(args[i])
+            i += 1
+        return {"kind": kind, "name": md.get("name", "demo-llm"), "namespace": md.get("namespace", "local"), "args": keep, "replicas": replicas, "gpus": gpus,
+                "partition": (md.get("labels") or {}).get("kvmini/partition"), "gpu_resource": gpu_key, "env": {e["name"]: str(e.get("value", "")) for e in (wl.get("env") or []) if "name" in e}}
+
+    def apply(self, manifest: Dict[str, Any]) -> None:
+        """Start what the manifest describes as fresh child processes of this one: ``kvmini serve`` for
+        one replica (which starts its own tensor-parallel ranks), ``kvmini router --replicas N`` in
+        front of N of them.  Applying a service that already runs replaces it, as ``kubectl apply`` of
+        a changed spec rolls the revision (reference flow: ``deploy.sh:108-114``,
+        ``sweeps/autoscale-sweep.sh:131-163``, ``scripts/compare_backends.py:244-345``).  Returns
+        once the processes exist; :meth:`wait_ready` waits for ``/health``."""
+        import socket
+        import sys
+
+        if manifest.get("kind") != "InferenceService":
+            return  # namespaces, secrets, serving runtimes: nothing to do on a bare node
+        spec = self.local_spec(manifest)
+        ns, name = spec["namespace"], spec["name"]
+        self.delete_isvc(ns, name)
+        want_port = str(((manifest.get("metadata") or {}).get("annotations") or {}).get("kvmini/local-port", ""))
+        if want_port.isdigit() and int(want_port) > 0:
+            port = int(want_port)
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = int(sk.getsockname()[1])
+        args = list(spec["args"])
+        cpu_only = "--device" in args and args[args.index("--device") + 1] == "cpu"
+        no_gpu = os.environ.get("KVMINI_LOCAL_DEVICE") == "cpu"
+        if spec["kind"] == "native" and no_gpu and not cpu_only:
+            args += ["--device", "cpu"]
+            cpu_only = True
+        tp = max(1, spec["gpus"]) if spec["kind"] == "native" and not cpu_only else 1
+        if "--tensor-parallel-size" in args:
+            tp = int(args[args.index("--tensor-parallel-size") + 1])
+        elif tp > 1:
+            args += ["--tensor-parallel-size", str(tp)]
+        py = [sys.executable, "-m", "kvmini"]
+        if spec["kind"] == "mock":
+            cmd = py + ["mock", "--port", str(port), "--service", name, "--register"] + args
+        elif spec["replicas"] > 1:
+            front = ["router", "--port", str(port), "--replicas", str(spec["replicas"]), "--gpus-per-replica", str(tp), "--service", name, "--namespace", ns]
+            if cpu_only:
+                front += ["--device", "cpu"]
+            inner = [a for a in args]
+            if "--tensor-parallel-size" in inner:  # the router hands the degree to every replica itself
+                k = inner.index("--tensor-parallel-size")
+                del inner[k : k + 2]
+            cmd = py + front + ["--"] + inner
+        else:
+            cmd = py + ["serve", "--port", str(port), "--service", name, "--namespace", ns] + args
+        log_dir = self.registry.parent / ".local_logs"
+        log_dir.mkdir(parents=True, exist_ok=True)
+        log = open(log_dir / f"{name}.log", "ab")
+        pkg_root = str(Path(__file__).resolve().parents[2])
+        env = dict(os.environ)
+        env.update({k: v for k, v in spec["env"].items() if k.isupper()})
+        env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        env["KVMINI_LOCAL_REGISTRY"] = str(self.registry.resolve())
+        # A compute partition cannot be switched without root on a bare node; what a partition profile
+        # changes for the engine is the number of CUs it gets, and that the HSA runtime can restrict per
+        # process (CU mask: CPX = one XCD = 32 CUs, QPX 64, DPX 128).  The whole HBM stays visible — the
+        # cost model prices the partition's share through the resource key either way.
+        cus = PARTITION_CUS.get(str(spec["partition"] or "").lower())
+        if cus and not cpu_only and os.environ.get("KVMINI_LOCAL_PARTITION_EMULATION", "cu-mask") == "cu-mask":
+            env["HSA_CU_MASK"] = f"0:0-{cus - 1}"
+        proc = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, start_new_session=True)
+        self._children = getattr(self, "_children", {})
+        self._children[proc.pid] = proc
+        reg = self._load()
+        reg.setdefault("isvc", {})[f"{ns}/{name}"] = {"url": f"http://127.0.0.1:{port}", "pid": proc.pid, "applied_at": time.time(), "replicas": spec["replicas"], "gpus_per_replica": tp,
+                                                      "kind": spec["kind"], "partition": spec["partition"], "gpu_resource": spec["gpu_resource"], "cu_mask": env.get("HSA_CU_MASK"), "command": cmd, "log": str(log_dir / f"{name}.log"), "manifest": manifest}
+        self._save(reg)
 
     def wait_ready(self, namespace: str, service: str, timeout_s: float = 600.0) -> float:
         import urllib.request
 
         t0 = time.time()
         while time.time() - t0 < timeout_s:
+            dep = (self._load().get("isvc") or {}).get(f"{namespace}/{service}")
+            if dep:
+                child = getattr(self, "_children", {}).get(int(dep["pid"]))
+                if (child is not None and child.poll() is not None) or not self._alive(int(dep["pid"])):
+                    raise RuntimeError(f"{service}: the server process exited before it became ready (see {dep.get('log')})")
             url = self.get_isvc_url(namespace, service)
             if url:
                 try:
@@ -487,6 +638,35 @@ class LocalBackend(ClusterBackend):
     def delete_isvc(self, namespace: str, service: str) -> None:
         import signal
 
+        reg = self._load()
+        dep = (reg.get("isvc") or {}).pop(f"{namespace}/{service}", None)
+        if dep:
+            self._save(reg)
+            pid = int(dep.get("pid", 0))
+            if self._alive(pid):
+                # the deployment was started in a session of its own: the signal reaches the router, the
+                # replicas and the tensor-parallel ranks alike
+                for sig, wait_s in ((signal.SIGTERM, 15.0), (signal.SIGKILL, 5.0)):
+                    try:
+                        os.killpg(pid, sig)
+                    except OSError:
+                        try:
+                            os.kill(pid, sig)
+                        except OSError:
+                            break
+                    child = getattr(self, "_children", {}).get(pid)
+                    t_end = time.time() + wait_s
+                    while time.time() < t_end:
+                        if child is not None:
+                            if child.poll() is not None:
+                                break
+                        elif not self._alive(pid):
+                            break
+                        time.sleep(0.05)
+                    else:
+                        continue
+                    break
+            getattr(self, "_children", {}).pop(pid, None)
         for s in self._records(namespace, service):
             if s.get("finished_at") is None:
                 try:

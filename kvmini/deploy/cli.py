@@ -54,48 +54,52 @@ def build_manifest(a: argparse.Namespace) -> Dict[str, Any]:
     return m
 
 
-def start_local_server(a: argparse.Namespace) -> Dict[str, Any]:
-    """Spawn the native engine (or the mock) as a detached child and wait for /health."""
-    port = a.port
-    if a.local_server == "mock":
-        cmd = [sys.executable, "-m", "kvmini", "mock", "--port", str(port), "--model", a.model_name or "mock-llm", "--service", a.service, "--register"]
-    else:
-        cmd = [sys.executable, "-m", "kvmini", "serve", "--port", str(port), "--model", a.model_name or "llama-3-8b", "--service", a.service, "--namespace", a.namespace]
-        prof = load_profile(a.profile) if a.profile else None
-        if prof and prof.native_engine.get("draft_model"):
-            cmd += ["--speculative-model", str(prof.native_engine["draft_model"]), "--num-speculative-tokens", str(prof.native_engine.get("num_speculative_tokens", 4))]
-        if prof and prof.vllm_features.get("quantization") == "fp8":
-            cmd += ["--quantization", "fp8"]
-    cmd += [str(x) for x in (getattr(a, "serve_args", None) or [])]
-    log_dir = os.path.join("runs", ".local_logs")
-    os.makedirs(log_dir, exist_ok=True)
-    log = open(os.path.join(log_dir, f"{a.service}.log"), "ab")
-    t0 = time.time()
-    # the child must import this very package, whatever the caller's working directory is
-    pkg_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ)
-    env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-    proc = subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, start_new_session=True, env=env)
-    lb = LocalBackend()
-    url = f"http://127.0.0.1:{port}"
-    deadline = t0 + a.timeout
-    import urllib.request
+def local_manifest(a: argparse.Namespace) -> Dict[str, Any]:
+    """The InferenceService a local deployment stands for: the native engine's manifest (profile-driven
+    server flags and ``serve_args`` in the container args) or, for ``--local-server mock``, a
+    container whose command is ``kvmini mock``.  ``LocalBackend.apply`` turns either into processes."""
+    port = getattr(a, "port", None)
+    ann = {"kvmini/local-port": str(port)} if port else {}
+    if getattr(a, "local_server", "native") == "mock":
+        container = {"name": "kserve-container", "image": "kvmini/mock:latest", "command": ["kvmini", "mock"],
+                     "args": ["--model", a.model_name or "mock-llm"] + [str(x) for x in (getattr(a, "serve_args", None) or [])]}
+        return {"apiVersion": "serving.kserve.io/v1beta1", "kind": "InferenceService", "metadata": mf._meta(a.service, a.namespace, "mock", ann),
+                "spec": {"predictor": {"containers": [container]}}}
+    serve_args: List[str] = []
+    prof = load_profile(a.profile) if getattr(a, "profile", None) else None
+    if prof and prof.native_engine.get("draft_model"):
+        serve_args += ["--speculative-model", str(prof.native_engine["draft_model"]), "--num-speculative-tokens", str(prof.native_engine.get("num_speculative_tokens", 4))]
+    if prof and prof.vllm_features.get("quantization") == "fp8":
+        serve_args += ["--quantization", "fp8"]
+    serve_args += [str(x) for x in (getattr(a, "serve_args", None) or [])]
+    tp = int(getattr(a, "tensor_parallel_size", None) or 1)
+    if "--tensor-parallel-size" in serve_args:
+        tp = int(serve_args[serve_args.index("--tensor-parallel-size") + 1])
+    m = mf.native_isvc(a.service, a.namespace, a.model_name or "llama-3-8b", gpus=tp, serve_args=serve_args, annotations=ann)
+    replicas = int(getattr(a, "replicas", None) or 1)
+    if replicas > 1:
+        m = mf.apply_autoscaling(m, initial_scale=replicas, min_scale=replicas)
+    if getattr(a, "partition_profile", None):
+        m = mf.apply_partition_profile(m, load_yaml(a.partition_profile))
+    return m
 
-    while time.time() < deadline:
-        if proc.poll() is not None:
-            raise SystemExit(f"local server exited with code {proc.returncode}; see {log.name}")
-        try:
-            with urllib.request.urlopen(url + "/health", timeout=1) as r:
-                if r.status == 200:
-                    break
-        except Exception:
-            time.sleep(0.2)
-    else:
-        proc.terminate()
-        raise SystemExit(f"local server not ready after {a.timeout}s")
-    if a.local_server != "mock" and not lb.get_isvc_url(a.namespace, a.service):
-        lb.register_server(a.service, url, proc.pid, t0, namespace=a.namespace)
-    return {"url": url, "pid": proc.pid, "ready_s": time.time() - t0}
+
+def start_local_server(a: argparse.Namespace) -> Dict[str, Any]:
+    """Deploy on this host through the local cluster backend's write side (``LocalBackend.apply`` +
+    ``wait_ready``): the one way every harness starts, resizes and replaces a local server."""
+    lb = LocalBackend()
+    manifest = local_manifest(a)
+    ns, name = manifest["metadata"]["namespace"], manifest["metadata"]["name"]
+    t0 = time.time()
+    lb.apply(manifest)
+    try:
+        lb.wait_ready(ns, name, float(getattr(a, "timeout", 600.0)))
+    except (RuntimeError, TimeoutError) as e:
+        lb.delete_isvc(ns, name)
+        raise SystemExit(f"local server failed to start: {e}")
+    dep = lb.get_isvc(ns, name)
+    reg = (lb._load().get("isvc") or {}).get(f"{ns}/{name}", {})
+    return {"url": dep["status"]["url"], "pid": reg.get("pid"), "ready_s": time.time() - t0}
 
 
 def main(argv: Optional[List[str]] = None) -> int:
@@ -114,6 +118,10 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--cluster-backend", default=None, choices=["auto", "kubectl", "local", "fake"])
     ap.add_argument("--local-server", default="native", choices=["native", "mock"])
     ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--replicas", type=int, default=None, help="local backend: engine replicas behind the data-parallel router (clusters: initialScale / minScale)")
+    ap.add_argument("--device", default=None, choices=["cpu", "cuda"], help="local native server: run the engine on this device (cpu: tests)")
+    ap.add_argument("--delete", action="store_true", help="remove the service instead of creating it")
+    ap.add_argument("--serve-arg", action="append", default=[], dest="serve_args", help="extra flag for the local server (repeatable, e.g. --serve-arg=--max-model-len --serve-arg=4096)")
     ap.add_argument("--timeout", type=float, default=600.0)
     ap.add_argument("--skip-preflight", action="store_true")
     a = ap.parse_args(argv)
@@ -125,13 +133,22 @@ def main(argv: Optional[List[str]] = None) -> int:
     if a.model_uri:
         print(f"Model URI: {a.model_uri}")
     print("")
-    manifest = build_manifest(a)
+    if a.device:
+        a.serve_args = list(a.serve_args) + ["--device", a.device]
+    local = a.cluster_backend == "local"
+    if a.delete:
+        backend = get_backend(a.cluster_backend)
+        backend.delete_isvc(a.namespace, mf.dns1123_label(a.service))
+        print(f"Deleted {a.namespace}/{a.service}")
+        return 0
+    # a bare node runs this repository's servers (the other runtimes' images need a cluster): the manifest is the native engine's
+    manifest = local_manifest(a) if local else build_manifest(a)
     if a.dry_run:
         print("--- Generated InferenceService manifest ---")
         print(mf.to_yaml(manifest))
         return 0
     backend = get_backend(a.cluster_backend)
-    if isinstance(backend, LocalBackend) or a.cluster_backend == "local":
+    if isinstance(backend, LocalBackend) or local:
         info = start_local_server(a)
         print(f"Local server ready in {info['ready_s']:.1f}s: {info['url']} (pid {info['pid']})")
         return 0

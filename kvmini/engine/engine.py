@@ -248,11 +248,13 @@ class LLMEngine:
 
     def check_collectives(self) -> None:
         """Raise if a peer-memory collective timed out waiting for a peer (its results are garbage)."""
-        x = self.runner.xgmi
-        if x is not None:
-            n = x.errors()
-            if n:
-                raise RuntimeError(f"{n} xGMI collective wait(s) timed out: a tensor-parallel rank did not take part in a step")
+        for x in (self.runner.xgmi, getattr(self.runner, "xgmi_ids", None)):
+            if x is not None:
+                n = x.errors()
+                if n:
+                    # the communicator is poisoned from here on (a late peer leaves stale flags behind): the
+                    # group has to be restarted, so this is raised to whoever drives the engine
+                    raise RuntimeError(f"{n} xGMI collective wait(s) timed out: a tensor-parallel rank did not take part in a step")
 
     def set_token_classes(self, cls: Any) -> None:
         """Token classes for guided decoding (``kvmini.engine.guided.token_classes`` of the
@@ -316,6 +318,11 @@ class LLMEngine:
                 events += self._commit(batch, ids, logits)
                 launched = True
         if launched:
+            # a peer-memory collective that timed out leaves garbage behind and its flags unreliable:
+            # look at the error word now and then (reading it waits for the device, hence not per step)
+            self._collective_check = getattr(self, "_collective_check", 0) + 1
+            if self.runner.xgmi is not None and self.runner.tp_size > 1 and self._collective_check % 512 == 0:
+                self.check_collectives()
             dt = time.perf_counter() - t0
             st = self.stats
             st.steps += 1
@@ -456,18 +463,17 @@ class LLMEngine:
         on the device when that step runs (argmax, or unseeded sampling done by device ops), and
         no preemption (a preempted sequence is rescheduled from its token list, which may not
         hold placeholders)."""
-        r, sch = self.runner, self.scheduler
-        # tensor parallelism: the followers run the forward pass and the argmax only, so a token
-        # that is fed on the device must be the argmax on every rank — greedy requests pipeline,
-        # sampled ones are stepped synchronously (their ids reach the followers staged by the host)
-        greedy_only = r.tp_size > 1
+        sch = self.scheduler
+        # (tensor parallelism: the followers run the forward pass and the argmax; when the scheduling
+        # rank samples or masks rows on the device, its ids reach them on the device as well —
+        # ModelRunner.sync_sampled_ids — so sampled and guided requests are launched ahead there too)
         for s in sch.running:
-            if self._needs_host_sampling(s.params) or (greedy_only and (s.params.temperature > 0 or s.params.guided)):
+            if self._needs_host_sampling(s.params):
                 return False
         room = sch.max_num_seqs - len(sch.running)
         if room > 0 and sch.waiting:
             for s in itertools.islice(sch.waiting, room):
-                if self._needs_host_sampling(s.params) or (greedy_only and (s.params.temperature > 0 or s.params.guided)):
+                if self._needs_host_sampling(s.params):
                     return False
         return self.bm.num_free >= len(sch.running) + sch.max_batched_tokens // self.bm.block_size + 2
 

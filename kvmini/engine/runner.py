@@ -162,6 +162,14 @@ class ModelRunner:
             # slots sized for the widest step the fused epilogue should serve: 256 rows of the residual stream
             slot = max(4 << 20, 256 * cfg_hidden(self.cfg) * 2)
             self.xgmi = XgmiComm(group=tp_group, device=self.device, slot_bytes=slot) if self.tp_size > 1 else XgmiComm(device=self.device, slot_bytes=slot, world=1, rank=0)
+        # sampled / guided ids travel from the scheduling rank to the followers on the device, behind the
+        # sampling ops (a communicator of its own: one call per step on every rank, so its slot parity
+        # never depends on what the captured graphs hold)
+        self.xgmi_ids = None
+        if self.xgmi is not None and self.tp_size > 1:
+            from kvmini.parallel.xgmi import XgmiComm
+
+            self.xgmi_ids = XgmiComm(group=tp_group, device=self.device, slot_bytes=max(4096, rcfg.max_batched_tokens * 8))
         self.num_blocks = rcfg.num_blocks or self._auto_num_blocks()
         if tp_group is not None and self.tp_size > 1:
             # only the scheduling rank hands out block ids, so every rank's cache must hold the
@@ -529,6 +537,29 @@ class ModelRunner:
         g = self.tp_group
         return 0 if g is None else torch.distributed.get_global_rank(g, 0)
 
+    def sync_sampled_ids(self, n: int) -> None:
+        """Tensor parallelism: make the first ``n`` entries of ``out_ids`` on every rank those of the
+        scheduling rank, with device ops only (queued behind the step, so steps stay launched
+        ahead).  Every rank of the group calls this for the same steps (header field ``ids_sync``).
+        Peer-memory all-gather when the hand-written collectives are up; else a broadcast of the
+        group's backend (RCCL on GPUs; a host-side group of ranks sharing one GPU goes through the
+        host, which waits for the step)."""
+        if self.tp_size <= 1 or n <= 0:
+            return
+        ids = self.out_ids[: min((n + 1) // 2 * 2, self.out_ids.numel())]  # whole 16-byte units for the peer-memory kernel
+        if self.xgmi_ids is not None:
+            table = self.xgmi_ids.all_gather(ids.view(torch.uint8))
+            ids.copy_(table[0].view(torch.int64))
+            return
+        import torch.distributed as dist
+
+        if ids.is_cuda and dist.get_backend(self.tp_group) != "nccl":
+            host = ids.cpu()
+            dist.broadcast(host, src=self._tp_src(), group=self.tp_group)
+            ids.copy_(host)
+        else:
+            dist.broadcast(ids, src=self._tp_src(), group=self.tp_group)
+
     def follow(self) -> int:
         """Tensor-parallel follower loop (ranks > 0 of the TP group): take every step's staged
         image from the host channel, copy it to the device and enqueue the same pass on the local
@@ -543,12 +574,16 @@ class ModelRunner:
             self._cur ^= 1
             if sb.event is not None:
                 sb.event.synchronize()  # the copy that last read this pinned buffer is done
-            self.channel.receive(sb.np)
-            t_pad, _n_samples, max_ctx, cmd, dec, quads, dec_split = (int(v) for v in sb.np[o_h : o_h + 7])
+            while not self.channel.receive(sb.np, timeout_s=1.0):
+                if not self.channel.writer_alive():
+                    raise RuntimeError("tensor parallelism: the scheduling rank is gone (no stop command was published); this follower exits")
+            t_pad, n_samples, max_ctx, cmd, dec, quads, dec_split, ids_sync = (int(v) for v in sb.np[o_h : o_h + 8])
             if cmd == 1:
                 return n
             self.stage_dev.copy_(sb.cpu, non_blocking=True)
             self._run_staged(t_pad, max_ctx, dec, bool(quads), dec_split)
+            if ids_sync:
+                self.sync_sampled_ids(n_samples)  # the scheduling rank sampled: take its ids instead of the local argmax
             if self.device.type == "cuda":
                 if sb.event is None:
                     sb.event = torch.cuda.Event()
@@ -561,7 +596,7 @@ class ModelRunner:
             return
         o_h = self._off["header"][0]
         img = np.zeros(self.stages[0].np.size, dtype=np.int32)
-        img[o_h : o_h + 5] = (0, 0, 0, 1, 0)
+        img[o_h : o_h + 8] = (0, 0, 0, 1, 0, 0, 0, 0)
         try:
             self.channel.publish(img, timeout_s=10.0)
         except TimeoutError:
@@ -711,7 +746,8 @@ class ModelRunner:
         if self.dec_split_ok and not decode_only and 0 < n_dec <= self.DEC_SPLIT_ROWS and dec_max_ctx >= self.DEC_SPLIT_MIN_CTX:
             dec_split = 1 << (n_dec - 1).bit_length()
         st[o_dr + min(n_dec, self.DEC_SPLIT_ROWS) : o_dr + self.DEC_SPLIT_ROWS] = -1
-        st[o_h : o_h + 7] = (t_pad, n_samples, max_ctx, 0, decode_only, quads, dec_split)
+        ids_sync = int(sampler is not None and self.tp_size > 1)  # the followers must take this rank's sampled ids
+        st[o_h : o_h + 8] = (t_pad, n_samples, max_ctx, 0, decode_only, quads, dec_split, ids_sync)
         if self.channel is not None:
             # every rank runs the same step: hand the staged image to the followers first (host
             # shared memory, see follow()), so that they enqueue it while this rank does
@@ -720,6 +756,8 @@ class ModelRunner:
         logits = self._run_staged(t_pad, max_ctx, decode_only, bool(quads), dec_split)
         if sampler is not None:
             sampler(logits, self.out_ids)
+            if ids_sync:
+                self.sync_sampled_ids(n_samples)
         # the ids leave the device right behind the step, before a later launch overwrites them
         sb.out_cpu[:n_samples].copy_(self.out_ids[:n_samples], non_blocking=True)
         if self.device.type == "cuda":

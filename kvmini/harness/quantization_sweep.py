@@ -150,6 +150,7 @@ class QuantizationSweepRunner:
                     ns.serve_args += ["--max-num-seqs", str(config["max_num_seqs"])]
                 if str(config.get("kv_cache_dtype", "auto")).startswith("fp8"):
                     ns.serve_args += ["--kv-cache-dtype", "fp8"]
+                ns.tensor_parallel_size = int(config.get("tensor_parallel_size", 1) or 1)  # the server starts its own ranks
             info = start_local_server(ns)
             self._local_pid = info["pid"]
             return info["url"]
@@ -396,6 +397,8 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--url", default=None, help="benchmark this endpoint for every configuration (already deployed / shared service)")
     ap.add_argument("--resume", action="store_true", help="keep the configurations that <output-dir>/sweep_results_intermediate.csv already holds without an error")
     ap.add_argument("--no-quality", action="store_true", help="skip the quality mini-eval even if the config enables it")
+    ap.add_argument("--model", default=None, help="override benchmark.model of the config (e.g. llama-3-70b on an 8-GPU node)")
+    ap.add_argument("--tensor-parallel-size", type=int, default=None, help="override tensor_parallel_size of every configuration")
     a = ap.parse_args(argv)
     if a.create_config:
         with open(a.config, "w") as f:
@@ -408,6 +411,11 @@ def main(argv: Optional[List[str]] = None) -> int:
     cfg = load_yaml(a.config)
     if a.no_quality:
         cfg["quality_eval"] = {"enabled": False}
+    if a.model:
+        cfg.setdefault("benchmark", {})["model"] = a.model
+    if a.tensor_parallel_size:
+        for c in cfg.get("configurations") or cfg.get("configs") or []:
+            c["tensor_parallel_size"] = a.tensor_parallel_size
     runner = QuantizationSweepRunner(cfg, a.output_dir, a.local, a.cluster_backend, a.runs_root, a.port, a.cost_file, url=a.url, resume=a.resume)
     if a.analyze_only:
         runner.results += runner.load_rows(a.analyze_only)

@@ -78,12 +78,30 @@ def _add_common(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--api-key", default=None)
     ap.add_argument("--cost-file", default="cost.yaml")
     ap.add_argument("--cluster-backend", default=None, choices=["auto", "kubectl", "local", "fake"])
+    ap.add_argument("--native-model", default="llama-3-8b", help="--backend native: the architecture preset the engine serves")
+    ap.add_argument("--serve-arg", action="append", default=[], dest="serve_args", help="--backend native: extra `kvmini serve` flag (repeatable)")
     ap.add_argument("--loadtest-args", default="")
     ap.add_argument("--resume", action="store_true", help="skip cells whose results.json already exists")
     ap.add_argument("--runs-root", default="runs")
 
 
 # ---------------------------------------------------------------------------------------------
+def _build_isvc(a: argparse.Namespace, backend: Any, svc: str) -> Dict[str, Any]:
+    """The cell's InferenceService.  On a bare node (local cluster backend) only this repository's
+    engine can be started, so the native manifest is used whatever ``--backend`` says."""
+    from kvmini.cluster import LocalBackend
+    from kvmini.deploy import manifests as mf
+
+    kind = a.backend
+    if isinstance(backend, LocalBackend) and kind != "native":
+        print(f"  local cluster backend: deploying the native engine instead of {kind}")
+        kind = "native"
+    if kind == "native":
+        return mf.native_isvc(svc, a.namespace, a.native_model, serve_args=[str(x) for x in a.serve_args])
+    builder = mf.BUILDERS[kind]
+    return builder(svc, a.namespace, a.model_uri) if kind.startswith("vllm") else builder(svc, a.namespace)
+
+
 def main_grid(argv: Optional[List[str]] = None) -> int:
     ap = argparse.ArgumentParser(prog="kvmini grid-sweep", description="concurrency x max_tokens x pattern sweep")
     _add_common(ap)
@@ -228,8 +246,7 @@ def main_autoscale(argv: Optional[List[str]] = None) -> int:
                 w.writerow(_autoscale_row(cc, init, grace, stable, panic, load_json(res_path), run_dir, load_json(res_path).get("deploy_time_sec", "")))
                 f.flush()
                 continue
-            builder = mf.BUILDERS[a.backend]
-            isvc = builder(svc, a.namespace, a.model_uri) if a.backend.startswith("vllm") else builder(svc, a.namespace)
+            isvc = _build_isvc(a, backend, svc)
             # panic window is a percentage of the stable window in Knative
             try:
                 pct = f"{100.0 * float(panic.rstrip('s')) / float(stable.rstrip('s')):.1f}"
@@ -305,8 +322,7 @@ def main_partition(argv: Optional[List[str]] = None) -> int:
             prof = load_yaml(resolve_profile_path(name))
             pname = str(prof.get("profile", name))
             svc = dns1123_label(f"{a.service}-{pname}")
-            builder = mf.BUILDERS[a.backend]
-            isvc = builder(svc, a.namespace, a.model_uri) if a.backend.startswith("vllm") else builder(svc, a.namespace)
+            isvc = _build_isvc(a, backend, svc)
             isvc = mf.apply_partition_profile(isvc, prof)
             run_dir = os.path.join(a.runs_root, f"partition_{ts if not a.resume else 'resume'}_{pname}")
             print(f"=== partition profile {pname} ===")

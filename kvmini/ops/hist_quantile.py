@@ -119,6 +119,97 @@ def batched_quantiles(samples: Any, ps: Sequence[float] = (0.5, 0.95, 0.99), ret
     return (out, stats) if return_stats else out
 
 
+def _float_keys(x: np.ndarray) -> np.ndarray:
+    """Order-preserving unsigned keys of float32 / float64 values (the kernels' ``KeyOf``): flip the
+    sign bit of non-negative numbers, all bits of negative ones."""
+    if x.dtype == np.float32:
+        b = x.view(np.uint32)
+        return np.where(b >> np.uint32(31), ~b, b | np.uint32(0x80000000)).astype(np.uint64) << np.uint64(32)
+    b = x.view(np.uint64)
+    return np.where(b >> np.uint64(63), ~b, b | np.uint64(0x8000000000000000))
+
+
+def distributed_quantiles(samples: Any, ps: Sequence[float], dist: Any, group: Any = None, device: Any = None) -> List[float]:
+    """EXACT quantiles (the reference's linear interpolation, ``analyze.py:59-81``) of samples that
+    are spread over the ranks of a ``torch.distributed`` group, without gathering them: an MSD
+    radix select in which every rank histograms the next 11-bit digit of its own samples, the ranks
+    sum the histograms (one all-reduce of 8 x 2048 counts per pass: 3 passes for float32, 6 for
+    float64) and every rank walks the summed counts — so the selection state is the same
+    everywhere and ends at the order statistics of the union.  NaN = missing.  On a GPU the
+    passes are ``radix_hist_kernel`` / ``radix_scan_kernel`` (csrc/hist_quantile.hip) and the
+    all-reduce is RCCL's; on the host the same protocol runs in numpy (CPU rehearsals, tests).
+    Every rank returns the same list; all NaN when no rank has a sample."""
+    torch = _torch()
+    ps = [max(0.0, min(float(p), 1.0)) for p in ps]
+    if not 1 <= len(ps) <= 4:
+        raise ValueError("1..4 quantile levels per call")
+    x = np.asarray(samples.cpu().numpy() if hasattr(samples, "cpu") else samples)
+    if x.dtype not in (np.float32, np.float64):
+        x = x.astype(np.float64)
+    x = np.ascontiguousarray(x.reshape(-1))
+    x = x[~np.isnan(x)]
+    is_double = x.dtype == np.float64
+    dev = torch.device(device) if device is not None else torch.device("cuda" if available() else "cpu")
+    on_gpu = dev.type == "cuda" and available()
+    cnt = torch.tensor([x.size], dtype=torch.int64, device=dev if on_gpu else "cpu")
+    dist.all_reduce(cnt, group=group)
+    n_all = int(cnt.item())
+    if n_all == 0:
+        return [float("nan")] * len(ps)
+    ranks: List[int] = []
+    for p in ps:
+        pos = p * (n_all - 1)
+        ranks += [math.floor(pos), math.ceil(pos)]
+    if on_gpu:
+        C = native()
+        xd = torch.from_numpy(x if x.size else np.zeros(1, dtype=x.dtype)).to(dev).reshape(1, -1)
+        state, _h = _new_stream_state(1, dev)
+        state.view(torch.int64)[0] = n_all  # the selection's ranks come from the global count
+        rstate = torch.zeros(C.radix_state_bytes(), dtype=torch.uint8, device=dev)
+        rhist = torch.zeros((1, 8, BINS), dtype=torch.int32, device=dev)
+        C.radix_init(state, torch.tensor(ps, dtype=torch.float64, device=dev), rstate)
+        for k in range(int(C.radix_num_passes(is_double))):
+            C.radix_pass_hist(xd, int(x.size), rstate, rhist, k)
+            dist.all_reduce(rhist, group=group)
+            C.radix_pass_scan(rstate, rhist, is_double, k)
+        prefixes = struct.unpack("<8Q", rstate.cpu().numpy()[:64].tobytes())
+        vals = [_key_to_value(prefixes[i], is_double) for i in range(2 * len(ps))]
+    else:
+        keys = _float_keys(x) if x.size else np.zeros(0, dtype=np.uint64)
+        key_bits = 64 if is_double else 32
+        prefix = [0] * len(ranks)   # decided high bits, left-aligned in 64
+        rem = list(ranks)           # rank remaining inside the prefix
+        top, decided = key_bits, 0
+        while top > 0:
+            db = 11 if top >= 11 else top
+            shift = top - db + (64 - key_bits)
+            uniq = sorted(set(prefix))
+            h = np.zeros((len(uniq), 1 << 11), dtype=np.int64)
+            for u, pre in enumerate(uniq):
+                sel = keys if decided == 0 else keys[(keys >> np.uint64(64 - decided)) == np.uint64(pre >> (64 - decided))]
+                if sel.size:
+                    h[u] = np.bincount(((sel >> np.uint64(shift)) & np.uint64((1 << db) - 1)).astype(np.int64), minlength=1 << 11)
+            ht = torch.from_numpy(h)
+            dist.all_reduce(ht, group=group)
+            h = ht.numpy()
+            for r in range(len(ranks)):
+                row = h[uniq.index(prefix[r])]
+                cum = np.cumsum(row)
+                b = int(np.searchsorted(cum, rem[r], side="right"))
+                rem[r] -= int(cum[b - 1]) if b else 0
+                prefix[r] |= b << shift
+            decided += db
+            top -= db
+        vals = [_key_to_value(pf, is_double) for pf in prefix]
+    out = []
+    for j, p in enumerate(ps):
+        pos = p * (n_all - 1)
+        lo = math.floor(pos)
+        v_lo, v_hi = vals[2 * j], vals[2 * j + 1]
+        out.append(v_lo if n_all == 1 or lo == math.ceil(pos) else v_lo + (pos - lo) * (v_hi - v_lo))
+    return out
+
+
 def quantiles(a: Iterable[float], ps: Sequence[float] = (0.5, 0.95, 0.99)) -> List[float]:
     arr = np.asarray(a, dtype=np.float64).reshape(1, -1)
     out: List[float] = []

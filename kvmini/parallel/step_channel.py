@@ -48,10 +48,30 @@ class StepChannel:
         self.nread = np.ndarray((1,), dtype=np.int64, buffer=self.shm.buf, offset=8)
         self.acks = np.ndarray((MAX_READERS,), dtype=np.int64, buffer=self.shm.buf, offset=HEADER_BYTES)
         self.slots = np.ndarray((self.ring, self.n_ints), dtype=np.int32, buffer=self.shm.buf, offset=HEADER_BYTES + MAX_READERS * 8)
+        self.writer_pid = np.ndarray((1,), dtype=np.int64, buffer=self.shm.buf, offset=16)
         self.reader = reader
         self.seq = 0  # writer: images published; reader: images consumed
         if create:
+            import os
+
             self.nread[0] = n_readers
+            self.writer_pid[0] = os.getpid()
+
+    def writer_alive(self) -> bool:
+        """Readers (same host): is the process that publishes the images still there?  A follower
+        whose scheduling rank died must exit and give its GPU back instead of polling for ever."""
+        import os
+
+        pid = int(self.writer_pid[0])
+        if pid <= 0:
+            return True
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+        return True
 
     # ---- writer ---------------------------------------------------------
     def publish(self, image: np.ndarray, timeout_s: float = 60.0) -> None:
@@ -84,7 +104,7 @@ class StepChannel:
 
     def close(self) -> None:
         # drop the numpy views first: SharedMemory.close() refuses while exported buffers exist
-        self.head = self.nread = self.acks = self.slots = None  # type: ignore[assignment]
+        self.head = self.nread = self.acks = self.slots = self.writer_pid = None  # type: ignore[assignment]
         try:
             self.shm.close()
             if self.owner:

@@ -594,7 +594,7 @@ def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--speculative-model", default=None, help="draft model preset for speculative decoding, or self:<K> (early exit after K layers of the served model)")
     ap.add_argument("--tail-damping", type=float, default=0.0, help="random-init + self:<K> only: damp layers >= K so the early-exit draft agrees with the full model (synthetic)")
     ap.add_argument("--num-speculative-tokens", type=int, default=0)
-    ap.add_argument("--tensor-parallel-size", type=int, default=1, help="shard the model over this many GPUs; launch with torchrun --nproc-per-node N (one rank per GPU, RCCL)")
+    ap.add_argument("--tensor-parallel-size", type=int, default=1, help="shard the model over this many GPUs: the command starts one rank process per GPU itself (RCCL over xGMI); under torchrun it joins the ranks torchrun started")
     ap.add_argument("--no-async-scheduling", action="store_true", help="read every step's tokens back before launching the next one (default: launch ahead; greedy requests only)")
     ap.add_argument("--launch-margin-ms", type=float, default=0.7, help="launch-ahead stepping: enqueue the next step this long before the one in flight should end, so late arrivals still make it (0 = at once)")
     ap.add_argument("--ride-along-limit", type=int, default=0, help="prompt backlogs up to this many tokens are fed to the running decodes in steps of <= 64 tokens instead of one wide step (better first-token time under bursts, slightly lower throughput; 0 = off)")
@@ -647,7 +647,7 @@ def init_tensor_parallel(a: argparse.Namespace) -> Any:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.tensor_parallel_size:
-        raise SystemExit(f"--tensor-parallel-size {a.tensor_parallel_size} needs torchrun --nproc-per-node {a.tensor_parallel_size} (WORLD_SIZE is {world})")
+        raise SystemExit(f"--tensor-parallel-size {a.tensor_parallel_size} does not match the launcher's WORLD_SIZE {world} (start the command without a launcher, or with torchrun --nproc-per-node {a.tensor_parallel_size})")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if a.device == "cpu":
@@ -658,6 +658,66 @@ def init_tensor_parallel(a: argparse.Namespace) -> Any:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     a.tp_rank = dist.get_rank()
     return dist.group.WORLD
+
+
+def launch_tensor_parallel(argv: List[str], n: int) -> int:
+    """``kvmini serve --tensor-parallel-size N`` typed without a launcher: start the N ranks as fresh
+    child processes of this one (which never touches the GPU and replaces no process image), the
+    way ``bench.py --gpus N`` does — rank r gets RANK / LOCAL_RANK = r and sees every GPU (RCCL's
+    and the peer-memory kernels' xGMI paths need the peers' devices visible).  SIGTERM / SIGINT are
+    handed on to the ranks; a rank that fails takes the others down and the exit code is non-zero.
+    The reference only ever sets a number (``runners/backends/vllm/deploy.sh:78-79``)."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = int(sk.getsockname()[1])
+    pkg_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    procs: List[Any] = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        procs.append(subprocess.Popen([sys.executable, "-m", "kvmini", "serve"] + list(argv), env=env))
+
+    def hand_on(signum: int, _frame: Any) -> None:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(signum)
+                except OSError:
+                    pass
+
+    signal.signal(signal.SIGTERM, hand_on)
+    signal.signal(signal.SIGINT, hand_on)
+    rc = 0
+    deadline = None
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    print(f"kvmini serve: tensor-parallel rank {r} exited with {code}", file=sys.stderr, flush=True)
+                    rc = rc or (code if code > 0 else 1)
+                # once any rank has left (the server was told to stop, or a rank failed) the others cannot
+                # finish a collective without it: give them a moment to leave by themselves
+                deadline = deadline or time.time() + (15.0 if code == 0 else 5.0)
+            if deadline is not None and time.time() > deadline:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                rc = rc or 1
+    return rc
 
 
 def main(argv: Optional[List[str]] = None) -> int:
@@ -671,6 +731,8 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--no-register", action="store_true")
     add_engine_args(ap)
     a = ap.parse_args(argv)
+    if a.tensor_parallel_size > 1 and "RANK" not in os.environ:
+        return launch_tensor_parallel(list(sys.argv[1:] if argv is None else argv), a.tensor_parallel_size)
     proc_start = time.time()
     import signal
 

@@ -167,11 +167,9 @@ def spawn_replicas(n: int, base_port: int, serve_args: List[str], gpus_per_repli
         if device != "cpu":
             env["HIP_VISIBLE_DEVICES"] = ",".join(str(i * gpus_per_replica + k) for k in range(gpus_per_replica))
         port = base_port + 1 + i
-        if gpus_per_replica > 1:
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus_per_replica}", "--master-addr", "127.0.0.1", "--master-port", str(29900 + i),
-                   "-m", "kvmini", "serve", "--tensor-parallel-size", str(gpus_per_replica)]
-        else:
-            cmd = [sys.executable, "-m", "kvmini", "serve"]
+        cmd = [sys.executable, "-m", "kvmini", "serve"]
+        if gpus_per_replica > 1:  # the command starts its own ranks (kvmini.server.native.launch_tensor_parallel)
+            cmd += ["--tensor-parallel-size", str(gpus_per_replica)]
         cmd += ["--port", str(port), "--service", f"replica-{i}", "--no-register", *serve_args]
         log = open(os.path.join(log_dir, f"router-replica-{i}.log"), "ab")
         procs.append(subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, start_new_session=True))

@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("KVMINI_DECODE_LAYERS_TIMELINE", "1")
+os.environ.setdefault("KVMINI_DECODE_LAYERS", "1")
 import torch
 
 from kvmini.engine.engine import EngineConfig, LLMEngine
