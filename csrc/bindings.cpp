@@ -47,8 +47,6 @@ int kv_guided_advance(const long long* out_ids, const long long* rows, const int
                       int* cursor, int L, hipStream_t stream);
 int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, void* y, int T, int H, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
-int kv_skinny_gemm(const void* W, const void* x, void* y, int M, int N, int K, long long ldx, long long ldy, int swiglu, int packed, int waves,
-                   hipStream_t stream);
 int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
 int kv_stream_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int ks_per_chunk, int splits,
@@ -503,19 +501,6 @@ void swiglu_interleaved(at::Tensor gu, at::Tensor act) {
   check(kv_swiglu_interleaved(gu.data_ptr(), act.data_ptr(), (int)gu.size(0), (int)act.size(1), cur_stream()), "kv_swiglu_interleaved");
 }
 
-// y[M, N(or N/2 with swiglu)] = x[M, K] @ W[N, K]^T.  x rows may be strided; M in {16,32,48,64}.
-void skinny_gemm(at::Tensor W, at::Tensor x, at::Tensor y, bool swiglu, bool packed, int64_t waves) {
-  CHECK_DEV(W); CHECK_BF16(W); CHECK_BF16(x); CHECK_BF16(y); CHECK_CONTIG(W);
-  TORCH_CHECK(W.dim() == 2 && x.dim() == 2 && y.dim() == 2 && x.stride(1) == 1 && y.stride(1) == 1, "W [N, K], x [M, K], y [M, N]");
-  const int64_t N = W.size(0), K = W.size(1), M = x.size(0);
-  TORCH_CHECK(x.size(1) == K && y.size(0) == M && y.size(1) == (swiglu ? N / 2 : N), "skinny_gemm shape mismatch");
-  TORCH_CHECK(x.stride(0) % 8 == 0 && y.stride(0) % 4 == 0, "row strides must keep 16-byte (x) / 8-byte (y) alignment");
-  TORCH_CHECK(waves == 0 || waves == 4 || waves == 8, "waves must be 0, 4 or 8");
-  check(kv_skinny_gemm(W.data_ptr(), x.data_ptr(), y.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), y.stride(0), swiglu ? 1 : 0, packed ? 1 : 0, (int)waves,
-                       cur_stream()),
-        "kv_skinny_gemm");
-}
-
 at::Tensor pack_weight(at::Tensor W) {
   CHECK_DEV(W); CHECK_BF16(W); CHECK_CONTIG(W);
   TORCH_CHECK(W.dim() == 2, "W must be [N, K]");
@@ -938,7 +923,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("script") = py::none(), py::arg("cursor") = py::none(), py::arg("cur_init") = py::none());
   m.def("guided_advance", &guided_advance, py::arg("out_ids"), py::arg("rows"), py::arg("slots"), py::arg("state"), py::arg("cls"), py::arg("script") = py::none(),
         py::arg("cursor") = py::none());
-  m.def("skinny_gemm", &skinny_gemm);
   m.def("pack_weight", &pack_weight);
   m.def("stream_gemm_plan", &stream_gemm_plan);
   m.def("stream_gemm", &stream_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("ks_per_chunk"), py::arg("splits"),

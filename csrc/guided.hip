@@ -14,11 +14,15 @@
 // Scripts (JSON schemas): a sequence may carry a script, int32 [2][L] = (entries, rest), and a
 // cursor into it.  Entry >= 0: a literal token of the document's skeleton (a required key with its
 // punctuation, the closing brace), FORCED — the mask leaves only that token — once the value in
-// front of it is complete at the top level; entry <= -2: a value slot whose first token is
-// restricted to the class set (-2 - entry); entry -1: end.  rest[i] = fewest tokens from entry i
-// to the end of the sequence, which keeps the "can still be closed within the tokens left" rule.
+// front of it is complete at the top level; -2 - mask: a value slot whose first token is
+// restricted to the class set; -1: end; JMP_BASE - t: continue at entry t; CHOICE_BASE - n: the
+// MODEL chooses among n alternatives — 2 n entries (key, target) follow, key >= 0 a first token,
+// key a slot code a first value — which is what enum values, anyOf alternatives and optional
+// array items compile to: the mask leaves the alternatives' tokens (and classes), the pick moves
+// the cursor.  rest[i] = fewest tokens from entry i to the end of the sequence, which keeps the
+// "can still be closed within the tokens left" rule (an alternative is offered only if it fits).
 // The automaton is SET at the end of a literal (merged tokens such as '":' have no class to
-// follow).  kvmini/engine/guided.py::allowed_scripted / advance_scripted are the reference.
+// follow).  kvmini/engine/guided.py::allowed_scripted / step_scripted are the reference.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,6 +31,17 @@ namespace {
 
 enum { C_OTHER, C_LBRACE, C_RBRACE, C_LBRACK, C_RBRACK, C_COLON, C_COMMA, C_QUOTE, C_STR, C_DIGIT_NZ, C_DIGIT, C_LIT, C_EOS, C_NULL, N_CLASSES };  // C_LIT: true / false
 constexpr int SCRIPT_END = -1;
+constexpr int JMP_BASE = -20000, CHOICE_BASE = -30000, MAX_ALTS = 16;
+enum { K_LIT, K_END, K_SLOT, K_JMP, K_CHOICE };
+__device__ inline int entry_kind(int e) { return e >= 0 ? K_LIT : e == SCRIPT_END ? K_END : e > JMP_BASE ? K_SLOT : e > CHOICE_BASE ? K_JMP : K_CHOICE; }
+// the cursor with jumps followed (compiled scripts chain two at most)
+__device__ inline int resolve(const int* __restrict__ ent, int cur, int L) {
+  for (int hop = 0; hop < 8; ++hop) {
+    if (cur < 0 || cur >= L || entry_kind(ent[cur]) != K_JMP) break;
+    cur = JMP_BASE - ent[cur];
+  }
+  return cur;
+}
 enum { S_OFF, S_START, S_OBJ_FIRST, S_KEY, S_AFTER_KEY, S_VALUE, S_STR, S_NUM, S_AFTER_VALUE, S_OBJ_NEXT, S_ARR_FIRST, S_DONE, S_END };
 constexpr int MAX_DEPTH = 16;
 constexpr int TPB = 1024;
@@ -140,19 +155,65 @@ __device__ inline unsigned allowed_classes(St a, int left, int vc) {
 // script's next literal token comes next
 __device__ inline bool forcing(int s, int depth) { return depth == 1 && (s == S_AFTER_VALUE || s == S_NUM || s == S_OBJ_NEXT); }
 
-// scripted sequences: class mask + the one token that is allowed whatever its class (-1: none)
-__device__ inline unsigned allowed_scripted(St a, int left, int vc, const int* __restrict__ ent, const int* __restrict__ rest, int cur, int L, int& forced) {
-  forced = -1;
+// (fits, grammar) class masks of the FIRST token of a value slot at the top level
+__device__ inline void slot_classes(unsigned mask, int after, int left, int vc, unsigned& fits, unsigned& grammar) {
+  fits = 0; grammar = 0;
+  const St v = {S_VALUE, 1, 0};
+#pragma unroll
+  for (int c = 1; c < N_CLASSES; ++c) {
+    bool ok;
+    const St n = transition(v, c, ok);
+    if (!ok || n.depth < 1) continue;
+    grammar |= 1u << c;
+    if (close_cost(n.s, n.depth, vc) - 2 + after <= left - 1) fits |= 1u << c;
+  }
+  if (mask & grammar) { grammar &= mask; fits &= mask; }
+}
+
+// scripted sequences: class mask + up to MAX_ALTS tokens that are allowed whatever their class
+__device__ inline unsigned allowed_scripted(St a, int left, int vc, const int* __restrict__ ent, const int* __restrict__ rest, int cur, int L, int* toks, int& n_toks) {
+  n_toks = 0;
   if (ent == nullptr || cur < 0 || cur >= L || ent[cur] == SCRIPT_END || a.s == S_OFF || a.s == S_END) return allowed_classes(a, left, vc);
   const int e = ent[cur];
+  const int kind = entry_kind(e);
   a.stack &= (1 << FIRST_SHIFT) - 1;
-  if (e >= 0 && forcing(a.s, a.depth)) {
-    forced = e;
+  if (kind != K_SLOT && forcing(a.s, a.depth)) {
     const bool more_digits = a.s == S_NUM && left - 1 >= rest[cur];
-    return more_digits ? ((1u << C_DIGIT) | (1u << C_DIGIT_NZ)) : 0u;
+    const unsigned digits = more_digits ? ((1u << C_DIGIT) | (1u << C_DIGIT_NZ)) : 0u;
+    if (kind == K_LIT) {
+      toks[0] = e;
+      n_toks = 1;
+      return digits;
+    }
+    // a choice: every alternative after which the document can still be closed in the tokens left
+    int n = CHOICE_BASE - e;
+    n = n > MAX_ALTS ? MAX_ALTS : n;
+    unsigned cls_fit = 0, cls_all = 0;
+    int n_fit = 0;
+    for (int k = 0; k < n; ++k) {
+      const int key = ent[cur + 1 + 2 * k], tgt = ent[cur + 2 + 2 * k];
+      const int after = (tgt >= 0 && tgt < L) ? rest[tgt] : 1;
+      if (key >= 0) {
+        if (after <= left - 1) toks[n_fit++] = key;
+      } else {
+        unsigned f, g;
+        slot_classes((unsigned)(-2 - key), after, left, vc, f, g);
+        cls_fit |= f;
+        cls_all |= g;
+      }
+    }
+    if (n_fit > 0 || cls_fit != 0) {
+      n_toks = n_fit;
+      return cls_fit | digits;
+    }
+    for (int k = 0; k < n; ++k) {  // budget too small from the start: stay in the script, the output is cut short
+      const int key = ent[cur + 1 + 2 * k];
+      if (key >= 0) toks[n_toks++] = key;
+    }
+    return cls_all | digits;
   }
-  const int after = e < 0 ? (cur + 1 < L ? rest[cur + 1] : 1) : rest[cur];
-  const unsigned first = (e < 0 && a.s == S_VALUE && a.depth == 1) ? (unsigned)(-2 - e) : 0u;
+  const int after = kind == K_SLOT ? (cur + 1 < L ? rest[cur + 1] : 1) : rest[cur];
+  const unsigned first = (kind == K_SLOT && a.s == S_VALUE && a.depth == 1) ? (unsigned)(-2 - e) : 0u;
   unsigned fits = 0, grammar = 0;
 #pragma unroll
   for (int c = 1; c < N_CLASSES; ++c) {
@@ -186,10 +247,27 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
   if (script != nullptr) cur = fresh ? cur_init[r] : cursor[slot];
   if (fresh && tid < 4) state[4 * slot + tid] = init[4 * r + tid];  // nobody reads state[] / cursor[] of this slot in this launch
   if (fresh && tid == 4 && script != nullptr) cursor[slot] = cur;
-  int forced;
-  const int* ent = script != nullptr ? script + (long long)slot * 2 * L : nullptr;
-  const unsigned allow = allowed_scripted(a, left, vc, ent, ent != nullptr ? ent + L : nullptr, cur, L, forced);
+  // the allowed set is worked out once per row and shared (it walks a choice's alternatives)
+  __shared__ unsigned allow_s;
+  __shared__ int toks_s[MAX_ALTS], n_toks_s;
+  if (tid == 0) {
+    const int* ent0 = script != nullptr ? script + (long long)slot * 2 * L : nullptr;
+    int tk[MAX_ALTS], nt = 0;
+    allow_s = allowed_scripted(a, left, vc, ent0, ent0 != nullptr ? ent0 + L : nullptr, cur, L, tk, nt);
+    n_toks_s = nt;
+    for (int k = 0; k < nt; ++k) toks_s[k] = tk[k];
+  }
+  __syncthreads();
+  const unsigned allow = allow_s;
+  const int n_toks = n_toks_s;
+  const int forced = n_toks > 0 ? toks_s[0] : -1;
   if (allow == (1u << N_CLASSES) - 1u) return;
+  // is token id `t` one of the alternatives' tokens (beyond the first, which the loops test inline)?
+  auto listed = [&](int t) -> bool {
+    for (int k = 1; k < n_toks; ++k)
+      if (toks_s[k] == t) return true;
+    return false;
+  };
   unsigned short* row = logits + rows[r] * row_stride;
   constexpr unsigned short NEG_INF = 0xFF80;
   int done = 0;
@@ -202,7 +280,7 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned c = (unsigned)(c8 >> (8 * j)) & 0xffu;
-        if (!((allow >> c) & 1u) && i * 8 + j != forced) { x[j] = NEG_INF; any = true; }
+        if (!((allow >> c) & 1u) && i * 8 + j != forced && !(n_toks > 1 && listed(i * 8 + j))) { x[j] = NEG_INF; any = true; }
       }
       if (any) reinterpret_cast<us8*>(row)[i] = x;
     }
@@ -210,7 +288,7 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
   }
   for (int i = done + tid; i < V; i += TPB) {
     const unsigned c = i < n_cls ? cls[i] : (unsigned)C_OTHER;  // ids past the tokenizer's vocabulary (padding columns) are never allowed
-    if (!((allow >> c) & 1u) && i != forced) row[i] = NEG_INF;
+    if (!((allow >> c) & 1u) && i != forced && !(n_toks > 1 && listed(i))) row[i] = NEG_INF;
   }
 }
 
@@ -230,17 +308,49 @@ __global__ void guided_advance_kernel(const long long* __restrict__ out_ids, con
     const int* ent = script + (long long)slot * 2 * L;
     if (cur >= 0 && cur < L && ent[cur] != SCRIPT_END) {
       const int e = ent[cur];
-      if (e >= 0 && forcing(a.s, a.depth) && tok == (long long)e) {
-        // a literal token was written: the automaton is set by what the script holds next
-        const int nx = cur + 1 < L ? ent[cur + 1] : SCRIPT_END;
-        cursor[slot] = cur + 1;
-        st[0] = nx == SCRIPT_END ? S_DONE : (nx < 0 ? S_VALUE : S_OBJ_NEXT);
-        st[1] = nx == SCRIPT_END ? 0 : 1;
+      const int kind = entry_kind(e);
+      // a skeleton token was written (a literal, or the token that picked an alternative): the cursor
+      // moves and the automaton is set by what the script holds there
+      auto land = [&](int at) {
+        const int nx = resolve(ent, at, L);
+        const int k2 = (nx >= 0 && nx < L) ? entry_kind(ent[nx]) : (int)K_END;
+        cursor[slot] = nx;
+        st[0] = k2 == K_END ? S_DONE : (k2 == K_SLOT ? S_VALUE : S_OBJ_NEXT);
+        st[1] = k2 == K_END ? 0 : 1;
         st[2] = 0;
         st[3] = st[3] - 1;
+      };
+      if (kind == K_LIT && forcing(a.s, a.depth) && tok == (long long)e) {
+        land(cur + 1);
         return;
       }
-      if (e < 0 && a.s == S_VALUE && a.depth == 1) cursor[slot] = cur + 1;  // the slot's value has begun
+      if (kind == K_CHOICE && forcing(a.s, a.depth)) {
+        int n = CHOICE_BASE - e;
+        n = n > MAX_ALTS ? MAX_ALTS : n;
+        for (int k = 0; k < n; ++k) {
+          const int key = ent[cur + 1 + 2 * k];
+          if (key >= 0 && tok == (long long)key) {
+            land(ent[cur + 2 + 2 * k]);
+            return;
+          }
+        }
+        if (!(a.s == S_NUM && (c == C_DIGIT || c == C_DIGIT_NZ))) {  // (a digit goes on with the number in front of the choice)
+          for (int k = 0; k < n; ++k) {
+            const int key = ent[cur + 1 + 2 * k];
+            if (key >= 0) continue;
+            const unsigned mask = (unsigned)(-2 - key);
+            bool ok2;
+            const St v = {S_VALUE, 1, 0};
+            const St n2 = transition(v, c, ok2);
+            if (ok2 && n2.depth >= 1 && (mask == 0u || ((mask >> c) & 1u))) {
+              cursor[slot] = resolve(ent, ent[cur + 2 + 2 * k], L);
+              st[0] = n2.s; st[1] = n2.depth; st[2] = n2.stack; st[3] = st[3] - 1;
+              return;
+            }
+          }
+        }
+      }
+      if (kind == K_SLOT && a.s == S_VALUE && a.depth == 1) cursor[slot] = resolve(ent, cur + 1, L);  // the slot's value has begun
     }
   }
   bool ok;

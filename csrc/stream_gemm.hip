@@ -2,7 +2,7 @@
 //     y[M, N] = x[M, K] @ W[N, K]^T     bf16 in, fp32 accumulate,  M in {16, 32, 48, 64}
 //
 // The op is bound by streaming W from HBM once; everything else has to stay out of the
-// way.  Measured on the v1 kernel (csrc/skinny_gemm.hip), the time grew linearly with M
+// way.  Measured on the first kernel of this kind (no LDS staging of x), the time grew linearly with M
 // because every wave re-read its x fragments from L2 in 64-byte row pieces.  Here:
 //
 //  * W is stored pre-packed in MFMA fragment order [N/16][K/32][64 lanes][8 bf16], so a
@@ -738,9 +738,35 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const unsigned cha
   dst[1] = hi;
 }
 
+// Re-order W[N, K] (row-major bf16) into MFMA fragment order [N/16][K/32][64 lanes][8]: every
+// wave-level load of the streaming kernels then reads one contiguous 1 KiB.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const unsigned short* __restrict__ W, unsigned short* __restrict__ Wp, int N, int K) {
+  typedef __attribute__((ext_vector_type(4))) unsigned short pk_us4;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;  // one 16-byte fragment per thread
+  const int ksteps = K >> 5;
+  const long long total = (long long)(N >> 4) * ksteps * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const long long tile = idx >> 6;
+  const int ks = (int)(tile % ksteps);
+  const long long nt = tile / ksteps;
+  const int r = lane & 15, q = lane >> 4;
+  const pk_us4* src = reinterpret_cast<const pk_us4*>(W + (nt * 16 + r) * K + (long long)ks * 32 + q * 8);
+  pk_us4* dst = reinterpret_cast<pk_us4*>(Wp + idx * 8);
+  dst[0] = src[0];
+  dst[1] = src[1];
+}
+
 }  // namespace
 
 extern "C" {
+
+int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream) {
+  if ((N & 15) || (K & 31)) return -1;
+  const long long total = (long long)(N >> 4) * (K >> 5) * 64;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const unsigned short*)W, (unsigned short*)Wp, N, K);
+  return (int)hipGetLastError();
+}
 
 // Number of K-splits the kernel will use for a shape when up to `max_splits` are allowed
 // (callers size the slab buffer with it).  Splits are chosen so that the grid has at

@@ -146,10 +146,42 @@ def _probs_rows(logits: torch.Tensor, params: List[SamplingParams]) -> torch.Ten
     return probs
 
 
-def _sample_rows_device(logits: torch.Tensor, params: List[SamplingParams]) -> torch.Tensor:
-    """Temperature / top-k / top-p sampling of many rows at once (unseeded): one softmax / sort /
-    multinomial over the batch; the ids stay on the device (int64 ``[R]``)."""
-    return torch.multinomial(_probs_rows(logits, params), 1).view(-1)
+def seeded_uniform(seed: int, k: int) -> float:
+    """The uniform variate in [0, 1) of draw ``k`` of a request with seed ``seed``: a counter-based
+    hash (splitmix64 finaliser), so the draw for a request's k-th token is the same whichever
+    step, batch, rank or replay computes it, and the host can hand it to a device sampler without
+    owning a generator whose state would have to follow the tokens."""
+    m = (1 << 64) - 1
+    x = ((int(seed) & m) * 0x9E3779B97F4A7C15 + (int(k) + 1) * 0xD1B54A32D192ED03) & m
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & m
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & m
+    x ^= x >> 31
+    return (x >> 40) / float(1 << 24)
+
+
+def _uniforms(draws: Optional[List[Optional[float]]], n: int, dev: torch.device) -> torch.Tensor:
+    """One uniform variate per sampled row: the request's own (seeded rows) or the device
+    generator's (``None`` entries)."""
+    u = torch.rand(n, dtype=torch.float32, device=dev)
+    if draws is not None and any(d is not None for d in draws):
+        own = _host_to_device([float("nan") if d is None else d for d in draws], torch.float32, dev)
+        u = torch.where(torch.isnan(own), u, own)
+    return u
+
+
+def _sample_rows_device(logits: torch.Tensor, params: List[SamplingParams], draws: Optional[List[Optional[float]]] = None) -> torch.Tensor:
+    """Temperature / top-k / top-p sampling of many rows at once: one softmax / sort / inverse
+    CDF over the batch, one uniform variate per row (``draws``: those of seeded requests); the
+    ids stay on the device (int64 ``[R]``)."""
+    probs = _probs_rows(logits, params)
+    cdf = torch.cumsum(probs, dim=-1)
+    u = _uniforms(draws, probs.shape[0], probs.device) * cdf[:, -1]
+    idx = torch.searchsorted(cdf, u[:, None].contiguous(), right=True).view(-1)
+    # (a variate that rounds up to the total lands behind the last token: the last one with mass instead)
+    last = (probs > 0).int().cumsum(-1).argmax(-1)
+    return torch.minimum(idx, last)
 
 
 def _sample_rows(logits: torch.Tensor, params: List[SamplingParams]) -> List[int]:
@@ -203,6 +235,7 @@ class LLMEngine:
             from .speculative import SpeculativeDecoder
 
             self.spec = SpeculativeDecoder(self, ecfg.draft_model, ecfg.num_speculative_tokens)
+            self.scheduler.guided_supported = False
         self.load_s = time.perf_counter() - t0
         self.stats = EngineStats()
         self._ids = itertools.count(1)
@@ -377,6 +410,7 @@ class LLMEngine:
         g_cur: List[int] = []
         g_scripts: List[Tuple[int, List[List[int]]]] = []  # (slot, [entries, rest]) to upload before the mask runs
         g_greedy: List[int] = []
+        draws: List[Optional[float]] = []
         r = 0
         for ch in batch.chunks:
             if ch.sample:
@@ -388,6 +422,7 @@ class LLMEngine:
                 if p.temperature > 0 and (p.guided or not guided_only):
                     rows.append(r)
                     plist.append(p)
+                    draws.append(self._draw_for(ch.seq))
                 r += 1
         if not rows and not g_rows:
             return None
@@ -404,7 +439,7 @@ class LLMEngine:
                     idx = gr if len(g_greedy) == len(g_rows) else _host_to_device(g_greedy, torch.int64, dev)
                     out_ids.index_copy_(0, idx, ops.greedy_sample(logits.index_select(0, idx)))
             if rows:
-                self._sample_into(logits, rows, plist, out_ids)
+                self._sample_into(logits, rows, plist, out_ids, draws)
             if g_rows:
                 ops.guided_advance(out_ids, gr, gs, self._guided_state, self._guided_cls, self._guided_script, self._guided_cursor)
 
@@ -438,25 +473,38 @@ class LLMEngine:
             g_init += [-1, 0, 0, 0]
             g_cur.append(-1)
 
-    def _sample_into(self, logits: torch.Tensor, rows: List[int], plist: List[SamplingParams], out_ids: torch.Tensor) -> torch.Tensor:
-        """Sample rows ``rows`` of ``logits`` (one SamplingParams each, unseeded) into
-        ``out_ids[rows]`` with device ops only; returns the device index tensor of the rows."""
+    def _sample_into(self, logits: torch.Tensor, rows: List[int], plist: List[SamplingParams], out_ids: torch.Tensor,
+                     draws: Optional[List[Optional[float]]] = None) -> torch.Tensor:
+        """Sample rows ``rows`` of ``logits`` (one SamplingParams each; ``draws``: the uniform
+        variate of a seeded request's row, None for the others) into ``out_ids[rows]`` with device
+        ops only; returns the device index tensor of the rows."""
         dev = logits.device
         idx = _host_to_device(rows, torch.int64, dev)
         kernel = getattr(self.runner.ops, "sample_rows", None)
         if kernel is not None and logits.dtype == torch.bfloat16 and logits.stride(1) == 1:
             # one launch, no sort: threshold search on the bf16 logits (csrc/sampling.hip)
             kernel(logits, idx, _host_to_device([max(p.temperature, 1e-5) for p in plist], torch.float32, dev),
-                   _host_to_device([int(p.top_k or 0) for p in plist], torch.int32, dev), _host_to_device([float(p.top_p) for p in plist], torch.float32, dev), out_ids)
+                   _host_to_device([int(p.top_k or 0) for p in plist], torch.int32, dev), _host_to_device([float(p.top_p) for p in plist], torch.float32, dev), out_ids,
+                   _uniforms(draws, len(rows), dev))
         else:
-            out_ids.index_copy_(0, idx, _sample_rows_device(logits.index_select(0, idx), plist))
+            out_ids.index_copy_(0, idx, _sample_rows_device(logits.index_select(0, idx), plist, draws))
         return idx
 
     @staticmethod
+    def _draw_for(seq: Sequence) -> Optional[float]:
+        """The uniform variate of the token a seeded sequence samples next (None: no seed).  The
+        counter is the number of tokens it has produced or has in flight, so a step that is
+        launched ahead draws what the synchronous path would have drawn."""
+        if seq.params.seed is None:
+            return None
+        return seeded_uniform(int(seq.params.seed), len(seq.output_ids))
+
+    @staticmethod
     def _needs_host_sampling(p: SamplingParams) -> bool:
-        # a per-request seed owns a generator that is advanced on the host; logprobs are read back
-        # (guided rows are always picked on the device: their automaton advances there)
-        return bool(p.logprobs) or (p.temperature > 0 and p.seed is not None and not p.guided)
+        # logprobs are read back with the logits.  (Seeded requests are sampled by the device ops
+        # like unseeded ones: their variates are a function of (seed, token index) — seeded_uniform —
+        # that the host computes at launch time; guided rows are always picked on the device.)
+        return bool(p.logprobs)
 
     def _can_pipeline(self) -> bool:
         """Pipelined stepping needs every token of the next step to be either known or already
@@ -538,14 +586,14 @@ class LLMEngine:
 
     def _commit(self, batch: Batch, ids: List[int], logits: Optional[torch.Tensor]) -> List[TokenEvent]:
         events: List[TokenEvent] = []
-        # unseeded temperature sampling: all such rows of the step in one batched call
+        # temperature sampling: all such rows of the step in one batched call
         batched: Dict[int, int] = {}
         if logits is not None:
-            rows_b = [r for r, ch in enumerate(c for c in batch.chunks if c.sample) if ch.seq.params.temperature > 0 and ch.seq.params.seed is None and not ch.seq.params.guided]
+            sampled = [ch.seq for ch in batch.chunks if ch.sample]
+            rows_b = [r for r, sq in enumerate(sampled) if sq.params.temperature > 0 and not sq.params.guided]
             if rows_b:
-                plist = [ch.seq.params for ch in batch.chunks if ch.sample]
                 tmp = torch.zeros(logits.shape[0], dtype=torch.int64, device=logits.device)
-                idx = self._sample_into(logits, rows_b, [plist[r] for r in rows_b], tmp)
+                idx = self._sample_into(logits, rows_b, [sampled[r].params for r in rows_b], tmp, [self._draw_for(sampled[r]) for r in rows_b])
                 batched = dict(zip(rows_b, tmp[idx].tolist()))
         row = 0
         for ch in batch.chunks:
@@ -559,8 +607,6 @@ class LLMEngine:
             p = seq.params
             if row in batched:
                 tok = batched[row]
-            elif p.temperature > 0 and logits is not None and not p.guided:
-                tok = _sample_row(logits[row], p, self.generator_for(seq))
             lp_entry = None
             if p.logprobs > 0 and logits is not None:
                 lp = torch.log_softmax(logits[row].float(), -1)

@@ -143,6 +143,9 @@ class Scheduler:
         # sequences the scheduler gave up on by itself (finish reason "error: ..."); the engine
         # drains this list into token events
         self.failed: List[Sequence] = []
+        # False on an engine whose steps do not run the guided sampler (speculative decoding verifies
+        # drafts against unmasked logits): such a request is refused at intake instead of running unconstrained
+        self.guided_supported = True
 
     # ------------------------------------------------------------------
     def validate(self, seq: Sequence) -> Optional[str]:
@@ -163,6 +166,8 @@ class Scheduler:
                 return f"{name} must be a finite non-negative number, got {v!r}"
         if p.guided not in (None, "json"):
             return f"unknown guided decoding mode {p.guided!r}"
+        if p.guided and not self.guided_supported:
+            return "guided decoding is not available on an engine that runs speculative decoding"
         if p.guided_script is not None:
             from .guided import SCRIPT_END, SCRIPT_MAX
 

@@ -77,30 +77,48 @@ class ParityProber:
         ch = data.get("choices") or [{}]
         return ch[0] if isinstance(ch[0], dict) else {}
 
+    RETRIES = 6  # sampled re-asks when the model's own choice under "auto" did not show the capability
+
+    async def _tool_calls(self, payload: Dict[str, Any], enough: int) -> Tuple[int, int, str]:
+        """(status, most tool calls seen in one completion, which request showed them).  The first
+        request is the reference's (``tool_choice: auto``, ``scripts/openai_parity_probe.py:98,147``).
+        Under "auto" a server may let the MODEL decide between text and calls, and how many: a text
+        answer there says nothing about the server, so the question is asked again with
+        ``tool_choice: required`` (sampled, a few times) before the capability counts as absent."""
+        status, data = await self._chat({**payload, "tool_choice": "auto"})
+        calls = (self._choice(data).get("message") or {}).get("tool_calls")
+        best, how = (len(calls), "auto") if status == 200 and isinstance(calls, list) else (-1, "auto")
+        for k in range(self.RETRIES if status == 200 and best < enough else 0):
+            st2, data = await self._chat({**payload, "tool_choice": "required", "temperature": 1.0, "max_tokens": 256})
+            calls = (self._choice(data).get("message") or {}).get("tool_calls")
+            if st2 == 200 and isinstance(calls, list) and len(calls) > best:
+                best, how = len(calls), f"required, sampled (attempt {k + 1}); under auto the model chose otherwise"
+            if best >= enough:
+                break
+        return status, best, how
+
     async def probe_tools(self) -> ProbeResult:
-        status, data = await self._chat(
+        status, best, how = await self._tool_calls(
             {
                 "messages": [{"role": "user", "content": "What is the weather in San Francisco?"}],
                 "tools": [_fn("get_current_weather", {"location": {"type": "string"}, "unit": {"type": "string", "enum": ["celsius", "fahrenheit"]}}, ["location"], "Get the current weather")],
-                "tool_choice": "auto",
-            }
+            },
+            enough=0,
         )
-        calls = (self._choice(data).get("message") or {}).get("tool_calls")
-        ok = status == 200 and isinstance(calls, list)
-        return ProbeResult(ok, None if ok else f"status={status}, tool_calls={calls}")
+        ok = status == 200 and best >= 0
+        return ProbeResult(ok, (None if how == "auto" else how) if ok else f"status={status}, no tool_calls list")
 
     async def probe_parallel_tools(self) -> ProbeResult:
-        status, data = await self._chat(
+        status, best, how = await self._tool_calls(
             {
                 "messages": [{"role": "user", "content": "For NYC and SF, get weather and timezone."}],
                 "tools": [_fn("get_weather", {"city": {"type": "string"}}), _fn("get_timezone", {"city": {"type": "string"}})],
-                "tool_choice": "auto",
-            }
+            },
+            enough=2,
         )
         if status != 200:
             return ProbeResult(False, f"status={status}")
-        calls = (self._choice(data).get("message") or {}).get("tool_calls") or []
-        return ProbeResult(len(calls) >= 2, f"tool_calls={len(calls)}")
+        return ProbeResult(best >= 2, f"tool_calls={max(best, 0)}" + ("" if how == "auto" else f" ({how})"))
 
     async def probe_json_mode(self) -> ProbeResult:
         status, data = await self._chat({"messages": [{"role": "user", "content": "Return a JSON with keys city and temp."}], "response_format": {"type": "json_object"}})

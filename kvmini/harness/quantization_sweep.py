@@ -368,17 +368,25 @@ class QuantizationSweepRunner:
 
 
 def create_default_config() -> Dict[str, Any]:
-    base = {"max_model_len": 2048, "gpu_memory_utilization": 0.9, "max_tokens": 64}
+    """The default sweep: every (weight format, KV-cache dtype) point an MI355X deployment really has —
+    bf16 / FP8 (e4m3) / 4-bit weights x bf16 / FP8 KV — with one decoding variation per weight format, so
+    no two rows measure the same configuration.  The six-entry sweep of the reference
+    (``sweeps/quantization_sweep.yaml:11-73``) names two 4-bit checkpoint formats (AWQ, GPTQ); on this
+    stack they are one kernel format, hence one 4-bit column with two KV dtypes instead."""
+    def row(name: str, q: str, kv: str, ctx: int = 2048, util: float = 0.9, **decoding: Any) -> Dict[str, Any]:
+        return {"name": name, "quantization": q, "kv_cache_dtype": kv, "max_model_len": ctx, "gpu_memory_utilization": util, "max_tokens": 64,
+                "decoding": {"temperature": 0.0, "top_p": 1.0, **decoding}}
+
     return {
         "benchmark": {"namespace": "benchmark", "service": "llama3-8b-sweep", "model": "llama-3-8b", "requests": 100, "concurrency": 10},
         "quality_eval": {"enabled": True},
         "sweep_configurations": [
-            {"name": "baseline", "quantization": "none", "kv_cache_dtype": "auto", **base, "decoding": {"temperature": 0.0, "top_p": 1.0}},
-            {"name": "fp8-dynamic", "quantization": "fp8", "kv_cache_dtype": "fp8", **base, "decoding": {"temperature": 0.2, "top_p": 0.9}},
-            {"name": "fp8-kv", "quantization": "none", "kv_cache_dtype": "fp8", **base, "max_model_len": 4096, "decoding": {"temperature": 0.0, "top_p": 1.0}},
-            {"name": "awq-optimized", "quantization": "awq", "kv_cache_dtype": "auto", **base, "gpu_memory_utilization": 0.95, "decoding": {"temperature": 0.7, "top_p": 0.9}},
-            {"name": "fp8-aggressive", "quantization": "fp8", "kv_cache_dtype": "fp8", **base, "max_model_len": 4096, "gpu_memory_utilization": 0.95, "decoding": {"temperature": 0.0, "top_p": 1.0, "extra_openai": {"use_beam_search": True, "best_of": 4}}},
-            {"name": "gptq-balanced", "quantization": "gptq", "kv_cache_dtype": "auto", **base, "decoding": {"temperature": 0.3, "top_p": 0.95}},
+            row("bf16-reference", "none", "auto"),
+            row("bf16-fp8kv-long-context", "none", "fp8", ctx=8192),
+            row("fp8-weights", "fp8", "auto", temperature=0.2, top_p=0.9),
+            row("fp8-weights-fp8kv-best-of-4", "fp8", "fp8", ctx=4096, util=0.95, extra_openai={"use_beam_search": True, "best_of": 4}),
+            row("w4-weights-sampled", "mxfp4", "auto", util=0.95, temperature=0.7, top_p=0.9),
+            row("w4-weights-fp8kv", "mxfp4", "fp8", ctx=4096),
         ],
     }
 
@@ -414,7 +422,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     if a.model:
         cfg.setdefault("benchmark", {})["model"] = a.model
     if a.tensor_parallel_size:
-        for c in cfg.get("configurations") or cfg.get("configs") or []:
+        for c in cfg.get("sweep_configurations") or []:
             c["tensor_parallel_size"] = a.tensor_parallel_size
     runner = QuantizationSweepRunner(cfg, a.output_dir, a.local, a.cluster_backend, a.runs_root, a.port, a.cost_file, url=a.url, resume=a.resume)
     if a.analyze_only:

@@ -125,6 +125,7 @@ def pack_mxfp4(codes: torch.Tensor, scales: torch.Tensor) -> Tuple[torch.Tensor,
 # matrices above the cap (an LM head: wide steps need logits for a few rows only) keep the passes.
 _W4_SCRATCH_MAX_ELEMS = 256 * 1024 * 1024  # 512 MiB of bf16
 _w4_scratch: Dict[torch.device, torch.Tensor] = {}
+_w4_scratch_outgrown: List[torch.Tensor] = []
 
 
 def _reserve_w4_scratch(device: torch.device, elems: int) -> None:
@@ -132,6 +133,10 @@ def _reserve_w4_scratch(device: torch.device, elems: int) -> None:
         return
     cur = _w4_scratch.get(device)
     if cur is None or cur.numel() < elems:
+        if cur is not None:
+            # a graph captured earlier (another engine of this process, before a draft model was
+            # packed) expands into and reads from the old buffer on every replay: it stays allocated
+            _w4_scratch_outgrown.append(cur)
         _w4_scratch[device] = torch.empty(elems, dtype=torch.bfloat16, device=device)
 
 
@@ -1007,13 +1012,16 @@ def pad_tiles_to_quads(tiles: Sequence[Tuple[int, int, int, int]]) -> list:
     return out
 
 
-def sample_rows(logits: torch.Tensor, rows: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor, top_p: torch.Tensor, out: torch.Tensor) -> None:
+def sample_rows(logits: torch.Tensor, rows: torch.Tensor, temperature: torch.Tensor, top_k: torch.Tensor, top_p: torch.Tensor, out: torch.Tensor,
+                uniform: Optional[torch.Tensor] = None) -> None:
     """Temperature / top-k / top-p sampling of rows ``rows`` (int64, each < ``logits.shape[0]``)
     of bf16 ``logits`` ``[S, V]`` without a sort; ``out[rows[r]]`` receives the token id.  One
-    parameter per sampled row (fp32 / int32 / fp32 device tensors); the uniform variates come
-    from the device generator."""
-    u = torch.rand(rows.numel(), dtype=torch.float32, device=logits.device)
-    native().sample_rows(logits, rows, temperature, top_k, top_p, u, out)
+    parameter per sampled row (fp32 / int32 / fp32 device tensors); ``uniform``: one variate in
+    [0, 1) per row (fp32; a seeded request's own), else drawn from the device generator."""
+    u = uniform if uniform is not None else torch.rand(rows.numel(), dtype=torch.float32, device=logits.device)
+    if u.dtype != torch.float32 or u.numel() != rows.numel() or u.device != logits.device:
+        raise ValueError("sample_rows: one fp32 uniform variate per row, on the logits' device")
+    native().sample_rows(logits, rows, temperature, top_k, top_p, u.contiguous(), out)
 
 
 def guided_mask(logits: torch.Tensor, rows: torch.Tensor, slots: torch.Tensor, init: torch.Tensor, state: torch.Tensor, cls: torch.Tensor, vc: int,

@@ -114,13 +114,50 @@ class NativeServer:
 
         return G.schema_script(schema if isinstance(schema, dict) else {}, self.tok.encode_pieces)
 
+    @staticmethod
+    def _tool_choice_schema(tools: List[Dict[str, Any]], allow_text: bool, parallel: bool) -> Dict[str, Any]:
+        """The document a tool-choosing sequence writes: ``{"tool_calls": [{"name": <one of the
+        tools>, "arguments": <that tool's parameters>}, ...]}`` with at least one call, or — when
+        the model may also answer in text — ``{"content": "..."}``.  Every decision in it (text or
+        calls, which tool, one more call or none, optional arguments, enum values) is a choice of
+        the guided-decoding script, so the model takes it with its own logits."""
+        calls = []
+        for t in tools:
+            params = t["function"].get("parameters")
+            calls.append({"type": "object", "required": ["name", "arguments"],
+                          "properties": {"name": {"const": str(t["function"]["name"])}, "arguments": params if isinstance(params, dict) and params else {"type": "object"}}})
+        arr: Dict[str, Any] = {"type": "array", "minItems": 1, "items": calls[0] if len(calls) == 1 else {"oneOf": calls}}
+        if not parallel:
+            arr["maxItems"] = 1
+        called = {"type": "object", "required": ["tool_calls"], "properties": {"tool_calls": arr}}
+        if not allow_text:
+            return called
+        return {"oneOf": [called, {"type": "object", "required": ["content"], "properties": {"content": {"type": "string"}}}]}
+
+    @staticmethod
+    def _chosen_reply(text: str) -> Tuple[Optional[str], List[Dict[str, Any]]]:
+        """(content, tool calls) of the document a tool-choosing sequence wrote (a document cut
+        short by ``max_tokens`` that does not parse is returned as content, as it is)."""
+        try:
+            doc = json.loads(text)
+        except ValueError:
+            return text, []
+        if not isinstance(doc, dict):
+            return text, []
+        calls = [{"id": "call_" + uuid.uuid4().hex[:24], "type": "function",
+                  "function": {"name": str(c.get("name")), "arguments": json.dumps(c.get("arguments", {}), separators=(",", ":"))}}
+                 for c in doc.get("tool_calls") or [] if isinstance(c, dict)]
+        content = doc.get("content")
+        return (content if isinstance(content, str) else None), calls
+
     def _guided_plan(self, body: Dict[str, Any], chat: bool) -> Tuple[Optional[List[Dict[str, Any]]], bool]:
         """What a request asks the automaton for.  Returns (sub-requests, they are tool calls):
         ``response_format`` json_object / json_schema (or vLLM's ``guided_json``) = one guided
-        sequence per choice; ``tools`` with a ``tool_choice`` other than "none" = one guided
-        sequence per tool that is called (every tool of the list with "auto" / "required" unless
-        ``parallel_tool_calls`` is false, the named one otherwise), each writing the arguments
-        object of its call."""
+        sequence per choice.  ``tools`` with a ``tool_choice`` other than "none": a NAMED function
+        is one guided sequence that writes the arguments object of that call; "auto" and
+        "required" are one guided sequence in which the MODEL chooses — which tools to call, how
+        many calls (one when ``parallel_tool_calls`` is false), and under "auto" whether to call
+        at all or to answer in text — by walking the choices of :meth:`_tool_choice_schema`."""
         rf = body.get("response_format") or {}
         tools = body.get("tools") if chat else None
         choice = body.get("tool_choice", "auto" if tools else "none")
@@ -133,7 +170,9 @@ class NativeServer:
                 if not called:
                     raise ValueError(f"tool_choice names an unknown function {want!r}")
             elif choice in ("auto", "required"):
-                called = tools if body.get("parallel_tool_calls", True) else tools[:1]
+                schema = self._tool_choice_schema(tools[:16], allow_text=choice == "auto", parallel=bool(body.get("parallel_tool_calls", True)))
+                prefix, start, script, texts = self._schema_start(schema)
+                return [{"name": None, "chosen": True, "prefix": prefix, "start": start, "lead": prefix, "script": script, "texts": texts}], True
             else:
                 raise ValueError(f"tool_choice must be none, auto, required or a function, got {choice!r}")
             subs = []
@@ -238,6 +277,7 @@ class NativeServer:
         q: asyncio.Queue = asyncio.Queue()
         rids: List[int] = []
         lead_of = [""] * n  # text the server wrote in front of a choice's generated tokens
+        chosen = False  # one guided sequence in which the model chooses its tool calls (tool_choice auto / required)
         detok: List[Any] = [None] * n  # schema-guided choices: forced skeleton tokens stand for the schema's own text
         if subs is None:
             for i in range(n):
@@ -249,6 +289,7 @@ class NativeServer:
             # writes itself (schema key, tool name) is appended to the prompt so the model sees it
             if as_tools:
                 n = len(subs)
+                chosen = bool(subs[0].get("chosen"))
             plan = subs if as_tools else subs * n
             budget = max(8, params.max_tokens // len(plan)) if as_tools else params.max_tokens
             lead_of = [sb["prefix"] for sb in plan]
@@ -328,9 +369,16 @@ class NativeServer:
             usage = {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
             choices = []
             if as_tools:
-                calls = [{"id": "call_" + uuid.uuid4().hex[:24], "type": "function", "function": {"name": sb["name"], "arguments": text_of[i]}} for i, sb in enumerate(subs or [])]
                 cut = any(r == "length" for r in reason_of)
-                choices.append({"index": 0, "message": {"role": "assistant", "content": None, "tool_calls": calls}, "finish_reason": "length" if cut else "tool_calls"})
+                if chosen:
+                    content, calls = self._chosen_reply(text_of[0])
+                    msg: Dict[str, Any] = {"role": "assistant", "content": content}
+                    if calls:
+                        msg["tool_calls"] = calls
+                    choices.append({"index": 0, "message": msg, "finish_reason": "length" if cut else ("tool_calls" if calls else "stop")})
+                else:
+                    calls = [{"id": "call_" + uuid.uuid4().hex[:24], "type": "function", "function": {"name": sb["name"], "arguments": text_of[i]}} for i, sb in enumerate(subs or [])]
+                    choices.append({"index": 0, "message": {"role": "assistant", "content": None, "tool_calls": calls}, "finish_reason": "length" if cut else "tool_calls"})
             for i in range(0 if as_tools else n):
                 if chat:
                     ch: Dict[str, Any] = {"index": i, "message": {"role": "assistant", "content": text_of[i]}, "finish_reason": reason_of[i]}
@@ -348,7 +396,26 @@ class NativeServer:
             base = {"id": oid, "object": (obj + ".chunk") if chat else obj, "created": created, "model": model}
             finished = False
             try:
-                if as_tools:
+                if chosen:
+                    # the model decides between text and calls inside the document: it is folded into
+                    # the reply when it is complete (a call's name is not known before its text is)
+                    yield sse_event({**base, "choices": [{"index": 0, "delta": {"role": "assistant", "content": None}, "finish_reason": None}]})
+                    doc_text = lead_of[0]
+                    while open_choices:
+                        idx, toks, done, reason, seq = await q.get()
+                        toks_of[idx] += toks
+                        doc_text += "".join(piece_of(idx, t, "") for t in toks)
+                        if done:
+                            reason_of[idx] = reason
+                            open_choices.discard(idx)
+                    content, calls = self._chosen_reply(doc_text)
+                    for i, call in enumerate(calls):
+                        yield sse_event({**base, "choices": [{"index": 0, "delta": {"tool_calls": [{"index": i, **call}]}, "finish_reason": None}]})
+                    if content is not None:
+                        yield sse_event({**base, "choices": [{"index": 0, "delta": {"content": content}, "finish_reason": None}]})
+                    cut = reason_of[0] == "length"
+                    yield sse_event({**base, "choices": [{"index": 0, "delta": {}, "finish_reason": "length" if cut else ("tool_calls" if calls else "stop")}]})
+                elif as_tools:
                     # one choice; every tool call is an entry of delta.tool_calls that the argument pieces are appended to
                     yield sse_event({**base, "choices": [{"index": 0, "delta": {"role": "assistant", "content": None}, "finish_reason": None}]})
                     for i, sb in enumerate(subs or []):

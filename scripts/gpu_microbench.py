@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel- and step-level timings on one MI355X (writes JSON under gpurun_out/).
 
-* skinny GEMM variants vs the library GEMM for the Llama-3-8B decode shapes;
+* streaming GEMM variants vs the library GEMM for the Llama-3-8B decode shapes;
   reports achieved weight-streaming bandwidth (HBM roofline is ~6.3 TB/s achievable);
 * one full decode step of the engine (HIP graph) at a given batch.
 All variants are timed interleaved in one process (median of rounds).
@@ -97,8 +97,6 @@ def gemm_bench(out):
                 "v2_ks4_slab": sg(4, True),
                 "v2_ks8_slab": sg(8, True),
                 "hipblaslt": lambda: torch.nn.functional.linear(x, nxt(Ws)),
-                "skinny_w4": lambda: C.skinny_gemm(nxt(Ws), x, y, False, False, 4),
-                "packed_w4": lambda: C.skinny_gemm(nxt(Wps), x, y, False, True, 4),
             }
             t = time_fns(fns)
             row = {"shape": name, "N": N, "K": K, "M": M, "us": t, "TBps": {k: N * K * 2 / (v * 1e-6) / 1e12 for k, v in t.items()}}

@@ -461,19 +461,50 @@ def test_pipelined_stepping_equals_synchronous_stepping():
         assert [e[1:] for e in pipe_ev if e[0] == rid] == [e[1:] for e in sync_ev if e[0] == rid]
 
 
-def test_pipelined_stepping_hands_over_to_synchronous_for_sampled_requests():
-    eng, w = _engine(max_num_seqs=4)
+def test_seeded_requests_stay_launched_ahead_and_requests_with_logprobs_hand_over():
+    """A seeded request's variates are a function of (seed, token index), so its rows are sampled
+    by the device ops of a step that was launched ahead: same tokens as the synchronous path, step
+    by step, whatever else shares the batch.  Requests that want logprobs are read back first."""
+    from kvmini.engine.engine import seeded_uniform
+
+    us = [seeded_uniform(7, k) for k in range(2000)]
+    assert all(0.0 <= u < 1.0 for u in us) and abs(sum(us) / len(us) - 0.5) < 0.03 and len(set(us)) > 1990
+    assert seeded_uniform(7, 3) == us[3] and seeded_uniform(8, 3) != us[3]
+    outs = {}
+    for mode in (True, False):
+        eng, w = _engine(max_num_seqs=4, async_scheduling=mode)
+        a = eng.make_sequence(PROMPTS[0], SamplingParams(max_tokens=10, ignore_eos=True))
+        eng.scheduler.add(a)
+        for _ in range(4):
+            eng.step()
+        if mode:
+            assert eng._pending is not None and eng.pipelined_steps == 4
+        b = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=9, temperature=0.8, top_p=0.95, seed=3, ignore_eos=True))
+        c = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=9, temperature=0.8, top_p=0.95, seed=4, ignore_eos=True))
+        eng.scheduler.add(b)
+        eng.scheduler.add(c)
+        before = eng.pipelined_steps
+        while eng.scheduler.has_work():
+            eng.step()
+        if mode:
+            assert eng.pipelined_steps - before >= 9  # the seeded rows did not stop the launch-ahead
+        assert eng._pending is None and a.output_ids == dense_greedy(w, PROMPTS[0], 10) and -1 not in b.output_ids
+        outs[mode] = (b.output_ids, c.output_ids)
+    assert outs[True] == outs[False] and outs[True][0] != outs[True][1] and len(outs[True][0]) == 9
+    # alone in the batch: the same tokens again
+    eng, _w = _engine(max_num_seqs=4)
+    assert eng.generate([PROMPTS[1]], SamplingParams(max_tokens=9, temperature=0.8, top_p=0.95, seed=3, ignore_eos=True))[0] == outs[True][0]
+    # logprobs: read back with the logits, so the step in flight is collected first
     a = eng.make_sequence(PROMPTS[0], SamplingParams(max_tokens=10, ignore_eos=True))
     eng.scheduler.add(a)
     for _ in range(4):
         eng.step()
-    assert eng._pending is not None and eng.pipelined_steps == 4
-    b = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=5, temperature=0.8, seed=3, ignore_eos=True))
-    eng.scheduler.add(b)
+    assert eng._pending is not None
+    d = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=5, logprobs=2, ignore_eos=True))
+    eng.scheduler.add(d)
     while eng.scheduler.has_work():
         eng.step()
-    assert eng._pending is None
-    assert a.output_ids == dense_greedy(w, PROMPTS[0], 10) and len(b.output_ids) == 5 and -1 not in b.output_ids
+    assert eng._pending is None and len(d.logprob_log) == 5
 
 
 def test_gemm_workgroup_planner_fills_the_cus_evenly():

@@ -24,45 +24,6 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("M", [16, 32, 48, 64])
-@pytest.mark.parametrize("N,K", [(256, 128), (4096, 4096), (6144, 4096), (4096, 14336), (1024, 96 * 32)])
-@pytest.mark.parametrize("packed", [False, True])
-def test_skinny_gemm_matches_fp32(C, M, N, K, packed):
-    torch.manual_seed(0)
-    W = (torch.randn(N, K, device=_dev()) * 0.05).bfloat16()
-    x = torch.randn(M, K, device=_dev()).bfloat16()
-    # asymmetric data: catches transposed output maps
-    x[:, 0] += torch.arange(M, device=_dev()).bfloat16()
-    y = torch.empty(M, N, device=_dev(), dtype=torch.bfloat16)
-    Wk = C.pack_weight(W) if packed else W
-    for waves in (4, 8):
-        y.zero_()
-        C.skinny_gemm(Wk, x, y, False, packed, waves)
-        ref = x.float() @ W.float().T
-        err = (y.float() - ref).abs().max().item()
-        tol = 2e-2 * ref.abs().max().item() + 1e-2
-        assert err <= tol, (M, N, K, packed, waves, err, tol)
-
-
-@pytest.mark.parametrize("M", [16, 48])
-@pytest.mark.parametrize("packed", [False, True])
-def test_skinny_gemm_swiglu(C, M, packed):
-    from kvmini.models.llama import interleave_gate_up
-
-    torch.manual_seed(1)
-    I, K = 1024, 512
-    wg = (torch.randn(I, K, device=_dev()) * 0.05).bfloat16()
-    wu = (torch.randn(I, K, device=_dev()) * 0.05).bfloat16()
-    wgu = interleave_gate_up(wg, wu).contiguous()
-    x = torch.randn(M, K, device=_dev()).bfloat16()
-    act = torch.empty(M, I, device=_dev(), dtype=torch.bfloat16)
-    C.skinny_gemm(C.pack_weight(wgu) if packed else wgu, x, act, True, packed, 4)
-    g = x.float() @ wg.float().T
-    u = x.float() @ wu.float().T
-    ref = torch.nn.functional.silu(g) * u
-    assert (act.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-2
-
-
 def test_add_rmsnorm(C):
     from kvmini.ops import torch_ops
 
@@ -1346,6 +1307,16 @@ if r == 0:
     # two shards sum in a different order than one GEMM: equal lengths, equal first tokens
     ok = [len(o) for o in outs] == [len(o) for o in want] and all(a[:3] == b[:3] for a, b in zip(outs, want)) and eng.pipelined_steps > 0
     print("OUTS", outs, want, eng.pipelined_steps, flush=True)
+    # sampled requests (seeded and not): the scheduling rank's picks reach the follower on the device,
+    # so these steps are launched ahead as well; the seeded request repeats itself
+    before, steps0 = eng.pipelined_steps, eng.stats.steps
+    sp = SamplingParams(max_tokens=12, ignore_eos=True, temperature=0.8, top_p=0.9, seed=11)
+    s1 = eng.generate([prompts[1], prompts[0]], sp)
+    s2 = eng.generate([prompts[1]], sp)
+    s3 = eng.generate([prompts[2]], SamplingParams(max_tokens=12, ignore_eos=True, temperature=0.8))
+    ran, ahead = eng.stats.steps - steps0, eng.pipelined_steps - before
+    ok = ok and s1[0] == s2[0] and len(s3[0]) == 12 and ahead >= ran - 6
+    print("SAMPLED", s1, s2, s3, ran, ahead, flush=True)
 else:
     ok = eng.follow() >= 10
 ok = ok and eng.runner.xgmi.errors() == 0 and eng.runner.xgmi.calls % 2 == 0
@@ -1370,6 +1341,40 @@ def test_tensor_parallel_two_rank_processes_share_one_gpu(tmp_path):
                        capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "RANK0 OK=True" in r.stdout and "RANK1 OK=True" in r.stdout
+
+
+@pytest.mark.gpu
+def test_seeded_requests_are_sampled_on_the_device_and_stay_launched_ahead():
+    """A seeded request's variate for its k-th token is a function of (seed, k) that the host
+    computes at launch time and the sampling kernel consumes: the same tokens with and without
+    launch-ahead, alone or in company, and the steps are launched ahead.  A guided request honours
+    its seed as well."""
+    from kvmini.engine import guided as G
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.engine.tokenizer import get_tokenizer
+    from kvmini.models.llama import get_config, random_weights
+
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # noqa: E731
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip")
+    prompts = [[1, 50, 60, 70, 80], list(range(1, 30))]
+    sp = SamplingParams(max_tokens=16, ignore_eos=True, temperature=0.8, top_p=0.9, top_k=40, seed=5)
+    outs = {}
+    for mode in (True, False):
+        eng = LLMEngine(EngineConfig(**common, async_scheduling=mode), weights=w())
+        eng.warmup()
+        p0 = eng.pipelined_steps
+        outs[mode] = eng.generate(prompts, sp)
+        if mode:
+            assert eng.pipelined_steps - p0 >= 14
+            alone = eng.generate([prompts[1]], sp)[0]
+            other = eng.generate([prompts[1]], SamplingParams(**{**vars(sp), "seed": 6}))[0]
+            tok = get_tokenizer(eng.mcfg.vocab_size, 1, eng.mcfg.eos_token_id)
+            eng.set_token_classes(G.token_classes(tok, eng.mcfg.vocab_size, eng.mcfg.eos_token_id))
+            gp = SamplingParams(max_tokens=24, temperature=1.0, seed=9, guided="json", guided_start=(G.S_START, 0, 0))
+            g1, g2 = eng.generate([prompts[0]], gp)[0], eng.generate([prompts[0]], gp)[0]
+            assert g1 == g2 and isinstance(__import__("json").loads(tok.decode(g1)), (dict, list))
+    assert outs[True] == outs[False] and alone == outs[True][1] and other != alone
 
 
 # ---------------------------------------------------------------- FP8 (e4m3) KV cache

@@ -227,16 +227,19 @@ def test_quant_sweep_config_and_analysis(in_tmp):
 
     cfg = yaml.safe_load(open("q.yaml"))
     assert len(cfg["sweep_configurations"]) == 6 and cfg["benchmark"]["requests"] == 100
-    assert qs.vllm_args_for(cfg["sweep_configurations"][1]) == ["--quantization", "fp8", "--kv-cache-dtype", "fp8"]
-    lt = qs.loadtest_args_for(cfg["sweep_configurations"][4]["decoding"], str(in_tmp), "fp8-aggressive")
+    # no two rows measure the same (weights, KV, context, decoding) point
+    pts = [(c["quantization"], c["kv_cache_dtype"], c["max_model_len"], json.dumps(c["decoding"], sort_keys=True)) for c in cfg["sweep_configurations"]]
+    assert len(set(pts)) == 6 and len({(q, kv) for q, kv, _c, _d in pts}) == 6
+    assert qs.vllm_args_for(cfg["sweep_configurations"][3])[:4] == ["--quantization", "fp8", "--kv-cache-dtype", "fp8"]
+    lt = qs.loadtest_args_for(cfg["sweep_configurations"][3]["decoding"], str(in_tmp), "fp8-best-of-4")
     assert "--extra-openai-json" in lt and json.load(open(lt[-1]))["use_beam_search"] is True
     id1 = qs.config_run_id(cfg["sweep_configurations"][0]).rsplit("_", 1)[0]
     id2 = qs.config_run_id(dict(cfg["sweep_configurations"][0])).rsplit("_", 1)[0]
     assert id1 == id2 and id1.startswith("quant_sweep_")
 
     runner = qs.QuantizationSweepRunner(cfg, str(in_tmp / "out"), cluster_backend="fake")
-    m = runner.manifest_for(cfg["sweep_configurations"][1])
-    assert m["metadata"]["name"] == "llama3-8b-sweep-fp8-dynamic"
+    m = runner.manifest_for(cfg["sweep_configurations"][2])
+    assert m["metadata"]["name"] == "llama3-8b-sweep-fp8-weights"
     assert "--quantization" in m["spec"]["predictor"]["model"]["args"]
     assert "amd.com/gpu" in json.dumps(m) and "nvidia" not in json.dumps(m)
     runner.results = [
