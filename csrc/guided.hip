@@ -260,15 +260,18 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
   __syncthreads();
   const unsigned allow = allow_s;
   const int n_toks = n_toks_s;
-  const int forced = n_toks > 0 ? toks_s[0] : -1;
   if (allow == (1u << N_CLASSES) - 1u) return;
-  // is token id `t` one of the alternatives' tokens (beyond the first, which the loops test inline)?
-  auto listed = [&](int t) -> bool {
-    for (int k = 1; k < n_toks; ++k)
-      if (toks_s[k] == t) return true;
-    return false;
-  };
+  // Tokens that are allowed whatever their class (the forced literal, the keys of a choice) keep
+  // their logits: thread k saves the k-th one before the row is masked by class and puts it back
+  // afterwards (all barriers below are taken by every thread: n_toks is the same for all of them).
   unsigned short* row = logits + rows[r] * row_stride;
+  unsigned short saved = 0;
+  int mine = -1;
+  if (tid < n_toks) {
+    mine = toks_s[tid];
+    if (mine >= 0 && mine < V) saved = row[mine]; else mine = -1;
+  }
+  __syncthreads();
   constexpr unsigned short NEG_INF = 0xFF80;
   int done = 0;
   if ((((uintptr_t)row) & 15) == 0 && (((uintptr_t)cls) & 7) == 0) {
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned c = (unsigned)(c8 >> (8 * j)) & 0xffu;
-        if (!((allow >> c) & 1u) && i * 8 + j != forced && !(n_toks > 1 && listed(i * 8 + j))) { x[j] = NEG_INF; any = true; }
+        if (!((allow >> c) & 1u)) { x[j] = NEG_INF; any = true; }
       }
       if (any) reinterpret_cast<us8*>(row)[i] = x;
     }
@@ -288,7 +291,11 @@ __global__ __launch_bounds__(TPB) void guided_mask_kernel(unsigned short* __rest
   }
   for (int i = done + tid; i < V; i += TPB) {
     const unsigned c = i < n_cls ? cls[i] : (unsigned)C_OTHER;  // ids past the tokenizer's vocabulary (padding columns) are never allowed
-    if (!((allow >> c) & 1u) && i != forced && !(n_toks > 1 && listed(i))) row[i] = NEG_INF;
+    if (!((allow >> c) & 1u)) row[i] = NEG_INF;
+  }
+  if (n_toks > 0) {
+    __syncthreads();  // every masking store of this workgroup is complete (and visible to it) before the listed tokens are restored
+    if (mine >= 0) row[mine] = saved;
   }
 }
 

@@ -1300,7 +1300,6 @@ assert eng.runner.xgmi is not None and eng.runner.graphs
 prompts = [[1, 50, 60, 70, 80], list(range(1, 30)), [1, 9, 8, 7]]
 if r == 0:
     outs = eng.generate(prompts, SamplingParams(max_tokens=10, ignore_eos=True))
-    eng.release_followers()
     base = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", use_graphs=False),
                      weights=random_weights(cfg, "cuda:0", torch.bfloat16, seed=3))
     want = base.generate(prompts, SamplingParams(max_tokens=10, ignore_eos=True))
@@ -1317,6 +1316,7 @@ if r == 0:
     ran, ahead = eng.stats.steps - steps0, eng.pipelined_steps - before
     ok = ok and s1[0] == s2[0] and len(s3[0]) == 12 and ahead >= ran - 6
     print("SAMPLED", s1, s2, s3, ran, ahead, flush=True)
+    eng.release_followers()
 else:
     ok = eng.follow() >= 10
 ok = ok and eng.runner.xgmi.errors() == 0 and eng.runner.xgmi.calls % 2 == 0
