@@ -100,7 +100,7 @@ helm-package: ## Package the parent chart into dist/
 helm-test: ## helm test (smoke pod curls the endpoint)
 	helm test $(RELEASE) -n $(NS)
 
-airgap: airgap-images airgap-artifacts airgap-docs airgap-dashboards airgap-finalize ## Complete air-gapped bundle
+airgap: airgap-images airgap-artifacts airgap-examples airgap-docs airgap-dashboards airgap-finalize ## Complete air-gapped bundle
 
 airgap-clean: ## Remove the bundle directory
 	rm -rf $(AIRGAP_DIR)
@@ -123,6 +123,21 @@ airgap-artifacts: airgap-charts airgap-wheels ## Charts + wheels + configs
 	mkdir -p $(AIRGAP_DIR)/config
 	cp -r cost.yaml slo.json reference-matrix.yaml isvc.yaml example-config.yaml runners profiles policies $(AIRGAP_DIR)/config/
 
+airgap-examples: ## Example configuration and a run script that works from the bundle alone
+	mkdir -p $(AIRGAP_DIR)/examples
+	cp example-config.yaml cost.yaml slo.json $(AIRGAP_DIR)/examples/
+	cp runners/profiles/standard.yaml runners/profiles/tool-calling.yaml $(AIRGAP_DIR)/examples/ 2>/dev/null || true
+	$(PY) -m kvmini.deploy.cli --backend native --model-name llama-3-8b --service llama3-8b-demo --namespace demo --dry-run | sed -n '/^apiVersion:/,$$p' > $(AIRGAP_DIR)/examples/isvc-native.yaml
+	printf '%s\n' '#!/usr/bin/env bash' '# Deploy the native engine from the bundled images and benchmark it; no registry, no index.' 'set -euo pipefail' \
+	  'here="$$(cd "$$(dirname "$$0")" && pwd)"' \
+	  'for f in "$$here"/../images/*.tar.gz; do [ -e "$$f" ] && gunzip -c "$$f" | docker load; done' \
+	  'kubectl apply -f "$$here/isvc-native.yaml"' \
+	  'kubectl wait --for=condition=Ready inferenceservice/llama3-8b-demo -n demo --timeout=900s' \
+	  'kvmini bench --namespace demo --service llama3-8b-demo --model llama-3-8b --requests 100 --concurrency 10 --cost-file "$$here/cost.yaml"' \
+	  'kvmini gate --slo "$$here/slo.json" --results "$$(ls -dt runs/*/ | head -1)results.json"' \
+	  'echo "results under runs/"' > $(AIRGAP_DIR)/examples/run-benchmark.sh
+	chmod +x $(AIRGAP_DIR)/examples/run-benchmark.sh
+
 airgap-docs: ## Documentation
 	mkdir -p $(AIRGAP_DIR)/docs && cp -r README.md docs/* $(AIRGAP_DIR)/docs/ 2>/dev/null || true
 
@@ -132,6 +147,18 @@ airgap-dashboards: ## Grafana dashboards
 airgap-finalize: ## Checksums + tarball
 	cd $(AIRGAP_DIR) && find . -type f ! -name SHA256SUMS -print0 | sort -z | xargs -0 sha256sum > SHA256SUMS
 	tar -czf $(AIRGAP_DIR).tar.gz $(AIRGAP_DIR) && echo "bundle: $(AIRGAP_DIR).tar.gz"
+
+install-deps: ## Python dependencies of the harness (the engine's torch comes with the ROCm image)
+	$(PY) -m pip install -e .
+	@if [ -f requirements-dev.txt ]; then $(PY) -m pip install -r requirements-dev.txt; else $(PY) -m pip install -e ".[dev]" || echo "(no dev extras installed)"; fi
+
+install-tools: ## Developer tools: ruff, mypy, yamllint (pip); shellcheck, shfmt, helm (system package manager)
+	$(PY) -m pip install ruff mypy yamllint pytest pytest-timeout || true
+	@if command -v apt-get >/dev/null 2>&1; then sudo apt-get update && sudo apt-get install -y shellcheck shfmt; \
+	elif command -v dnf >/dev/null 2>&1; then sudo dnf install -y ShellCheck shfmt; \
+	elif command -v brew >/dev/null 2>&1; then brew install shellcheck shfmt helm; \
+	else echo "install shellcheck, shfmt and helm with your package manager"; fi
+	@command -v hipcc >/dev/null 2>&1 || echo "hipcc not on PATH: 'make native' needs ROCm (/opt/rocm/bin)"
 
 dev-setup: ## Editable install + native build
 	$(PY) -m pip install -e ".[dev]" || true

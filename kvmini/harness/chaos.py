@@ -62,7 +62,10 @@ class ChaosRunner:
         """Returns an error string when the fault could not be injected."""
         try:
             if self.a.admin_url:
-                _admin_post(self.a.admin_url, ADMIN_FAULTS[fault])
+                payload = dict(ADMIN_FAULTS[fault])
+                if payload.get("restart") and self.a.admin_down_s > 0:
+                    payload["down_s"] = self.a.admin_down_s  # the mock stays away this long: what MTTR then measures
+                _admin_post(self.a.admin_url, payload)
             else:
                 self.backend.inject_fault(fault, self.a.namespace, self.a.service)
             return None
@@ -79,11 +82,25 @@ class ChaosRunner:
             pass
 
     def wait_ready(self) -> Optional[float]:
+        """Seconds until the service answers again (None: not within ``--ready-timeout``).  With an
+        admin URL the server's ``/health`` is polled until it returns 200: a server that is down
+        refuses the connection or answers 503 at once, so one request would measure nothing."""
         t0 = time.time()
         try:
             if self.a.admin_url:
-                with urllib.request.urlopen(self.a.admin_url.rstrip("/") + "/health", timeout=self.a.ready_timeout) as r:
-                    r.read()
+                deadline = t0 + float(self.a.ready_timeout)
+                url = self.a.admin_url.rstrip("/") + "/health"
+                while True:
+                    try:
+                        with urllib.request.urlopen(url, timeout=max(0.2, min(2.0, deadline - time.time()))) as r:
+                            r.read()
+                            if r.status == 200:
+                                break
+                    except Exception:
+                        pass
+                    if time.time() >= deadline:
+                        return None
+                    time.sleep(0.05)
             else:
                 self.backend.wait_ready(self.a.namespace, self.a.service, self.a.ready_timeout)
         except Exception:
@@ -181,6 +198,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--ready-timeout", type=float, default=600.0)
     ap.add_argument("--cluster-backend", default=None, choices=["auto", "kubectl", "local", "fake"])
     ap.add_argument("--admin-url", default=None, help="inject faults through a mock server's /admin/chaos instead of the cluster")
+    ap.add_argument("--admin-down-s", type=float, default=0.0, help="with --admin-url: seconds a restart fault keeps the mock server answering 503")
     ap.add_argument("--runs-root", default=None, help="directory for the per-fault run dirs (default runs/)")
     ap.add_argument("--out", default=None, help="resilience_table.json path")
     ap.add_argument("--fail-on-gate", action="store_true", help="exit 3 when any fault run fails the SLO gate")

@@ -64,6 +64,7 @@ class MockLLM:
         self.seen_prompts: set = set()
         self.stats = {"requests": 0, "errors": 0, "prompt_tokens": 0, "generation_tokens": 0, "cache_hits": 0, "cache_queries": 0}
         self.extra_latency_ms = 0.0  # chaos: injected latency
+        self.down_until = 0.0  # chaos: "restarting" until this wall-clock time
         self.drop_rate = 0.0  # chaos: injected connection failure rate
 
     # --- latency model ---------------------------------------------------
@@ -116,6 +117,9 @@ class MockLLM:
             return Response.json({"error": {"message": "invalid api key", "type": "authentication_error"}}, 401)
         body = req.json() or {}
         self.stats["requests"] += 1
+        if time.time() < self.down_until:
+            self.stats["errors"] += 1
+            return Response.json({"error": {"message": "service restarting", "type": "unavailable"}}, 503)
         if self.cfg.tenant_shed and req.headers.get("x-tenant") == self.cfg.tenant_shed:
             return Response.json({"error": {"message": "tenant throttled", "type": "rate_limit"}}, 429)
         if self._should_fail():
@@ -220,6 +224,8 @@ class MockLLM:
         return Response.json({"object": "list", "data": [{"id": self.cfg.model, "object": "model", "created": int(self.started_at), "owned_by": "kvmini"}]})
 
     async def health(self, req: Request) -> Response:
+        if time.time() < self.down_until:  # "restarting" (POST /admin/chaos {"restart": true, "down_s": ...})
+            return Response.json({"status": "starting"}, 503)
         return Response.json({"status": "ok", "uptime_s": time.time() - self.started_at})
 
     async def metrics(self, req: Request) -> Response:
@@ -318,7 +324,7 @@ class MockLLM:
 
     # --- chaos / admin -------------------------------------------------------
     async def admin(self, req: Request) -> Response:
-        """POST /admin/chaos {"extra_latency_ms":..,"error_rate":..,"restart":true,"tenant_shed":..}"""
+        """POST /admin/chaos {"extra_latency_ms":..,"error_rate":..,"restart":true,"down_s":..,"tenant_shed":..}"""
         body = req.json() or {}
         if "extra_latency_ms" in body:
             self.extra_latency_ms = float(body["extra_latency_ms"])
@@ -329,6 +335,7 @@ class MockLLM:
         if body.get("restart"):
             self.started_at = time.time()
             self.seen_prompts.clear()
+            self.down_until = time.time() + float(body.get("down_s") or 0.0)  # /health and the API answer 503 until then
         return Response.json({"ok": True, "started_at": self.started_at})
 
     def build_server(self) -> HttpServer:

@@ -184,6 +184,28 @@ def test_chaos_against_mock_admin(mock_server, in_tmp):
     assert "chaos_mock-llm_pod_delete_" in rows["pod-delete"]["run_dir"]
 
 
+def test_chaos_admin_mode_mttr_is_the_time_the_server_stays_away(mock_server, in_tmp):
+    """A restart fault keeps the mock away for a second (503 on /health and on the API): the
+    recorded MTTR is that second, not the round trip of one /health request; a server that does
+    not come back within --ready-timeout has no MTTR (reference: ``chaos/chaos-harness.sh:70-80``
+    waits for the pod to be Ready again)."""
+    from kvmini.harness import chaos
+
+    _mock, url = mock_server
+    rc = chaos.main(["--service", "mock-llm", "--url", url, "--model", "mock-llm", "--admin-url", url, "--admin-down-s", "1.0", "--requests", "8", "--concurrency", "2", "--max-tokens", "2",
+                     "--faults", "pod-delete", "--skip-baseline", "--runs-root", str(in_tmp / "runs"), "--out", "t.json", "--ready-timeout", "10"])
+    assert rc == 0
+    row = load_json("t.json")["results"][-1]
+    assert row["fault"] == "pod-delete" and 0.8 <= row["mttr_s"] <= 3.0, row
+    assert row["error_rate"] == 0  # the benchmark ran after recovery
+    rc = chaos.main(["--service", "mock-llm", "--url", url, "--model", "mock-llm", "--admin-url", url, "--admin-down-s", "3.0", "--requests", "4", "--concurrency", "2", "--max-tokens", "2",
+                     "--faults", "container-kill", "--skip-baseline", "--runs-root", str(in_tmp / "runs"), "--out", "t2.json", "--ready-timeout", "0.5"])
+    assert load_json("t2.json")["results"][-1]["mttr_s"] is None
+    import time
+
+    time.sleep(2.7)  # (the shared mock comes back before the next test)
+
+
 def test_chaos_uninjectable_fault_is_recorded(in_tmp, mock_server):
     from kvmini.harness import chaos
 
