@@ -249,6 +249,7 @@ def main() -> int:
     steps_before = engine.stats.steps
     barrier()
     t0_wall = time.time()
+    cpu0 = os.times()
     t0 = time.perf_counter()
     for k in range(args.steps):
         c = dict(cmd)
@@ -260,6 +261,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     t1_wall = time.time()
+    cpu1 = os.times()
     engine_steps = engine.stats.steps - steps_before
     samples = sampler.stop()
 
@@ -326,6 +328,21 @@ def main() -> int:
         lb = LocalBackend(os.path.join(args.out_dir or td, f"local_cluster_rank{rank}.json"))
         lb.register_server("bench", url, os.getpid(), proc_start, gpus=1)
         rsecs = sum_resource_seconds(lb.get_pods("local", "bench"), float(tw[0]), float(tw[0]) + elapsed_max, pricing)
+    # CPU and memory are MEASURED for this server process (engine thread + HTTP front end; the load
+    # generator is a child and not counted): user + system seconds over the timed window, memory
+    # charged at the peak resident set.  The GPU is charged whole for the window.
+    server_cpu_s = (cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)
+    peak_rss = 0.0
+    try:
+        with open("/proc/self/status") as f:
+            for line in f:
+                if line.startswith("VmHWM:"):
+                    peak_rss = float(line.split()[1]) * 1024.0
+    except OSError:
+        pass
+    if server_cpu_s > 0 and peak_rss > 0:
+        rsecs["cpu_core_seconds"] = server_cpu_s
+        rsecs["mem_gib_seconds"] = peak_rss / float(2**30) * elapsed_max
     rs_t = torch.tensor([rsecs["gpu_seconds"], rsecs["cpu_core_seconds"], rsecs["mem_gib_seconds"]], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(rs_t)
@@ -447,7 +464,7 @@ def main() -> int:
             "collective_backend": (dist.get_backend() if world > 1 else None),
             "telemetry": pj["source"] if watts else "unavailable",
             **({"telemetry_native_fallback": tg.native_error} if tg.native_error else {}),
-            "resource_seconds": {"gpu": gpu_s, "cpu_core": cpu_s, "mem_gib": mem_s},
+            "resource_seconds": {"gpu": gpu_s, "cpu_core": cpu_s, "mem_gib": mem_s, "cpu_memory_source": "measured: os.times() and VmHWM of each server rank over the timed window"},
         }
         if n_ok == 0:
             out["error"] = passes[-1].get("errors")

@@ -10,6 +10,7 @@
 extern "C" {
 size_t kv_stream_state_bytes();
 size_t kv_radix_state_bytes();
+int kv_token_gaps(const long long* ev, int n, unsigned long long* keys, long long* vals, int slots, long long* last_t, long long n_last, float* gaps, hipStream_t stream);
 int kv_stream_hist(const void* x, long long n, long long row_stride, int n_metrics, int dtype, unsigned int* hist, void* state, float lo_log2, float hi_log2,
                    hipStream_t stream);
 int kv_radix_init(const void* stream_state, void* st, const double* ps, int n_ps, int n_metrics, hipStream_t stream);
@@ -122,6 +123,24 @@ int sample_dtype(const at::Tensor& x) {
 // ---- latency statistics ------------------------------------------------------------
 int64_t stream_state_bytes() { return (int64_t)kv_stream_state_bytes(); }
 int64_t radix_state_bytes() { return (int64_t)kv_radix_state_bytes(); }
+
+// events int64 [n, 3] (request id, token index, t_ns) on the device -> gaps fp32 [n] in ms (NaN: no gap);
+// last_t int64 [n_last] is the per-request time table that persists between calls; scratch_keys /
+// scratch_vals int64 [slots], slots a power of two >= 2 n.
+void token_gaps(at::Tensor events, at::Tensor scratch_keys, at::Tensor scratch_vals, at::Tensor last_t, at::Tensor gaps) {
+  CHECK_DEV(events); CHECK_DEV(scratch_keys); CHECK_DEV(scratch_vals); CHECK_DEV(last_t); CHECK_DEV(gaps);
+  CHECK_CONTIG(events); CHECK_CONTIG(scratch_keys); CHECK_CONTIG(scratch_vals); CHECK_CONTIG(last_t); CHECK_CONTIG(gaps);
+  TORCH_CHECK(events.scalar_type() == at::kLong && events.dim() == 2 && events.size(1) == 3, "events must be int64 [n, 3]");
+  TORCH_CHECK(scratch_keys.scalar_type() == at::kLong && scratch_vals.scalar_type() == at::kLong && last_t.scalar_type() == at::kLong, "tables must be int64");
+  TORCH_CHECK(gaps.scalar_type() == at::kFloat && gaps.numel() >= events.size(0), "gaps must be fp32 [n]");
+  const int64_t n = events.size(0), slots = scratch_keys.numel();
+  TORCH_CHECK(n < (1 << 30) && scratch_vals.numel() == slots, "scratch tables of equal size");
+  if (n == 0) return;
+  check((int)hipMemsetAsync(scratch_keys.data_ptr(), 0, (size_t)slots * 8, cur_stream()), "hipMemsetAsync");
+  check(kv_token_gaps((const long long*)events.data_ptr(), (int)n, (unsigned long long*)scratch_keys.data_ptr(), (long long*)scratch_vals.data_ptr(), (int)slots,
+                      (long long*)last_t.data_ptr(), last_t.numel(), (float*)gaps.data_ptr(), cur_stream()),
+        "kv_token_gaps");
+}
 
 void stream_hist(at::Tensor x, int64_t n, at::Tensor hist, at::Tensor state, double lo_log2, double hi_log2) {
   CHECK_DEV(x); CHECK_DEV(hist); CHECK_DEV(state); CHECK_CONTIG(x); CHECK_CONTIG(hist); CHECK_CONTIG(state);
@@ -895,6 +914,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("stream_state_bytes", &stream_state_bytes);
   m.def("radix_state_bytes", &radix_state_bytes);
   m.def("stream_hist", &stream_hist);
+  m.def("token_gaps", &token_gaps);
   m.def("radix_select", &radix_select);
   m.def("radix_num_passes", &radix_num_passes);
   m.def("radix_init", &radix_init);

@@ -418,9 +418,85 @@ inline int grid_x(long long n, int per_thread) {
   return (int)blocks;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Live inter-token gaps from raw token events.  events: int64 [n][3] = (request id, token index,
+// t_ns) in arrival order, as the load generator's SSE parser appended them; token index < 0 marks
+// the end of a request.  The gap of an event with index k > 0 is its time minus the time of the
+// same request's previous event: event (req, k - 1) of this batch if it is here, else the time the
+// request was last seen in an earlier batch (last_t[req], -1: never).  Three launches:
+//   insert: (req, index) -> t of every event into a batch-local open-addressing table
+//   emit  : gaps[i] (ms, fp32; NaN for events without a gap) — what stream_hist_kernel then bins
+//   commit: last_t[req] = max(last_t[req], t) over the batch (timestamps of a request only grow)
+// so the host does no per-event work at all: one copy of the ring's new slice, then launches.
+__device__ inline unsigned long long event_key(long long req, long long idx) {
+  return ((((unsigned long long)req) << 24) | ((unsigned long long)idx & 0xFFFFFFull)) + 1ull;  // 0 = empty slot
+}
+__device__ inline unsigned int event_hash(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (unsigned int)k;
+}
+
+__global__ __launch_bounds__(256) void gap_insert_kernel(const long long* __restrict__ ev, int n, unsigned long long* __restrict__ keys, long long* __restrict__ vals,
+                                                         unsigned int mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long req = ev[3 * i], idx = ev[3 * i + 1], t = ev[3 * i + 2];
+  if (idx < 0 || req < 0) return;
+  const unsigned long long key = event_key(req, idx);
+  unsigned int h = event_hash(key) & mask;
+  for (unsigned int probe = 0; probe <= mask; ++probe) {  // the table holds at least 2 n slots: a free one exists
+    const unsigned long long old = atomicCAS(&keys[h], 0ull, key);
+    if (old == 0ull || old == key) { vals[h] = t; return; }
+    h = (h + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(256) void gap_emit_kernel(const long long* __restrict__ ev, int n, const unsigned long long* __restrict__ keys,
+                                                       const long long* __restrict__ vals, unsigned int mask, const long long* __restrict__ last_t, long long n_last,
+                                                       float* __restrict__ gaps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long req = ev[3 * i], idx = ev[3 * i + 1], t = ev[3 * i + 2];
+  float gap = __builtin_nanf("");
+  if (idx > 0 && req >= 0) {
+    long long prev = -1;
+    const unsigned long long key = event_key(req, idx - 1);
+    unsigned int h = event_hash(key) & mask;
+    for (unsigned int probe = 0; probe <= mask; ++probe) {
+      const unsigned long long k = keys[h];
+      if (k == key) { prev = vals[h]; break; }
+      if (k == 0ull) break;
+      h = (h + 1) & mask;
+    }
+    if (prev < 0 && req < n_last) prev = last_t[req];
+    if (prev >= 0) gap = (float)((double)(t - prev) * 1e-6);
+  }
+  gaps[i] = gap;
+}
+
+__global__ __launch_bounds__(256) void gap_commit_kernel(const long long* __restrict__ ev, int n, long long* __restrict__ last_t, long long n_last) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long req = ev[3 * i], idx = ev[3 * i + 1], t = ev[3 * i + 2];
+  if (idx < 0 || req < 0 || req >= n_last) return;
+  atomicMax(&last_t[req], t);
+}
+
 }  // namespace
 
 extern "C" {
+
+// keys / vals: scratch tables of `slots` entries (a power of two >= 2 n); keys must be zero on entry
+// (the caller clears it: hipMemsetAsync in the binding).  last_t: int64 [n_last], -1 = never seen.
+int kv_token_gaps(const long long* ev, int n, unsigned long long* keys, long long* vals, int slots, long long* last_t, long long n_last, float* gaps, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (slots < 2 * n || (slots & (slots - 1)) != 0 || n_last < 0) return -1;
+  const dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL(gap_insert_kernel, grid, block, 0, stream, ev, n, keys, vals, (unsigned int)(slots - 1));
+  hipLaunchKernelGGL(gap_emit_kernel, grid, block, 0, stream, ev, n, keys, vals, (unsigned int)(slots - 1), last_t, n_last, gaps);
+  hipLaunchKernelGGL(gap_commit_kernel, grid, block, 0, stream, ev, n, last_t, n_last);
+  return (int)hipGetLastError();
+}
 
 size_t kv_stream_state_bytes() { return sizeof(StreamState); }
 size_t kv_radix_state_bytes() { return sizeof(RadixState); }

@@ -101,6 +101,13 @@ class ClusterBackend:
     def cluster_facts(self) -> Dict[str, Any]:
         return {"backend": self.name}
 
+    def usage_snapshot(self, namespace: str, service: str) -> Optional[Dict[str, Any]]:
+        """Measured resource use of the service's processes so far: ``{"t": wall clock,
+        "cpu_seconds": user + system time of every process, "rss_bytes": resident memory now,
+        "peak_rss_bytes": its high-water mark, "processes": n}``; None when this backend cannot
+        measure (the cost record then prices the declared requests / limits)."""
+        return None
+
     # --- write side ------------------------------------------------------
     def apply(self, manifest: Dict[str, Any]) -> None:
         raise NotImplementedError
@@ -448,6 +455,61 @@ class LocalBackend(ClusterBackend):
                 )
             )
         return pods
+
+    @staticmethod
+    def _process_tree(roots: List[int]) -> List[int]:
+        """``roots`` and all their descendants that are alive (one pass over /proc)."""
+        parent: Dict[int, int] = {}
+        for name in os.listdir("/proc"):
+            if not name.isdigit():
+                continue
+            try:
+                with open(f"/proc/{name}/stat", "rb") as f:
+                    rest = f.read().rsplit(b")", 1)[1].split()
+                parent[int(name)] = int(rest[1])  # field 4 (ppid); the split starts at field 3
+            except (OSError, IndexError, ValueError):
+                continue
+        want = {r for r in roots if r in parent}
+        grew = True
+        while grew:
+            grew = False
+            for pid, pp in parent.items():
+                if pp in want and pid not in want:
+                    want.add(pid)
+                    grew = True
+        return sorted(want)
+
+    def usage_snapshot(self, namespace: str, service: str) -> Optional[Dict[str, Any]]:
+        """user + system CPU seconds and resident memory of the service's process trees (the
+        server, its tensor-parallel ranks, a router's replicas), read from ``/proc/<pid>/stat``
+        and ``/proc/<pid>/status``.  Two snapshots around a load test give the CPU-seconds the
+        test really used; the peak RSS is what the memory price is charged on."""
+        reg = self._load()
+        roots = [int(s["pid"]) for s in self._records(namespace, service) if s.get("finished_at") is None]
+        dep = (reg.get("isvc") or {}).get(f"{namespace}/{service}") or {}
+        if dep.get("pid"):
+            roots.append(int(dep["pid"]))
+        pids = self._process_tree(sorted(set(roots)))
+        if not pids:
+            return None
+        tick = float(os.sysconf("SC_CLK_TCK"))
+        cpu = rss = peak = 0.0
+        n = 0
+        for pid in pids:
+            try:
+                with open(f"/proc/{pid}/stat", "rb") as f:
+                    rest = f.read().rsplit(b")", 1)[1].split()
+                with open(f"/proc/{pid}/status") as f:
+                    status = dict(line.split(":", 1) for line in f if ":" in line)
+            except OSError:
+                continue
+            cpu += (int(rest[11]) + int(rest[12])) / tick  # utime + stime
+            rss += float(status.get("VmRSS", "0 kB").split()[0]) * 1024.0
+            peak += float(status.get("VmHWM", "0 kB").split()[0]) * 1024.0
+            n += 1
+        if n == 0:
+            return None
+        return {"t": time.time(), "cpu_seconds": cpu, "rss_bytes": rss, "peak_rss_bytes": peak, "processes": n}
 
     def get_node(self, node_name: str) -> Dict[str, Any]:
         product = None

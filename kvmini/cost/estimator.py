@@ -183,6 +183,22 @@ def estimate_cost(run_dir: str, namespace: str, service: str, cost_file: Optiona
     if not pods:
         warnings.append(f"no pods found for {namespace}/{service} via backend '{backend.name}': resource-seconds are zero")
     rsecs = sum_resource_seconds(pods, w0, w1, pricing)
+    resource_source = "declared requests" if pricing.use_requests else "declared limits"
+    usage_path = os.path.join(run_dir, "resource_usage.json")
+    if os.path.exists(usage_path):
+        # measured around the load test by the benchmark (cluster backends that can read the
+        # processes): CPU-seconds really consumed, memory charged at the peak resident set
+        try:
+            with open(usage_path) as f:
+                use = json.load(f)
+            cpu_s, peak = float(use["cpu_core_seconds"]), float(use["peak_rss_bytes"])
+            if cpu_s >= 0 and peak > 0:
+                scale = (w1 - w0) / float(use["window_s"]) if float(use.get("window_s") or 0) > 0 else 1.0
+                rsecs["cpu_core_seconds"] = cpu_s * min(scale, 1.0)  # (the snapshots bracket the request window)
+                rsecs["mem_gib_seconds"] = peak / float(2**30) * (w1 - w0)
+                resource_source = "measured: " + str(use.get("source", "process accounting"))
+        except (OSError, ValueError, KeyError, TypeError) as e:
+            warnings.append(f"resource_usage.json ignored: {e}")
     product = node_gpu_label(backend, pods[0]) if pods else None
     gpu_hr = pricing.gpu_hourly(product)
     total = (rsecs["gpu_seconds"] * gpu_hr + rsecs["cpu_core_seconds"] * pricing.cpu_hourly_per_core + rsecs["mem_gib_seconds"] * pricing.mem_hourly_per_gib) / 3600.0
@@ -203,6 +219,7 @@ def estimate_cost(run_dir: str, namespace: str, service: str, cost_file: Optiona
             "use_requests": pricing.use_requests,
             "include_sidecars": pricing.include_sidecars,
             "cluster_backend": backend.name,
+            "cpu_memory_source": resource_source,
         },
     }
     if warnings:

@@ -214,7 +214,14 @@ def main(argv: Optional[List[str]] = None) -> int:
         # activator) instead of failing fast: their latency carries the cold start
         cfg_l.connect_retry_s = max(cfg_l.connect_retry_s, 300.0)
 
+    def usage() -> Any:
+        try:
+            return backend.usage_snapshot(a.namespace, a.service)
+        except Exception:
+            return None
+
     t0 = time.time()
+    use0 = usage()
     try:
         results = lg.run_load_sync(cfg_l)
     except KeyboardInterrupt:
@@ -224,6 +231,15 @@ def main(argv: Optional[List[str]] = None) -> int:
         if sampler is not None:
             sampler.stop()
             write_json(os.path.join(run_dir, "power.json"), sampler.to_power_json())
+    use1 = usage()
+    if use0 and use1 and use1["cpu_seconds"] >= use0["cpu_seconds"]:
+        # what the service's processes really used during the load test (the cost record prices this
+        # instead of the manifest's nominal requests)
+        write_json(os.path.join(run_dir, "resource_usage.json"), {
+            "source": f"/proc of {use1['processes']} process(es) via cluster backend '{backend.name}'",
+            "window_s": use1["t"] - use0["t"], "cpu_core_seconds": use1["cpu_seconds"] - use0["cpu_seconds"],
+            "mean_cpu_cores": (use1["cpu_seconds"] - use0["cpu_seconds"]) / max(use1["t"] - use0["t"], 1e-9),
+            "rss_bytes_start": use0["rss_bytes"], "rss_bytes_end": use1["rss_bytes"], "peak_rss_bytes": max(use0["peak_rss_bytes"], use1["peak_rss_bytes"])})
     n_ok = sum(1 for r in results if r.status == 200)
     print(f"Load test: {len(results)} requests, {n_ok} ok, {time.time() - t0:.1f}s")
 

@@ -3,11 +3,13 @@
 The reference has one aggregate per request, ``(tllt - ttfb) / completion_tokens``
 (``analyze.py:143-146``), computed after the run.  Here every content event the SSE parser
 sees is appended as ``(request id, token index, t_ns)`` to a preallocated ring; a background
-task wakes every ``interval_s`` (250 ms), takes the events that arrived since its last pass
-(the *delta* — nothing is re-read), turns them into inter-token gaps with the last timestamp
-it remembers per request, and bins the gaps into the persistent 2048-bin log-spaced histogram
-(:class:`kvmini.ops.hist_quantile.StreamingHistogram`: one launch of ``stream_hist_kernel`` on
-the GPU when the load generator's host has one, the same bins in numpy otherwise).  Rolling
+task wakes every ``interval_s`` (250 ms) and takes the events that arrived since its last pass
+(the *delta* — nothing is re-read) in ONE copy.  The raw events go to the device as they are:
+``kvmini.ops.hist_quantile.TokenGaps`` (three small kernels around a batch-local hash table and a
+per-request "last seen" table that lives on the device) turns them into inter-token gaps, and
+``StreamingHistogram`` (one launch of ``stream_hist_kernel``) bins the gaps into the persistent
+2048-bin log-spaced histogram — no per-event work on the host.  Without a GPU on the load
+generator's host the same two steps run vectorised in numpy.  Rolling
 p50 / p95 / p99 are printed and exported as Prometheus text; after the last request the final
 flush holds exactly the gaps the offline analysis derives from ``token_events.npy``.
 """
@@ -65,11 +67,11 @@ class LiveQuantiles:
         if device is None:
             device = "cuda" if hq.available() else "cpu"
         self.hist = hq.StreamingHistogram(1, device=device)
-        self.engine = "hip:stream_hist_kernel" if self.hist.on_gpu else "numpy"
+        self.engine = "hip:token_gaps+stream_hist_kernel" if self.hist.on_gpu else "numpy"
         self.ring = TokenEventRing(capacity)
         self.interval_s = float(interval_s)
         self.verbose = verbose
-        self._last: Dict[int, int] = {}  # request id -> t_ns of its latest token
+        self.gaps = hq.TokenGaps(device=device)  # per-request "last seen" table + the gap kernels (numpy on a host without a GPU)
         self.updates = 0
         self.gaps_seen = 0
         self.history: List[Tuple[float, Dict[float, float]]] = []  # (wall time, quantiles) per update
@@ -88,26 +90,20 @@ class LiveQuantiles:
 
     # ---- consumer side -----------------------------------------------------
     def drain(self) -> int:
-        """Bin the gaps of the events that arrived since the last pass.  Returns the number of gaps."""
+        """Bin the gaps of the events that arrived since the last pass: one ``take()`` of the
+        ring's new slice, then the gap kernels and the histogram kernel on it (no per-event host
+        work).  Returns the number of token events that can carry a gap (index > 0)."""
         ev = self.ring.take()
         if not ev.shape[0]:
             return 0
-        gaps: List[float] = []
-        last = self._last
-        for req, idx, t_ns in ev.tolist():
-            if idx < 0:
-                last.pop(req, None)
-                continue
-            prev = last.get(req)
-            if prev is not None and idx > 0:
-                gaps.append((t_ns - prev) * 1e-6)
-            last[req] = t_ns
-        if gaps:
+        n = int((ev[:, 1] > 0).sum())
+        g = self.gaps.gaps(ev)
+        if n:
             with self._lock:
-                self.hist.update(np.asarray(gaps, dtype=np.float32))
+                self.hist.update(g)
                 self.updates += 1
-                self.gaps_seen += len(gaps)
-        return len(gaps)
+                self.gaps_seen += n
+        return n
 
     def snapshot(self) -> Dict[str, Any]:
         with self._lock:

@@ -261,6 +261,77 @@ def log_bins_numpy(x: np.ndarray) -> np.ndarray:
     return np.clip(f.astype(np.int64), 0, BINS - 1)
 
 
+class TokenGaps:
+    """Inter-token gaps from raw ``(request id, token index, t_ns)`` events, batch after batch,
+    without per-event host work.  The gap of an event with index k > 0 is its time minus the time
+    of the same request's previous event (in this batch, or remembered from an earlier one).
+
+    On a GPU: the batch is copied once and three launches of ``csrc/hist_quantile.hip`` (insert
+    into a batch-local hash table, emit the gaps, commit the per-request time table) leave an
+    fp32 device vector (ms, NaN where an event has no gap) that :class:`StreamingHistogram` bins
+    as it is.  Without one: the same result with a stable argsort by request in numpy."""
+
+    def __init__(self, device: Any = "cuda", requests_hint: int = 4096):
+        torch = _torch()
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        n = max(16, int(requests_hint))
+        if self.on_gpu:
+            self.last_t = torch.full((n,), -1, dtype=torch.int64, device=self.device)
+            self._keys = self._vals = None
+        else:
+            self.last_np = np.full(n, -1, dtype=np.int64)
+
+    def _grow(self, need: int) -> None:
+        torch = _torch()
+        if self.on_gpu:
+            if need > self.last_t.numel():
+                bigger = torch.full((max(need, 2 * self.last_t.numel()),), -1, dtype=torch.int64, device=self.device)
+                bigger[: self.last_t.numel()] = self.last_t
+                self.last_t = bigger
+        elif need > self.last_np.size:
+            bigger_np = np.full(max(need, 2 * self.last_np.size), -1, dtype=np.int64)
+            bigger_np[: self.last_np.size] = self.last_np
+            self.last_np = bigger_np
+
+    def gaps(self, events: np.ndarray) -> Any:
+        """``events``: int64 ``[n, 3]`` in arrival order.  Returns the gaps in ms: a device fp32
+        tensor ``[n]`` with NaN for events without a gap (GPU), or a float32 numpy vector of the
+        gaps only (host)."""
+        torch = _torch()
+        ev = np.ascontiguousarray(events, dtype=np.int64).reshape(-1, 3)
+        n = ev.shape[0]
+        if n == 0:
+            return torch.empty(0, dtype=torch.float32, device=self.device) if self.on_gpu else np.empty(0, dtype=np.float32)
+        if int(ev[:, 0].min()) < 0:
+            raise ValueError("request ids must be non-negative")
+        self._grow(int(ev[:, 0].max()) + 1)
+        if self.on_gpu:
+            slots = 1 << max(5, int(2 * n - 1).bit_length())
+            if self._keys is None or self._keys.numel() < slots:
+                self._keys = torch.empty(slots, dtype=torch.int64, device=self.device)
+                self._vals = torch.empty(slots, dtype=torch.int64, device=self.device)
+            ev_d = torch.from_numpy(ev).to(self.device, non_blocking=True)
+            out = torch.empty(n, dtype=torch.float32, device=self.device)
+            native().token_gaps(ev_d, self._keys[:slots], self._vals[:slots], self.last_t, out)
+            return out
+        tok = ev[ev[:, 1] >= 0]
+        if not tok.shape[0]:
+            return np.empty(0, dtype=np.float32)
+        order = np.argsort(tok[:, 0], kind="stable")  # by request, arrival order kept inside a request
+        req, idx, t = tok[order, 0], tok[order, 1], tok[order, 2]
+        first = np.ones(req.size, dtype=bool)
+        first[1:] = req[1:] != req[:-1]
+        prev = np.empty_like(t)
+        prev[1:] = t[:-1]
+        prev[first] = self.last_np[req[first]]
+        keep = (idx > 0) & (prev >= 0)
+        last = np.ones(req.size, dtype=bool)
+        last[:-1] = req[1:] != req[:-1]
+        self.last_np[req[last]] = np.maximum(self.last_np[req[last]], t[last])
+        return ((t[keep] - prev[keep]) * 1e-6).astype(np.float32)
+
+
 class StreamingHistogram:
     """Persistent histogram for live inter-token-latency statistics.
 

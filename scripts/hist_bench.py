@@ -19,7 +19,53 @@ import torch
 from kvmini.ops import hist_quantile as hq
 
 
+def live() -> None:
+    """The live path's consumer side: raw (request, index, t_ns) events -> gaps -> histogram bins,
+    in events per second, one drain at a time (ring slice -> device -> token-gap kernels ->
+    stream_hist_kernel), against the per-event Python loop it replaced."""
+    from kvmini.loadgen.live import LiveQuantiles
+
+    rng = np.random.default_rng(1)
+    for n in (1 << 12, 1 << 16, 1 << 18, 1 << 20):
+        n_req = max(16, n // 64)
+        req = rng.integers(0, n_req, n)
+        order = np.argsort(req, kind="stable")
+        idx = np.empty(n, dtype=np.int64)
+        idx[order] = np.arange(n) - np.searchsorted(req[order], req[order], side="left")  # 0, 1, 2, ... inside each request, in arrival order
+        ev = np.stack([req, idx, np.arange(n, dtype=np.int64) * 3_000_000 // max(1, n_req)], axis=1).astype(np.int64)
+        out = {"bench": "live_drain", "events": n, "requests": n_req}
+        for device in ("cuda", "cpu"):
+            lq = LiveQuantiles(device=device, capacity=max(n, 1 << 18))
+            reps = 5
+            best = 1e9
+            for _ in range(reps):
+                lq.ring.buf[:n] = ev
+                lq.ring.head += n
+                if device == "cuda":
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lq.drain()
+                if device == "cuda":
+                    torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+                ev[:, 2] += 10_000_000_000
+            out[f"{device}_ms"] = round(best * 1e3, 3)
+            out[f"{device}_events_per_s"] = round(n / best)
+        # the loop this path replaced (per-event Python on the host)
+        last, gaps = {}, []
+        t0 = time.perf_counter()
+        for r, k, t in ev[: min(n, 1 << 16)].tolist():
+            prev = last.get(r)
+            if prev is not None and k > 0:
+                gaps.append((t - prev) * 1e-6)
+            last[r] = t
+        out["python_loop_events_per_s"] = round(min(n, 1 << 16) / (time.perf_counter() - t0))
+        print(json.dumps(out), flush=True)
+
+
 def main() -> None:
+    if "--live" in sys.argv[1:]:
+        return live()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
     ps = (0.5, 0.95, 0.99)

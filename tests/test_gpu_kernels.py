@@ -2039,3 +2039,31 @@ def test_persistent_decode_layers_equal_the_kernel_per_phase_path(n_seqs, kv_dty
     assert kv_a.shape == kv_b.shape
     diff = (kv_a.view(torch.uint8) != kv_b.view(torch.uint8))
     assert not bool(diff.any()), f"{int(diff.sum())} KV bytes differ, first at {diff.nonzero()[0].tolist()}"
+
+
+@pytest.mark.gpu
+def test_token_gap_kernels_equal_the_per_event_model_and_feed_the_histogram():
+    """Raw (request, index, t_ns) events -> gaps on the device (hash insert / emit / commit), over
+    batches cut anywhere; the gaps binned by stream_hist_kernel give the quantiles of the model's gaps."""
+    import numpy as np
+
+    from kvmini.ops import hist_quantile as hq
+    from test_loadgen import _event_batches, _gaps_model
+
+    batches = _event_batches(5, n_req=2000, n_batches=9)
+    want = _gaps_model(batches)
+    tg = hq.TokenGaps(device="cuda:0", requests_hint=16)
+    hist = hq.StreamingHistogram(1, device="cuda:0")
+    allg = []
+    for ev, w in zip(batches, want):
+        g = tg.gaps(ev)
+        assert g.shape[0] == ev.shape[0] and g.dtype == torch.float32
+        got = g[~torch.isnan(g)].sort().values.cpu().numpy()
+        assert got.shape[0] == len(w) and np.allclose(got, np.asarray(w, dtype=np.float32), rtol=1e-6), (got.shape, len(w))
+        hist.update(g)
+        allg += w
+    st = hist.snapshot((0.5, 0.95, 0.99))[0]
+    assert int(st["count"]) == len(allg)
+    ref = np.quantile(np.asarray(allg), (0.5, 0.95, 0.99))
+    for q, r in zip((0.5, 0.95, 0.99), ref):
+        assert abs(st["quantiles"][q] - r) <= 0.02 * r

@@ -269,3 +269,52 @@ def test_traces_are_posted_to_an_otlp_collector(mock_server, tmp_path):
     # nobody listening: the run still completes and keeps its artifacts
     res = run_load_sync(LoadConfig(url=url, run_dir=str(tmp_path / "r2"), requests=2, concurrency=1, quiet=True, spec=RequestSpec(model="m", max_tokens=2), otlp_endpoint="http://127.0.0.1:9"))
     assert all(r.status == 200 for r in res) and (tmp_path / "r2" / "requests.csv").exists()
+
+def _gaps_model(batches):
+    """Per-event reference: the gap of an event with index > 0 is its time minus the time its request was last seen."""
+    last, out = {}, []
+    for ev in batches:
+        g = []
+        for req, idx, t in ev.tolist():
+            if idx < 0:
+                continue
+            prev = last.get(req)
+            if prev is not None and idx > 0:
+                g.append((t - prev) * 1e-6)
+            last[req] = t
+        out.append(sorted(g))
+    return out
+
+
+def _event_batches(seed, n_req=300, n_batches=7):
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    evs = []
+    for r in range(n_req):
+        t = int(rng.integers(0, 5_000_000_000))
+        for k in range(int(rng.integers(1, 90))):
+            t += int(rng.integers(200_000, 30_000_000))
+            evs.append((t, r, k))
+        evs.append((t + 1, r, -1))  # end-of-request marker
+    evs.sort()
+    arr = np.array([(r, (k if k >= 0 else -1), (t if k >= 0 else 0)) for t, r, k in evs], dtype=np.int64)
+    cuts = sorted(rng.integers(0, arr.shape[0], n_batches - 1).tolist())
+    return [b for b in np.split(arr, cuts)]
+
+
+def test_token_gaps_vectorised_host_path_equals_the_per_event_model():
+    """The live path's gap computation without per-event Python: batches cut anywhere (inside a
+    request's stream too), requests interleaved, end markers in between, the request table growing."""
+    import numpy as np
+
+    from kvmini.ops.hist_quantile import TokenGaps
+
+    batches = _event_batches(3)
+    want = _gaps_model(batches)
+    tg = TokenGaps(device="cpu", requests_hint=16)
+    for ev, w in zip(batches, want):
+        got = np.sort(tg.gaps(ev))
+        assert got.shape[0] == len(w) and np.allclose(got, np.asarray(w, dtype=np.float32), rtol=1e-6)
+    assert tg.gaps(np.empty((0, 3), dtype=np.int64)).shape[0] == 0
+    assert sum(len(w) for w in want) > 5000

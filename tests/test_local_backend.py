@@ -198,3 +198,30 @@ def test_follower_notices_a_dead_scheduling_rank():
     finally:
         r.close()
         w.close()
+
+
+def test_cost_record_prices_measured_cpu_seconds_and_peak_rss(local_env):
+    """`kvmini bench` on the local backend snapshots /proc of the service's process tree around the
+    load test; the cost record then holds the CPU-seconds really used and memory at the peak
+    resident set instead of the manifest's nominal 8 cores / 64 GiB (reference: ``cost_estimator.py:139-175``
+    prices requests x lifetime, which is all a cluster exposes)."""
+    from kvmini.deploy import manifests as mf
+    from kvmini.harness import bench
+
+    lb = local_env
+    lb.apply(mf.native_isvc("meas", "local", "tiny", serve_args=TINY))
+    lb.wait_ready("local", "meas", 120)
+    snap = lb.usage_snapshot("local", "meas")
+    assert snap and snap["processes"] >= 1 and snap["cpu_seconds"] > 0 and snap["peak_rss_bytes"] >= snap["rss_bytes"] > 50e6
+    assert lb.usage_snapshot("local", "nobody") is None
+    rc = bench.main(["--namespace", "local", "--service", "meas", "--model", "tiny", "--requests", "12", "--concurrency", "3", "--max-tokens", "8", "--run-dir", "runs/meas", "--cluster-backend", "local", "--no-energy"])
+    assert rc == 0
+    use = json.load(open("runs/meas/resource_usage.json"))
+    assert use["cpu_core_seconds"] > 0 and use["window_s"] > 0 and use["peak_rss_bytes"] > 50e6
+    cb = json.load(open("runs/meas/results.json"))["cost_breakdown"]
+    assert cb["cpu_memory_source"].startswith("measured")
+    assert 0 < cb["cpu_core_seconds"] <= use["cpu_core_seconds"] + 1e-9
+    window = cb["mem_gib_seconds"] / (use["peak_rss_bytes"] / 2**30)  # memory is charged at the peak resident set for the request window
+    assert 0 < window <= use["window_s"] + 1e-6
+    assert cb["mem_gib_seconds"] < 0.5 * 64 * window  # far below the nominal 64 GiB
+    lb.delete_isvc("local", "meas")
