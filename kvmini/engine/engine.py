@@ -248,6 +248,10 @@ class LLMEngine:
         self._rejected: List[Sequence] = []
         self.warm_s = 0.0
         self._pending: Optional[Tuple[Batch, Any]] = None  # (batch, runner handle) of the step in flight
+        # logprobs of a step that was launched ahead leave the device right behind its ids: two host
+        # buffers in turn (the step in flight and the one being launched), pinned on a GPU
+        self._lp_host: List[Optional[Tuple[torch.Tensor, torch.Tensor]]] = [None, None]
+        self._lp_turn = 0
         self.pipelined_steps = 0
         self._step_dur: Dict[Tuple[int, int], float] = {}  # measured device time of a step, by runner key
         self._probe_ctr: Dict[Tuple[int, int], int] = {}
@@ -411,10 +415,15 @@ class LLMEngine:
         g_scripts: List[Tuple[int, List[List[int]]]] = []  # (slot, [entries, rest]) to upload before the mask runs
         g_greedy: List[int] = []
         draws: List[Optional[float]] = []
+        lp_rows: List[int] = []
+        lp_k: List[int] = []
         r = 0
         for ch in batch.chunks:
             if ch.sample:
                 p = ch.seq.params
+                if p.logprobs > 0 and not guided_only:  # (the synchronous path reads them off the logits it gets back)
+                    lp_rows.append(r)
+                    lp_k.append(int(p.logprobs))
                 if p.guided:
                     self._stage_guided(ch.seq, r, g_rows, g_slots, g_init, g_cur, g_scripts)
                     if p.temperature <= 0:
@@ -424,8 +433,10 @@ class LLMEngine:
                     plist.append(p)
                     draws.append(self._draw_for(ch.seq))
                 r += 1
-        if not rows and not g_rows:
+        if not rows and not g_rows and not lp_rows:
             return None
+        if lp_rows:
+            batch.logprob_rows = self._logprob_holder(lp_rows, lp_k)
 
         def run(logits: torch.Tensor, out_ids: torch.Tensor) -> None:
             ops, dev = self.runner.ops, logits.device
@@ -442,8 +453,34 @@ class LLMEngine:
                 self._sample_into(logits, rows, plist, out_ids, draws)
             if g_rows:
                 ops.guided_advance(out_ids, gr, gs, self._guided_state, self._guided_cls, self._guided_script, self._guided_cursor)
+            if lp_rows:
+                # log-probability of the picked token and the top-k of its row, from the logits the pick was
+                # made on (masked ones for guided rows): device ops, then a copy to the host buffer that the
+                # step's completion event covers — nothing is read back here
+                _rows, ks, hv, hi = batch.logprob_rows
+                li = _host_to_device(lp_rows, torch.int64, dev)
+                lp = torch.log_softmax(logits.index_select(0, li).float(), -1)
+                kmax = min(max(ks), lp.shape[1])
+                tv, ti = torch.topk(lp, kmax, dim=-1)
+                hv[: len(lp_rows), 0:1].copy_(lp.gather(1, out_ids.index_select(0, li).view(-1, 1)), non_blocking=True)
+                hv[: len(lp_rows), 1 : 1 + kmax].copy_(tv, non_blocking=True)
+                hi[: len(lp_rows), :kmax].copy_(ti, non_blocking=True)
 
         return run
+
+    LOGPROBS_MAX = 20  # top-logprobs per token the host buffers hold (the OpenAI API's limit)
+
+    def _logprob_holder(self, rows: List[int], ks: List[int]) -> Tuple[Dict[int, int], List[int], torch.Tensor, torch.Tensor]:
+        """(row -> line, k per line, values ``[lines, 1 + K]``, ids ``[lines, K]``) for the step being launched."""
+        turn = self._lp_turn
+        self._lp_turn ^= 1
+        if self._lp_host[turn] is None:
+            n, pin = self.ecfg.max_num_seqs * 4, self.device.type == "cuda"
+            self._lp_host[turn] = (torch.zeros((n, 1 + self.LOGPROBS_MAX), dtype=torch.float32, pin_memory=pin), torch.zeros((n, self.LOGPROBS_MAX), dtype=torch.int64, pin_memory=pin))
+        hv, hi = self._lp_host[turn]
+        if len(rows) > hv.shape[0]:
+            raise RuntimeError(f"{len(rows)} rows with logprobs in one step; the host buffers hold {hv.shape[0]}")
+        return {r: j for j, r in enumerate(rows)}, [min(k, self.LOGPROBS_MAX) for k in ks], hv, hi
 
     def _stage_guided(self, seq: Sequence, row: int, g_rows: List[int], g_slots: List[int], g_init: List[int], g_cur: List[int],
                       g_scripts: List[Tuple[int, List[List[int]]]]) -> None:
@@ -501,10 +538,12 @@ class LLMEngine:
 
     @staticmethod
     def _needs_host_sampling(p: SamplingParams) -> bool:
-        # logprobs are read back with the logits.  (Seeded requests are sampled by the device ops
-        # like unseeded ones: their variates are a function of (seed, token index) — seeded_uniform —
-        # that the host computes at launch time; guided rows are always picked on the device.)
-        return bool(p.logprobs)
+        # Nothing a request can ask for needs the logits on the host any more: seeded requests are
+        # sampled by the device ops like unseeded ones (their variates are a function of (seed, token
+        # index) — seeded_uniform — that the host computes at launch time), guided rows are picked on
+        # the device, and logprobs are extracted by device ops behind the pick (_logprob_holder).
+        # Only a top-logprobs count beyond what the host buffers hold takes the synchronous path.
+        return int(p.logprobs or 0) > LLMEngine.LOGPROBS_MAX
 
     def _can_pipeline(self) -> bool:
         """Pipelined stepping needs every token of the next step to be either known or already
@@ -558,6 +597,11 @@ class LLMEngine:
                 self._step_dur[handle.key] = d if old is None else 0.5 * (old + d)
         self._t_collect = now
         events: List[TokenEvent] = []
+        lp_map = lp_ks = lp_vals = lp_ids = None
+        holder = getattr(batch, "logprob_rows", None)
+        if holder is not None:  # (the copies into the host buffers completed with the step's event)
+            lp_map, lp_ks, hv, hi = holder
+            lp_vals, lp_ids = hv[: len(lp_map)].tolist(), hi[: len(lp_map)].tolist()
         row = 0
         for ch in batch.chunks:
             seq = ch.seq
@@ -573,6 +617,10 @@ class LLMEngine:
             new = self.scheduler.finalize(ch, tok)
             if not ch.sample:
                 continue
+            if lp_map is not None and (row - 1) in lp_map and new:
+                j = lp_map[row - 1]
+                k = lp_ks[j]
+                seq.logprob_log.append((float(lp_vals[j][0]), list(zip(lp_ids[j][:k], lp_vals[j][1 : 1 + k]))))
             if first and seq.first_token_time is not None:
                 self.stats.first_token_s += seq.first_token_time - seq.arrival
                 self.stats.first_token_n += 1

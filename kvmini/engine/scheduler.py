@@ -108,6 +108,8 @@ class ScheduledChunk:
 class Batch:
     chunks: List[ScheduledChunk]
     num_tokens: int
+    # set by the engine for a step launched ahead that carries rows with logprobs: where their values land on the host
+    logprob_rows: Any = None
 
     @property
     def num_samples(self) -> int:

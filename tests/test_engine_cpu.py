@@ -461,10 +461,12 @@ def test_pipelined_stepping_equals_synchronous_stepping():
         assert [e[1:] for e in pipe_ev if e[0] == rid] == [e[1:] for e in sync_ev if e[0] == rid]
 
 
-def test_seeded_requests_stay_launched_ahead_and_requests_with_logprobs_hand_over():
+def test_seeded_requests_and_requests_with_logprobs_stay_launched_ahead():
     """A seeded request's variates are a function of (seed, token index), so its rows are sampled
     by the device ops of a step that was launched ahead: same tokens as the synchronous path, step
-    by step, whatever else shares the batch.  Requests that want logprobs are read back first."""
+    by step, whatever else shares the batch.  Logprobs are extracted by device ops behind the pick
+    and reach the host with the step's ids: the same values as the synchronous path reads off the
+    logits, without leaving the launch-ahead."""
     from kvmini.engine.engine import seeded_uniform
 
     us = [seeded_uniform(7, k) for k in range(2000)]
@@ -494,17 +496,33 @@ def test_seeded_requests_stay_launched_ahead_and_requests_with_logprobs_hand_ove
     # alone in the batch: the same tokens again
     eng, _w = _engine(max_num_seqs=4)
     assert eng.generate([PROMPTS[1]], SamplingParams(max_tokens=9, temperature=0.8, top_p=0.95, seed=3, ignore_eos=True))[0] == outs[True][0]
-    # logprobs: read back with the logits, so the step in flight is collected first
-    a = eng.make_sequence(PROMPTS[0], SamplingParams(max_tokens=10, ignore_eos=True))
-    eng.scheduler.add(a)
-    for _ in range(4):
-        eng.step()
-    assert eng._pending is not None
-    d = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=5, logprobs=2, ignore_eos=True))
-    eng.scheduler.add(d)
-    while eng.scheduler.has_work():
-        eng.step()
-    assert eng._pending is None and len(d.logprob_log) == 5
+    # logprobs: greedy and sampled (seeded) requests, launched ahead and synchronous
+    logs = {}
+    for mode in (True, False):
+        eng, _w = _engine(max_num_seqs=4, async_scheduling=mode)
+        a = eng.make_sequence(PROMPTS[0], SamplingParams(max_tokens=10, ignore_eos=True))
+        eng.scheduler.add(a)
+        for _ in range(4):
+            eng.step()
+        if mode:
+            assert eng._pending is not None
+        d = eng.make_sequence(PROMPTS[1], SamplingParams(max_tokens=6, logprobs=3, ignore_eos=True))
+        e = eng.make_sequence(PROMPTS[2], SamplingParams(max_tokens=6, logprobs=2, temperature=0.7, seed=5, ignore_eos=True))
+        eng.scheduler.add(d)
+        eng.scheduler.add(e)
+        before = eng.pipelined_steps
+        while eng.scheduler.has_work():
+            eng.step()
+        if mode:
+            assert eng.pipelined_steps - before >= 6
+        assert eng._pending is None and len(d.logprob_log) == 6 and len(e.logprob_log) == 6
+        logs[mode] = (d.output_ids, e.output_ids, d.logprob_log, e.logprob_log)
+    assert logs[True][0] == logs[False][0] and logs[True][1] == logs[False][1]
+    for la, lb in zip(logs[True][2] + logs[True][3], logs[False][2] + logs[False][3]):
+        assert abs(la[0] - lb[0]) < 1e-4 and [i for i, _ in la[1]] == [i for i, _ in lb[1]]
+        assert all(abs(x - y) < 1e-4 for (_, x), (_, y) in zip(la[1], lb[1]))
+    assert all(len(top) == 3 for _lp, top in logs[True][2]) and all(len(top) == 2 for _lp, top in logs[True][3])
+    assert all(lp == top[0][1] for lp, top in logs[True][2])  # greedy: the picked token is the most likely one
 
 
 def test_gemm_workgroup_planner_fills_the_cus_evenly():
