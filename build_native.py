@@ -28,7 +28,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-KERNEL_SOURCES = ["hist_quantile.hip", "energy_trapz.hip", "engine_kernels.hip", "stream_gemm.hip", "wide_gemm.hip", "sampling.hip", "guided.hip", "xgmi_collectives.hip"]
+KERNEL_SOURCES = ["hist_quantile.hip", "energy_trapz.hip", "engine_kernels.hip", "stream_gemm.hip", "wide_gemm.hip", "mfma_scaled.hip", "sampling.hip", "guided.hip", "xgmi_collectives.hip"]
 
 
 def run(cmd: list[str]) -> None:

@@ -67,6 +67,11 @@ int kvx_allreduce(void* h, const void* x, void* out, long long n, int two_shot, 
 int kvx_residual_allreduce(void* h, const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T,
                            int H, hipStream_t stream);
 int kvx_destroy(void* h);
+int kv_mfma_scale_probe(const int* a, const int* b, const int* sa, const int* sb, float* out, int fmt_a, int fmt_b, hipStream_t stream);
+int kv_quantize_rows_fp8(const void* x, long long ldx, int M, int K, void* x8, float* scale, hipStream_t stream);
+int kv_wide_gemm_fp8a(const void* Wp, const void* x8, void* out, int M, int N, int K, long long ldx8, long long ldy, int epi, int bm, int bn, int variant, int splits,
+                      int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, const float* a_scale,
+                      int m_fastest, hipStream_t stream);
 int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant);
 int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, long long ldx, long long ldy, int epi, int bm, int bn, int variant, int splits,
                  int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, int m_fastest,
@@ -791,6 +796,59 @@ void wide_gemm(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor out
         "kv_wide_gemm");
 }
 
+// FP8 weights x FP8 activations on the block-scaled MFMA.  x8: uint8 [M, K] from quantize_rows_fp8, a_scale fp32 [M], w_scale fp32 [N].
+void wide_gemm_fp8a(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x8, at::Tensor a_scale, at::Tensor out, int64_t epi, int64_t bm, int64_t bn, int64_t variant,
+                    int64_t splits, int64_t stages_per_split, c10::optional<at::Tensor> row_ss, double eps, at::Tensor w_scale, bool m_fastest) {
+  CHECK_DEV(Wp); CHECK_CONTIG(Wp); CHECK_DEV(out); CHECK_DEV(x8); CHECK_DEV(a_scale); CHECK_DEV(w_scale);
+  TORCH_CHECK(Wp.scalar_type() == at::kByte && x8.scalar_type() == at::kByte, "FP8 weights and activations are passed as uint8 bytes");
+  TORCH_CHECK(w_scale.scalar_type() == at::kFloat && w_scale.is_contiguous() && w_scale.numel() == N, "w_scale must be contiguous fp32 [N]");
+  TORCH_CHECK(Wp.numel() == N * K, "packed weight must hold N*K elements");
+  TORCH_CHECK(K % 128 == 0 && N % bn == 0, "wide_gemm_fp8a: K must be a multiple of 128 and N of the feature tile");
+  TORCH_CHECK(x8.dim() == 2 && x8.size(1) == K && x8.stride(1) == 1 && x8.stride(0) % 16 == 0, "x8 must be [M, K] bytes with 16-byte aligned rows");
+  const int64_t M = x8.size(0);
+  TORCH_CHECK(a_scale.scalar_type() == at::kFloat && a_scale.is_contiguous() && a_scale.numel() == M, "a_scale must be contiguous fp32 [M]");
+  int parts = 0;
+  const float* ssp = ss_ptr(row_ss, M, &parts);
+  long long ldy = 0, slab_stride = 0;
+  if (epi == 1) {
+    TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && out.dim() == 3 && out.size(0) == splits && out.size(1) == M && out.size(2) == N,
+                "slab output must be contiguous fp32 [splits, M, N]");
+    ldy = N; slab_stride = M * N;
+  } else {
+    CHECK_BF16(out);
+    TORCH_CHECK(out.dim() == 2 && out.size(0) == M && out.size(1) == (epi == 2 ? N / 2 : N) && out.stride(1) == 1 && out.stride(0) % 4 == 0, "bad output shape");
+    TORCH_CHECK(splits == 1, "bf16 / SwiGLU epilogues need a single split");
+    ldy = out.stride(0);
+  }
+  check(kv_wide_gemm_fp8a(Wp.data_ptr(), x8.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x8.stride(0), ldy, (int)epi, (int)bm, (int)bn, (int)variant, (int)splits,
+                          (int)stages_per_split, slab_stride, ssp, parts, (float)eps, (const float*)w_scale.data_ptr(), (const float*)a_scale.data_ptr(), m_fastest ? 1 : 0,
+                          cur_stream()),
+        "kv_wide_gemm_fp8a");
+}
+
+// x bf16 [M, K] (rows may be strided) -> (x8 uint8 [M, K] in the packed weights' k order, per-token scale fp32 [M])
+std::vector<at::Tensor> quantize_rows_fp8(at::Tensor x) {
+  CHECK_BF16(x);
+  TORCH_CHECK(x.dim() == 2 && x.stride(1) == 1 && x.stride(0) % 8 == 0 && x.size(1) % 64 == 0, "x must be bf16 [M, K], K a multiple of 64, 16-byte aligned rows");
+  const int64_t M = x.size(0), K = x.size(1);
+  at::Tensor x8 = at::empty({M, K}, x.options().dtype(at::kByte));
+  at::Tensor sc = at::empty({M}, x.options().dtype(at::kFloat));
+  check(kv_quantize_rows_fp8(x.data_ptr(), x.stride(0), (int)M, (int)K, x8.data_ptr(), (float*)sc.data_ptr(), cur_stream()), "kv_quantize_rows_fp8");
+  return {x8, sc};
+}
+
+// ONE v_mfma_scale_f32_16x16x128_f8f6f4 on caller-supplied operand registers (int32 [64, 8] each, scale dwords int32 [64]) -> fp32 [64, 4]
+at::Tensor mfma_scale_probe(at::Tensor a, at::Tensor b, at::Tensor sa, at::Tensor sb, int64_t fmt_a, int64_t fmt_b) {
+  CHECK_DEV(a); CHECK_DEV(b); CHECK_DEV(sa); CHECK_DEV(sb); CHECK_CONTIG(a); CHECK_CONTIG(b); CHECK_CONTIG(sa); CHECK_CONTIG(sb);
+  TORCH_CHECK(a.scalar_type() == at::kInt && b.scalar_type() == at::kInt && sa.scalar_type() == at::kInt && sb.scalar_type() == at::kInt, "int32 operands");
+  TORCH_CHECK(a.numel() == 512 && b.numel() == 512 && sa.numel() == 64 && sb.numel() == 64, "operands are [64, 8], scales [64]");
+  at::Tensor out = at::empty({64, 4}, a.options().dtype(at::kFloat));
+  check(kv_mfma_scale_probe((const int*)a.data_ptr(), (const int*)b.data_ptr(), (const int*)sa.data_ptr(), (const int*)sb.data_ptr(), (float*)out.data_ptr(), (int)fmt_a, (int)fmt_b,
+                            cur_stream()),
+        "kv_mfma_scale_probe");
+  return out;
+}
+
 void add_rmsnorm_slabs(at::Tensor slabs, at::Tensor residual, at::Tensor w, at::Tensor y, double eps) {
   CHECK_DEV(slabs); CHECK_CONTIG(slabs); CHECK_BF16(residual); CHECK_BF16(w); CHECK_BF16(y); CHECK_CONTIG(residual); CHECK_CONTIG(w); CHECK_CONTIG(y);
   TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3, "slabs must be fp32 [S, T, H]");
@@ -961,6 +1019,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("decode_layers_layout", &decode_layers_layout);
   m.def("decode_layers", &decode_layers);
   m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
+  m.def("wide_gemm_fp8a", &wide_gemm_fp8a);
+  m.def("quantize_rows_fp8", &quantize_rows_fp8);
+  m.def("mfma_scale_probe", &mfma_scale_probe);
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);
   m.def("xgmi_create", &xgmi_create);

@@ -42,6 +42,15 @@ typedef __attribute__((ext_vector_type(4))) float frag_cd;
 typedef __attribute__((ext_vector_type(4))) unsigned short us4;
 typedef __attribute__((ext_vector_type(4))) unsigned int raw16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) int v8i;
+
+// the 32-byte operand of the scaled MFMA from two 16-byte pieces
+__device__ inline v8i join16(raw16 a, raw16 b) {
+  v8i v;
+  v[0] = (int)a[0]; v[1] = (int)a[1]; v[2] = (int)a[2]; v[3] = (int)a[3];
+  v[4] = (int)b[0]; v[5] = (int)b[1]; v[6] = (int)b[2]; v[7] = (int)b[3];
+  return v;
+}
 
 enum Epilogue { EPI_BF16 = 0, EPI_SLAB = 1, EPI_SWIGLU = 2 };
 
@@ -77,11 +86,12 @@ struct Params {
   int stages_per_split, splits; long long slab_stride;
   const float* row_ss; int ss_parts; float inv_k, eps; const float* w_scale;
   int n_mtiles, n_ntiles, m_fastest;
+  const float* a_scale;  // FP8 activations: per-token scale (x ~= x8 * a_scale[t]); p.x then points at e4m3 bytes and K, ldx count PAIRS of them
 };
 
 // Epilogue shared by the kernels below:
 // acc[i][j][e] = y[token m0 + wm TM + 16 j + r][feature n0 + wn TN + 16 i + 4 q + e]
-template <int FA, int FB, int TM, int TN, int EPI, bool W8>
+template <int FA, int FB, int TM, int TN, int EPI, bool W8, bool A8 = false>
 __device__ inline void wide_epilogue(frag_cd (&acc)[FA][FB], const Params& p, int m0, int n0, int wm, int wn, int r, int q, int split) {
   const int tok0 = m0 + wm * TM + r;
   const int feat0 = n0 + wn * TN + 4 * q;
@@ -94,6 +104,10 @@ __device__ inline void wide_epilogue(frag_cd (&acc)[FA][FB], const Params& p, in
       float ssum = 0.f;
       for (int k = 0; k < p.ss_parts; ++k) ssum += p.row_ss[(long long)t * p.ss_parts + k];
       rs[j] = rsqrtf(ssum * p.inv_k + p.eps);
+    }
+    if constexpr (A8) {  // per-token scale of the FP8 activations (fp32 slabs carry it too: it differs from row to row, not from split to split)
+      const int t = tok0 + 16 * j < p.M ? tok0 + 16 * j : p.M - 1;
+      rs[j] *= p.a_scale[t];
     }
   }
 #pragma unroll
@@ -144,8 +158,10 @@ __device__ inline void wide_epilogue(frag_cd (&acc)[FA][FB], const Params& p, in
 // version of this kernel (all DMAs, then all reads, then all MFMAs per stage) those took 23 %,
 // 13 % and 22 % (barrier skew) of a step next to 38 % for the MFMAs.
 // Stages past the end of the K range are re-reads of the last one (the counts stay exact).
-template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, bool W8>
+template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, int WQ>
 __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p) {
+  constexpr bool W8 = WQ == 1, A8 = WQ == 2;  // FP8 weights widened to bf16 in registers / FP8 weights x FP8 activations on the scaled MFMA
+  static_assert(!A8 || KS == 2, "the scaled MFMA takes a whole 64-byte-wide stage pair");
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tokens x features
   constexpr int FB = TM / 16, FA = TN / 16;  // B (x) and A (W) fragment tiles per wave and k-step
@@ -290,11 +306,20 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
     const int st_ = i_ + NS < n ? i_ + NS : n - 1;                                                                          \
     _Pragma("unroll") for (int g = 0; g < NGRP; ++g) {                                                                      \
       const int s = g / FA, ii = g % FA;                                                                                    \
+      if constexpr (A8) {                                                                                                   \
+        /* one 16x16x128 scaled MFMA per (W tile, token tile): both 16-byte pieces of the stage on either side; the   */  \
+        /* token tiles of a W tile are shared out between its two groups so that the mem ops stay evenly interleaved */  \
+        const v8i av = join16(ra[CUR][(ii * 2) < AR ? ii * 2 : 0], ra[CUR][(ii * 2 + 1) < AR ? ii * 2 + 1 : 0]);            \
+        _Pragma("unroll") for (int j = s * ((FB + 1) / 2); j < (s == 0 ? (FB + 1) / 2 : FB); ++j)                           \
+            acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, join16(__builtin_bit_cast(raw16, fb[CUR][0][j]), __builtin_bit_cast(raw16, fb[CUR][KS - 1][j])), \
+                                                                          acc[ii][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);  \
+      } else {                                                                                                              \
       frag_ab af;                                                                                                           \
       if constexpr (W8) af = s == 0 ? fp8x8_to_bf16(ra[CUR][ii][0], ra[CUR][ii][1]) : fp8x8_to_bf16(ra[CUR][ii][2], ra[CUR][ii][3]); \
       else af = __builtin_bit_cast(frag_ab, ra[CUR][(ii * KS + s) < AR ? ii * KS + s : 0]);                                  \
       _Pragma("unroll") for (int j = 0; j < FB; ++j)                                                                        \
           acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, fb[CUR][s][j], acc[ii][j], 0, 0, 0);                      \
+      }                                                                                                                     \
       _Pragma("unroll") for (int m = g * PER; m < (g + 1) * PER; ++m)                                                       \
           if (m < MEM) WG_MEMOP(m, NXT, dst_, src_, st_);                                                                   \
       __builtin_amdgcn_sched_barrier(0); /* keep the hand-placed interleave: the scheduler would sink the reads to their use */ \
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
 #undef WG_MEMOP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-read stages of the tail
 
-  wide_epilogue<FA, FB, TM, TN, EPI, W8>(acc, p, m0, n0, wm, wn, r, q, split);
+  wide_epilogue<FA, FB, TM, TN, EPI, (WQ != 0), A8>(acc, p, m0, n0, wm, wn, r, q, split);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -326,8 +351,9 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
 // Here the waves split the copying: the first half issue ONLY W pieces into a deep ring of NSW
 // stages, the second half ONLY x pieces into a ring of NSX stages; each wave's counter then
 // covers one ring, and all waves multiply as before.  64-wide stages (KS = 2).
-template <int BM, int BN, int WM, int WN, int NSX, int NSW, int EPI, bool W8>
+template <int BM, int BN, int WM, int WN, int NSX, int NSW, int EPI, int WQ>
 __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_rs_kernel(const Params p) {
+  constexpr bool W8 = WQ == 1, A8 = WQ == 2;  // FP8 weights widened to bf16 in registers / FP8 weights x FP8 activations on the scaled MFMA
   constexpr int KS = 2;
   constexpr int NW = WM * WN, NL = NW / 2;  // waves, loader waves per operand
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -465,11 +491,18 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_rs_kernel(const Params
     const int st_ = i_ + depth < n ? i_ + depth : n - 1;                                                             \
     _Pragma("unroll") for (int g = 0; g < NGRP; ++g) {                                                               \
       const int s = g / FA, ii = g % FA;                                                                             \
+      if constexpr (A8) {                                                                                            \
+        const v8i av = join16(ra[CUR][(ii * 2) < AR ? ii * 2 : 0], ra[CUR][(ii * 2 + 1) < AR ? ii * 2 + 1 : 0]);     \
+        _Pragma("unroll") for (int j = s * ((FB + 1) / 2); j < (s == 0 ? (FB + 1) / 2 : FB); ++j)                    \
+            acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, join16(__builtin_bit_cast(raw16, fb[CUR][0][j]), __builtin_bit_cast(raw16, fb[CUR][1][j])), \
+                                                                          acc[ii][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+      } else {                                                                                                       \
       frag_ab af;                                                                                                    \
       if constexpr (W8) af = s == 0 ? fp8x8_to_bf16(ra[CUR][ii][0], ra[CUR][ii][1]) : fp8x8_to_bf16(ra[CUR][ii][2], ra[CUR][ii][3]); \
       else af = __builtin_bit_cast(frag_ab, ra[CUR][(ii * KS + s) < AR ? ii * KS + s : 0]);                           \
       _Pragma("unroll") for (int j = 0; j < FB; ++j)                                                                 \
           acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, fb[CUR][s][j], acc[ii][j], 0, 0, 0);               \
+      }                                                                                                              \
       _Pragma("unroll") for (int m = g * PER; m < (g + 1) * PER; ++m)                                                \
           if (m < MEM) RS_MEMOP(m, NXT, lb, sa_, sx_, st_);                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -489,15 +522,15 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_rs_kernel(const Params
 #undef RS_MEMOP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  wide_epilogue<FA, FB, TM, TN, EPI, W8>(acc, p, m0, n0, wm, wn, r, q, split);
+  wide_epilogue<FA, FB, TM, TN, EPI, (WQ != 0), A8>(acc, p, m0, n0, wm, wn, r, q, split);
 }
 
-template <int BM, int BN, int WM, int WN, int NSX, int NSW, int EPI, bool W8>
+template <int BM, int BN, int WM, int WN, int NSX, int NSW, int EPI, int WQ>
 int launch_rs(const Params& p, hipStream_t stream) {
-  constexpr int A_BYTES = (BN / 16) * (W8 ? 1024 : 2048);
+  constexpr int A_BYTES = (BN / 16) * (WQ == 1 ? 1024 : 2048);
   constexpr int LDS = NSW * A_BYTES + NSX * BM * 128;
   static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
-  auto kern = wide_gemm_rs_kernel<BM, BN, WM, WN, NSX, NSW, EPI, W8>;
+  auto kern = wide_gemm_rs_kernel<BM, BN, WM, WN, NSX, NSW, EPI, WQ>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
@@ -508,22 +541,22 @@ int launch_rs(const Params& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int NSX, int NSW, bool W8>
+template <int BM, int BN, int WM, int WN, int NSX, int NSW, int WQ>
 int dispatch_epi_rs(int epi, const Params& p, hipStream_t s) {
   switch (epi) {
-    case EPI_BF16: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_BF16, W8>(p, s);
-    case EPI_SLAB: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_SLAB, W8>(p, s);
-    case EPI_SWIGLU: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_SWIGLU, W8>(p, s);
+    case EPI_BF16: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_BF16, WQ>(p, s);
+    case EPI_SLAB: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_SLAB, WQ>(p, s);
+    case EPI_SWIGLU: return launch_rs<BM, BN, WM, WN, NSX, NSW, EPI_SWIGLU, WQ>(p, s);
   }
   return -1;
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, bool W8>
+template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, int WQ>
 int launch(const Params& p, hipStream_t stream) {
-  constexpr int A_BYTES = (BN / 16) * (W8 ? 1024 : KS * 1024);
+  constexpr int A_BYTES = (BN / 16) * (WQ == 1 ? 1024 : KS * 1024);
   constexpr int LDS = NS * (A_BYTES + BM * KS * 64);
   static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
-  auto kern = wide_gemm_kernel<BM, BN, WM, WN, KS, NS, EPI, W8>;
+  auto kern = wide_gemm_kernel<BM, BN, WM, WN, KS, NS, EPI, WQ>;
   static bool attr_set = false;  // per instantiation; LDS above the 64 KiB default has to be requested once
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
@@ -534,12 +567,12 @@ int launch(const Params& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NS, bool W8>
+template <int BM, int BN, int WM, int WN, int KS, int NS, int WQ>
 int dispatch_epi(int epi, const Params& p, hipStream_t s) {
   switch (epi) {
-    case EPI_BF16: return launch<BM, BN, WM, WN, KS, NS, EPI_BF16, W8>(p, s);
-    case EPI_SLAB: return launch<BM, BN, WM, WN, KS, NS, EPI_SLAB, W8>(p, s);
-    case EPI_SWIGLU: return launch<BM, BN, WM, WN, KS, NS, EPI_SWIGLU, W8>(p, s);
+    case EPI_BF16: return launch<BM, BN, WM, WN, KS, NS, EPI_BF16, WQ>(p, s);
+    case EPI_SLAB: return launch<BM, BN, WM, WN, KS, NS, EPI_SLAB, WQ>(p, s);
+    case EPI_SWIGLU: return launch<BM, BN, WM, WN, KS, NS, EPI_SWIGLU, WQ>(p, s);
   }
   return -1;
 }
@@ -547,48 +580,48 @@ int dispatch_epi(int epi, const Params& p, hipStream_t s) {
 // variant = pipeline shape of a tile: 0 = 64-wide stages in the deepest ring the LDS holds,
 // 1 / 3 = 32-wide stages (bf16 weights only), 2 = 64-wide stages in a two-stage ring,
 // 4 / 5 = role-split rings (64-wide stages; W and x in rings of different depth)
-template <bool W8>
+template <int WQ>
 int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStream_t s) {
   const int key = bm * 1000 + bn;
   switch (key * 10 + variant) {
     // 256 x 256, 8 waves (wave: 64 tokens x 128 features)
-    case 2562560: return dispatch_epi<256, 256, 4, 2, 2, 2, W8>(epi, p, s);
+    case 2562560: return dispatch_epi<256, 256, 4, 2, 2, 2, WQ>(epi, p, s);
     // 256 x 224 and 256 x 192, 8 waves (wave: 64 x 112 / 64 x 96): feature counts that are a
     // multiple of 7 x 32 or 3 x 64 but leave a ragged last round of 256-wide tiles over the CUs
-    case 2562240: return dispatch_epi<256, 224, 4, 2, 2, 2, W8>(epi, p, s);
-    case 2561920: return dispatch_epi<256, 192, 4, 2, 2, 2, W8>(epi, p, s);
+    case 2562240: return dispatch_epi<256, 224, 4, 2, 2, 2, WQ>(epi, p, s);
+    case 2561920: return dispatch_epi<256, 192, 4, 2, 2, 2, WQ>(epi, p, s);
     // 256 x 128, 8 waves (wave: 64 x 64)
-    case 2561280: return dispatch_epi<256, 128, 4, 2, 2, 3, W8>(epi, p, s);
-    case 2561282: return dispatch_epi<256, 128, 4, 2, 2, 2, W8>(epi, p, s);
+    case 2561280: return dispatch_epi<256, 128, 4, 2, 2, 3, WQ>(epi, p, s);
+    case 2561282: return dispatch_epi<256, 128, 4, 2, 2, 2, WQ>(epi, p, s);
     // 128 x 256, 8 waves (wave: 64 x 64)
-    case 1282560: return dispatch_epi<128, 256, 2, 4, 2, 3, W8>(epi, p, s);
-    case 1282562: return dispatch_epi<128, 256, 2, 4, 2, 2, W8>(epi, p, s);
+    case 1282560: return dispatch_epi<128, 256, 2, 4, 2, 3, WQ>(epi, p, s);
+    case 1282562: return dispatch_epi<128, 256, 2, 4, 2, 2, WQ>(epi, p, s);
     // 128 x 128, 4 waves (wave: 64 x 64); two workgroups per CU with two stages
-    case 1281280: return dispatch_epi<128, 128, 2, 2, 2, 4, W8>(epi, p, s);
-    case 1281282: return dispatch_epi<128, 128, 2, 2, 2, 2, W8>(epi, p, s);
+    case 1281280: return dispatch_epi<128, 128, 2, 2, 2, 4, WQ>(epi, p, s);
+    case 1281282: return dispatch_epi<128, 128, 2, 2, 2, 2, WQ>(epi, p, s);
   }
   switch (key * 10 + variant) {
     // role-split rings (wide_gemm_rs_kernel): 4 = x ring of 3 + the deepest W ring the LDS holds,
     // 5 = x ring of 2 and a deeper W ring still (128 x 128: small enough for two workgroups per CU)
-    case 2561284: return dispatch_epi_rs<256, 128, 4, 2, 3, 4, W8>(epi, p, s);
-    case 2561285: return dispatch_epi_rs<256, 128, 4, 2, 2, 6, W8>(epi, p, s);
-    case 1281284: return dispatch_epi_rs<128, 128, 2, 2, 3, 6, W8>(epi, p, s);
-    case 1281285: return dispatch_epi_rs<128, 128, 2, 2, 2, 3, W8>(epi, p, s);
-    case 1282564: return dispatch_epi_rs<128, 256, 2, 4, 2, 4, W8>(epi, p, s);
+    case 2561284: return dispatch_epi_rs<256, 128, 4, 2, 3, 4, WQ>(epi, p, s);
+    case 2561285: return dispatch_epi_rs<256, 128, 4, 2, 2, 6, WQ>(epi, p, s);
+    case 1281284: return dispatch_epi_rs<128, 128, 2, 2, 3, 6, WQ>(epi, p, s);
+    case 1281285: return dispatch_epi_rs<128, 128, 2, 2, 2, 3, WQ>(epi, p, s);
+    case 1282564: return dispatch_epi_rs<128, 256, 2, 4, 2, 4, WQ>(epi, p, s);
   }
-  if constexpr (!W8) {
+  if constexpr (WQ == 0) {
     switch (key * 10 + variant) {
       // 32-wide stages: deeper rings in the same LDS
-      case 2562561: return dispatch_epi<256, 256, 4, 2, 1, 4, false>(epi, p, s);
-      case 2562563: return dispatch_epi<256, 256, 4, 2, 1, 5, false>(epi, p, s);
-      case 2561281: return dispatch_epi<256, 128, 4, 2, 1, 6, false>(epi, p, s);
-      case 2562241: return dispatch_epi<256, 224, 4, 2, 1, 4, false>(epi, p, s);
-      case 2562243: return dispatch_epi<256, 224, 4, 2, 1, 5, false>(epi, p, s);
-      case 2561921: return dispatch_epi<256, 192, 4, 2, 1, 4, false>(epi, p, s);
-      case 2561923: return dispatch_epi<256, 192, 4, 2, 1, 5, false>(epi, p, s);
+      case 2562561: return dispatch_epi<256, 256, 4, 2, 1, 4, 0>(epi, p, s);
+      case 2562563: return dispatch_epi<256, 256, 4, 2, 1, 5, 0>(epi, p, s);
+      case 2561281: return dispatch_epi<256, 128, 4, 2, 1, 6, 0>(epi, p, s);
+      case 2562241: return dispatch_epi<256, 224, 4, 2, 1, 4, 0>(epi, p, s);
+      case 2562243: return dispatch_epi<256, 224, 4, 2, 1, 5, 0>(epi, p, s);
+      case 2561921: return dispatch_epi<256, 192, 4, 2, 1, 4, 0>(epi, p, s);
+      case 2561923: return dispatch_epi<256, 192, 4, 2, 1, 5, 0>(epi, p, s);
       // 256 x 64, 8 waves (wave: 32 x 64); an FP8 stage of it would be 4 pieces for 8 waves
-      case 2560640: return dispatch_epi<256, 64, 8, 1, 2, 3, false>(epi, p, s);
-      case 2560642: return dispatch_epi<256, 64, 8, 1, 2, 2, false>(epi, p, s);
+      case 2560640: return dispatch_epi<256, 64, 8, 1, 2, 3, 0>(epi, p, s);
+      case 2560642: return dispatch_epi<256, 64, 8, 1, 2, 2, 0>(epi, p, s);
     }
   }
   return -1;
@@ -619,8 +652,31 @@ int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, 
   p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
   p.stages_per_split = stages_per_split; p.splits = splits; p.slab_stride = slab_stride;
   p.row_ss = row_ss; p.ss_parts = ss_parts; p.inv_k = 1.f / (float)K; p.eps = eps; p.w_scale = w_scale;
+  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest; p.a_scale = nullptr;
+  return w_scale ? dispatch_tile<1>(bm, bn, variant, epi, p, stream) : dispatch_tile<0>(bm, bn, variant, epi, p, stream);
+}
+
+// FP8 weights x FP8 activations on the block-scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4,
+// e4m3 operands, unit block scales: twice the bf16 MFMA rate).  x8: e4m3 [M][ldx8 bytes] as kv_quantize_rows_fp8
+// writes it (the k order of the packed weights inside every 64 elements), a_scale[M] its per-token scales, w_scale[N]
+// the weight row scales.  Byte for byte the data movement of the bf16 kernel on K / 2 columns: the same tiles and
+// variants (64-wide stages only: variants 0, 2, 4, 5), stages counted in 128 K-elements.  K % 128 == 0, ldx8 % 16 == 0.
+int kv_wide_gemm_fp8a(const void* Wp, const void* x8, void* out, int M, int N, int K, long long ldx8, long long ldy, int epi, int bm, int bn, int variant, int splits,
+                      int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, const float* a_scale,
+                      int m_fastest, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 127) || bn <= 0 || (N % bn) || w_scale == nullptr || a_scale == nullptr) return -1;
+  if (variant == 1 || variant == 3) return -1;
+  if (epi != EPI_SLAB && splits != 1) return -1;
+  const int nst = K / 128;
+  if (splits < 1 || stages_per_split < 1 || (long long)splits * stages_per_split < nst || (long long)(splits - 1) * stages_per_split >= nst) return -1;
+  if ((ldx8 & 15) || (ldy & 3)) return -1;
+  Params p;
+  p.Wp = (const unsigned char*)Wp; p.x = (const __bf16*)x8; p.out = out;
+  p.M = M; p.N = N; p.K = K / 2; p.ldx = ldx8 / 2; p.ldy = ldy;  // in pairs of bytes: what the bf16 data movement counts in
+  p.stages_per_split = stages_per_split; p.splits = splits; p.slab_stride = slab_stride;
+  p.row_ss = row_ss; p.ss_parts = ss_parts; p.inv_k = 1.f / (float)K; p.eps = eps; p.w_scale = w_scale; p.a_scale = a_scale;
   p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest;
-  return w_scale ? dispatch_tile<true>(bm, bn, variant, epi, p, stream) : dispatch_tile<false>(bm, bn, variant, epi, p, stream);
+  return dispatch_tile<2>(bm, bn, variant, epi, p, stream);
 }
 
 }  // extern "C"

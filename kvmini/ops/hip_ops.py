@@ -295,18 +295,26 @@ _WIDE_TILES_FP8 = (((256, 256, 0), 1.9), ((256, 224, 0), 1.85), ((256, 192, 0), 
 # The 128-wide tiles move 1.5 x the operand bytes per MAC of the 256-wide ones from L2 into LDS; on
 # grids of many rounds that traffic shows: + this many microseconds per step and round
 # (28672 x 4096 at 2048 rows: 1.01 us per step over 7 rounds, 0.86 over 1-2 rounds).
+# FP8 weights x FP8 activations (scaled MFMA): byte for byte the bf16 kernel's data movement on K / 2
+# columns, 64-wide stages only; the step times are per stage of 128 K-elements.
+_WIDE_TILES_FP8A = (((256, 256, 0), 1.75), ((256, 224, 0), 1.65), ((256, 192, 0), 1.40), ((256, 128, 0), 0.86), ((128, 256, 0), 0.90), ((128, 128, 0), 0.64))
+# Wide steps with FP8 weights quantise the activations per token to e4m3 as well and multiply on the
+# block-scaled matrix instruction (twice the bf16 MFMA rate); "0" keeps bf16 activations (the weights
+# are then widened to bf16 in registers).
+FP8_ACTIVATIONS = os.environ.get("KVMINI_FP8_ACT", "1") == "1"
 _WIDE_ROUND_SLOPE = {(256, 128): 0.025, (128, 256): 0.025}
 _WIDE_STAGE_KSTEPS = {1: 1, 3: 1}  # pipeline variants with 32-wide stages (kv_wide_gemm_stage_ksteps)
 
 
 @functools.lru_cache(maxsize=None)
-def _plan_wide(m: int, n_pad: int, k: int, fp8: bool, may_split: bool) -> Tuple[int, int, int, int, int]:
+def _plan_wide(m: int, n_pad: int, k: int, fp8: int, may_split: bool) -> Tuple[int, int, int, int, int]:
     """(token tile, feature tile, variant, K splits, pipeline stages per split) of the tiled GEMM
     for a shape: the candidate with the lowest modelled time = rounds over the 256 CUs x K steps
     x measured step time of the tile, plus, for split K, the slab bytes written and read back by
     the consumer (2 x splits x m x n x 4 bytes at ~2.5 TB/s: slabs stay in the Infinity Cache)."""
     best: Optional[Tuple[float, Tuple[int, int, int, int, int]]] = None
-    for (bm, bn, variant), step_us in (_WIDE_TILES_FP8 if fp8 else _WIDE_TILES_BF16):
+    # fp8: 0 = bf16 weights, 1 = FP8 weights with bf16 activations, 2 = FP8 weights and activations (k then counts PAIRS of elements)
+    for (bm, bn, variant), step_us in (_WIDE_TILES_BF16, _WIDE_TILES_FP8, _WIDE_TILES_FP8A)[int(fp8)]:
         if n_pad % bn:
             continue
         tiles = -(-m // bm) * (n_pad // bn)
@@ -337,7 +345,20 @@ def _wide(w: Union[PackedLinear, "_ExpandedView"], h: Union[torch.Tensor, "Norme
         x = x.contiguous()
     m = x.shape[0]
     may_split = allow_slabs and epi == 0 and w.n == w.n_pad
-    bm, bn, variant, splits, sps = _plan_wide(m, w.n_pad, w.k, w.wscale is not None, may_split)
+    if FP8_ACTIVATIONS and isinstance(w, PackedLinear) and w.bits == 8 and w.k % 128 == 0:
+        # FP8 x FP8: the activations get one dynamic scale per token (1/rms of a folded norm stays in the epilogue)
+        x8, a_scale = C.quantize_rows_fp8(x)
+        bm, bn, variant, splits, sps = _plan_wide(m, w.n_pad, w.k // 2, 2, may_split)
+        if splits > 1:
+            out = torch.empty((splits, m, w.n_pad), dtype=torch.float32, device=x.device)
+            C.wide_gemm_fp8a(w.wp, w.n_pad, w.k, x8, a_scale, out, 1, bm, bn, variant, splits, sps, None, 0.0, w.wscale, True)
+            return Partial(out, ss, eps, w.k)
+        n_out = w.n_pad // 2 if epi == 2 else w.n_pad
+        out = torch.empty((m, n_out), dtype=torch.bfloat16, device=x.device)
+        C.wide_gemm_fp8a(w.wp, w.n_pad, w.k, x8, a_scale, out, epi, bm, bn, variant, 1, sps, ss, eps, w.wscale, True)
+        n_true = w.n // 2 if epi == 2 else w.n
+        return out if n_true == n_out else out[:, :n_true]
+    bm, bn, variant, splits, sps = _plan_wide(m, w.n_pad, w.k, int(w.wscale is not None), may_split)
     if splits > 1:
         out = torch.empty((splits, m, w.n_pad), dtype=torch.float32, device=x.device)
         C.wide_gemm(w.wp, w.n_pad, w.k, x, out, 1, bm, bn, variant, splits, sps, None, 0.0, w.wscale, True)

@@ -2067,3 +2067,110 @@ def test_token_gap_kernels_equal_the_per_event_model_and_feed_the_histogram():
     ref = np.quantile(np.asarray(allg), (0.5, 0.95, 0.99))
     for q, r in zip((0.5, 0.95, 0.99), ref):
         assert abs(st["quantiles"][q] - r) <= 0.02 * r
+
+
+# ---------------------------------------------------------------- block-scaled MFMA (FP8 x FP8, FP4)
+def _e4m3_bytes(vals):
+    return vals.to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+_E2M1 = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
+
+
+@pytest.mark.gpu
+def test_scaled_mfma_operand_map_with_exact_integer_data(C):
+    """One v_mfma_scale_f32_16x16x128_f8f6f4 on hand-built registers pins the operand map the FP8
+    GEMM relies on (found with one-hot probes, ``scripts/mfma_scale_map.py``).  Lane l = (r = l & 15,
+    q = l >> 4) supplies row r of A / column r of B:
+      * 8-bit formats: bytes 0..15 of its eight dwords are k = 16 q + j, bytes 16..31 are k = 64 + 16 q + j;
+      * FP4: nibble j (low nibble first) of its first four dwords is k = 32 q + j;
+      * the scale byte of lane (r, b) scales the 32 elements k = 32 b .. 32 b + 31 of row / column r;
+      * D in the 16x16 C layout: lane (c, q), register e = D[4 q + e][c].
+    Asymmetric integer data and power-of-two scales: the comparison is exact."""
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-4, 5, (16, 128), generator=g).float()
+    B = torch.randint(-3, 4, (128, 16), generator=g).float()
+    A[:, 5] += torch.arange(16).float() % 3  # rows differ
+    ea = torch.randint(-2, 3, (16, 4), generator=g)  # block exponents per (row, 32-block)
+    eb = torch.randint(-2, 3, (16, 4), generator=g)  # per (column, 32-block)
+    lanes = torch.arange(64)
+    r, q = lanes & 15, lanes >> 4
+    k8 = torch.stack([torch.cat((torch.arange(16) + 16 * qq, torch.arange(16) + 64 + 16 * qq)) for qq in range(4)])  # [q, 32] -> k
+    a_reg = _e4m3_bytes(torch.stack([A[r[l], k8[q[l]]] for l in range(64)])).contiguous().view(torch.int32).view(64, 8)
+    b_reg = _e4m3_bytes(torch.stack([B[k8[q[l]], r[l]] for l in range(64)])).contiguous().view(torch.int32).view(64, 8)
+    sa = (127 + ea[r, q]).int()
+    sb = (127 + eb[r, q]).int()
+    out = C.mfma_scale_probe(a_reg.to(_dev()), b_reg.to(_dev()), sa.to(_dev()), sb.to(_dev()), 0, 0).cpu()
+    As = A * (2.0 ** ea.float()).repeat_interleave(32, dim=1)
+    Bs = B * (2.0 ** eb.float()).repeat_interleave(32, dim=1).T
+    D = As @ Bs
+    want = torch.stack([D[4 * q[l] : 4 * q[l] + 4, r[l]] for l in range(64)])
+    assert torch.equal(out, want), (out - want).abs().max()
+    # FP4 (e2m1) A against FP8 B: 32 nibbles in the first four dwords, k = 32 q + j
+    codes = torch.randint(0, 16, (16, 128), generator=g)
+    A4 = torch.tensor(_E2M1)[codes & 7] * torch.where(codes >= 8, -1.0, 1.0)
+    nib = torch.stack([codes[r[l], 32 * q[l] : 32 * q[l] + 32] for l in range(64)])  # [64, 32]
+    packed = (nib[:, 0::2] | (nib[:, 1::2] << 4)).to(torch.uint8)  # [64, 16] bytes
+    a4_reg = torch.cat([packed, torch.zeros(64, 16, dtype=torch.uint8)], 1).contiguous().view(torch.int32).view(64, 8)
+    out4 = C.mfma_scale_probe(a4_reg.to(_dev()), b_reg.to(_dev()), sa.to(_dev()), sb.to(_dev()), 4, 0).cpu()
+    D4 = (A4 * (2.0 ** ea.float()).repeat_interleave(32, dim=1)) @ Bs
+    want4 = torch.stack([D4[4 * q[l] : 4 * q[l] + 4, r[l]] for l in range(64)])
+    assert torch.equal(out4, want4), (out4 - want4).abs().max()
+
+
+@pytest.mark.gpu
+def test_quantize_rows_fp8_scale_and_fragment_order(C):
+    torch.manual_seed(2)
+    M, K = 37, 512
+    x = (torch.randn(M, K + 64, device=_dev()) * 3).bfloat16()[:, :K]  # strided rows
+    x[3] = 0
+    x8, sc = C.quantize_rows_fp8(x)
+    amax = x.float().abs().amax(1)
+    want_sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(sc, want_sc, rtol=1e-6)
+    q = (x.float() / want_sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)  # [M, K] in natural k order
+    # inside every 64 elements: byte 16 qq + 8 half + j <- k = 32 half + 8 qq + j
+    nat = q.view(M, K // 64, 2, 4, 8)  # group, half, qq, j
+    perm = nat.permute(0, 1, 3, 2, 4).contiguous().view(M, K)
+    assert torch.equal(x8, perm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [129, 254, 512, 1024, 2048])
+@pytest.mark.parametrize("N,K,epi", [(4096, 4096, 0), (6144, 4096, 0), (28672, 4096, 2), (4096, 14336, 0)])
+def test_fp8_weights_times_fp8_activations_matches_fp32_matmul_of_the_quantised_operands(M, N, K, epi):
+    """The wide step of an FP8 model: activations quantised per token to e4m3, weights per row,
+    multiplied on the scaled MFMA.  Reference: fp32 matmul of the DEQUANTISED operands (what the
+    instruction computes exactly, up to fp32 summation order), bf16 rounding of the output on top."""
+    from kvmini.models.llama import interleave_gate_up
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(M + N)
+    W = torch.randn(N, K, device=_dev()) * 0.03
+    if epi == 2:
+        W = interleave_gate_up(W[: N // 2], W[N // 2 :]).contiguous()
+    pw = hip_ops.PackedLinear(W.bfloat16(), fp8=True)
+    x = (torch.randn(M, K, device=_dev()) * 1.5).bfloat16()
+    x[:, 7] *= 20  # an outlier column: the per-token scale follows it
+    assert hip_ops.FP8_ACTIVATIONS
+    y = hip_ops._wide(pw, x, epi, allow_slabs=False)
+    # reference from the quantised operands
+    C = hip_ops.native()
+    _x8, sc = C.quantize_rows_fp8(x)
+    xq = (x.float() / sc[:, None]).to(torch.float8_e4m3fn).float() * sc[:, None]
+    from kvmini.models.llama import quantize_fp8_rows
+
+    qw, wsc = quantize_fp8_rows(W.bfloat16())
+    wq = qw.float() * wsc.float().view(-1, 1)
+    ref = xq @ wq.T
+    if epi == 2:
+        half = ref.view(M, N // 16, 2, 8)
+        ref = (torch.nn.functional.silu(half[:, :, 0]) * half[:, :, 1]).reshape(M, N // 2)
+    err = (y.float() - ref).abs().max().item()
+    tol = 1.2e-2 * ref.abs().max().item() + 1e-2
+    assert y.shape == ref.shape and err <= tol, (err, tol)
+    # and it stays close to the unquantised product (what the model wanted)
+    full = x.float() @ W.bfloat16().float().T
+    if epi == 0:
+        rel = (y.float() - full).norm() / full.norm()
+        assert rel < 0.06, rel
