@@ -68,7 +68,10 @@ int kvx_residual_allreduce(void* h, const float* slabs, int n_slabs, long long s
                            int H, hipStream_t stream);
 int kvx_destroy(void* h);
 int kv_mfma_scale_probe(const int* a, const int* b, const int* sa, const int* sb, float* out, int fmt_a, int fmt_b, hipStream_t stream);
-int kv_quantize_rows_fp8(const void* x, long long ldx, int M, int K, void* x8, float* scale, hipStream_t stream);
+int kv_quantize_rows_fp8(const void* x, long long ldx, int M, int K, void* x8, float* scale, int permute, hipStream_t stream);
+int kv_wide_gemm_w4a8(const void* Wp4, const int* w_blk, const void* x8, void* out, int M, int N, int K, long long ldx8, long long ldy, int epi, int bm, int bn, int variant,
+                      int splits, int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* a_scale, int m_fastest,
+                      hipStream_t stream);
 int kv_wide_gemm_fp8a(const void* Wp, const void* x8, void* out, int M, int N, int K, long long ldx8, long long ldy, int epi, int bm, int bn, int variant, int splits,
                       int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, const float* a_scale,
                       int m_fastest, hipStream_t stream);
@@ -826,14 +829,41 @@ void wide_gemm_fp8a(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x8, at::Tens
         "kv_wide_gemm_fp8a");
 }
 
+// MXFP4 weights (pack_mxfp4 layout + block scale words) x FP8 activations (natural k order) on the block-scaled MFMA
+void wide_gemm_w4a8(at::Tensor Wp4, at::Tensor w_blk, int64_t N, int64_t K, at::Tensor x8, at::Tensor a_scale, at::Tensor out, int64_t epi, int64_t bm, int64_t bn, int64_t variant,
+                    int64_t splits, int64_t stages_per_split, c10::optional<at::Tensor> row_ss, double eps, bool m_fastest) {
+  CHECK_DEV(Wp4); CHECK_CONTIG(Wp4); CHECK_DEV(w_blk); CHECK_CONTIG(w_blk); CHECK_DEV(out); CHECK_DEV(x8); CHECK_DEV(a_scale);
+  TORCH_CHECK(Wp4.scalar_type() == at::kByte && x8.scalar_type() == at::kByte && w_blk.scalar_type() == at::kInt, "MXFP4 weights / FP8 activations as uint8, block scales as int32");
+  TORCH_CHECK(K % 128 == 0 && N % bn == 0 && Wp4.numel() == N * K / 2 && w_blk.numel() == N * (K / 128), "wide_gemm_w4a8: packed weights [N/16, K/128, 64, 16] and scales [N/16, K/128, 16]");
+  TORCH_CHECK(x8.dim() == 2 && x8.size(1) == K && x8.stride(1) == 1 && x8.stride(0) % 16 == 0, "x8 must be [M, K] bytes with 16-byte aligned rows");
+  const int64_t M = x8.size(0);
+  TORCH_CHECK(a_scale.scalar_type() == at::kFloat && a_scale.is_contiguous() && a_scale.numel() == M, "a_scale must be contiguous fp32 [M]");
+  int parts = 0;
+  const float* ssp = ss_ptr(row_ss, M, &parts);
+  long long ldy = 0, slab_stride = 0;
+  if (epi == 1) {
+    TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && out.dim() == 3 && out.size(0) == splits && out.size(1) == M && out.size(2) == N,
+                "slab output must be contiguous fp32 [splits, M, N]");
+    ldy = N; slab_stride = M * N;
+  } else {
+    CHECK_BF16(out);
+    TORCH_CHECK(out.dim() == 2 && out.size(0) == M && out.size(1) == (epi == 2 ? N / 2 : N) && out.stride(1) == 1 && out.stride(0) % 4 == 0, "bad output shape");
+    TORCH_CHECK(splits == 1, "bf16 / SwiGLU epilogues need a single split");
+    ldy = out.stride(0);
+  }
+  check(kv_wide_gemm_w4a8(Wp4.data_ptr(), (const int*)w_blk.data_ptr(), x8.data_ptr(), out.data_ptr(), (int)M, (int)N, (int)K, x8.stride(0), ldy, (int)epi, (int)bm, (int)bn, (int)variant,
+                          (int)splits, (int)stages_per_split, slab_stride, ssp, parts, (float)eps, (const float*)a_scale.data_ptr(), m_fastest ? 1 : 0, cur_stream()),
+        "kv_wide_gemm_w4a8");
+}
+
 // x bf16 [M, K] (rows may be strided) -> (x8 uint8 [M, K] in the packed weights' k order, per-token scale fp32 [M])
-std::vector<at::Tensor> quantize_rows_fp8(at::Tensor x) {
+std::vector<at::Tensor> quantize_rows_fp8(at::Tensor x, bool permute) {
   CHECK_BF16(x);
   TORCH_CHECK(x.dim() == 2 && x.stride(1) == 1 && x.stride(0) % 8 == 0 && x.size(1) % 64 == 0, "x must be bf16 [M, K], K a multiple of 64, 16-byte aligned rows");
   const int64_t M = x.size(0), K = x.size(1);
   at::Tensor x8 = at::empty({M, K}, x.options().dtype(at::kByte));
   at::Tensor sc = at::empty({M}, x.options().dtype(at::kFloat));
-  check(kv_quantize_rows_fp8(x.data_ptr(), x.stride(0), (int)M, (int)K, x8.data_ptr(), (float*)sc.data_ptr(), cur_stream()), "kv_quantize_rows_fp8");
+  check(kv_quantize_rows_fp8(x.data_ptr(), x.stride(0), (int)M, (int)K, x8.data_ptr(), (float*)sc.data_ptr(), permute ? 1 : 0, cur_stream()), "kv_quantize_rows_fp8");
   return {x8, sc};
 }
 
@@ -1020,7 +1050,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("decode_layers", &decode_layers);
   m.def("wide_gemm_stage_ksteps", &wide_gemm_stage_ksteps);
   m.def("wide_gemm_fp8a", &wide_gemm_fp8a);
-  m.def("quantize_rows_fp8", &quantize_rows_fp8);
+  m.def("quantize_rows_fp8", &quantize_rows_fp8, py::arg("x"), py::arg("permute") = true);
+  m.def("wide_gemm_w4a8", &wide_gemm_w4a8);
   m.def("mfma_scale_probe", &mfma_scale_probe);
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);

@@ -44,6 +44,7 @@ __device__ inline float bf2f(unsigned short b) { return __uint_as_float(((unsign
 // are stored in the order of the packed FP8 weight fragments (kv_pack_weight_fp8): byte 16 q + j
 // holds k = 8 q + j for j < 8 and k = 32 + 8 q + (j - 8) for j >= 8, so that a 16-byte chunk of
 // the row is exactly what lane quarter q of a weight fragment multiplies.
+template <bool PERMUTE>
 __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned short* __restrict__ x, long long ldx, int K, unsigned char* __restrict__ x8,
                                                                 float* __restrict__ scale) {
   __shared__ float red[4];
@@ -81,9 +82,13 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const unsigned s
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-    const int g = i >> 6, w = i & 63;           // 64-element group, offset inside it (a multiple of 8)
-    const int half = w >> 5, qq = (w & 31) >> 3;  // k = 32 half + 8 qq + j
-    *reinterpret_cast<raw8*>(orow + g * 64 + 16 * qq + 8 * half) = (raw8){lo, hi};
+    if constexpr (PERMUTE) {
+      const int g = i >> 6, w = i & 63;           // 64-element group, offset inside it (a multiple of 8)
+      const int half = w >> 5, qq = (w & 31) >> 3;  // k = 32 half + 8 qq + j
+      *reinterpret_cast<raw8*>(orow + g * 64 + 16 * qq + 8 * half) = (raw8){lo, hi};
+    } else {
+      *reinterpret_cast<raw8*>(orow + i) = (raw8){lo, hi};  // natural k order (MXFP4 weights: the FP4 operand is in k order)
+    }
   }
 }
 
@@ -104,11 +109,13 @@ int kv_mfma_scale_probe(const int* a, const int* b, const int* sa, const int* sb
   return (int)hipGetLastError();
 }
 
-// x bf16 [M][ldx] -> x8 e4m3 [M][K] (permuted inside 64-element groups, see the kernel), scale fp32 [M].  K % 64 == 0, ldx % 8 == 0.
-int kv_quantize_rows_fp8(const void* x, long long ldx, int M, int K, void* x8, float* scale, hipStream_t stream) {
+// x bf16 [M][ldx] -> x8 e4m3 [M][K] (permute != 0: permuted inside 64-element groups into the FP8 weight fragments' order,
+// see the kernel; 0: natural order), scale fp32 [M].  K % 64 == 0, ldx % 8 == 0.
+int kv_quantize_rows_fp8(const void* x, long long ldx, int M, int K, void* x8, float* scale, int permute, hipStream_t stream) {
   if (M <= 0) return 0;
   if ((K & 63) || (ldx & 7) || ldx < K) return -1;
-  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(M), dim3(256), 0, stream, (const unsigned short*)x, ldx, K, (unsigned char*)x8, scale);
+  if (permute) hipLaunchKernelGGL(quantize_rows_fp8_kernel<true>, dim3(M), dim3(256), 0, stream, (const unsigned short*)x, ldx, K, (unsigned char*)x8, scale);
+  else hipLaunchKernelGGL(quantize_rows_fp8_kernel<false>, dim3(M), dim3(256), 0, stream, (const unsigned short*)x, ldx, K, (unsigned char*)x8, scale);
   return (int)hipGetLastError();
 }
 

@@ -43,6 +43,28 @@ typedef __attribute__((ext_vector_type(4))) unsigned short us4;
 typedef __attribute__((ext_vector_type(4))) unsigned int raw16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(8))) int v8i;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// one LDS-DMA piece of 4-byte units: lane l's dword at `src` lands at lds_base + 4 * l
+__device__ inline void dma4(const void* src, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_base, 4, 0, 0);
+}
+
+// MXFP4 fragment as packed (lane (r, q), dword u = the 8 values k = 32 u + 8 q .. of row r) -> the FP4
+// operand of the scaled MFMA (lane (r, q) holds k = 32 q .. 32 q + 31 in order): a 4 x 4 transpose of
+// dwords across the four lane quarters, two swap levels (rows of 16 lanes, then halves of 32).
+__device__ inline v8i fp4_operand(raw16 w) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+  u2 a = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false);
+  u2 b = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false);
+  u2 c = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+  u2 d = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+  v8i v;
+  v[0] = (int)c[0]; v[1] = (int)d[0]; v[2] = (int)c[1]; v[3] = (int)d[1];
+  v[4] = 0; v[5] = 0; v[6] = 0; v[7] = 0;
+  return v;
+}
 
 // the 32-byte operand of the scaled MFMA from two 16-byte pieces
 __device__ inline v8i join16(raw16 a, raw16 b) {
@@ -72,8 +94,6 @@ __device__ inline frag_ab fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
   return a;
 }
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
 
 // one LDS-DMA piece: lane l's 16 bytes at `src` land at lds_base + 16 * l
 __device__ inline void dma16(const void* src, void* lds_base) {
@@ -86,6 +106,7 @@ struct Params {
   int stages_per_split, splits; long long slab_stride;
   const float* row_ss; int ss_parts; float inv_k, eps; const float* w_scale;
   int n_mtiles, n_ntiles, m_fastest;
+  const int* w_blk;      // MXFP4: packed E8M0 block scales, int32 [N/16][K/128][16 rows] (byte u = block u of the 128 columns)
   const float* a_scale;  // FP8 activations: per-token scale (x ~= x8 * a_scale[t]); p.x then points at e4m3 bytes and K, ldx count PAIRS of them
 };
 
@@ -160,7 +181,11 @@ __device__ inline void wide_epilogue(frag_cd (&acc)[FA][FB], const Params& p, in
 // Stages past the end of the K range are re-reads of the last one (the counts stay exact).
 template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, int WQ>
 __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p) {
-  constexpr bool W8 = WQ == 1, A8 = WQ == 2;  // FP8 weights widened to bf16 in registers / FP8 weights x FP8 activations on the scaled MFMA
+  // WQ: 0 bf16 | 1 FP8 weights widened to bf16 in registers | 2 FP8 weights x FP8 activations | 3 MXFP4 weights x FP8
+  // activations (2, 3: on the block-scaled MFMA; x is e4m3 bytes, a stage covers 128 K-elements)
+  constexpr bool W4 = WQ == 3;
+  constexpr bool W8 = WQ == 1 || W4;  // one 16-byte unit per (tile, stage) and lane: 1 KiB of W per tile and stage
+  constexpr bool A8 = WQ == 2 || W4;
   static_assert(!A8 || KS == 2, "the scaled MFMA takes a whole 64-byte-wide stage pair");
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tokens x features
@@ -171,17 +196,20 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
   constexpr int A_BYTES = (BN / 16) * A_TILE;
   constexpr int XROW = KS * 64;                  // bytes of an x row per stage
   constexpr int X_BYTES = BM * XROW;
-  constexpr int STAGE = A_BYTES + X_BYTES;
+  constexpr int SC_BYTES = W4 ? (BN / 16) * 64 : 0;  // MXFP4: the E8M0 scale words of the stage, one per (tile, row)
+  constexpr int STAGE = A_BYTES + X_BYTES + SC_BYTES;
   constexpr int PA = A_BYTES / 1024, PX = X_BYTES / 1024;  // 1 KiB LDS-DMA pieces per stage
+  constexpr int PS = SC_BYTES / 256, PS_W = W4 ? 1 : 0;    // 256-byte pieces of scale words (four tiles each); one slot per wave (waves beyond PS repeat a piece)
+  constexpr int SR = W4 ? (BN / WN) / 16 : 0;              // scale words a lane reads per stage
   // Every wave issues the same number of LDS-DMA pieces per stage (the vmcnt counts are exact).
   // When the W pieces do not divide by the waves (224- and 192-feature tiles), the surplus slots
   // copy a piece a second time: same source, same destination, same bytes.
   static_assert(PX % NW == 0, "x pieces divide by the waves");
   constexpr int PA_W = (PA + NW - 1) / NW, PX_W = PX / NW;
   static_assert(PA_W * NW - PA <= PA, "a surplus slot repeats a real piece");
-  constexpr int G = PA_W + PX_W;         // LDS-DMA instructions per wave and stage
+  constexpr int G = PA_W + PX_W + PS_W;  // LDS-DMA instructions per wave and stage
   constexpr int AR = W8 ? FA : KS * FA;  // 16-byte LDS reads of W per wave and stage
-  constexpr int NREAD = AR + KS * FB;    // LDS reads per wave and stage
+  constexpr int NREAD = AR + SR + KS * FB;  // LDS reads per wave and stage
   constexpr int NGRP = KS * FA;          // MFMA groups (FB MFMAs each) per stage
   constexpr int MEM = NREAD + G;         // mem ops to spread over the groups
   constexpr int PER = (MEM + NGRP - 1) / NGRP;
@@ -244,6 +272,10 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
     xsrc[i] = reinterpret_cast<const unsigned char*>(p.x + (long long)row * p.ldx + (long long)s0 * (32 * KS)) + chunk * 16;
   }
 
+  // MXFP4 block scales: int32 [N/16][K/128][16 rows]; this wave's 256-byte piece = four tiles of the stage
+  const int spc = PS > 0 ? wave % (PS > 0 ? PS : 1) : 0;
+  const unsigned char* ssrc = W4 ? reinterpret_cast<const unsigned char*>(p.w_blk + ((((long long)(n0 >> 4) + 4 * spc + (lane >> 4)) * nst + s0) * 16 + (lane & 15))) : nullptr;
+
   frag_cd acc[FA][FB];
 #pragma unroll
   for (int i = 0; i < FA; ++i)
@@ -252,6 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
 
   // lane-constant LDS read offsets
   const int a_off = wn * (FA * A_TILE) + lane * 16;
+  const int s_off = A_BYTES + X_BYTES + wn * (FA * 64) + r * 4;
   int x_off[KS];
   if constexpr (KS == 2) {
     x_off[0] = A_BYTES + (wm * TM + r) * 128 + (((0 + q) ^ (r >> 1)) << 4);
@@ -264,16 +297,19 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
   // FP8: both k-steps of a tile in one read), x per k-step and token tile
   raw16 ra[2][AR];
   frag_ab fb[2][KS][FB];
+  int sreg[2][SR > 0 ? SR : 1];  // MXFP4: the lane's scale byte (block q of row r) per W tile
 
   // mem op m of a step: m < G -> LDS-DMA piece m of stage `st` into `dst`; else fragment read m - G
   // of the stage at `src` into register set SET
 #define WG_MEMOP(m, SET, dst, src, st)                                                                                                   \
   do {                                                                                                                                  \
     if ((m) < PA_W) dma16(asrc[(m) < PA_W ? (m) : 0] + (long long)(st) * A_TILE, (dst) + apc[(m) < PA_W ? (m) : 0] * 1024);             \
-    else if ((m) < G) dma16(xsrc[(m) >= PA_W && (m) < G ? (m) - PA_W : 0] + (long long)(st) * XROW, (dst) + A_BYTES + (wave + NW * ((m) - PA_W)) * 1024); \
+    else if ((m) < PA_W + PX_W) dma16(xsrc[(m) >= PA_W && (m) < PA_W + PX_W ? (m) - PA_W : 0] + (long long)(st) * XROW, (dst) + A_BYTES + (wave + NW * ((m) - PA_W)) * 1024); \
+    else if ((m) < G) dma4(ssrc + (long long)(st) * 64, (dst) + A_BYTES + X_BYTES + spc * 256);                                         \
     else if ((m) - G < AR) ra[SET][(m) >= G && (m) - G < AR ? (m) - G : 0] = *reinterpret_cast<const raw16*>((src) + a_off + ((m) - G) * 1024); \
+    else if ((m) - G - AR < SR) sreg[SET][(m) - G - AR >= 0 && (m) - G - AR < SR ? (m) - G - AR : 0] = *reinterpret_cast<const int*>((src) + s_off + ((m) - G - AR) * 64) >> (8 * q); \
     else {                                                                                                                              \
-      const int kk_ = (m) - G - AR;                                                                                                     \
+      const int kk_ = (m) - G - AR - SR;                                                                                                \
       const int ss_ = kk_ >= 0 && kk_ < KS * FB ? kk_ / FB : 0, jj_ = kk_ >= 0 ? kk_ % FB : 0;                                          \
       fb[SET][ss_][jj_] = *reinterpret_cast<const frag_ab*>((src) + x_off[ss_] + jj_ * (16 * XROW));                                    \
     }                                                                                                                                   \
@@ -306,7 +342,14 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
     const int st_ = i_ + NS < n ? i_ + NS : n - 1;                                                                          \
     _Pragma("unroll") for (int g = 0; g < NGRP; ++g) {                                                                      \
       const int s = g / FA, ii = g % FA;                                                                                    \
-      if constexpr (A8) {                                                                                                   \
+      if constexpr (W4) {                                                                                                   \
+        /* MXFP4 x FP8: the packed fragment is transposed across the lane quarters into the FP4 operand; the lane's */     \
+        /* scale byte goes with it (block q of its row), the activations carry unit block scales                     */     \
+        const v8i av = fp4_operand(ra[CUR][ii < AR ? ii : 0]);                                                              \
+        _Pragma("unroll") for (int j = s * ((FB + 1) / 2); j < (s == 0 ? (FB + 1) / 2 : FB); ++j)                           \
+            acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, join16(__builtin_bit_cast(raw16, fb[CUR][0][j]), __builtin_bit_cast(raw16, fb[CUR][KS - 1][j])), \
+                                                                          acc[ii][j], 4, 0, 0, sreg[CUR][ii < SR ? ii : 0], 0, 0x7f7f7f7f); \
+      } else if constexpr (A8) {                                                                                            \
         /* one 16x16x128 scaled MFMA per (W tile, token tile): both 16-byte pieces of the stage on either side; the   */  \
         /* token tiles of a W tile are shared out between its two groups so that the mem ops stay evenly interleaved */  \
         const v8i av = join16(ra[CUR][(ii * 2) < AR ? ii * 2 : 0], ra[CUR][(ii * 2 + 1) < AR ? ii * 2 + 1 : 0]);            \
@@ -336,7 +379,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
 #undef WG_MEMOP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-read stages of the tail
 
-  wide_epilogue<FA, FB, TM, TN, EPI, (WQ != 0), A8>(acc, p, m0, n0, wm, wn, r, q, split);
+  wide_epilogue<FA, FB, TM, TN, EPI, (WQ == 1 || WQ == 2), A8>(acc, p, m0, n0, wm, wn, r, q, split);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -353,6 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_kernel(const Params p)
 // covers one ring, and all waves multiply as before.  64-wide stages (KS = 2).
 template <int BM, int BN, int WM, int WN, int NSX, int NSW, int EPI, int WQ>
 __global__ __launch_bounds__(WM * WN * 64) void wide_gemm_rs_kernel(const Params p) {
+  static_assert(WQ != 3, "MXFP4 weights run in the single-ring kernel");
   constexpr bool W8 = WQ == 1, A8 = WQ == 2;  // FP8 weights widened to bf16 in registers / FP8 weights x FP8 activations on the scaled MFMA
   constexpr int KS = 2;
   constexpr int NW = WM * WN, NL = NW / 2;  // waves, loader waves per operand
@@ -553,8 +597,8 @@ int dispatch_epi_rs(int epi, const Params& p, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int KS, int NS, int EPI, int WQ>
 int launch(const Params& p, hipStream_t stream) {
-  constexpr int A_BYTES = (BN / 16) * (WQ == 1 ? 1024 : KS * 1024);
-  constexpr int LDS = NS * (A_BYTES + BM * KS * 64);
+  constexpr int A_BYTES = (BN / 16) * ((WQ == 1 || WQ == 3) ? 1024 : KS * 1024);
+  constexpr int LDS = NS * (A_BYTES + BM * KS * 64 + (WQ == 3 ? (BN / 16) * 64 : 0));
   static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
   auto kern = wide_gemm_kernel<BM, BN, WM, WN, KS, NS, EPI, WQ>;
   static bool attr_set = false;  // per instantiation; LDS above the 64 KiB default has to be requested once
@@ -600,7 +644,7 @@ int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStre
     case 1281280: return dispatch_epi<128, 128, 2, 2, 2, 4, WQ>(epi, p, s);
     case 1281282: return dispatch_epi<128, 128, 2, 2, 2, 2, WQ>(epi, p, s);
   }
-  switch (key * 10 + variant) {
+  if constexpr (WQ != 3) switch (key * 10 + variant) {
     // role-split rings (wide_gemm_rs_kernel): 4 = x ring of 3 + the deepest W ring the LDS holds,
     // 5 = x ring of 2 and a deeper W ring still (128 x 128: small enough for two workgroups per CU)
     case 2561284: return dispatch_epi_rs<256, 128, 4, 2, 3, 4, WQ>(epi, p, s);
@@ -652,7 +696,7 @@ int kv_wide_gemm(const void* Wp, const void* x, void* out, int M, int N, int K, 
   p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldy = ldy;
   p.stages_per_split = stages_per_split; p.splits = splits; p.slab_stride = slab_stride;
   p.row_ss = row_ss; p.ss_parts = ss_parts; p.inv_k = 1.f / (float)K; p.eps = eps; p.w_scale = w_scale;
-  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest; p.a_scale = nullptr;
+  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest; p.a_scale = nullptr; p.w_blk = nullptr;
   return w_scale ? dispatch_tile<1>(bm, bn, variant, epi, p, stream) : dispatch_tile<0>(bm, bn, variant, epi, p, stream);
 }
 
@@ -675,8 +719,31 @@ int kv_wide_gemm_fp8a(const void* Wp, const void* x8, void* out, int M, int N, i
   p.M = M; p.N = N; p.K = K / 2; p.ldx = ldx8 / 2; p.ldy = ldy;  // in pairs of bytes: what the bf16 data movement counts in
   p.stages_per_split = stages_per_split; p.splits = splits; p.slab_stride = slab_stride;
   p.row_ss = row_ss; p.ss_parts = ss_parts; p.inv_k = 1.f / (float)K; p.eps = eps; p.w_scale = w_scale; p.a_scale = a_scale;
-  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest;
+  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest; p.w_blk = nullptr;
   return dispatch_tile<2>(bm, bn, variant, epi, p, stream);
+}
+
+// MXFP4 weights x FP8 activations on the block-scaled MFMA: the weights as kv_pack_mxfp4 lays them out (the streaming
+// kernels' layout: [N/16][K/128][64 lanes][16 B]) with their E8M0 block scales w_blk (int32 [N/16][K/128][16]) applied by
+// the instruction itself; x8: e4m3 [M][ldx8] in NATURAL k order (kv_quantize_rows_fp8 with permute = 0), a_scale[M].
+// Tiles (256,128), (128,256), (128,128), variants 0 and 2.  K % 128 == 0, N % 64 == 0.
+int kv_wide_gemm_w4a8(const void* Wp4, const int* w_blk, const void* x8, void* out, int M, int N, int K, long long ldx8, long long ldy, int epi, int bm, int bn, int variant,
+                      int splits, int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* a_scale, int m_fastest,
+                      hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 127) || bn <= 0 || (N % bn) || (bn & 63) || w_blk == nullptr || a_scale == nullptr) return -1;
+  if (variant != 0 && variant != 2) return -1;
+  if (epi != EPI_SLAB && splits != 1) return -1;
+  const int nst = K / 128;
+  if (splits < 1 || stages_per_split < 1 || (long long)splits * stages_per_split < nst || (long long)(splits - 1) * stages_per_split >= nst) return -1;
+  if ((ldx8 & 15) || (ldy & 3)) return -1;
+  Params p;
+  p.Wp = (const unsigned char*)Wp4; p.x = (const __bf16*)x8; p.out = out;
+  p.M = M; p.N = N; p.K = K / 2; p.ldx = ldx8 / 2; p.ldy = ldy;
+  p.stages_per_split = stages_per_split; p.splits = splits; p.slab_stride = slab_stride;
+  p.row_ss = row_ss; p.ss_parts = ss_parts; p.inv_k = 1.f / (float)K; p.eps = eps; p.w_scale = nullptr; p.a_scale = a_scale; p.w_blk = w_blk;
+  p.n_mtiles = (M + bm - 1) / bm; p.n_ntiles = N / bn; p.m_fastest = m_fastest;
+  if (bm == 256 && bn == 256) return -1;
+  return dispatch_tile<3>(bm, bn, variant, epi, p, stream);
 }
 
 }  // extern "C"

@@ -297,7 +297,12 @@ _WIDE_TILES_FP8 = (((256, 256, 0), 1.9), ((256, 224, 0), 1.85), ((256, 192, 0), 
 # (28672 x 4096 at 2048 rows: 1.01 us per step over 7 rounds, 0.86 over 1-2 rounds).
 # FP8 weights x FP8 activations (scaled MFMA): byte for byte the bf16 kernel's data movement on K / 2
 # columns, 64-wide stages only; the step times are per stage of 128 K-elements.
-_WIDE_TILES_FP8A = (((256, 256, 0), 1.75), ((256, 224, 0), 1.65), ((256, 192, 0), 1.40), ((256, 128, 0), 0.86), ((128, 256, 0), 0.90), ((128, 128, 0), 0.64))
+# Measured (Llama-3-8B shapes): 256 x 128 runs the gate/up projection at 2048 rows in 258 us (1.87 PFLOP/s; bf16: 413 us)
+# and the down projection in 102 us (2.35 PFLOP/s; bf16: 200 us).  The 256 x 256 tile is not offered: its accumulators
+# plus 32-byte operands do not fit the register file (630 us on the down projection).
+# Third number: microseconds per round outside the K loop (ring prologue, epilogue), fitted on pairs of shapes with
+# K = 4096 and K = 14336 (e.g. 128 x 128 at 256 rows: o projection 24.4 us over 32 stages, down 67.5 us over 112).
+_WIDE_TILES_FP8A = (((256, 128, 0), 0.92, 7.4), ((128, 256, 0), 0.92, 8.8), ((128, 128, 0), 0.54, 7.2))
 # Wide steps with FP8 weights quantise the activations per token to e4m3 as well and multiply on the
 # block-scaled matrix instruction (twice the bf16 MFMA rate); "0" keeps bf16 activations (the weights
 # are then widened to bf16 in registers).
@@ -313,8 +318,10 @@ def _plan_wide(m: int, n_pad: int, k: int, fp8: int, may_split: bool) -> Tuple[i
     x measured step time of the tile, plus, for split K, the slab bytes written and read back by
     the consumer (2 x splits x m x n x 4 bytes at ~2.5 TB/s: slabs stay in the Infinity Cache)."""
     best: Optional[Tuple[float, Tuple[int, int, int, int, int]]] = None
-    # fp8: 0 = bf16 weights, 1 = FP8 weights with bf16 activations, 2 = FP8 weights and activations (k then counts PAIRS of elements)
-    for (bm, bn, variant), step_us in (_WIDE_TILES_BF16, _WIDE_TILES_FP8, _WIDE_TILES_FP8A)[int(fp8)]:
+    # fp8: 0 = bf16 weights, 1 = FP8 weights with bf16 activations, 2 = FP8 weights and activations, 3 = MXFP4 weights and FP8
+    # activations (2, 3: k counts PAIRS of elements, i.e. bytes of activations / 2)
+    for entry in (_WIDE_TILES_BF16, _WIDE_TILES_FP8, _WIDE_TILES_FP8A, _WIDE_TILES_FP8A)[int(fp8)]:
+        (bm, bn, variant), step_us, round_us = entry[0], entry[1], (entry[2] if len(entry) > 2 else 0.0)
         if n_pad % bn:
             continue
         tiles = -(-m // bm) * (n_pad // bn)
@@ -327,7 +334,8 @@ def _plan_wide(m: int, n_pad: int, k: int, fp8: int, may_split: bool) -> Tuple[i
             if (splits - 1) * sps >= nst:
                 continue
             rounds = -(-tiles * splits // _num_cus())
-            t = rounds * (sps * per_stage / 64.0) * (step_us + _WIDE_ROUND_SLOPE.get((bm, bn), 0.0) * rounds) + (2.0 * splits * m * n_pad * 4 / 2.5e6 if splits > 1 else 0.0)
+            slope = _WIDE_ROUND_SLOPE.get((bm, bn), 0.0) if int(fp8) < 2 else (0.004 if (bm, bn) == (128, 128) else 0.0)
+            t = rounds * ((sps * per_stage / 64.0) * (step_us + slope * rounds) + round_us) + (2.0 * splits * m * n_pad * 4 / 2.5e6 if splits > 1 else 0.0)
             # token rows of the last tile that are padding still cost MFMAs
             if best is None or t < best[0] - 1e-9:
                 best = (t, (bm, bn, variant, splits, sps))
@@ -507,8 +515,21 @@ def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow
     m = x.shape[0]
     n_out = w.n_pad // 2 if epi == 2 else w.n_pad
     n_true = w.n // 2 if epi == 2 else w.n
+    if m > 128 and FP8_ACTIVATIONS and w.k % 128 == 0 and w.n_pad % 128 == 0:
+        # the tiled kernel reads the MXFP4 weights themselves: FP4 operand + hardware block scales on the scaled
+        # MFMA against per-token FP8 activations (no expansion pass, no scratch buffer, any matrix size)
+        x8, a_scale = C.quantize_rows_fp8(x, False)
+        may_split = allow_slabs and epi == 0 and w.n == w.n_pad
+        bm, bn, variant, splits, sps = _plan_wide(m, w.n_pad, w.k // 2, 3, may_split)
+        if splits > 1:
+            out = torch.empty((splits, m, w.n_pad), dtype=torch.float32, device=x.device)
+            C.wide_gemm_w4a8(w.wp, w.wscale, w.n_pad, w.k, x8, a_scale, out, 1, bm, bn, variant, splits, sps, None, 0.0, True)
+            return Partial(out, ss, eps, w.k)
+        out = torch.empty((m, n_out), dtype=torch.bfloat16, device=x.device)
+        C.wide_gemm_w4a8(w.wp, w.wscale, w.n_pad, w.k, x8, a_scale, out, epi, bm, bn, variant, 1, sps, ss, eps, True)
+        return out if n_true == n_out else out[:, :n_true]
     if m > 128 and w.k % 64 == 0 and w.n_pad * w.k <= _W4_SCRATCH_MAX_ELEMS:
-        return _wide(_ExpandedView(w), h, epi, allow_slabs)
+        return _wide(_ExpandedView(w), h, epi, allow_slabs)  # (KVMINI_FP8_ACT=0: bf16 activations on an exact bf16 expansion of the matrix)
     if m > 128:
         out = torch.empty((m, n_true), dtype=torch.bfloat16, device=x.device)
         for r0 in range(0, m, 128):

@@ -169,8 +169,66 @@ def bench(C, dev, rows, out, fp8, only=None):
         torch.cuda.empty_cache()
 
 
+def bench_fp8a(C, dev, rows, out, only=None):
+    """FP8 weights x FP8 activations (scaled MFMA) against the same tiles with bf16 activations
+    (FP8 weights widened in registers) and against the bf16 kernel's best tile; the per-token
+    quantisation of the activations is timed on its own and is part of the fp8a totals."""
+    from kvmini.models.llama import quantize_fp8_rows
+    from kvmini.ops import hip_ops
+
+    shapes = {"qkv": (6144, 4096, 0), "o": (4096, 4096, 0), "gate_up": (28672, 4096, 2), "down": (4096, 14336, 0)}
+    for name, (N, K, epi) in shapes.items():
+        if only and name not in only:
+            continue
+        copies = max(2, int(600e6 // (N * K)) + 1)
+        Ws = [(torch.randn(N, K, device=dev) * 0.02).bfloat16() for _ in range(copies)]
+        qs = [quantize_fp8_rows(w) for w in Ws]
+        Wp8 = [C.pack_weight_fp8(q.view(torch.uint8).contiguous()) for q, _ in qs]
+        scales = [s.contiguous() for _, s in qs]
+        Wp16 = [C.pack_weight(w) for w in Ws[:2]]
+        del Ws, qs
+        for M in rows:
+            x = torch.randn(M, K, device=dev).bfloat16()
+            x8, a_scale = C.quantize_rows_fp8(x)
+            n_out = N // 2 if epi == 2 else N
+            y = torch.empty((M, n_out), dtype=torch.bfloat16, device=dev)
+            st = {"i": 0}
+
+            def nxt(n=copies):
+                st["i"] = (st["i"] + 1) % n
+                return st["i"]
+
+            fns = {"quantize_rows": lambda: C.quantize_rows_fp8(x)}
+            bm, bn, variant, _sp, sps = hip_ops._plan_wide(M, N, K, 0, False)
+            fns["bf16_planned"] = lambda bm=bm, bn=bn, variant=variant, sps=sps: C.wide_gemm(Wp16[nxt(2)], N, K, x, y, epi, bm, bn, variant, 1, sps, None, 0.0, None, True)
+            bm, bn, variant, _sp, sps = hip_ops._plan_wide(M, N, K, 1, False)
+            fns["w8a16_planned"] = lambda bm=bm, bn=bn, variant=variant, sps=sps: (lambda i: C.wide_gemm(Wp8[i], N, K, x, y, epi, bm, bn, variant, 1, sps, None, 0.0, scales[i], True))(nxt())
+            for (tbm, tbn), variants in VARIANTS_FP8.items():
+                if N % tbn:
+                    continue
+                for variant in variants:
+                    for mf in (True, False):
+                        def mk(tbm=tbm, tbn=tbn, variant=variant, mf=mf):
+                            def f():
+                                i = nxt()
+                                C.wide_gemm_fp8a(Wp8[i], N, K, x8, a_scale, y, epi, tbm, tbn, variant, 1, K // 128, None, 0.0, scales[i], mf)
+                            return f
+                        fns[f"fp8a_{tbm}x{tbn}_v{variant}_{'m' if mf else 'n'}"] = mk()
+            t = time_fns(fns)
+            flop = 2.0 * M * N * K
+            best = min((v[0], k) for k, v in t.items() if k.startswith("fp8a_"))
+            rec = {"bench": "fp8a", "shape": name, "M": M, "N": N, "K": K, "us": {k: round(v[0], 2) for k, v in t.items()}, "best": best[1], "best_us": round(best[0], 2),
+                   "best_with_quantize_us": round(best[0] + t["quantize_rows"][0], 2), "best_tflops": round(flop / best[0] / 1e6, 1),
+                   "bf16_tflops": round(flop / t["bf16_planned"][0] / 1e6, 1), "speedup_vs_bf16_incl_quantize": round(t["bf16_planned"][0] / (best[0] + t["quantize_rows"][0]), 3)}
+            out.append(rec)
+            print(json.dumps(rec), flush=True)
+        del Wp8, Wp16
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--fp8a", action="store_true", help="FP8 weights x FP8 activations (scaled MFMA) against bf16 / weight-only FP8")
     ap.add_argument("--out", default="gpurun_out/wide_gemm.json")
     ap.add_argument("--rows", default="256,512,1024,2048")
     ap.add_argument("--fp8", action="store_true")
@@ -182,6 +240,12 @@ def main():
     C = native()
     dev = torch.device("cuda:0")
     out: list = []
+    if a.fp8a:
+        bench_fp8a(C, dev, [int(r) for r in a.rows.split(",")], out, a.shapes.split(","))
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(out, f, indent=1)
+        return
     check(C, dev, out)
     if not a.no_bench:
         bench(C, dev, [int(r) for r in a.rows.split(",")], out, a.fp8, a.shapes.split(","))

@@ -2174,3 +2174,38 @@ def test_fp8_weights_times_fp8_activations_matches_fp32_matmul_of_the_quantised_
     if epi == 0:
         rel = (y.float() - full).norm() / full.norm()
         assert rel < 0.06, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [129, 254, 512, 1024, 2048])
+@pytest.mark.parametrize("N,K,epi", [(4096, 4096, 0), (6144, 4096, 0), (28672, 4096, 2), (4096, 14336, 0)])
+def test_mxfp4_weights_times_fp8_activations_matches_fp32_matmul_of_the_quantised_operands(M, N, K, epi):
+    """The wide step of an MXFP4 model on the scaled MFMA: the packed e2m1 fragments are transposed
+    across the lane quarters into the FP4 operand, their E8M0 block scales are applied by the
+    instruction, the activations are per-token e4m3.  Reference: fp32 matmul of the dequantised
+    operands."""
+    from kvmini.models.llama import dequantize_mxfp4, interleave_gate_up, quantize_mxfp4
+    from kvmini.ops import hip_ops
+
+    torch.manual_seed(M + N + 1)
+    W = torch.randn(N, K, device=_dev()) * 0.03
+    W[:, 100:132] *= 8  # blocks with very different scales
+    if epi == 2:
+        W = interleave_gate_up(W[: N // 2], W[N // 2 :]).contiguous()
+    Wb = W.bfloat16()
+    pw = hip_ops.PackedLinear(Wb.clone(), mxfp4=True)
+    x = (torch.randn(M, K, device=_dev()) * 1.5).bfloat16()
+    x[:, 7] *= 20
+    y = hip_ops._stream_fp4(pw, x, epi, False)
+    codes, scales = quantize_mxfp4(Wb)
+    wq = dequantize_mxfp4(codes, scales, torch.float32)
+    C = hip_ops.native()
+    _x8, sc = C.quantize_rows_fp8(x, False)
+    xq = (x.float() / sc[:, None]).to(torch.float8_e4m3fn).float() * sc[:, None]
+    ref = xq @ wq.T
+    if epi == 2:
+        half = ref.view(M, N // 16, 2, 8)
+        ref = (torch.nn.functional.silu(half[:, :, 0]) * half[:, :, 1]).reshape(M, N // 2)
+    err = (y.float() - ref).abs().max().item()
+    tol = 1.2e-2 * ref.abs().max().item() + 1e-2
+    assert y.shape == ref.shape and err <= tol, (err, tol)
