@@ -67,6 +67,8 @@ int kvx_allreduce(void* h, const void* x, void* out, long long n, int two_shot, 
 int kvx_residual_allreduce(void* h, const float* slabs, int n_slabs, long long slab_stride, const void* x, void* residual, int has_residual, float* ss_part, int T,
                            int H, hipStream_t stream);
 int kvx_destroy(void* h);
+void kv_set_attention_mfma(int on);
+int kv_get_attention_mfma();
 int kv_mfma_scale_probe(const int* a, const int* b, const int* sa, const int* sb, float* out, int fmt_a, int fmt_b, hipStream_t stream);
 int kv_quantize_rows_fp8(const void* x, long long ldx, int M, int K, void* x8, float* scale, int permute, hipStream_t stream);
 int kv_wide_gemm_w4a8(const void* Wp4, const int* w_blk, const void* x8, void* out, int M, int N, int K, long long ldx8, long long ldy, int epi, int bm, int bn, int variant,
@@ -1053,6 +1055,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("quantize_rows_fp8", &quantize_rows_fp8, py::arg("x"), py::arg("permute") = true);
   m.def("wide_gemm_w4a8", &wide_gemm_w4a8);
   m.def("mfma_scale_probe", &mfma_scale_probe);
+  m.def("set_attention_mfma", [](bool on) { kv_set_attention_mfma(on ? 1 : 0); });
+  m.def("get_attention_mfma", []() { return kv_get_attention_mfma() != 0; });
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);
   m.def("xgmi_create", &xgmi_create);

@@ -1655,12 +1655,39 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
 // (a few KB of slabs); only split 0 writes the cache and folds in the token's own key / value.
 constexpr int SPLIT_MIN_BLOCKS = 16;
 
+// all-reduce over the four lane quarters (lanes l, l ^ 16, l ^ 32, l ^ 48) with the two gfx950 row / half swaps
+__device__ inline float quarters_max(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+  const u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ inline float quarters_sum(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+  const u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ inline float lane_value(float v, int lane) { return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane)); }
+
 //
 // ATTN (with SPLIT; decode tokens of a step that also carries prompt chunks): phase A is another
 // kernel's work — q arrives rotated (`q_in`, bf16 rows of `q_row_stride` elements) and the token's
 // own key / value are in the cache already, so the walk covers all `ctx` positions and nothing is
 // folded in from LDS.  `row_list` names the token rows to serve (grid.z entries; -1 = none).
-template <int REP, int NWAVE, bool KV8, bool SPLIT, bool ATTN = false>
+//
+// MF (long contexts): the scores of a block come from the matrix cores.  S^T[token][head] = K[16 tokens x 128] . Q^T is
+// four mfma_f32_16x16x32_bf16 per block with K as the A operand — lane (token = lane & 15, chunk = lane >> 4) holds
+// 32 dims of a key exactly as it loads them, and since a dot product may run over the dims in any order, k-step v of
+// the instruction is "piece v of every chunk" on both operands — and Q^T as the B operand (lane (head = lane & 15,
+// chunk): 16 registers instead of the 16 per head of the dot-product form).  A lane (head, quarter c) then owns the
+// scores of tokens 4 c .. 4 c + 3 of its head: block maximum and sum by two row / half swaps, per-head values to
+// every lane by v_readlane.  P . V stays on the vector ALU in packed fp32 pairs (V rows are head-dim-major: the
+// matrix form would need the block transposed).  With an e4m3 cache this halves the vector work per block, which
+// is what bounds that kernel (the bf16 cache is bound by the KV stream already).
+template <int REP, int NWAVE, bool KV8, bool SPLIT, bool ATTN = false, bool MF = false>
 __device__ __forceinline__ void decode_attention_body(const int bx, const int by, const int bz, const int gdx, const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                                      const int* __restrict__ positions, const float* __restrict__ cos_t,
                                                                      const float* __restrict__ sin_t, void* __restrict__ k_cache,
@@ -1725,7 +1752,8 @@ __device__ __forceinline__ void decode_attention_body(const int bx, const int by
     b0 = z * per;
     n_blocks = b0 + per < all_blocks ? b0 + per : all_blocks;
   }
-  const int qk_tok = lane >> 2, qk_c = lane & 3;
+  static_assert(!MF || REP <= 16, "one head per lane column");
+  const int qk_tok = MF ? (lane & 15) : (lane >> 2), qk_c = MF ? (lane >> 4) : (lane & 3);
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
   KVStage<KV8> st_cur, st_nxt;  // this wave's first block and the one after: two blocks (16 KB of bf16) per wave in flight at any time
   if (b0 + wave < n_blocks) st_cur.load(k_cache, v_cache, ((long long)bt[b0 + wave] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
@@ -1814,15 +1842,19 @@ __device__ __forceinline__ void decode_attention_body(const int bx, const int by
   // q stays packed as bf16 pairs (16 registers per head instead of 32) and meets the keys in
   // v_dot2_f32_bf16: half the multiply instructions, no bf16 -> fp32 unpacking of K, and a
   // register footprint that lets 8 waves per workgroup (2 per SIMD) run without spilling
+  const int tail_c = lane & 3;  // dim chunk of the lane in the quad layout (the token's own key below)
   bf16x2 qp[REP][16];
+  auto load_qp = [&]() {
 #pragma unroll
-  for (int h = 0; h < REP; ++h)
+    for (int h = 0; h < REP; ++h)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const bf16x2x4 qw = __builtin_bit_cast(bf16x2x4, *reinterpret_cast<const bf16x8*>(&xb_lds[h][qk_c * 32 + v * 8]));
+      for (int v = 0; v < 4; ++v) {
+        const bf16x2x4 qw = __builtin_bit_cast(bf16x2x4, *reinterpret_cast<const bf16x8*>(&xb_lds[h][tail_c * 32 + v * 8]));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) qp[h][v * 4 + j] = qw.p[j];
-    }
+        for (int j = 0; j < 4; ++j) qp[h][v * 4 + j] = qw.p[j];
+      }
+  };
+  if constexpr (!MF) load_qp();  // (MF: only the token's own key below needs q in this form)
   float acc[REP][8];
   float m_run[REP], l_run[REP];
 #pragma unroll
@@ -1831,6 +1863,90 @@ __device__ __forceinline__ void decode_attention_body(const int bx, const int by
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
   }
+  if constexpr (MF) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 mf_ab;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const int col = lane & 15;  // the head whose scores this lane ends up with
+    mf_ab qb[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      bf16x8 raw = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (col < REP) raw = *reinterpret_cast<const bf16x8*>(&xb_lds[col][qk_c * 32 + v * 8]);
+      qb[v] = __builtin_bit_cast(mf_ab, raw);
+    }
+    f32x2 a2[REP][4];
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a2[h][j] = (f32x2){0.f, 0.f};
+    float m_own = -1e30f;  // running maximum of this lane's own head (equals m_run[col])
+    // Three K/V stages in a ring of NAMED registers: a stage is refilled (with the block three rounds ahead) right
+    // after its contents were taken, and nothing is ever copied from stage to stage — a copy of registers that a
+    // load is still filling waits for that load, which leaves one block in flight per wave instead of three.
+    KVStage<KV8> st_third;
+    if (b0 + wave + 2 * NWAVE < n_blocks) st_third.load(k_cache, v_cache, ((long long)bt[b0 + wave + 2 * NWAVE] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
+    auto one_block = [&](KVStage<KV8>& st, const int b) __attribute__((always_inline)) {
+      bf16x8 kv[4], vv[4];
+      st.unpack(kv, vv, pv_dv);
+      if (b + 3 * NWAVE < n_blocks) st.load(k_cache, v_cache, ((long long)bt[b + 3 * NWAVE] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
+      f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_ab, kv[v]), qb[v], sc, 0, 0, 0);
+      // lane (head col, quarter qk_c): sc[e] = q_col . k of token 4 qk_c + e
+      float mx = -1e30f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = (col < REP && b * BS + 4 * qk_c + e < prev) ? sc[e] * scale_log2e : -1e30f;
+        mx = fmaxf(mx, sc[e]);
+      }
+      mx = quarters_max(mx);
+      const float m_own_new = fmaxf(m_own, mx);
+      f32x4 pe;
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pe[e] = __builtin_amdgcn_exp2f(sc[e] - m_own_new);
+        ps += pe[e];
+      }
+      m_own = m_own_new;
+      ps = quarters_sum(ps);
+      if (col < REP) *reinterpret_cast<f32x4*>(&p_lds[wave][col][4 * qk_c]) = pe;
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float m_new = fmaxf(m_run[h], lane_value(mx, h));
+        const float corr = __builtin_amdgcn_exp2f(m_run[h] - m_new);
+        l_run[h] = l_run[h] * corr + lane_value(ps, h);
+        m_run[h] = m_new;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a2[h][j] *= (f32x2){corr, corr};
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tok = pv_tg + 4 * i;
+        f32x2 vf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vf[j] = (f32x2){bf2f(vv[i][2 * j]), bf2f(vv[i][2 * j + 1])};
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+          const float pw = p_lds[wave][h][tok];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a2[h][j] += (f32x2){pw, pw} * vf[j];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    for (int b = b0 + wave; b < n_blocks; b += 3 * NWAVE) {
+      one_block(st_cur, b);
+      if (b + NWAVE < n_blocks) one_block(st_nxt, b + NWAVE);
+      if (b + 2 * NWAVE < n_blocks) one_block(st_third, b + 2 * NWAVE);
+    }
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[h][j] = a2[h][j >> 1][j & 1];
+  } else
   for (int b = b0 + wave; b < n_blocks; b += NWAVE) {
     // this block's K / V and the next one's are in registers or on their way (loaded before
     // phase A, or by earlier iterations); start the loads of the block after those
@@ -1891,10 +2007,11 @@ __device__ __forceinline__ void decode_attention_body(const int bx, const int by
   }
   // ---- the token's own key / value (wave 0 of split 0; one token group adds the value)
   if (!ATTN && wave == 0 && z == 0) {
+    if constexpr (MF) load_qp();
     bf16x2 kp2[16];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const bf16x2x4 kw = __builtin_bit_cast(bf16x2x4, *reinterpret_cast<const bf16x8*>(&xb_lds[REP][qk_c * 32 + v * 8]));
+      const bf16x2x4 kw = __builtin_bit_cast(bf16x2x4, *reinterpret_cast<const bf16x8*>(&xb_lds[REP][tail_c * 32 + v * 8]));
 #pragma unroll
       for (int j = 0; j < 4; ++j) kp2[v * 4 + j] = kw.p[j];
     }
@@ -2010,7 +2127,7 @@ __device__ __forceinline__ void decode_attention_body(const int bx, const int by
 // The kernel: one workgroup per (token, kv head[, split]) of the launch grid; grid rows past the kv
 // heads of an unsplit launch are weight-prefetch workgroups (see prefetch_role).  The same body runs
 // as the attention phase of the persistent decode kernel below, one (token, kv head) at a time.
-template <int REP, int NWAVE, bool KV8, bool SPLIT, bool ATTN = false>
+template <int REP, int NWAVE, bool KV8, bool SPLIT, bool ATTN = false, bool MF = false>
 __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                                      const int* __restrict__ positions, const float* __restrict__ cos_t,
                                                                      const float* __restrict__ sin_t, void* __restrict__ k_cache,
@@ -2033,7 +2150,7 @@ __global__ __launch_bounds__(64 * NWAVE) void decode_attention_fused_kernel(cons
       return;
     }
   }
-  decode_attention_body<REP, NWAVE, KV8, SPLIT, ATTN>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, slabs, n_slabs, slab_stride, positions, cos_t, sin_t,
+  decode_attention_body<REP, NWAVE, KV8, SPLIT, ATTN, MF>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, slabs, n_slabs, slab_stride, positions, cos_t, sin_t,
                                                       k_cache, v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, out, nh, nkv, row_ss,
                                                       ss_parts, inv_h, eps, scale_log2e, kv_scale, part_o, part_ml, counters, q_in, q_row_stride, row_list);
 }
@@ -2719,6 +2836,14 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
   return (int)hipGetLastError();
 }
 
+// Split-KV launches (long contexts) of head groups of 4 and 8 over an e4m3 cache take their scores from the matrix cores
+// when this is set (decode_attention_body, MF); the dot-product form stays as the A/B, for the other group sizes and
+// for the bf16 cache (bound by the KV stream already; measured slower in the matrix form: 8.0 against 6.5 ms per step
+// at 128k tokens, the three bf16 stages of the ring cost too many registers).
+static int g_attention_mfma = 1;
+void kv_set_attention_mfma(int on) { g_attention_mfma = on ? 1 : 0; }
+int kv_get_attention_mfma() { return g_attention_mfma; }
+
 // slabs: fp32 [n_slabs][T][(nh + 2 nkv) * 128] split-K partial sums of the fused QKV projection.
 // Valid only when every token of the step is the sole new token of its sequence.
 int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_stride, const int* positions, const float* cos_t, const float* sin_t, void* k_cache,
@@ -2745,11 +2870,33 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
   hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8, SP>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t, k_cache, \
                      v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, row_ss, ss_parts,        \
                      inv_h, eps, sl, kv_scale, part_o, part_ml, counters, plan)
+#define KV_LAUNCH_MF(R, W, K8)                                                                                                                            \
+  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8, true, false, true>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t, \
+                     k_cache, v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, row_ss, ss_parts,      \
+                     inv_h, eps, sl, kv_scale, part_o, part_ml, counters, plan)
 #define KV_LAUNCH_K(R, W, K8)       \
   if (n_split > 1) {                \
     KV_LAUNCH_S(R, W, K8, true);    \
   } else {                          \
     KV_LAUNCH_S(R, W, K8, false);   \
+  }
+#define KV_LAUNCH_KM(R, W, K8)                        \
+  if (n_split > 1 && g_attention_mfma) {              \
+    KV_LAUNCH_MF(R, W, K8);                           \
+  } else {                                            \
+    KV_LAUNCH_K(R, W, K8);                            \
+  }
+#define KV_LAUNCH_WM(R, W)      \
+  if (kv_scale) {               \
+    KV_LAUNCH_KM(R, W, true);   \
+  } else {                      \
+    KV_LAUNCH_K(R, W, false);   \
+  }
+#define KV_LAUNCHM(R)     \
+  if (waves == 8) {       \
+    KV_LAUNCH_WM(R, ((R) <= 4 ? 8 : 4)); \
+  } else {                \
+    KV_LAUNCH_WM(R, 4);   \
   }
 #define KV_LAUNCH_W(R, W)       \
   if (kv_scale) {               \
@@ -2767,15 +2914,19 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
     case 1: KV_LAUNCH(1); break;
     case 2: KV_LAUNCH(2); break;
     case 3: KV_LAUNCH(3); break;
-    case 4: KV_LAUNCH(4); break;
+    case 4: KV_LAUNCHM(4); break;
     case 6: KV_LAUNCH(6); break;
     case 7: KV_LAUNCH(7); break;
-    case 8: KV_LAUNCH(8); break;
+    case 8: KV_LAUNCHM(8); break;
     default: return -1;
   }
 #undef KV_LAUNCH
 #undef KV_LAUNCH_W
 #undef KV_LAUNCH_K
+#undef KV_LAUNCH_MF
+#undef KV_LAUNCH_KM
+#undef KV_LAUNCH_WM
+#undef KV_LAUNCHM
 #undef KV_LAUNCH_S
   return (int)hipGetLastError();
 }
@@ -2799,11 +2950,31 @@ int kv_split_decode_attention(const void* q, long long q_row_stride, const void*
                      (const float*)nullptr, (const float*)nullptr, const_cast<void*>(k_cache), const_cast<void*>(v_cache), (const int*)nullptr, block_tables, \
                      max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, (const float*)nullptr, 0, 0.f, 0.f, sl, kv_scale, part_o, part_ml,   \
                      counters, plan, (const unsigned short*)q, q_row_stride, row_list)
+#define KV_LAUNCH_MF(R, W, K8)                                                                                                                                 \
+  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8, true, true, true>), grid, block, 0, stream, (const float*)nullptr, 0, 0LL, (const int*)nullptr,  \
+                     (const float*)nullptr, (const float*)nullptr, const_cast<void*>(k_cache), const_cast<void*>(v_cache), (const int*)nullptr, block_tables, \
+                     max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, (const float*)nullptr, 0, 0.f, 0.f, sl, kv_scale, part_o, part_ml,   \
+                     counters, plan, (const unsigned short*)q, q_row_stride, row_list)
+#define KV_LAUNCH_X(R, W, K8)                             \
+  if (g_attention_mfma) { KV_LAUNCH_MF(R, W, K8); }       \
+  else { KV_LAUNCH_S(R, W, K8); }
 #define KV_LAUNCH_W(R, W)     \
   if (kv_scale) {             \
     KV_LAUNCH_S(R, W, true);  \
   } else {                    \
     KV_LAUNCH_S(R, W, false); \
+  }
+#define KV_LAUNCH_WM(R, W)    \
+  if (kv_scale) {             \
+    KV_LAUNCH_X(R, W, true);  \
+  } else {                    \
+    KV_LAUNCH_S(R, W, false); \
+  }
+#define KV_LAUNCHM(R)                       \
+  if (waves == 8) {                         \
+    KV_LAUNCH_WM(R, ((R) <= 4 ? 8 : 4));    \
+  } else {                                  \
+    KV_LAUNCH_WM(R, 4);                     \
   }
 #define KV_LAUNCH(R)                        \
   if (waves == 8) {                         \
@@ -2815,14 +2986,18 @@ int kv_split_decode_attention(const void* q, long long q_row_stride, const void*
     case 1: KV_LAUNCH(1); break;
     case 2: KV_LAUNCH(2); break;
     case 3: KV_LAUNCH(3); break;
-    case 4: KV_LAUNCH(4); break;
+    case 4: KV_LAUNCHM(4); break;
     case 6: KV_LAUNCH(6); break;
     case 7: KV_LAUNCH(7); break;
-    case 8: KV_LAUNCH(8); break;
+    case 8: KV_LAUNCHM(8); break;
     default: return -1;
   }
 #undef KV_LAUNCH
 #undef KV_LAUNCH_W
+#undef KV_LAUNCH_WM
+#undef KV_LAUNCHM
+#undef KV_LAUNCH_X
+#undef KV_LAUNCH_MF
 #undef KV_LAUNCH_S
   return (int)hipGetLastError();
 }

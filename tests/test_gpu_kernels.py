@@ -1531,7 +1531,7 @@ def test_engine_fp8_kv_cache_tracks_the_bf16_engine(graphs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rep,kv8", [(4, False), (8, False), (1, False), (4, True)])
+@pytest.mark.parametrize("rep,kv8", [(4, False), (8, False), (1, False), (4, True), (8, True)])
 def test_split_kv_decode_attention_matches_the_unsplit_kernel(rep, kv8):
     """Several workgroups per (token, kv head), merged by the last to arrive, against one workgroup
     per pair: contexts from one token (one split does everything) to 3000 tokens (12 splits of 16
@@ -1573,7 +1573,7 @@ def test_split_kv_decode_attention_matches_the_unsplit_kernel(rep, kv8):
             assert out[5].abs().max().item() == 0
     torch.cuda.synchronize()
     assert int(hip_ops._split_ws[_dev()][:4096].view(torch.int32).abs().sum()) == 0  # every arrival counter is back at zero
-    assert hip_ops.decode_attention_splits(1, 8) == 32 and hip_ops.decode_attention_splits(16, 8) == 16 and hip_ops.decode_attention_splits(32, 8) == 1
+    assert hip_ops.decode_attention_splits(1, 8) == 32 and hip_ops.decode_attention_splits(16, 8) == 32 and hip_ops.decode_attention_splits(32, 8) == 1
 
 
 @pytest.mark.gpu
