@@ -1126,8 +1126,23 @@ def test_tiled_gemm_through_the_op_layer_matches_fp32(M):
     from kvmini.models.llama import quantize_fp8_rows
 
     q, scale = quantize_fp8_rows(W)
-    ref8 = x.float() @ (q.float() * scale[:, None]).T
-    y8 = ops.linear(x, ops.PackedLinear(W, fp8=True))
+    wq = q.float() * scale[:, None]
+    ref8 = x.float() @ wq.T
+    pw8 = ops.PackedLinear(W, fp8=True)
+    # wide steps quantise the activations per token as well (FP8 x FP8 on the scaled MFMA): exact against the
+    # product of the quantised operands, within the e4m3 rounding noise of the unquantised activations
+    y8 = ops.linear(x, pw8)
+    _x8, a_sc = ops.native().quantize_rows_fp8(x)
+    xq = (x.float() / a_sc[:, None]).to(torch.float8_e4m3fn).float() * a_sc[:, None]
+    ref88 = xq @ wq.T
+    assert (y8.float() - ref88).abs().max().item() <= 1e-2 * ref88.abs().max().item()
+    assert ((y8.float() - ref8).norm() / ref8.norm()).item() < 0.05
+    # KVMINI_FP8_ACT=0: bf16 activations, the weight bytes widened in registers
+    prev, ops.FP8_ACTIVATIONS = ops.FP8_ACTIVATIONS, False
+    try:
+        y8 = ops.linear(x, pw8)
+    finally:
+        ops.FP8_ACTIVATIONS = prev
     assert (y8.float() - ref8).abs().max().item() <= 1e-2 * ref8.abs().max().item()
 
 
@@ -1732,6 +1747,14 @@ def test_short_chunks_deep_in_a_context_are_served_as_listed_rows(monkeypatch):
 
 
 # ---------------------------------------------------------------- MXFP4 (4-bit) weights
+def _fp8_rows(x):
+    """x as wide steps of quantised models see it: per-token dynamic e4m3 (scale = absmax / 448), dequantised."""
+    from kvmini.ops import hip_ops
+
+    _x8, sc = hip_ops.native().quantize_rows_fp8(x, False)
+    return (x.float() / sc[:, None]).to(torch.float8_e4m3fn).float() * sc[:, None]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [16, 32, 64, 20, 100, 128, 300])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (4096, 14336), (256, 256), (1000, 512)])
@@ -1750,7 +1773,9 @@ def test_stream_gemm_mxfp4_weights(M, N, K):
     x = torch.randn(M, K, device=_dev()).bfloat16()
     codes, scales = quantize_mxfp4(W)
     Wdq = dequantize_mxfp4(codes, scales, torch.float32)
-    ref = x.float() @ Wdq.T
+    # (more than 128 rows with a width the tiled kernel takes: MXFP4 x FP8 on the scaled MFMA — the activations are e4m3 there)
+    wide = M > 128 and K % 128 == 0 and ((N + 63) // 64 * 64) % 128 == 0
+    ref = (_fp8_rows(x) if wide else x.float()) @ Wdq.T
     tol = 1e-2 * ref.abs().max().item() + 1e-2
     pw = hip_ops.PackedLinear(W, mxfp4=True)
     assert pw.bits == 4 and pw.wp.dtype == torch.uint8 and pw.wp.numel() * 2 == pw.n_pad * K and pw.wscale.numel() * 128 == pw.n_pad * K
@@ -1763,6 +1788,14 @@ def test_stream_gemm_mxfp4_weights(M, N, K):
     # the quantisation error itself: e2m1 has one mantissa bit (relative step up to 1/3 inside a block)
     full = x.float() @ W.float().T
     assert ((ref - full).norm() / full.norm()).item() < 0.2
+    if wide:  # KVMINI_FP8_ACT=0: bf16 activations on the exact bf16 expansion of the matrix
+        prev, hip_ops.FP8_ACTIVATIONS = hip_ops.FP8_ACTIVATIONS, False
+        try:
+            y = hip_ops.linear(x, pw)
+        finally:
+            hip_ops.FP8_ACTIVATIONS = prev
+        ref16 = x.float() @ Wdq.T
+        assert (y.float() - ref16).abs().max().item() <= 1e-2 * ref16.abs().max().item() + 1e-2
 
 
 @pytest.mark.gpu
@@ -1839,8 +1872,15 @@ def test_mxfp4_expansion_is_the_packed_bf16_weight_bit_for_bit(C):
     for M in (254, 2048):
         x = torch.randn(M, K, device=_dev()).bfloat16()
         ref = x.float() @ Wf.T
-        y = hip_ops.linear(x, pw)
+        prev, hip_ops.FP8_ACTIVATIONS = hip_ops.FP8_ACTIVATIONS, False  # the expansion path (bf16 activations)
+        try:
+            y = hip_ops.linear(x, pw)
+        finally:
+            hip_ops.FP8_ACTIVATIONS = prev
         assert y.shape == (M, N) and (y.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-2
+        ref8 = _fp8_rows(x) @ Wf.T  # the default: the tiled kernel reads the MXFP4 weights themselves
+        y = hip_ops.linear(x, pw)
+        assert y.shape == (M, N) and (y.float() - ref8).abs().max().item() <= 1e-2 * ref8.abs().max().item() + 1e-2
 
 
 @pytest.mark.gpu
@@ -1855,14 +1895,15 @@ def test_stream_gemm_mxfp4_swiglu_and_folded_norm(M):
     x = torch.randn(M, K, device=_dev()).bfloat16()
     Wdq = dequantize_mxfp4(*quantize_mxfp4(W), torch.float32)
     pw = hip_ops.PackedLinear(W, mxfp4=True)
-    ref = torch_ops.swiglu_interleaved((x.float() @ Wdq.T))
+    xr = _fp8_rows(x) if M > 128 else x.float()  # wide steps: e4m3 activations on the scaled MFMA
+    ref = torch_ops.swiglu_interleaved((xr @ Wdq.T))
     y = hip_ops.linear_swiglu(x, pw)
     assert y.shape == (M, I)
     assert (y.float() - ref.float()).abs().max().item() <= 2e-2 * ref.abs().max().item() + 2e-2
     # a Normed input: the row scale 1/rms is applied by the epilogue
     ss = (x.float() ** 2).view(M, -1, 512).sum(-1)
     yn = hip_ops.linear(hip_ops.Normed(x, ss.contiguous(), 1e-5), pw)
-    refn = (x.float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)) @ Wdq.T
+    refn = (xr * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)) @ Wdq.T
     assert (yn.float() - refn).abs().max().item() <= 2e-2 * refn.abs().max().item() + 2e-2
     assert GU_GROUP > 0
 
