@@ -660,9 +660,12 @@ class ModelRunner:
                 sb.bt_np[seq.slot, nb_have : len(blocks)] = blocks[nb_have:]
             sb.bt_owner[seq.slot] = (key, len(blocks))
             p0 = ch.start
-            if n == 1 and not seq.draft_ids:
+            # (a draft runner launching proposal j + 1 on top of proposal j: the chunk's one token is the
+            # previous proposal, still a placeholder in draft_ids and fed on the device like any other)
+            drafting = bool(seq.draft_ids) and seq.draft_feed and p0 >= seq.num_tokens
+            if n == 1 and (not seq.draft_ids or drafting):
                 npmt = len(seq.prompt_ids)
-                tok = seq.prompt_ids[p0] if p0 < npmt else seq.output_ids[p0 - npmt]
+                tok = seq.draft_ids[p0 - seq.num_tokens] if drafting else (seq.prompt_ids[p0] if p0 < npmt else seq.output_ids[p0 - npmt])
                 if tok == PLACEHOLDER:
                     st[o_tok + i] = 0
                     st[o_fd + i] = seq.pending_row + 1

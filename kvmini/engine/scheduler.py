@@ -71,6 +71,7 @@ class Sequence:
     user: Any = None  # opaque handle for the front-end (stream queue, ...)
     # speculative decoding state: draft tokens proposed for the next verify step
     draft_ids: List[int] = field(default_factory=list)
+    draft_feed: bool = False  # a draft runner is proposing launch-ahead: the last draft id may be a placeholder (fed on the device)
     preemptions: int = 0
     # pipelined stepping: row of this sequence's sample in the step in flight; set when the
     # in-flight sample is known (by length) to be the sequence's last

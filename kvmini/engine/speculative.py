@@ -69,6 +69,11 @@ class SpeculativeDecoder:
     def __init__(self, engine: "LLMEngine", draft_model: str, k: int):
         self.engine = engine
         self.k = int(k)
+        # greedy proposals are enqueued back to back, each fed by its predecessor on the device
+        # (KVMINI_SPEC_LAUNCH_AHEAD=0: one read-back per proposal, the A/B)
+        import os
+
+        self.launch_ahead = os.environ.get("KVMINI_SPEC_LAUNCH_AHEAD", "1") == "1"
         tgt = engine.runner
         ecfg = engine.ecfg
         if ecfg.tp_size > 1:
@@ -151,6 +156,8 @@ class SpeculativeDecoder:
         for s in seqs:
             s.draft_ids = []
         sampled = [i for i, s in enumerate(seqs) if s.params.temperature > 0]
+        if not sampled and self.launch_ahead:
+            return self._propose_launch_ahead(seqs)
         qs: List[torch.Tensor] = []
         for _ in range(self.k):
             chunks = []
@@ -178,6 +185,42 @@ class SpeculativeDecoder:
             stack = torch.stack(qs, 1)  # [sampled, k, V]
             for j, i in enumerate(sampled):
                 self.draft_q[seqs[i].req_id] = stack[j]
+
+    def _propose_launch_ahead(self, seqs: List[Sequence]) -> None:
+        """The k greedy draft steps enqueued back to back: proposal j + 1 is launched on top of
+        proposal j, whose token it takes on the device (a placeholder in ``draft_ids`` until the
+        host reads it back one launch later), so the device never waits for the host between
+        proposals — one exposed read-back per propose phase (the last one) instead of k."""
+        from .scheduler import PLACEHOLDER
+
+        prev = None
+        try:
+            for j in range(self.k):
+                chunks = []
+                total = 0
+                for s in seqs:
+                    s.draft_feed = j > 0
+                    start = self.draft_computed[s.req_id]
+                    n = s.num_tokens + len(s.draft_ids) - start
+                    chunks.append(ScheduledChunk(s, start, n, True, 1))
+                    total += n
+                handle = self.draft.launch(Batch(chunks, total))
+                for row, s in enumerate(seqs):
+                    self.draft_computed[s.req_id] = s.num_tokens + len(s.draft_ids)
+                    s.pending_row = row
+                    s.draft_ids.append(PLACEHOLDER)
+                if prev is not None:
+                    ids, _ = self.draft.collect(prev)
+                    for s, tok in zip(seqs, ids):
+                        s.draft_ids[j - 1] = int(tok)
+                prev = handle
+            ids, _ = self.draft.collect(prev)
+            for s, tok in zip(seqs, ids):
+                s.draft_ids[self.k - 1] = int(tok)
+        finally:
+            for s in seqs:
+                s.draft_feed = False
+                s.pending_row = -1
 
     # ------------------------------------------------------------------
     def step(self) -> "List[TokenEvent]":

@@ -290,6 +290,13 @@ def test_self_speculation_early_exit_draft_is_exact_and_accepts_with_damped_tail
     assert st.spec_proposed > 0 and st.spec_accepted / st.spec_proposed > 0.5, (st.spec_proposed, st.spec_accepted)
     # fewer target passes than tokens generated
     assert st.steps < sum(len(o) for o in got)
+    # the proposals were enqueued back to back (each fed by its predecessor on the device); one read-back
+    # per proposal gives the same drafts, hence the same acceptance
+    slow = LLMEngine(EngineConfig(**common, draft_model="self:2", num_speculative_tokens=3), weights=weights())
+    assert spec.spec.launch_ahead
+    slow.spec.launch_ahead = False
+    assert slow.generate(prompts, params) == want
+    assert (slow.stats.spec_proposed, slow.stats.spec_accepted) == (st.spec_proposed, st.spec_accepted)
 
 
 def test_batched_sampling_matches_greedy_under_top_k_1_and_respects_top_p():
