@@ -643,6 +643,19 @@ def prefetch_plan(w: Weight, rows: int, site: str) -> Optional[Tuple[torch.Tenso
     return w.wp, [w.n_pad // (16 * nw), gy, nw, min(kib, split_bytes // 1024), tile_bytes, split_bytes, wgs], sink
 
 
+def prefetch_weight(w: Weight, workgroups: int) -> None:
+    """Reads the packed weights of ``w`` once on the current stream without using them (a kernel of
+    its own, for a side stream that runs beside a latency-bound kernel): the bytes stay in the
+    memory-side cache for the GEMM that streams them next."""
+    dev = w.wp.device
+    sink = _prefetch_sinks.get(dev)
+    if sink is None:
+        if torch.cuda.is_current_stream_capturing():
+            return
+        sink = _prefetch_sinks[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+    native().prefetch(w.wp, int(workgroups), sink)
+
+
 _resid_counters: Dict[Any, torch.Tensor] = {}
 FUSE_RESIDUAL = os.environ.get("KVMINI_FUSE_RESIDUAL", "0") == "1"  # measured slower than the two-kernel path (see linear_residual): off unless asked for
 
