@@ -30,6 +30,9 @@ int kv_paged_attention(const void* q, long long q_row_stride, const void* k_cach
 int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                          const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
                          int block_size, float scale, const float* kv_scale, int quads, hipStream_t stream);
+int kv_prefill_attention_split(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                               const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
+                               int block_size, float scale, const float* kv_scale, int n_split, float* part_o, float* part_ml, hipStream_t stream);
 int kv_split_decode_attention(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
                               const int* tok_seq, const int* ctx_lens, const int* row_list, int n_rows, void* out, int nh, int nkv, int hd, int block_size, float scale,
                               int waves, const float* kv_scale, int n_split, float* part_o, float* part_ml, int* counters, hipStream_t stream);
@@ -313,6 +316,31 @@ void prefill_attention(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at:
                              tp + n_tiles, tp + 2 * n_tiles, tp + 3 * n_tiles, out.data_ptr(), (int)n_tiles, (int)nh, (int)k_cache.size(1), (int)hd,
                              (int)k_cache.size(2), (float)scale, ksc, quads ? 1 : 0, cur_stream()),
         "kv_prefill_attention");
+}
+
+// The first `n_tiles` tiles of `tiles` ([4, max_tiles]) with every tile's key range in `n_split` shares; part_o / part_ml: fp32 workspaces
+// of at least n_split * 16 * n_tiles * nh * 128 and ... * 2 elements.
+void prefill_attention_split(at::Tensor q, at::Tensor k_cache, at::Tensor v_cache, at::Tensor block_tables, at::Tensor tiles, int64_t n_tiles, at::Tensor out, double scale,
+                             c10::optional<at::Tensor> kv_scale, int64_t n_split, at::Tensor part_o, at::Tensor part_ml) {
+  CHECK_DEV(q); CHECK_BF16(q); CHECK_BF16(out); CHECK_I32(block_tables); CHECK_I32(tiles); CHECK_DEV(part_o); CHECK_DEV(part_ml);
+  const float* ksc = check_cache(k_cache, v_cache, kv_scale);
+  CHECK_CONTIG(block_tables); CHECK_CONTIG(out); CHECK_CONTIG(tiles); CHECK_CONTIG(part_o); CHECK_CONTIG(part_ml);
+  TORCH_CHECK(q.dim() == 3 && q.stride(2) == 1 && q.stride(1) == q.size(2) && q.stride(0) % 8 == 0, "q must be [T, nh, hd] with contiguous heads and 16-byte aligned rows");
+  const int64_t T = q.size(0), nh = q.size(1), hd = q.size(2);
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(3) == hd && v_cache.sizes() == k_cache.sizes(), "cache must be [blocks, nkv, block_size, hd]");
+  TORCH_CHECK(tiles.dim() == 2 && tiles.size(0) == 4 && n_tiles >= 0 && n_tiles <= tiles.size(1), "tiles must be int32 [4, max_tiles] with n_tiles <= max_tiles");
+  TORCH_CHECK(block_tables.dim() == 2 && out.dim() == 2 && out.size(0) == T && out.size(1) == nh * hd, "bad block_tables/out shape");
+  TORCH_CHECK(n_split >= 1 && n_split <= 64, "n_split must be 1..64");
+  TORCH_CHECK(part_o.scalar_type() == at::kFloat && part_ml.scalar_type() == at::kFloat, "workspaces must be fp32");
+  const int64_t rows = n_split * 16 * n_tiles;
+  TORCH_CHECK(part_o.numel() >= rows * nh * hd && part_ml.numel() >= rows * nh * 2, "workspace too small for n_split x tiles");
+  TORCH_CHECK(((uintptr_t)part_o.data_ptr() & 15) == 0 && ((uintptr_t)part_ml.data_ptr() & 7) == 0, "workspaces must be 16-byte aligned");
+  const int* tp = (const int*)tiles.data_ptr();
+  const int64_t mt = tiles.size(1);
+  check(kv_prefill_attention_split(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), (const int*)block_tables.data_ptr(), (int)block_tables.size(1), tp,
+                                   tp + mt, tp + 2 * mt, tp + 3 * mt, out.data_ptr(), (int)n_tiles, (int)nh, (int)k_cache.size(1), (int)hd, (int)k_cache.size(2),
+                                   (float)scale, ksc, (int)n_split, (float*)part_o.data_ptr(), (float*)part_ml.data_ptr(), cur_stream()),
+        "kv_prefill_attention_split");
 }
 
 const float* ss_ptr(const c10::optional<at::Tensor>& row_ss, int64_t rows, int* parts);
@@ -1019,6 +1047,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("out"), py::arg("scale"), py::arg("kv_scale") = py::none());
   m.def("prefill_attention", &prefill_attention, py::arg("q"), py::arg("k_cache"), py::arg("v_cache"), py::arg("block_tables"), py::arg("tiles"), py::arg("out"),
         py::arg("scale"), py::arg("kv_scale") = py::none(), py::arg("quads") = false);
+  m.def("prefill_attention_split", &prefill_attention_split);
   m.def("split_decode_attention", &split_decode_attention);
   m.def("decode_attention_fused", &decode_attention_fused, py::arg("slabs"), py::arg("positions"), py::arg("cos_t"), py::arg("sin_t"), py::arg("k_cache"),
         py::arg("v_cache"), py::arg("slot_mapping"), py::arg("block_tables"), py::arg("tok_seq"), py::arg("ctx_lens"), py::arg("out"), py::arg("nh"),

@@ -1037,11 +1037,16 @@ __device__ inline float half_rows_sum(float x) {
   return __uint_as_float(a[0]) + __uint_as_float(a[1]);
 }
 
-template <int REP, int HPW, bool KV8>
+// PART (a chunk deep inside a long context, its key range split over several workgroups): the pass covers the keys
+// [key_lo, key_hi) only (key_lo a multiple of 32; the causal bound still applies) and leaves, per query and head, its
+// output normalised by ITS OWN sum as fp32 in `part_o` ([query][nh][128], query 0 = the tile's first) and
+// (reference, sum) in `part_ml` ([query][nh][2], reference in units of log2) for prefill_split_combine_kernel.
+template <int REP, int HPW, bool KV8, bool PART = false>
 __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
                                                           const void* __restrict__ v_cache, const int* __restrict__ bt, int row0, int pos0, int n_q,
                                                           unsigned short* __restrict__ out, int nh, int nkv, float scale_log2e, float v_scale, unsigned short* v_lds,
-                                                          unsigned short* k_lds) {
+                                                          unsigned short* k_lds, int key_lo = 0, int key_hi = 0x7fffffff, float* __restrict__ part_o = nullptr,
+                                                          float* __restrict__ part_ml = nullptr) {
   static_assert((HPW == 1 || HPW == 2) && REP <= 4 * HPW && REP > 4 * (HPW - 1), "32 columns = HPW heads x 32 / HPW queries");
   constexpr int HD = 128, BS = 16, KSTEP = 32;
   constexpr int K_RS = PA32_K_RS, V_RS = PA32_V_RS;         // row strides (elements) of the padded images
@@ -1053,6 +1058,8 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
   const int qi = HPW == 2 ? (lr & 15) : lr, hh = HPW == 2 ? (lr >> 4) : 0;
   const int h = wave + 4 * hh;
   const int last_key = pos0 + n_q - 1;                // highest key index any query of the tiles may see
+  const int kb0 = PART ? key_lo : 0;                  // first key of the pass
+  const int lim_key = PART ? (last_key < key_hi - 1 ? last_key : key_hi - 1) : last_key;  // last key of the pass (cache reads run ahead up to last_key)
   const bool head_on = REP % 4 == 0 || wave < REP;   // wave-uniform: a wave without any head only stages
   const bool col_on = REP % 4 == 0 || h < REP;       // head groups of 5-7: some waves own one head, their other 16 columns idle
 
@@ -1137,15 +1144,15 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
     *reinterpret_cast<bf16x8*>(vd) = v0;
     *reinterpret_cast<bf16x8*>(vd + 16 * V_RS) = v1;
   }
-  BT_LOAD(0, blk0, blk1);
-  KV_LOAD_STEP(0, blk0, blk1);
-  BT_LOAD(KSTEP, blk0, blk1);
+  BT_LOAD(kb0, blk0, blk1);
+  KV_LOAD_STEP(kb0, blk0, blk1);
+  BT_LOAD(kb0 + KSTEP, blk0, blk1);
   STAGE_TILES(0, 0);
-  KV_LOAD_STEP(KSTEP, blk0, blk1);
-  BT_LOAD(2 * KSTEP, blk0, blk1);
+  KV_LOAD_STEP(kb0 + KSTEP, blk0, blk1);
+  BT_LOAD(kb0 + 2 * KSTEP, blk0, blk1);
   STAGE_TILES(1, 1);
-  KV_LOAD_STEP(2 * KSTEP, blk0, blk1);
-  BT_LOAD(3 * KSTEP, blk0, blk1);
+  KV_LOAD_STEP(kb0 + 2 * KSTEP, blk0, blk1);
+  BT_LOAD(kb0 + 3 * KSTEP, blk0, blk1);
   __syncthreads();
   if (head_on) S_MFMAS(0, st_cur);
 
@@ -1260,7 +1267,7 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
     __syncthreads();  // the tiles of step i+2 are staged, and every wave is done with K slot (i+1) % 3 and V slot (i-1) % 4
   };
 
-  int kb = 0, it = 0, s_i = 0, s_k = 1, s_w = 2;  // K slots: idle, read (step i+1), written (step i+2)
+  int kb = kb0, it = 0, s_i = 0, s_k = 1, s_w = 2;  // K slots: idle, read (step i+1), written (step i+2)
 #define ROTATE_SLOTS()       \
   do {                       \
     const int s_t = s_i;     \
@@ -1269,16 +1276,16 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
     s_w = s_t;               \
     ++it;                    \
   } while (0)
-  if (KSTEP - 1 <= pos0) {  // the first step sets the reference: exact (its mask hides nothing)
+  if (kb + KSTEP - 1 <= pos0 && kb <= lim_key) {  // the first step sets the reference: exact (its mask hides nothing)
     step(std::true_type{}, kb, it, s_k, s_w);
     ROTATE_SLOTS();
     kb += KSTEP;
   }
-  for (; kb + KSTEP - 1 <= pos0; kb += KSTEP) {
+  for (; kb + KSTEP - 1 <= pos0 && kb <= lim_key; kb += KSTEP) {
     step(std::false_type{}, kb, it, s_k, s_w);
     ROTATE_SLOTS();
   }
-  for (; kb <= last_key; kb += KSTEP) {
+  for (; kb <= lim_key; kb += KSTEP) {
     step(std::true_type{}, kb, it, s_k, s_w);
     ROTATE_SLOTS();
   }
@@ -1303,6 +1310,25 @@ __device__ __forceinline__ void prefill_attention_tiles32(const unsigned short* 
   const float l = half_rows_sum(l_run);  // before any lane leaves: the exchange wants both lanes of a query
   if (!head_on || !col_on || qi >= n_q) return;
   const float inv = l > 0.f ? v_scale / l : 0.f;
+  if constexpr (PART) {
+    const long long e = (long long)qi * nh + (g * REP + h);
+    float* po = part_o + e * HD + 4 * hi;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        typedef __attribute__((ext_vector_type(4))) float f4;
+        f4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = o[nt][4 * rq + r] * inv;
+        *reinterpret_cast<f4*>(po + 32 * nt + 8 * rq) = w;
+      }
+    if (hi == 0) {
+      typedef __attribute__((ext_vector_type(2))) float f2;
+      *reinterpret_cast<f2*>(part_ml + 2 * e) = (f2){m_run, l};
+    }
+    return;
+  }
   unsigned short* op = out + (long long)(row0 + qi) * nh * HD + (long long)(g * REP + h) * HD + 4 * hi;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -1628,6 +1654,111 @@ __global__ __launch_bounds__(256, 2) void prefill_attention_kernel(const unsigne
                                              n0, out, nh, nkv, scale_log2e, v_scale, v_lds, k_lds);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// The split form, for a few tiles deep inside a long context (a short new turn after a cached prefix of 100k tokens):
+// grid = (kv heads, tile groups, splits) — workgroup z of a group walks the z-th share of the keys its queries may see
+// (shares of whole 32-key steps, the same for every group of one chunk) on the 32-column pass and leaves partial
+// results (see PART above); prefill_split_combine_kernel folds them.  Head groups of at most 4: two tiles per group
+// when they are consecutive tiles of one chunk (else one pass each); head groups of 5-8: one tile per group.
+// Workspace rows go by tile slot: [split][16 * tile + query][nh][..].
+template <int REP, bool KV8>
+__global__ __launch_bounds__(256, 2) void prefill_attention_split_kernel(const unsigned short* __restrict__ q, long long q_row_stride, const void* __restrict__ k_cache,
+                                                                      const void* __restrict__ v_cache, const int* __restrict__ block_tables, int max_blocks_per_seq,
+                                                                      const int* __restrict__ tile_row0, const int* __restrict__ tile_n,
+                                                                      const int* __restrict__ tile_pos0, const int* __restrict__ tile_seq, int n_tiles, int nh, int nkv,
+                                                                      float scale_log2e, const float* __restrict__ kv_scale, float* __restrict__ part_o,
+                                                                      float* __restrict__ part_ml) {
+  float v_scale = 1.f;
+  if constexpr (KV8) {
+    scale_log2e *= kv_scale[blockIdx.x];
+    v_scale = kv_scale[nkv + blockIdx.x];
+  }
+  __shared__ __attribute__((aligned(256))) unsigned short v_lds[4 * 32 * PA32_V_RS];
+  __shared__ __attribute__((aligned(256))) unsigned short k_lds[3 * 32 * PA32_K_RS];
+  constexpr int QT = REP <= 4 ? 2 : 1, HPW = REP <= 4 ? 1 : 2;
+  const int z = blockIdx.z, ns = gridDim.z;
+  const long long split_rows = (long long)z * n_tiles * 16;
+  auto pass = [&](int t, int nq) __attribute__((always_inline)) {
+    const int pos0 = tile_pos0[t];
+    const int steps = (pos0 + nq + 31) >> 5;           // 32-key steps up to the last visible key
+    const int per = ((steps + ns - 1) / ns) << 5;      // keys per split
+    float* po = part_o + (split_rows + 16 * t) * nh * 128;
+    float* pml = part_ml + (split_rows + 16 * t) * nh * 2;
+    if (z * per >= pos0 + nq) {  // nothing left for this split: an empty partial (sum 0), the outputs are not read
+      const int e = threadIdx.x;
+      if (e < nq * REP) {
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        *reinterpret_cast<f2*>(pml + 2 * ((long long)(e / REP) * nh + blockIdx.x * REP + e % REP)) = (f2){-1e30f, 0.f};
+      }
+      return;
+    }
+    prefill_attention_tiles32<REP, HPW, KV8, true>(q, q_row_stride, k_cache, v_cache, block_tables + (long long)tile_seq[t] * max_blocks_per_seq, tile_row0[t], pos0, nq,
+                                                   nullptr, nh, nkv, scale_log2e, v_scale, v_lds, k_lds, z * per, (z + 1) * per, po, pml);
+  };
+  const int t0 = blockIdx.y * QT;
+  const int n0 = tile_n[t0];
+  if constexpr (QT == 2) {
+    const int t1 = t0 + 1;
+    const int n1 = t1 < n_tiles ? tile_n[t1] : 0;
+    if (n0 == 16 && n1 > 0 && tile_seq[t1] == tile_seq[t0] && tile_pos0[t1] == tile_pos0[t0] + 16 && tile_row0[t1] == tile_row0[t0] + 16) {
+      pass(t0, 16 + n1);
+      return;
+    }
+    if (n0 > 0) pass(t0, n0);
+    if (n1 > 0) {
+      __syncthreads();  // the first pass is done with the LDS tiles
+      pass(t1, n1);
+    }
+  } else {
+    if (n0 > 0) pass(t0, n0);
+  }
+}
+
+// out[tile_row0[t] + r] = sum over splits of w_s * o_s / sum of w_s,  w_s = l_s * 2^(m_s - max m): grid (tile, query row,
+// 8 heads), a thread per 4 dims of a head.
+__global__ __launch_bounds__(256) void prefill_split_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int n_split, int n_tiles,
+                                                                    const int* __restrict__ tile_row0, const int* __restrict__ tile_n, unsigned short* __restrict__ out,
+                                                                    int nh) {
+  const int t = blockIdx.x, r = blockIdx.y;
+  if (r >= tile_n[t]) return;
+  const long long ws_row = 16 * t + r, split_rows = (long long)n_tiles * 16;
+  unsigned short* orow = out + (long long)(tile_row0[t] + r) * nh * 128;
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+  const int c = blockIdx.z * 256 + threadIdx.x;  // 4 dims of one head
+  if (c >= nh * 32) return;
+  const int head = c >> 5, d = (c & 31) << 2;
+  const f2* ml = reinterpret_cast<const f2*>(part_ml) + ws_row * nh + head;
+  const float* po = part_o + (ws_row * nh + head) * 128 + d;
+  const long long ml_stride = split_rows * nh, o_stride = split_rows * nh * 128;
+  // every load of a loop is independent of the others (an empty share's outputs were never written: they are
+  // read all the same and dropped, so that no load waits for a comparison)
+  float mx = -1e30f;
+#pragma unroll 8
+  for (int s = 0; s < n_split; ++s) {
+    const f2 v = ml[s * ml_stride];
+    mx = v[1] > 0.f ? fmaxf(mx, v[0]) : mx;
+  }
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  float wsum = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < n_split; ++s) {
+    const f2 v = ml[s * ml_stride];
+    const f4 o = *reinterpret_cast<const f4*>(po + s * o_stride);
+    const bool on = v[1] > 0.f;
+    const float w = on ? v[1] * __builtin_amdgcn_exp2f(v[0] - mx) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += on ? o[j] * w : 0.f;
+    wsum += w;
+  }
+  const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+  us4 w4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w4[j] = f2bf(acc[j] * inv);
+  *reinterpret_cast<us4*>(orow + head * 128 + d) = w4;
 }
 
 // ---------------------------------------------------------------------------------
@@ -2833,6 +2964,41 @@ int kv_prefill_attention(const void* q, long long q_row_stride, const void* k_ca
 #undef KV_LAUNCH
 #undef KV_LAUNCH_Q
 #undef KV_LAUNCH_K
+  return (int)hipGetLastError();
+}
+
+// The split form of the tiled prompt attention (prefill_attention_split_kernel + combine): the first n_tiles entries of
+// the tile arrays, every tile's key range in n_split shares.  part_o: fp32 [n_split][16 * n_tiles][nh][128], part_ml:
+// fp32 [n_split][16 * n_tiles][nh][2] (the caller's workspace).
+int kv_prefill_attention_split(const void* q, long long q_row_stride, const void* k_cache, const void* v_cache, const int* block_tables, int max_blocks_per_seq,
+                               const int* tile_row0, const int* tile_n, const int* tile_pos0, const int* tile_seq, void* out, int n_tiles, int nh, int nkv, int hd,
+                               int block_size, float scale, const float* kv_scale, int n_split, float* part_o, float* part_ml, hipStream_t stream) {
+  if (n_tiles <= 0) return 0;
+  if (hd != 128 || block_size != 16 || nh % nkv || n_split < 1 || n_split > 64 || !part_o || !part_ml) return -1;
+  const int rep = nh / nkv;
+  const float sl = scale * 1.4426950408889634f;
+  const int qt = rep <= 4 ? 2 : 1;
+  dim3 grid(nkv, (n_tiles + qt - 1) / qt, n_split), block(256);
+#define KV_LAUNCH_S(R)                                                                                                                              \
+  if (kv_scale)                                                                                                                                     \
+    hipLaunchKernelGGL((prefill_attention_split_kernel<R, true>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, k_cache, v_cache,  \
+                       block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, n_tiles, nh, nkv, sl, kv_scale, part_o, part_ml);   \
+  else                                                                                                                                              \
+    hipLaunchKernelGGL((prefill_attention_split_kernel<R, false>), grid, block, 0, stream, (const unsigned short*)q, q_row_stride, k_cache, v_cache, \
+                       block_tables, max_blocks_per_seq, tile_row0, tile_n, tile_pos0, tile_seq, n_tiles, nh, nkv, sl, kv_scale, part_o, part_ml)
+  switch (rep) {
+    case 1: KV_LAUNCH_S(1); break;
+    case 2: KV_LAUNCH_S(2); break;
+    case 3: KV_LAUNCH_S(3); break;
+    case 4: KV_LAUNCH_S(4); break;
+    case 6: KV_LAUNCH_S(6); break;
+    case 7: KV_LAUNCH_S(7); break;
+    case 8: KV_LAUNCH_S(8); break;
+    default: return -1;
+  }
+#undef KV_LAUNCH_S
+  hipLaunchKernelGGL(prefill_split_combine_kernel, dim3(n_tiles, 16, (nh * 32 + 255) / 256), dim3(256), 0, stream, (const float*)part_o, (const float*)part_ml, n_split, n_tiles, tile_row0,
+                     tile_n, (unsigned short*)out, nh);
   return (int)hipGetLastError();
 }
 

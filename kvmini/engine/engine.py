@@ -799,7 +799,9 @@ class LLMEngine:
             "preemptions": self.scheduler.num_preemptions,
             "spec_proposed": st.spec_proposed,
             "spec_accepted": st.spec_accepted,
-            "graphs": sorted({b for b, _ in self.runner.graphs}),
+            "graphs": sorted({k[0] for k in self.runner.graphs}),
+            "variant_graphs": sum(1 for k in self.runner.graphs if len(k) > 2),
+            "variant_graph_steps": getattr(self.runner, "variant_graph_steps", 0),
             "pipelined_steps": self.pipelined_steps,
             "engine_first_token_ms": st.first_token_s / st.first_token_n * 1e3 if st.first_token_n else None,
             "engine_first_token_steps": st.first_token_steps / st.first_token_n if st.first_token_n else None,

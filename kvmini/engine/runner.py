@@ -230,6 +230,13 @@ class ModelRunner:
         # attention kernel, which spreads each context over many workgroups — the per-token kernel
         # walks a context with one workgroup per kv head (a 128k-token context: 1.9 ms per layer)
         self.dec_split_ok = bool(hasattr(self.ops, "split_decode_attention") and self.device.type == "cuda" and self.hd == 128 and self.block_size == 16)
+        # a few prompt tiles deep inside a long context: every tile's key range is shared out over several workgroups
+        self.pf_split_ok = bool(hasattr(self.ops, "prefill_attention_split") and self.device.type == "cuda" and self.hd == 128 and self.block_size == 16
+                                and os.environ.get("KVMINI_PREFILL_SPLIT", "1") != "0")
+        # steps of the special attention forms get a graph of their own the second time their shape comes up
+        self.variant_graphs_max = int(os.environ.get("KVMINI_VARIANT_GRAPHS", "24"))
+        self._variant_seen: Dict[Tuple[int, ...], int] = {}
+        self.variant_graph_steps = 0
         self._off["dec_rows"] = (off, self.DEC_SPLIT_ROWS)
         off += self.DEC_SPLIT_ROWS
         # step header (tensor parallelism: rank 0 broadcasts the whole staging buffer, followers
@@ -253,7 +260,7 @@ class ModelRunner:
         self.set_spec_width(1)
         # (token bucket, step kind) -> (graph, logits); kind 0 = mixed step, 1 = decode-only (fused
         # RoPE + attention kernel), 2 = decode-only with the context split over several workgroups
-        self.graphs: Dict[Tuple[int, int], Any] = {}
+        self.graphs: Dict[Tuple[int, ...], Any] = {}
         self._graph_pool = None
         # Weight read-ahead on a second stream beside the decode attention kernel (a parallel branch of the
         # captured graph, joined at the end of the step): KVMINI_SIDE_PREFETCH = workgroups of the reading kernel.
@@ -328,6 +335,10 @@ class ModelRunner:
     # from DEC_SPLIT_MIN_CTX tokens on (such steps run without a graph)
     DEC_SPLIT_ROWS = 16  # from ~64 consecutive decode rows on the per-token kernel fills the chip as well (measured equal)
     DEC_SPLIT_MIN_CTX = int(os.environ.get("KVMINI_DEC_SPLIT_MIN_CTX", "4096"))
+    # Prompt chunks of 17 to ~512 tokens whose queries see at least this many keys go to the split form of the tile kernel
+    # (measured on MI355X behind a 128k-token prefix, per layer: 64 new tokens 2505 -> 257 us, 256: 2480 -> 632 us, 512: 2513 -> 1130 us).
+    PF_SPLIT_MAX_TILES = 32
+    PF_SPLIT_MIN_CTX = int(os.environ.get("KVMINI_PREFILL_SPLIT_MIN_CTX", "4096"))
 
     def step_kind(self, t_pad: int, decode_only: bool, max_ctx: int) -> int:
         if not decode_only:
@@ -335,12 +346,13 @@ class ModelRunner:
         splits = getattr(self.ops, "decode_attention_splits", None)
         return 2 if splits is not None and max_ctx >= self.SPLIT_KV_MIN_CTX and splits(t_pad, self.nkv) > 1 else 1
 
-    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: int = 0, quads: bool = False, dec_split: int = 0) -> torch.Tensor:
+    def forward(self, t_pad: int, max_blocks: Optional[int] = None, decode_only: int = 0, quads: bool = False, dec_split: int = 0, pf_split: int = 0) -> torch.Tensor:
         """The ragged forward pass over the first ``t_pad`` staged tokens; writes
         sampled ids into ``out_ids[:t_pad]`` and returns the logits ``[t_pad, V]``.
         ``decode_only`` (a step kind, see ``self.graphs``): every staged token is the only new token of its sequence, which
         allows RoPE + KV write + attention to run as one kernel.  ``quads``: the step's prompt chunks go to
-        the 8-wave attention kernel (see ``tile_quads``)."""
+        the 8-wave attention kernel (see ``tile_quads``).  ``pf_split``: ``shares | tiles << 8`` — the step's first ``tiles`` prompt tiles
+        go to the split form of the tile kernel with ``shares`` key ranges each (see ``PF_SPLIT_MAX_TILES``)."""
         ops, cfg, w = self.ops, self.cfg, self.w
         tokens = self._dev("tokens", t_pad)
         positions = self._dev("positions", t_pad)
@@ -395,7 +407,10 @@ class ModelRunner:
                                                    torch.zeros((t_pad, self.nh * self.hd), dtype=q.dtype, device=q.device), self.scale, **kw)
                 else:
                     a = ops.paged_attention(q, kc, vc, bt, tok_seq, self._dev("ctx_decode", t_pad), self.scale, max_blocks, **kw)
-                ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale, **kw, **({"quads": True} if quads else {}))
+                if pf_split:
+                    ops.prefill_attention_split(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), pf_split >> 8, a, self.scale, pf_split & 255, **kw)
+                else:
+                    ops.prefill_attention(q, kc, vc, bt, self._dev("tiles").view(4, self.max_tiles), a, self.scale, **kw, **({"quads": True} if quads else {}))
             else:
                 q = ops.rope_kv_write(qkv, positions, self.cos, self.sin, kc, vc, slots, self.nh, self.nkv, self.hd, **kw)
                 a = ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, self.scale, max_blocks, **kw)
@@ -534,15 +549,49 @@ class ModelRunner:
                 self._graph_pool = g.pool()
             self.graphs[key] = (g, logits)
 
-    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: int = 0, quads: bool = False, dec_split: int = 0) -> torch.Tensor:
-        # (a step for the 8-wave attention kernel or the listed-rows split-KV kernel runs eagerly: captured graphs hold the other kernels)
-        entry = None if quads or dec_split else self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, 0))
+    def _variant_graph(self, t_pad: int, quads: bool, dec_split: int, pf_split: int) -> Optional[Tuple[Any, torch.Tensor]]:
+        """The graph of a step shape that uses a special attention form (8-wave prompt kernel, listed-rows split-KV,
+        split prompt tiles): their grids depend on the step, so they are not part of the start-up set.  The first step
+        of a shape runs eagerly (which also brings the kernels' workspaces into being), the second one captures,
+        later ones replay; at most ``variant_graphs_max`` shapes are kept."""
+        key = (t_pad, 0, int(quads), dec_split, pf_split)
+        entry = self.graphs.get(key)
+        if entry is not None:
+            return entry
+        if self.device.type != "cuda" or not self.rcfg.use_graphs or self.tp_active or not self.graphs:
+            return None
+        seen = self._variant_seen.get(key, 0)
+        self._variant_seen[key] = seen + 1
+        if seen == 0 or sum(1 for k in self.graphs if len(k) > 2) >= self.variant_graphs_max:
+            return None
+        import gc
+
+        gc_was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()  # nothing may free device memory while the stream captures (see capture_graphs)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+                logits = self.forward(t_pad, decode_only=0, quads=quads, dec_split=dec_split, pf_split=pf_split)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+        self.graphs[key] = (g, logits)
+        return g, logits
+
+    def _run_staged(self, t_pad: int, max_ctx: int, decode_only: int = 0, quads: bool = False, dec_split: int = 0, pf_split: int = 0) -> torch.Tensor:
+        if quads or dec_split or pf_split:
+            entry = self._variant_graph(t_pad, quads, dec_split, pf_split)
+            self.variant_graph_steps += entry is not None
+        else:
+            entry = self.graphs.get((t_pad, decode_only)) or self.graphs.get((t_pad, 0))
         if entry is not None:
             g, logits = entry
             g.replay()
         else:
             with torch.no_grad():
-                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size, decode_only=decode_only, quads=quads, dec_split=dec_split)
+                logits = self.forward(t_pad, max_blocks=(max_ctx + self.block_size - 1) // self.block_size, decode_only=decode_only, quads=quads, dec_split=dec_split,
+                                      pf_split=pf_split)
         self.steps += 1
         return logits
 
@@ -591,11 +640,11 @@ class ModelRunner:
             while not self.channel.receive(sb.np, timeout_s=1.0):
                 if not self.channel.writer_alive():
                     raise RuntimeError("tensor parallelism: the scheduling rank is gone (no stop command was published); this follower exits")
-            t_pad, n_samples, max_ctx, cmd, dec, quads, dec_split, ids_sync = (int(v) for v in sb.np[o_h : o_h + 8])
+            t_pad, n_samples, max_ctx, cmd, dec, tile_form, dec_split, ids_sync = (int(v) for v in sb.np[o_h : o_h + 8])
             if cmd == 1:
                 return n
             self.stage_dev.copy_(sb.cpu, non_blocking=True)
-            self._run_staged(t_pad, max_ctx, dec, bool(quads), dec_split)
+            self._run_staged(t_pad, max_ctx, dec, bool(tile_form & 1), dec_split, tile_form >> 1)
             if ids_sync:
                 self.sync_sampled_ids(n_samples)  # the scheduling rank sampled: take its ids instead of the local argmax
             if self.device.type == "cuda":
@@ -658,6 +707,7 @@ class ModelRunner:
         o_dr, n_dec, dec_max_ctx = self._off["dec_rows"][0], 0, 0
         n_tiles = 0
         quad_groups, quad_min_pos = 0, 1 << 30  # groups of four tiles in multi-tile chunks, their shallowest start
+        tile_max_ctx = 0  # most keys any tiled prompt chunk of the step sees
         bs = self.block_size
         i = 0
         n_samples = 0
@@ -733,6 +783,8 @@ class ModelRunner:
                     if n > 16:
                         quad_groups += (n + 63) // 64
                         quad_min_pos = min(quad_min_pos, p0)
+                if not as_rows:
+                    tile_max_ctx = max(tile_max_ctx, p0 + n)
                 for off in range(0, 0 if as_rows else n, 16):
                     st[o_tl + n_tiles], st[o_tl + mt + n_tiles], st[o_tl + 2 * mt + n_tiles], st[o_tl + 3 * mt + n_tiles] = i + off, min(16, n - off), p0 + off, seq.slot
                     n_tiles += 1
@@ -758,19 +810,26 @@ class ModelRunner:
         decode_only = self.step_kind(t_pad, all(ch.n_tokens == 1 for ch in batch.chunks), max_ctx)
         o_h = self._off["header"][0]
         quads = int(self.tile_quads and not decode_only and quad_groups * self.nkv >= self.quads_min_groups and quad_min_pos >= self.quads_min_pos)
+        # a few tiles, deep inside a long context: key ranges shared out (the tile count rounded up to a power of two: fewer graph shapes)
+        pf_split = 0
+        if self.pf_split_ok and not decode_only and not quads and 0 < n_tiles <= self.PF_SPLIT_MAX_TILES and tile_max_ctx >= self.PF_SPLIT_MIN_CTX:
+            pf_tiles = min(self.max_tiles, max(2, 1 << (n_tiles - 1).bit_length()))
+            shares = self.ops.prefill_split_plan(pf_tiles, self.nh, self.nkv, tile_max_ctx)
+            if shares >= 2:
+                pf_split = shares | (pf_tiles << 8)
         # (the header carries the listed rows rounded up to a power of two: fewer rows, more workgroups per context)
         dec_split = 0
         if self.dec_split_ok and not decode_only and 0 < n_dec <= self.DEC_SPLIT_ROWS and dec_max_ctx >= self.DEC_SPLIT_MIN_CTX:
             dec_split = 1 << (n_dec - 1).bit_length()
         st[o_dr + min(n_dec, self.DEC_SPLIT_ROWS) : o_dr + self.DEC_SPLIT_ROWS] = -1
         ids_sync = int(sampler is not None and self.tp_size > 1)  # the followers must take this rank's sampled ids
-        st[o_h : o_h + 8] = (t_pad, n_samples, max_ctx, 0, decode_only, quads, dec_split, ids_sync)
+        st[o_h : o_h + 8] = (t_pad, n_samples, max_ctx, 0, decode_only, quads | (pf_split << 1), dec_split, ids_sync)
         if self.channel is not None:
             # every rank runs the same step: hand the staged image to the followers first (host
             # shared memory, see follow()), so that they enqueue it while this rank does
             self.channel.publish(st)
         self.stage_dev.copy_(sb.cpu, non_blocking=True)
-        logits = self._run_staged(t_pad, max_ctx, decode_only, bool(quads), dec_split)
+        logits = self._run_staged(t_pad, max_ctx, decode_only, bool(quads), dec_split, pf_split)
         if sampler is not None:
             sampler(logits, self.out_ids)
             if ids_sync:

@@ -1070,6 +1070,35 @@ def prefill_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     return out
 
 
+PREFILL_SPLIT_MAX = 32  # key-range shares per tile, at most
+
+
+def prefill_split_plan(n_tiles: int, nh: int, nkv: int, max_ctx: int, min_keys: int = 1024) -> int:
+    """Key-range shares for a step's ``n_tiles`` prompt tiles whose queries see up to ``max_ctx`` keys (0: the unsplit
+    kernel serves them): a power of two that brings the launch to about two workgroups per CU (all resident at once),
+    each share at least ``min_keys`` keys."""
+    groups = ((n_tiles + 1) // 2 if nh // nkv <= 4 else n_tiles) * nkv
+    if groups <= 0:
+        return 0
+    ns = min(PREFILL_SPLIT_MAX, 2 * _num_cus() // groups, max_ctx // max(32, min_keys))
+    if ns < 2:
+        return 0
+    return 1 << (ns.bit_length() - 1)
+
+
+def prefill_attention_split(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor, tiles: torch.Tensor, n_tiles: int, out: torch.Tensor,
+                            scale: float, n_split: int, kv_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """:func:`prefill_attention` for the first ``n_tiles`` tiles of ``tiles`` (``[4, max_tiles]``) with every tile's
+    key range walked by ``n_split`` workgroups (partials in an fp32 workspace, folded by a second launch): a few tiles
+    deep inside a long context — a short new turn after a cached prefix of 100k tokens — otherwise walk the whole
+    context with one workgroup per tile and kv head."""
+    nh = q.shape[1]
+    rows = n_split * 16 * n_tiles
+    ws = torch.empty(rows * nh * 130, dtype=torch.float32, device=q.device)  # [rows][nh][128] outputs, then [rows][nh][2] (reference, sum)
+    native().prefill_attention_split(q, k_cache, v_cache, block_tables, tiles, n_tiles, out, scale, kv_scale, n_split, ws[: rows * nh * 128], ws[rows * nh * 128 :])
+    return out
+
+
 def pad_tiles_to_quads(tiles: Sequence[Tuple[int, int, int, int]]) -> list:
     """``tiles`` (first row, valid queries, first position, block-table row; a chunk's tiles in
     order) with unused tiles inserted so that every chunk starts at a multiple of four."""

@@ -818,6 +818,66 @@ def test_prefill_attention_random_chunk_layouts(seed, rep, kv8, quads):
     assert (out.float() - ref.float()).abs().max().item() <= (4e-2 if kv8 else 2.5e-2)
 
 
+@pytest.mark.parametrize("seed,rep,kv8,n_split", [(1, 4, False, 2), (2, 4, True, 8), (3, 1, False, 4), (4, 2, True, 32), (5, 8, False, 8), (6, 6, True, 4), (7, 3, False, 16),
+                                                 (8, 7, False, 2), (9, 4, False, 32)])
+def test_prefill_attention_split_random_chunk_layouts(seed, rep, kv8, n_split):
+    """The split form of the tile kernel (every tile's key range in n_split shares + a combine launch) against the
+    per-token reference: short chunks at random depths of contexts of up to 3200 tokens — shares that are empty for
+    the shallow chunks, shares that end on the diagonal, partial tiles, pairs that are and are not neighbours,
+    unused tiles inside and behind the list."""
+    from kvmini.ops import hip_ops, torch_ops
+
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    nkv, hd, bs = 8, 128, 16
+    nh = nkv * rep
+    n_seqs, max_blocks = 5, 200
+    nb = n_seqs * max_blocks + 8
+    bt = torch.randperm(nb, device=_dev())[: n_seqs * max_blocks].view(n_seqs, max_blocks).int()
+    sc = None
+    if kv8:
+        kc, vc = _fp8_cache(nb, nkv, bs, hd, 1), _fp8_cache(nb, nkv, bs, hd, 2)
+        sc = (torch.rand(2, nkv, device=_dev()) + 0.5).contiguous()
+    else:
+        kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
+    rows, tok_seq, ctx, tiles = 0, [], [], []
+    for seq in rng.sample(range(n_seqs), 4):
+        n = rng.choice((rng.randint(1, 15), rng.randint(17, 40), rng.randint(41, 90)))
+        p0 = rng.choice((0, rng.randrange(0, 64), rng.randrange(500, max_blocks * bs - n), max_blocks * bs - n))
+        if rng.random() < 0.5:
+            tiles.append((0, 0, 0, 0))  # an unused tile inside the list
+        for off in range(0, n, 16):
+            tiles.append((rows + off, min(16, n - off), p0 + off, seq))
+        tok_seq += [seq] * n
+        ctx += [p0 + j + 1 for j in range(n)]
+        rows += n
+    n_tiles = len(tiles)
+    tiles += [(0, 0, 0, 0)] * 5  # the engine's tile arrays are wider than a step's list
+    q = torch.randn(rows, nh, hd, device=_dev()).bfloat16()
+    scale = 1 / math.sqrt(hd)
+    kw = {"kv_scale": sc} if kv8 else {}
+    ref = torch_ops.paged_attention(q, kc, vc, bt, torch.tensor(tok_seq, device=_dev(), dtype=torch.int32), torch.tensor(ctx, device=_dev(), dtype=torch.int32), scale, **kw)
+    out = torch.zeros((rows, nh * hd), device=_dev(), dtype=torch.bfloat16)
+    hip_ops.prefill_attention_split(q, kc, vc, bt, torch.tensor(tiles, device=_dev(), dtype=torch.int32).T.contiguous(), n_tiles, out, scale, n_split, **kw)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref.float()).abs().max().item() <= (4e-2 if kv8 else 2.5e-2)
+    # and the unsplit kernel agrees with it closely (same pass, other key ranges)
+    one = torch.zeros_like(out)
+    hip_ops.prefill_attention(q, kc, vc, bt, torch.tensor(tiles[:n_tiles], device=_dev(), dtype=torch.int32).T.contiguous(), one, scale, **kw)
+    assert (out.float() - one.float()).abs().max().item() <= 2e-2
+
+
+def test_prefill_split_plan():
+    from kvmini.ops import hip_ops
+
+    assert hip_ops.prefill_split_plan(16, 32, 8, 131072) == 8   # 256 new tokens: 64 groups x 8 shares = two workgroups per CU
+    assert hip_ops.prefill_split_plan(4, 32, 8, 131072) == 32   # 64 new tokens
+    assert hip_ops.prefill_split_plan(4, 32, 8, 4096) == 4      # shares of at least 1024 keys
+    assert hip_ops.prefill_split_plan(4, 32, 8, 1500) == 0
+    assert hip_ops.prefill_split_plan(128, 32, 8, 131072) == 0  # a long chunk fills the chip by itself
+    assert hip_ops.prefill_split_plan(8, 64, 8, 65536) == 8     # head groups of 8: one tile per group
+
+
 @pytest.mark.parametrize("quads", [False, True])
 @pytest.mark.parametrize("kv8", [False, True])
 def test_prefill_attention_follows_a_maximum_that_jumps_mid_pass(kv8, quads):
@@ -1744,6 +1804,44 @@ def test_short_chunks_deep_in_a_context_are_served_as_listed_rows(monkeypatch):
     assert set(calls_a) <= {1, 2, 4}, set(calls_a)  # three rows per verification, rounded up to four
     agree = sum(x == y for x, y in zip(a, b)) / len(b)
     assert len(a) == len(b) and agree >= 0.9 and a[:8] == b[:8], (agree, a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_new_turns_behind_a_cached_prefix_take_the_split_tile_kernel_inside_a_graph(monkeypatch, kv):
+    """Chat continuation: a 3000-token conversation is in the prefix cache and every request adds a new turn of 40
+    tokens.  The turn's tiles go to the split form of the tile kernel (key ranges shared out over the chip), from the
+    second step of that shape on inside a captured graph; tokens equal those of the unsplit, eager path."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.ops import hip_ops
+
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=4, max_batched_tokens=512, max_model_len=4096, kernels="hip", kv_cache_dtype=kv, kv_memory_fraction=0.02)
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # noqa: E731
+    history = [1] + [(7 * i) % 900 + 10 for i in range(2999)]
+    turns = [history + [(11 * i + 37 * t) % 900 + 10 for i in range(40)] for t in range(4)]
+    params = SamplingParams(max_tokens=6, ignore_eos=True)
+
+    def run(split):
+        eng = LLMEngine(EngineConfig(**common), weights=w())
+        eng.runner.PF_SPLIT_MIN_CTX = 2048 if split else 1 << 30
+        eng.warmup()
+        eng.generate([history], SamplingParams(max_tokens=1, ignore_eos=True))  # fills the prefix cache
+        calls = []
+        real = hip_ops.prefill_attention_split
+        monkeypatch.setattr(hip_ops, "prefill_attention_split", lambda *a, **k: (calls.append((int(a[5]), int(a[8]))), real(*a, **k))[1])
+        outs = [eng.generate([t], params)[0] for t in turns]
+        monkeypatch.setattr(hip_ops, "prefill_attention_split", real)
+        return outs, calls, eng.runner.variant_graph_steps, eng.bm.prefix_hits
+
+    a, calls_a, graph_steps, hits = run(True)
+    b, calls_b, _, _ = run(False)
+    assert hits > 0 and calls_a and not calls_b
+    assert all(tiles == 4 and shares >= 2 for tiles, shares in calls_a), calls_a  # 40 + a few re-computed tokens: 3-4 tiles, rounded up to 4
+    assert graph_steps >= 2, graph_steps  # first turn eager, second captures, the rest replay
+    for x, y in zip(a, b):
+        assert len(x) == len(y) and x[:3] == y[:3] and sum(p == q for p, q in zip(x, y)) >= len(y) - 1, (a, b)
 
 
 # ---------------------------------------------------------------- MXFP4 (4-bit) weights
