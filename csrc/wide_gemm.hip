@@ -658,6 +658,12 @@ int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStre
       // 32-wide stages: deeper rings in the same LDS
       case 2562561: return dispatch_epi<256, 256, 4, 2, 1, 4, 0>(epi, p, s);
       case 2562563: return dispatch_epi<256, 256, 4, 2, 1, 5, 0>(epi, p, s);
+      // 256 x 256, 4 waves (wave: 128 tokens x 128 features, one wave per SIMD): a k-step takes 16 fragment reads for 64
+      // MFMAs per wave where the 8-wave form takes 12 for 32 (64 KiB of LDS reads per CU and k-step instead of 96).  Not in
+      // the planner's table — measured on MI355X, 2048 x 28672 x 4096: 729 us against 444 us for the 8-wave form in the same
+      // run (library: 386): with one wave per SIMD nothing runs while that wave sits at the stage barrier, and the
+      // 64-wide-stage form of it spills (fragment sets of 256 registers next to 256 accumulators; 1142 us).
+      case 2562567: return dispatch_epi<256, 256, 2, 2, 1, 4, 0>(epi, p, s);
       case 2561281: return dispatch_epi<256, 128, 4, 2, 1, 6, 0>(epi, p, s);
       case 2562241: return dispatch_epi<256, 224, 4, 2, 1, 4, 0>(epi, p, s);
       case 2562243: return dispatch_epi<256, 224, 4, 2, 1, 5, 0>(epi, p, s);
@@ -676,7 +682,7 @@ int dispatch_tile(int bm, int bn, int variant, int epi, const Params& p, hipStre
 extern "C" {
 
 // k-steps (of 32) per pipeline stage of a (tile, variant): K splits are handed out in stages
-int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant) { (void)bm; (void)bn; return (variant == 1 || variant == 3) ? 1 : 2; }
+int kv_wide_gemm_stage_ksteps(int bm, int bn, int variant) { (void)bm; (void)bn; return (variant == 1 || variant == 3 || variant == 7) ? 1 : 2; }
 
 // epi: 0 = bf16 y[M, N], 1 = fp32 slabs out[splits][M][N], 2 = SwiGLU bf16 y[M, N/2].
 // (bm, bn): workgroup tile, one of (256,256) (256,224) (256,192) (256,128) (256,64) (128,128) (128,256); variant: see
@@ -709,7 +715,7 @@ int kv_wide_gemm_fp8a(const void* Wp, const void* x8, void* out, int M, int N, i
                       int stages_per_split, long long slab_stride, const float* row_ss, int ss_parts, float eps, const float* w_scale, const float* a_scale,
                       int m_fastest, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K & 127) || bn <= 0 || (N % bn) || w_scale == nullptr || a_scale == nullptr) return -1;
-  if (variant == 1 || variant == 3) return -1;
+  if (variant == 1 || variant == 3 || variant == 7) return -1;
   if (epi != EPI_SLAB && splits != 1) return -1;
   const int nst = K / 128;
   if (splits < 1 || stages_per_split < 1 || (long long)splits * stages_per_split < nst || (long long)(splits - 1) * stages_per_split >= nst) return -1;

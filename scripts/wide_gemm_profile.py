@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--n-fastest", action="store_true")
     ap.add_argument("--library", action="store_true")
+    ap.add_argument("--time", action="store_true", help="print the mean time per launch (events around a second round of launches)")
     a = ap.parse_args()
     from kvmini.ops import native
 
@@ -35,12 +36,29 @@ def main():
     x = torch.randn(a.m, a.k, device=dev).bfloat16()
     y = torch.empty((a.m, a.n // 2 if a.epi == 2 else a.n), dtype=torch.bfloat16, device=dev)
     nst = a.k // (32 * C.wide_gemm_stage_ksteps(bm, bn, a.variant))
-    for i in range(a.iters):
+    def run(i):
         if a.library:
             F.linear(x, Ws[i % copies])
         else:
             C.wide_gemm(Wps[i % copies], a.n, a.k, x, y, a.epi, bm, bn, a.variant, 1, nst, None, 0.0, None, not a.n_fastest)
+
+    for i in range(a.iters):
+        run(i)
     torch.cuda.synchronize()
+    if a.time:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(a.iters):
+            run(i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / a.iters * 1e3
+        if not a.library and a.epi == 0:
+            ref = x.float() @ Ws[(a.iters - 1) % copies].float().T
+            err = (y.float() - ref).abs().max().item()
+        else:
+            err = None
+        print(f"m={a.m} n={a.n} k={a.k} {'library' if a.library else f'tile {a.tile} variant {a.variant} epi {a.epi}'}: {us:.1f} us, {2.0 * a.m * a.n * a.k / us / 1e6:.0f} TFLOP/s, max err {err}", flush=True)
 
 
 if __name__ == "__main__":
