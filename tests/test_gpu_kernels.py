@@ -1761,11 +1761,13 @@ def test_engine_decodes_ride_along_with_a_prompt_on_the_split_kv_kernel(kv, monk
         while eng.scheduler.has_work():
             eng.step()
         monkeypatch.setattr(hip_ops, "split_decode_attention", real)
-        return list(s1.output_ids), list(s2.output_ids), len(calls)
+        return list(s1.output_ids), list(s2.output_ids), len(calls), eng.runner.variant_graph_steps
 
-    a1, a2, n_a = run(2048)
-    b1, b2, n_b = run(1 << 30)
-    assert n_a >= 5 * get_config("small-hd128").num_layers and n_b == 0, (n_a, n_b)
+    a1, a2, n_a, replays = run(2048)
+    b1, b2, n_b, _ = run(1 << 30)
+    layers = get_config("small-hd128").num_layers
+    # the first step of the shape runs eagerly, the second is captured (both call the op once per layer), later ones replay the graph
+    assert n_a >= 2 * layers and n_a + layers * replays >= 5 * layers and replays >= 3 and n_b == 0, (n_a, replays, n_b)
     agree = sum(x == y for x, y in zip(a1, b1)) / len(b1)
     assert agree >= 0.9 and a1[:8] == b1[:8], (agree, a1, b1)
     assert a2 == b2 or sum(x == y for x, y in zip(a2, b2)) >= 7
