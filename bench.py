@@ -185,12 +185,35 @@ def main() -> int:
     else:
         device = torch.device("cpu")
         args.kernels, args.no_graphs = "torch", True
+    # `cdev`: where the tensors of the result reductions live (a few KiB per rank).  On GPUs that is the device and
+    # the collectives are RCCL's over xGMI; when RCCL does not come up on this node (initialisation or the first
+    # all-reduce raises) every rank falls back to gloo with host tensors, says so in the JSON line, and the
+    # measurement goes ahead: the replicas do not talk to each other while they serve.
+    cdev = device
+    collective_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
-            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        want = os.environ.get("KVMINI_BENCH_COLLECTIVES", "rccl")  # "gloo": skip RCCL; "force-rccl": try it even in the CPU rehearsal (tests the fallback)
+        if (on_gpu and want != "gloo") or want == "force-rccl":
+            try:
+                dist.init_process_group("nccl", **({"device_id": device} if on_gpu else {}))  # RCCL over xGMI
+                probe = torch.ones(1, dtype=torch.int32, device=device)
+                dist.all_reduce(probe)
+                if on_gpu:
+                    torch.cuda.synchronize(device)
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"probe all-reduce returned {int(probe.item())}, expected {world}")
+            except Exception as e:  # noqa: BLE001 - whatever RCCL raises, the fallback is the same
+                collective_note = f"rccl unavailable ({type(e).__name__}: {str(e)[:120]}); reductions over gloo"
+                print(f"bench.py rank {rank}: {collective_note}", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)  # the first store may still hold the port
+                dist.init_process_group("gloo")
+                cdev = torch.device("cpu")
         else:
             dist.init_process_group("gloo")
+            cdev = torch.device("cpu")
 
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.server.native import start_native_in_thread
@@ -271,8 +294,8 @@ def main() -> int:
 
     local = {k: cat(k) for k in ("latency_ms", "ttfb_ms", "ttft_ms", "status", "completion_tokens", "total_tokens")}
     itl = cat("itl_ms")
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    one = torch.ones(1, dtype=torch.int32, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    one = torch.ones(1, dtype=torch.int32, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(one)  # every rank contributes a 1: the sum is the number of ranks that took part in a real collective
@@ -280,9 +303,9 @@ def main() -> int:
     collective_ranks = int(one.item())
 
     n_local = local["latency_ms"].size
-    mat = torch.from_numpy(np.stack([local[k] for k in ("latency_ms", "ttfb_ms", "ttft_ms", "status", "completion_tokens", "total_tokens")])).to(device)
+    mat = torch.from_numpy(np.stack([local[k] for k in ("latency_ms", "ttfb_ms", "ttft_ms", "status", "completion_tokens", "total_tokens")])).to(cdev)
     if world > 1:
-        g = torch.empty((world,) + tuple(mat.shape), dtype=mat.dtype, device=device)
+        g = torch.empty((world,) + tuple(mat.shape), dtype=mat.dtype, device=cdev)
         dist.all_gather_into_tensor(g.view(-1), mat.reshape(-1))
         mat_all = g.permute(1, 0, 2).reshape(mat.shape[0], world * n_local)
     else:
@@ -296,7 +319,7 @@ def main() -> int:
     itl_hist = None
     itl_exact = None
     if world > 1:
-        itl_hist = StreamingHistogram(1, device=device)
+        itl_hist = StreamingHistogram(1, device=cdev)
         if itl.size:
             itl_hist.update(itl.astype(np.float32))
         itl_hist.all_reduce(dist)
@@ -304,16 +327,16 @@ def main() -> int:
         # select): the ranks sum the radix-digit histograms of each selection pass instead of their samples
         from kvmini.ops.hist_quantile import distributed_quantiles
 
-        itl_exact = distributed_quantiles(itl, (0.5, 0.95, 0.99), dist, device=device)
+        itl_exact = distributed_quantiles(itl, (0.5, 0.95, 0.99), dist, device=cdev)
 
     # lock-step telemetry table: C++ ncclAllGather on its own communicator and stream when the
     # ranks are GPU processes, the torch.distributed path over gloo in the CPU rehearsal
     from kvmini.parallel.telemetry_gather import TelemetryGather, table_to_power_json
 
-    tw = torch.tensor([t0_wall, t1_wall], dtype=torch.float64, device=device)
+    tw = torch.tensor([t0_wall, t1_wall], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.broadcast(tw, 0)
-    tg = TelemetryGather(device=device, native=on_gpu and world > 1, device_index=local_rank)
+    tg = TelemetryGather(device=cdev, native=on_gpu and world > 1 and cdev.type == "cuda", device_index=local_rank)
     table = tg.gather_table(samples, float(tw[0]), float(tw[1]), 0.1)
 
     # resource-seconds of this replica through the same record `kvmini cost` reads
@@ -343,7 +366,7 @@ def main() -> int:
     if server_cpu_s > 0 and peak_rss > 0:
         rsecs["cpu_core_seconds"] = server_cpu_s
         rsecs["mem_gib_seconds"] = peak_rss / float(2**30) * elapsed_max
-    rs_t = torch.tensor([rsecs["gpu_seconds"], rsecs["cpu_core_seconds"], rsecs["mem_gib_seconds"]], dtype=torch.float64, device=device)
+    rs_t = torch.tensor([rsecs["gpu_seconds"], rsecs["cpu_core_seconds"], rsecs["mem_gib_seconds"]], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(rs_t)
     gpu_s, cpu_s, mem_s = (float(v) for v in rs_t.tolist())
@@ -358,7 +381,7 @@ def main() -> int:
         ttfb = torch.where(ok, mat_all[1], torch.full_like(mat_all[1], float("nan")))
         ttft = torch.where(ok, mat_all[2], torch.full_like(mat_all[2], float("nan")))
         if on_gpu:
-            q, stats = hq.batched_quantiles(torch.stack([lat, ttfb, ttft]), (0.5, 0.95, 0.99), return_stats=True)
+            q, stats = hq.batched_quantiles(torch.stack([lat, ttfb, ttft]).to(device), (0.5, 0.95, 0.99), return_stats=True)
         else:  # rehearsal: the same reduction on the host
             m3 = torch.stack([lat, ttfb, ttft]).numpy()
             q = np.nanquantile(m3, (0.5, 0.95, 0.99), axis=1).T
@@ -369,7 +392,7 @@ def main() -> int:
             itl_hist_q = [snap.get(p, float("nan")) for p in (0.5, 0.95, 0.99)]  # the live view's 2048-bin estimate, merged over the ranks
         if itl_exact is not None:
             qi = [itl_exact]
-            itl_engine = ("hip:radix_hist/scan" if on_gpu else "numpy radix select") + " + all-reduce of the digit histograms per pass (exact)"
+            itl_engine = ("hip:radix_hist/scan" if cdev.type == "cuda" else "numpy radix select") + " + all-reduce of the digit histograms per pass (exact)"
         elif on_gpu and itl.size:
             qi, _ = hq.batched_quantiles(torch.from_numpy(itl).to(device).reshape(1, -1), (0.5, 0.95, 0.99), return_stats=True)
             itl_engine = "hip:kv_radix_select"
@@ -462,6 +485,7 @@ def main() -> int:
             "itl_quantile_engine": itl_engine,
             "itl_histogram_p50_p95_p99_ms": itl_hist_q,
             "collective_backend": (dist.get_backend() if world > 1 else None),
+            **({"collective_note": collective_note} if collective_note else {}),
             "telemetry": pj["source"] if watts else "unavailable",
             **({"telemetry_native_fallback": tg.native_error} if tg.native_error else {}),
             "resource_seconds": {"gpu": gpu_s, "cpu_core": cpu_s, "mem_gib": mem_s, "cpu_memory_source": "measured: os.times() and VmHWM of each server rank over the timed window"},

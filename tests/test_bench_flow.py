@@ -78,6 +78,21 @@ def test_bench_four_and_eight_rank_rehearsals_on_cpu():
         assert out["error_rate"] == 0.0 and "exact" in out["itl_quantile_engine"]
 
 
+def test_bench_goes_on_over_gloo_when_rccl_does_not_come_up():
+    """Two ranks whose RCCL initialisation fails (forced here: there is no GPU) fall back to gloo for the result
+    reductions, say so in the JSON line and finish with every rank counted."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    env["KVMINI_BENCH_COLLECTIVES"] = "force-rccl"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--device", "cpu", "--model", "tiny", "--requests", "6",
+           "--concurrency", "2", "--max-tokens", "4", "--max-model-len", "128"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
+    assert "rccl unavailable" in out["collective_note"] and out["error_rate"] == 0.0
+
+
 def _dq_worker(rank, world, port, q):
     import numpy as np
     import torch.distributed as dist
