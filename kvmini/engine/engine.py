@@ -196,14 +196,21 @@ class LLMEngine:
         self.device = _resolve_device(ecfg.device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
-        self.mcfg = get_config(ecfg.model) if weights is None else weights.cfg
+        # `model`: a preset name, or a Hugging Face checkpoint directory (architecture from its config.json, weights from its *.safetensors)
+        weights_path = ecfg.weights_path
+        if weights is None:
+            from kvmini.models.llama import resolve_model
+
+            self.mcfg, weights_path = resolve_model(ecfg.model, ecfg.weights_path)
+        else:
+            self.mcfg = weights.cfg
         dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[ecfg.dtype]
         t0 = time.perf_counter()
         if weights is None:
-            if ecfg.weights_path:
+            if weights_path:
                 from kvmini.models.llama import load_hf_safetensors
 
-                weights = load_hf_safetensors(ecfg.weights_path, self.mcfg, self.device, dtype, ecfg.tp_rank, ecfg.tp_size)
+                weights = load_hf_safetensors(weights_path, self.mcfg, self.device, dtype, ecfg.tp_rank, ecfg.tp_size)
             else:
                 damp = None
                 if ecfg.tail_damping > 0 and ecfg.draft_model and ecfg.draft_model.startswith("self:"):

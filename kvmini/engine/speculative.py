@@ -91,10 +91,15 @@ class SpeculativeDecoder:
                 if hasattr(tw, attr):
                     setattr(dw, attr, getattr(tw, attr))
         else:
-            dcfg = get_config(draft_model)
+            from kvmini.models.llama import load_hf_safetensors, resolve_model
+
+            dcfg, dpath = resolve_model(draft_model)  # a preset name (random-init draft) or a checkpoint directory
             if dcfg.vocab_size != engine.mcfg.vocab_size:
                 raise ValueError(f"draft vocab {dcfg.vocab_size} != target vocab {engine.mcfg.vocab_size}")
-            dw = random_weights(dcfg, engine.device, engine.weights.embed.dtype, ecfg.seed + 1)
+            if dpath:
+                dw = load_hf_safetensors(dpath, dcfg, engine.device, engine.weights.embed.dtype)
+            else:
+                dw = random_weights(dcfg, engine.device, engine.weights.embed.dtype, ecfg.seed + 1)
         rcfg = RunnerConfig(max_num_seqs=ecfg.max_num_seqs, max_batched_tokens=ecfg.max_batched_tokens, max_model_len=ecfg.max_model_len, block_size=ecfg.block_size,
                             num_blocks=tgt.num_blocks, use_graphs=ecfg.use_graphs, kernels=ecfg.kernels)
         self.draft = ModelRunner(dw, rcfg)

@@ -239,57 +239,157 @@ def random_weights(
     return LlamaWeights(cfg, embed, layers, final_norm, lm_head, tp_rank, tp_size)
 
 
+def config_from_hf(config: "str | Dict[str, Any]", name: Optional[str] = None) -> LlamaConfig:
+    """The architecture of a Hugging Face checkpoint from its ``config.json`` (a path to the file or
+    its directory, or the parsed document): any decoder of the Llama form — ``model_type`` llama or
+    mistral; grouped-query attention, SwiGLU, RMSNorm, rotary positions (plain or "llama3" scaled),
+    tied or separate output embeddings, an explicit ``head_dim``.  What the engine has no kernels for
+    is refused here rather than loaded wrongly: projection biases (Qwen2), other rotary scalings
+    (linear / dynamic / yarn), mixture-of-experts layers.  A sliding attention window (Mistral-7B
+    v0.1: 4096) is honoured by limiting the context to the window, inside which it changes nothing."""
+    import json
+    import os
+
+    if isinstance(config, str):
+        path = os.path.join(config, "config.json") if os.path.isdir(config) else config
+        with open(path) as f:
+            hf = json.load(f)
+        if name is None:
+            name = os.path.basename(os.path.dirname(os.path.abspath(path))) or "hf-model"
+    else:
+        hf = dict(config)
+    mt = hf.get("model_type", "llama")
+    if mt not in ("llama", "mistral"):
+        raise ValueError(f"model_type {mt!r} is not a Llama-form decoder this engine serves (llama, mistral)")
+    if hf.get("attention_bias") or hf.get("mlp_bias"):
+        raise ValueError("projection biases (attention_bias / mlp_bias) are not supported")
+    if hf.get("hidden_act", "silu") not in ("silu", "swish"):
+        raise ValueError(f"hidden_act {hf.get('hidden_act')!r} is not supported (SwiGLU only)")
+    if hf.get("num_local_experts") or hf.get("num_experts"):
+        raise ValueError("mixture-of-experts checkpoints are not supported")
+    hidden, nh = int(hf["hidden_size"]), int(hf["num_attention_heads"])
+    hd = int(hf.get("head_dim") or hidden // nh)
+    rs = _hf_rope(hf)
+    scaling = None
+    if rs and (rs.get("rope_type") or rs.get("type")) not in (None, "default"):
+        kind = rs.get("rope_type") or rs.get("type")
+        if kind != "llama3":
+            raise ValueError(f"rope_scaling type {kind!r} is not supported (llama3 only)")
+        scaling = (float(rs.get("factor", 1.0)), float(rs.get("low_freq_factor", 1.0)), float(rs.get("high_freq_factor", 4.0)), int(rs.get("original_max_position_embeddings", 8192)))
+    max_pos = int(hf.get("max_position_embeddings", 8192))
+    window = hf.get("sliding_window")
+    if window and int(window) < max_pos:
+        max_pos = int(window)
+    rope_theta = hf.get("rope_theta", (rs or {}).get("rope_theta"))
+
+    def first(v: Any, default: int) -> int:
+        if isinstance(v, (list, tuple)):
+            v = v[0] if v else None
+        return default if v is None else int(v)
+
+    return LlamaConfig(
+        name=name or str(hf.get("_name_or_path") or "hf-model"),
+        vocab_size=int(hf["vocab_size"]),
+        hidden_size=hidden,
+        intermediate_size=int(hf["intermediate_size"]),
+        num_layers=int(hf["num_hidden_layers"]),
+        num_heads=nh,
+        num_kv_heads=int(hf.get("num_key_value_heads") or nh),
+        head_dim=hd,
+        rope_theta=float(rope_theta if rope_theta is not None else 10000.0),
+        rms_eps=float(hf.get("rms_norm_eps", 1e-5)),
+        max_position=max_pos,
+        bos_token_id=first(hf.get("bos_token_id"), 1),
+        eos_token_id=first(hf.get("eos_token_id"), 2),
+        rope_scaling=scaling,
+        tie_word_embeddings=bool(hf.get("tie_word_embeddings", False)),
+    )
+
+
+def _hf_rope(hf: Dict[str, Any]) -> Optional[Dict[str, Any]]:
+    """The rotary settings of a ``config.json``: ``rope_scaling`` (with ``rope_theta`` beside it) in
+    the older layout, one ``rope_parameters`` object (theta, type and factors together) in the newer."""
+    rs = hf.get("rope_scaling")
+    if not rs and isinstance(hf.get("rope_parameters"), dict):
+        rs = hf["rope_parameters"]
+    return rs if isinstance(rs, dict) else None
+
+
+def resolve_model(model: str, weights_path: Optional[str] = None) -> "tuple[LlamaConfig, Optional[str]]":
+    """``model`` is a preset name (``llama-3-8b``) or a Hugging Face checkpoint directory: the
+    architecture then comes from its ``config.json`` and, unless ``weights_path`` says otherwise,
+    the weights from its ``*.safetensors``.  With a preset name and a ``weights_path`` the
+    checkpoint's ``config.json`` is checked against the preset when the weights are loaded."""
+    import glob
+    import os
+
+    if os.path.isdir(model) and os.path.exists(os.path.join(model, "config.json")):
+        cfg = config_from_hf(model)
+        if weights_path is None and glob.glob(os.path.join(model, "*.safetensors")):
+            weights_path = model
+        return cfg, weights_path
+    return get_config(model), weights_path
+
+
 def load_hf_safetensors(path: str, cfg: LlamaConfig, device: torch.device | str = "cpu", dtype: torch.dtype = torch.bfloat16, tp_rank: int = 0, tp_size: int = 1) -> LlamaWeights:
-    """Load a Hugging Face Llama checkpoint directory (``*.safetensors``) into the
-    fused layout.  Only safetensors is read — nothing is unpickled."""
+    """Load a Hugging Face Llama checkpoint directory (``*.safetensors``) into the fused layout.
+    Only safetensors is read — nothing is unpickled.  The files are memory-mapped and read one
+    layer at a time, each tensor-parallel rank only its own rows / columns, so the host never
+    holds more than a layer of a 70B checkpoint."""
     import glob
     import os
 
     from safetensors import safe_open
 
-    tensors: Dict[str, torch.Tensor] = {}
     files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
     if not files:
         raise FileNotFoundError(f"no .safetensors files under {path}")
     if cfg.num_heads % tp_size or cfg.num_kv_heads % tp_size or cfg.intermediate_size % (tp_size * GU_GROUP):
         raise ValueError(f"{cfg.name}: {cfg.num_heads} heads / {cfg.num_kv_heads} kv heads / intermediate {cfg.intermediate_size} do not split over {tp_size} tensor-parallel ranks")
     check_hf_config(os.path.join(path, "config.json"), cfg)
-    for fpath in files:
-        with safe_open(fpath, framework="pt", device="cpu") as f:
-            for k in f.keys():
-                tensors[k] = f.get_tensor(k)
+    handles = [safe_open(fpath, framework="pt", device="cpu") for fpath in files]
+    where: Dict[str, Any] = {}
+    for h in handles:
+        for k in h.keys():
+            where[k] = h
     dev = torch.device(device)
-    hd = cfg.head_dim
+    hd = cfg.rope_dim or cfg.head_dim  # the checkpoint's head width (heads are zero-padded afterwards when the kernels want them wider)
     nh_l, nkv_l, i_l = cfg.num_heads // tp_size, cfg.num_kv_heads // tp_size, cfg.intermediate_size // tp_size
 
-    def rows(w: torch.Tensor, n: int) -> torch.Tensor:
-        return w[tp_rank * n : (tp_rank + 1) * n]
+    def need(name: str) -> Any:
+        if name not in where:
+            raise KeyError(f"{path}: tensor {name!r} is missing from the checkpoint")
+        return where[name]
 
-    def cols(w: torch.Tensor, n: int) -> torch.Tensor:
-        return w[:, tp_rank * n : (tp_rank + 1) * n]
+    def rows(name: str, n: int) -> torch.Tensor:  # this rank's n output rows
+        return need(name).get_slice(name)[tp_rank * n : (tp_rank + 1) * n].to(dtype)
 
-    def get(name: str) -> torch.Tensor:
-        return tensors[name].to(dtype)
+    def cols(name: str, n: int) -> torch.Tensor:  # this rank's n input columns
+        return need(name).get_slice(name)[:, tp_rank * n : (tp_rank + 1) * n].to(dtype)
 
+    def whole(name: str) -> torch.Tensor:
+        return need(name).get_tensor(name).to(dtype)
+
+    if any(k.endswith("self_attn.q_proj.bias") for k in where):
+        raise ValueError(f"{path}: the checkpoint has projection biases, which this engine does not apply")
     layers = []
     for li in range(cfg.num_layers):
         p = f"model.layers.{li}."
-        wqkv = torch.cat((rows(get(p + "self_attn.q_proj.weight"), nh_l * hd), rows(get(p + "self_attn.k_proj.weight"), nkv_l * hd), rows(get(p + "self_attn.v_proj.weight"), nkv_l * hd)), 0)
-        wgu = interleave_gate_up(rows(get(p + "mlp.gate_proj.weight"), i_l).contiguous(), rows(get(p + "mlp.up_proj.weight"), i_l).contiguous())
+        wqkv = torch.cat((rows(p + "self_attn.q_proj.weight", nh_l * hd), rows(p + "self_attn.k_proj.weight", nkv_l * hd), rows(p + "self_attn.v_proj.weight", nkv_l * hd)), 0)
+        wgu = interleave_gate_up(rows(p + "mlp.gate_proj.weight", i_l).contiguous(), rows(p + "mlp.up_proj.weight", i_l).contiguous())
         layers.append(
             LayerWeights(
-                attn_norm=get(p + "input_layernorm.weight").to(dev),
+                attn_norm=whole(p + "input_layernorm.weight").to(dev),
                 wqkv=wqkv.contiguous().to(dev),
-                wo=cols(get(p + "self_attn.o_proj.weight"), nh_l * hd).contiguous().to(dev),
-                mlp_norm=get(p + "post_attention_layernorm.weight").to(dev),
+                wo=cols(p + "self_attn.o_proj.weight", nh_l * hd).contiguous().to(dev),
+                mlp_norm=whole(p + "post_attention_layernorm.weight").to(dev),
                 wgu=wgu.contiguous().to(dev),
-                wdown=cols(get(p + "mlp.down_proj.weight"), i_l).contiguous().to(dev),
+                wdown=cols(p + "mlp.down_proj.weight", i_l).contiguous().to(dev),
             )
         )
-    embed = get("model.embed_tokens.weight").to(dev)
-    lm_head = tensors.get("lm_head.weight")
-    lm_head = embed if lm_head is None else lm_head.to(dtype).to(dev)
-    return LlamaWeights(cfg, embed, layers, get("model.norm.weight").to(dev), lm_head, tp_rank, tp_size)
+    embed = whole("model.embed_tokens.weight").to(dev)
+    lm_head = embed if "lm_head.weight" not in where else whole("lm_head.weight").to(dev)
+    return LlamaWeights(cfg, embed, layers, whole("model.norm.weight").to(dev), lm_head, tp_rank, tp_size)
 
 
 def check_hf_config(config_json: str, cfg: LlamaConfig) -> None:
@@ -314,7 +414,9 @@ def check_hf_config(config_json: str, cfg: LlamaConfig) -> None:
             bad.append(f"head_dim: checkpoint {hd}, preset {cfg.rope_dim or cfg.head_dim}")
     if "tie_word_embeddings" in hf and bool(hf["tie_word_embeddings"]) != cfg.tie_word_embeddings:
         bad.append(f"tie_word_embeddings: checkpoint {hf['tie_word_embeddings']}, preset {cfg.tie_word_embeddings}")
-    rs = hf.get("rope_scaling")
+    rs = _hf_rope(hf)
+    if "rope_theta" not in hf and rs and "rope_theta" in rs and abs(float(rs["rope_theta"]) - cfg.rope_theta) > 1e-9 * max(1.0, cfg.rope_theta):
+        bad.append(f"rope_theta: checkpoint {rs['rope_theta']!r}, preset {cfg.rope_theta!r}")
     if rs and (rs.get("rope_type") or rs.get("type")) not in (None, "default"):
         kind = rs.get("rope_type") or rs.get("type")
         got = (float(rs.get("factor", 1.0)), float(rs.get("low_freq_factor", 1.0)), float(rs.get("high_freq_factor", 4.0)), int(rs.get("original_max_position_embeddings", 8192)))
@@ -322,7 +424,7 @@ def check_hf_config(config_json: str, cfg: LlamaConfig) -> None:
             bad.append(f"rope_scaling type {kind!r} is not supported (llama3 only)")
         elif cfg.rope_scaling is None or any(abs(a - b) > 1e-9 for a, b in zip(got, cfg.rope_scaling)):
             bad.append(f"rope_scaling: checkpoint {got}, preset {cfg.rope_scaling}")
-    elif cfg.rope_scaling is not None and "rope_scaling" in hf:
+    elif cfg.rope_scaling is not None and ("rope_scaling" in hf or "rope_parameters" in hf):
         bad.append(f"rope_scaling: checkpoint has none, preset {cfg.rope_scaling}")
     if bad:
         raise ValueError(f"checkpoint config.json does not match preset {cfg.name!r}: " + "; ".join(bad))

@@ -639,12 +639,12 @@ def start_native_in_thread(engine: LLMEngine, port: int = 0, **kw: Any):
 
 
 def add_engine_args(ap: argparse.ArgumentParser) -> None:
-    ap.add_argument("--model", default="llama-3-8b", help="architecture preset (see kvmini.models.llama.PRESETS)")
+    ap.add_argument("--model", default="llama-3-8b", help="architecture preset (see kvmini.models.llama.PRESETS) or a Hugging Face checkpoint directory (config.json + *.safetensors [+ tokenizer.json]; Llama / Mistral form)")
     ap.add_argument("--device", default="auto")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--random-init", action="store_true", help="random-init weights (default when no --weights)")
-    ap.add_argument("--weights", default=None, help="directory with HF *.safetensors")
+    ap.add_argument("--weights", default=None, help="directory with HF *.safetensors (default: --model itself when that is a checkpoint directory)")
     ap.add_argument("--tokenizer", default=None, help="tokenizer.json (default: synthetic tokenizer)")
     ap.add_argument("--max-num-seqs", type=int, default=64)
     ap.add_argument("--max-batched-tokens", type=int, default=1024, help="token budget of one engine step (decode tokens + prompt chunk); larger = faster long-prompt prefill, longer worst-case step")
@@ -818,7 +818,10 @@ def main(argv: Optional[List[str]] = None) -> int:
         print(f"[tp rank {a.tp_rank}] served {served} steps", flush=True)
         dist.destroy_process_group()
         return 0
-    ns = NativeServer(engine, a.served_model_name or a.model, a.tokenizer, ignore_eos=not a.honor_eos, api_key=a.api_key)
+    tokenizer = a.tokenizer
+    if tokenizer is None and os.path.isfile(os.path.join(a.model, "tokenizer.json")):
+        tokenizer = os.path.join(a.model, "tokenizer.json")  # --model names a checkpoint directory: its tokenizer goes with it
+    ns = NativeServer(engine, a.served_model_name or a.model, tokenizer, ignore_eos=not a.honor_eos, api_key=a.api_key)
     ns.started_at = proc_start
     if not a.no_register:
         from kvmini.cluster import LocalBackend

@@ -256,7 +256,7 @@ def step_bench(out, model, batch, kernels_list, quantization=None):
     from kvmini.engine.scheduler import SamplingParams
 
     for kernels in kernels_list:
-        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=32, max_batched_tokens=256, max_model_len=512 if kernels == "torch" else 2048, kernels=kernels, kv_memory_fraction=0.2, quantization=quantization))
+        eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=max(32, batch), max_batched_tokens=max(256, batch), max_model_len=512 if kernels == "torch" else 2048, kernels=kernels, kv_memory_fraction=0.2, quantization=quantization))
         eng.warmup()
         prompts = [[1] + list(range(100 + i, 113 + i)) for i in range(batch)]
         for rep in range(2):

@@ -1,0 +1,143 @@
+"""The native engine against Hugging Face ``transformers`` on tiny random checkpoints: the architecture is read
+from ``config.json``, the weights from safetensors, and greedy tokens / logits must match the library's
+implementation of the same model (rotary convention, grouped-query attention, "llama3" rotary scaling, tied
+embeddings, explicit head widths, Mistral's config).  CPU, fp32, reference ops."""
+
+import json
+import os
+
+import pytest
+import torch
+
+transformers = pytest.importorskip("transformers")
+
+
+def _save(tmp_path, kind, **kw):
+    torch.manual_seed(7)
+    base = dict(vocab_size=160, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=512,
+                rms_norm_eps=1e-5, bos_token_id=1, eos_token_id=2, tie_word_embeddings=False)
+    base.update(kw)
+    if kind == "mistral":
+        cfg = transformers.MistralConfig(**base)
+        model = transformers.MistralForCausalLM(cfg)
+    else:
+        cfg = transformers.LlamaConfig(**base)
+        model = transformers.LlamaForCausalLM(cfg)
+    model = model.eval().float()
+    d = str(tmp_path / kind)
+    model.save_pretrained(d, safe_serialization=True)
+    return d, model
+
+
+def _engine(path, **kw):
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+
+    return LLMEngine(EngineConfig(model=path, device="cpu", dtype="fp32", kernels="torch", max_model_len=256, max_num_seqs=4, max_batched_tokens=64, use_graphs=False, **kw))
+
+
+CASES = {
+    "llama-gqa": ("llama", dict(rope_theta=10000.0)),
+    "llama3-scaled-tied": ("llama", dict(rope_theta=500000.0, tie_word_embeddings=True,
+                                         rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 64})),
+    "llama-mha-wide-heads": ("llama", dict(num_key_value_heads=4, head_dim=32)),
+    "mistral": ("mistral", dict(rope_theta=10000.0, sliding_window=None)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_greedy_tokens_and_logits_equal_transformers(tmp_path, case):
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import config_from_hf
+
+    kind, kw = CASES[case]
+    path, hf = _save(tmp_path, kind, **kw)
+    cfg = config_from_hf(path)
+    assert cfg.num_layers == 2 and cfg.num_heads == 4 and cfg.vocab_size == 160
+    assert cfg.tie_word_embeddings == bool(kw.get("tie_word_embeddings", False))
+    assert (cfg.rope_scaling is not None) == ("rope_scaling" in kw)
+    assert cfg.head_dim == kw.get("head_dim", 16)
+    eng = _engine(path)
+    prompts = [[1, 5, 9, 33, 77, 100, 4], [1] + [(7 * i) % 150 + 3 for i in range(90)]]  # the long one passes the scaled rotary table's original range
+    mine = eng.generate(prompts, SamplingParams(max_tokens=10, ignore_eos=True))
+    for p, got in zip(prompts, mine):
+        with torch.no_grad():
+            want = hf.generate(torch.tensor([p]), max_new_tokens=10, do_sample=False, pad_token_id=0)[0, len(p):].tolist()
+        assert got == want, (case, got, want)
+    # logits of the prompt's last position, through the reference forward pass on the loaded weights
+    from kvmini.models.reference import dense_logits
+
+    ids = torch.tensor([prompts[0]])
+    with torch.no_grad():
+        want = hf(ids).logits[0, -1]
+    got = dense_logits(eng.weights, prompts[0])[-1]
+    assert torch.allclose(got.float(), want.float(), atol=2e-4, rtol=1e-3), (got - want).abs().max()
+
+
+def test_unsupported_architectures_are_refused(tmp_path):
+    from kvmini.models.llama import config_from_hf
+
+    base = dict(model_type="llama", vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2)
+    for bad, msg in ((dict(model_type="qwen2"), "model_type"), (dict(attention_bias=True), "bias"), (dict(rope_scaling={"rope_type": "yarn", "factor": 4.0}), "rope_scaling"),
+                     (dict(num_local_experts=8), "experts"), (dict(hidden_act="gelu"), "hidden_act")):
+        with pytest.raises(ValueError, match=msg):
+            config_from_hf({**base, **bad})
+    cfg = config_from_hf({**base, "model_type": "mistral", "sliding_window": 128, "max_position_embeddings": 4096, "eos_token_id": [7, 9]})
+    assert cfg.max_position == 128 and cfg.eos_token_id == 7 and cfg.num_kv_heads == 2 and cfg.head_dim == 16
+
+
+def test_tensor_parallel_ranks_read_only_their_slices(tmp_path):
+    """Two ranks' shards of a checkpoint, concatenated, are the one-rank weights."""
+    from kvmini.models.llama import config_from_hf, load_hf_safetensors
+
+    path, _ = _save(tmp_path, "llama")
+    cfg = config_from_hf(path)
+    full = load_hf_safetensors(path, cfg, "cpu", torch.float32)
+    parts = [load_hf_safetensors(path, cfg, "cpu", torch.float32, tp_rank=r, tp_size=2) for r in range(2)]
+    hd, nh, nkv = cfg.head_dim, cfg.num_heads, cfg.num_kv_heads
+    for li in range(cfg.num_layers):
+        f = full.layers[li]
+        q = torch.cat([p.layers[li].wqkv[: nh // 2 * hd] for p in parts])
+        k = torch.cat([p.layers[li].wqkv[nh // 2 * hd : nh // 2 * hd + nkv // 2 * hd] for p in parts])
+        assert torch.equal(q, f.wqkv[: nh * hd]) and torch.equal(k, f.wqkv[nh * hd : nh * hd + nkv * hd])
+        assert torch.equal(torch.cat([p.layers[li].wo for p in parts], 1), f.wo)
+        assert torch.equal(torch.cat([p.layers[li].wdown for p in parts], 1), f.wdown)
+
+
+def test_server_takes_a_checkpoint_directory_with_its_tokenizer(tmp_path):
+    """`kvmini serve --model DIR`: architecture, weights and tokenizer.json all come from the directory."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+
+    path, _ = _save(tmp_path, "llama")
+    vocab = {f"w{i}": i for i in range(160)}
+    vocab["[UNK]"] = 0
+    tok = Tokenizer(models.WordLevel({**{k: v for k, v in vocab.items() if v != 0}, "[UNK]": 0}, unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.save(os.path.join(path, "tokenizer.json"))
+    from kvmini.server.native import NativeServer
+
+    eng = _engine(path)
+    ns = NativeServer(eng, "tiny-hf", os.path.join(path, "tokenizer.json"))
+    ids = ns.tok.encode("w5 w9 w33")
+    assert [i for i in ids if i in (5, 9, 33)] == [5, 9, 33]
+    assert json.load(open(os.path.join(path, "config.json")))["vocab_size"] == eng.mcfg.vocab_size
+
+
+@pytest.mark.gpu
+def test_hip_kernels_follow_transformers_on_a_checkpoint_directory(tmp_path):
+    """The same path on the GPU: bf16 weights through the HIP kernels (head width 128, grouped heads, HIP graphs)
+    against the library's fp32 forward pass on the host — the first tokens equal, the rest nearly so (bf16
+    rounding may flip a near-tie late in a random-weight model's sequence)."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+
+    path, hf = _save(tmp_path, "llama", vocab_size=1024, hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+                     rope_theta=500000.0, initializer_range=0.08)
+    eng = LLMEngine(EngineConfig(model=path, device="cuda:0", kernels="hip", max_model_len=512, max_num_seqs=4, max_batched_tokens=256, kv_memory_fraction=0.02))
+    eng.warmup()
+    prompts = [[1, 5, 9, 33, 77, 100, 4], [1] + [(7 * i) % 900 + 3 for i in range(150)]]
+    mine = eng.generate(prompts, SamplingParams(max_tokens=12, ignore_eos=True))
+    for p, got in zip(prompts, mine):
+        with torch.no_grad():
+            want = hf.generate(torch.tensor([p]), max_new_tokens=12, do_sample=False, pad_token_id=0)[0, len(p):].tolist()
+        agree = sum(a == b for a, b in zip(got, want))
+        assert got[:2] == want[:2] and agree >= 9, (got, want)
