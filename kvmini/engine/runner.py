@@ -328,11 +328,16 @@ class ModelRunner:
         raise ValueError(f"{t} tokens exceed max_batched_tokens={self.buckets[-1]}")
 
     # ------------------------------------------------------------------
+    # Widest token bucket that gets a decode-only graph (RoPE + KV write + attention in one launch instead of three).
+    # Wider buckets gain nothing from it — measured on MI355X, Llama-3-8B, per step with the limit at 64 / 256:
+    # batch 96: 5.39 / 5.36 ms, 128: 5.50 / 5.45, 192: 6.21 / 6.26, 256: 5.67 / 5.68 (one workgroup per token and
+    # kv head: from ~500 workgroups on the one launch takes as long as the three) — and cost start-up time.
+    DECODE_FUSED_MAX_ROWS = int(os.environ.get("KVMINI_DECODE_FUSED_MAX_ROWS", "64"))
     # contexts from this many tokens on take the split-KV variant of a decode-only step (when the
     # step's shape has one: few rows); below it the extra workgroups only cost launch time
     SPLIT_KV_MIN_CTX = 2048
     # steps that also carry prompt chunks: at most this many decode tokens, the longest context
-    # from DEC_SPLIT_MIN_CTX tokens on (such steps run without a graph)
+    # from DEC_SPLIT_MIN_CTX tokens on (such steps capture their graph on demand, see _variant_graph)
     DEC_SPLIT_ROWS = 16  # from ~64 consecutive decode rows on the per-token kernel fills the chip as well (measured equal)
     DEC_SPLIT_MIN_CTX = int(os.environ.get("KVMINI_DEC_SPLIT_MIN_CTX", "4096"))
     # Prompt chunks of 17 to ~512 tokens whose queries see at least this many keys go to the split form of the tile kernel
@@ -524,7 +529,7 @@ class ModelRunner:
         # decode-sized buckets also get the decode-only variant (fused RoPE + attention kernel)
         # (up to the bucket that holds max_num_seqs one-token rows: with 2 sequences that is still the 16-row bucket)
         dec_max = self.bucket_for(min(self.rcfg.max_num_seqs, self.tmax))
-        variants += [(b, 1) for b, _ in variants if b <= dec_max and b <= 64 and hasattr(self.ops, "rope_attention_fused")]
+        variants += [(b, 1) for b, _ in variants if b <= dec_max and b <= self.DECODE_FUSED_MAX_ROWS and hasattr(self.ops, "rope_attention_fused")]
         variants += [(b, 2) for b, k in variants if k == 1 and self.step_kind(b, True, self.rcfg.max_model_len) == 2]
         for b, dec in variants:
             key = (b, dec)

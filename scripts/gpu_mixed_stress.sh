@@ -1,14 +1,15 @@
 #!/bin/bash
 # Mixed traffic against one native server: greedy streaming, unseeded sampling, seeded sampling with
-# logprobs (forces the one-step-at-a-time path), long prompts — all at once, so the engine keeps
-# switching between launch-ahead and synchronous stepping.  Every request must succeed.
+# logprobs, long prompts, 5000-token prompts that hit the prefix cache (their short tails go to the
+# split-KV / split-tile attention forms, whose graphs are captured while other steps are in flight)
+# and guided JSON — all at once.  Every request must succeed.
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
 export PYTHONPATH="$R" KVMINI_CLUSTER_BACKEND=local DISABLE_IO_PROBE=1
 OUT="$R/gpurun_out/stress"
 rm -rf "$OUT"; mkdir -p "$OUT"
-python -m kvmini serve --port 8130 --service stress --model llama-3-8b --max-num-seqs 48 --no-register > "$OUT/server.log" 2>&1 &
+python -m kvmini serve --port 8130 --service stress --model llama-3-8b --max-num-seqs 48 --max-model-len 8192 --no-register > "$OUT/server.log" 2>&1 &
 PID=$!
 for _ in $(seq 1 600); do
   kill -0 $PID 2>/dev/null || { tail -20 "$OUT/server.log"; exit 1; }
@@ -21,12 +22,15 @@ timeout -k 10 200 $LT --requests 400 --concurrency 12 --max-tokens 48 --target-r
 timeout -k 10 200 $LT --requests 200 --concurrency 6 --max-tokens 40 --target-rps 1000 --temperature 0.9 --top-p 0.9 --top-k 40 --run-dir "$OUT/sampled" > "$OUT/sampled.log" 2>&1 & P2=$!
 timeout -k 10 200 $LT --requests 60 --concurrency 2 --max-tokens 24 --target-rps 5 --pattern poisson --no-stream --temperature 0.7 --extra-openai-json "$OUT/extra.json" --run-dir "$OUT/seeded" > "$OUT/seeded.log" 2>&1 & P3=$!
 timeout -k 10 200 $LT --requests 40 --concurrency 2 --max-tokens 16 --target-rps 4 --prompt-tokens 700 --run-dir "$OUT/long" > "$OUT/long.log" 2>&1 & P4=$!
+echo '{"response_format": {"type": "json_object"}}' > "$OUT/json.json"
+timeout -k 10 200 $LT --requests 40 --concurrency 2 --max-tokens 8 --target-rps 4 --prompt-tokens 5000 --run-dir "$OUT/deep" > "$OUT/deep.log" 2>&1 & P5=$!
+timeout -k 10 200 $LT --requests 60 --concurrency 3 --max-tokens 48 --target-rps 10 --no-stream --extra-openai-json "$OUT/json.json" --run-dir "$OUT/guided" > "$OUT/guided.log" 2>&1 & P6=$!
 rc=0
-for p in $P1 $P2 $P3 $P4; do wait $p || rc=1; done
+for p in $P1 $P2 $P3 $P4 $P5 $P6; do wait $p || rc=1; done
 python - "$OUT" <<'PY'
 import csv, sys, os
 bad = 0
-for name in ("greedy", "sampled", "seeded", "long"):
+for name in ("greedy", "sampled", "seeded", "long", "deep", "guided"):
     rows = list(csv.DictReader(open(os.path.join(sys.argv[1], name, "requests.csv"))))
     ok = sum(1 for r in rows if r["status"] == "200")
     lat = sorted(float(r["latency_ms"]) for r in rows if r["status"] == "200")
@@ -38,6 +42,6 @@ rc2=$?
 python -c "
 import json, urllib.request
 m = json.loads(urllib.request.urlopen('http://127.0.0.1:8130/info', timeout=5).read())['engine']
-print({k: m[k] for k in ('steps', 'pipelined_steps', 'running', 'waiting', 'preemptions', 'kv_blocks_free', 'kv_blocks_total')})"
+print({k: m[k] for k in ('steps', 'pipelined_steps', 'variant_graphs', 'variant_graph_steps', 'prefix_cache_hits', 'running', 'waiting', 'preemptions', 'kv_blocks_free', 'kv_blocks_total')})"
 kill $PID; wait $PID 2>/dev/null
 [ $rc -eq 0 ] && [ $rc2 -eq 0 ]
