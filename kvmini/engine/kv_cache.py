@@ -12,6 +12,7 @@ exactly this effect (TTFT of repeated vs unique prompts; reference
 
 from __future__ import annotations
 
+from array import array
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -28,6 +29,7 @@ class BlockManager:
         self._ref: List[int] = [0] * num_blocks
         self._hash_of: Dict[int, int] = {}  # block -> chain hash
         self._cached: Dict[int, int] = {}  # chain hash -> block
+        self._content: Dict[int, Tuple[int, bytes]] = {}  # block -> (parent key, its tokens): what a lookup is verified against
         self._lru: "OrderedDict[int, None]" = OrderedDict()  # unreferenced cached blocks
         self.prefix_queries = 0
         self.prefix_hits = 0
@@ -39,7 +41,28 @@ class BlockManager:
 
     @staticmethod
     def chain_hash(parent: int, tokens: Sequence[int]) -> int:
-        return hash((parent, tuple(tokens)))
+        """Key of a block in the hash table: (parent key, the block's tokens as bytes).  ``hash`` of a
+        bytes object is SipHash under the interpreter's per-process random key, so keys cannot be
+        predicted from outside; a key alone never serves a block — see ``_same``."""
+        return hash((parent, array("q", tokens).tobytes()))
+
+    def _chain(self, token_ids: Sequence[int], first: int, last: int, parent: int):
+        """(key, tokens as bytes) of blocks ``first .. last - 1`` of ``token_ids`` given the key of
+        block ``first - 1`` (0 before the first block): the ids become bytes once, every block is
+        one slice of them."""
+        bs8 = self.block_size * 8
+        buf = array("q", token_ids[first * self.block_size : last * self.block_size]).tobytes()
+        for i in range(last - first):
+            raw = buf[i * bs8 : (i + 1) * bs8]
+            key = hash((parent, raw))
+            yield key, parent, raw
+            parent = key
+
+    def _same(self, block: int, parent: int, raw: bytes) -> bool:
+        """A block found under a key is served to another request as that request's own KV, so the
+        key is only a lookup: the block must hold exactly these tokens behind exactly this parent
+        chain (compared, not hashed — by induction over the chain the whole prefix is equal)."""
+        return self._content.get(block) == (parent, raw)
 
     def _pop_block(self) -> Optional[int]:
         if self._free:
@@ -47,6 +70,7 @@ class BlockManager:
         if self._lru:
             blk, _ = self._lru.popitem(last=False)  # evict least-recently-used cached block
             h = self._hash_of.pop(blk, None)
+            self._content.pop(blk, None)
             if h is not None and self._cached.get(h) == blk:
                 del self._cached[h]
             return blk
@@ -75,6 +99,7 @@ class BlockManager:
                     self._lru[b] = None
                 else:
                     self._hash_of.pop(b, None)
+                    self._content.pop(b, None)
                     self._free.append(b)
 
     # prefix cache -------------------------------------------------------
@@ -89,16 +114,28 @@ class BlockManager:
         blocks: List[int] = []
         parent = 0
         max_full = (len(token_ids) - 1) // bs
-        for i in range(max_full):
-            h = self.chain_hash(parent, token_ids[i * bs : (i + 1) * bs])
-            b = self._cached.get(h)
-            if b is None:
+        # (the loop of a 100k-token prompt runs 6000+ times per request: everything in locals, no calls; the ids become
+        # bytes 512 blocks at a time, so a prompt that misses early does not pay for the conversion of all of it)
+        bs8, step = bs * 8, 512
+        cached, content, ref, lru = self._cached, self._content, self._ref, self._lru
+        done = False
+        for i0 in range(0, max_full, step):
+            n = min(step, max_full - i0)
+            buf = array("q", token_ids[i0 * bs : (i0 + n) * bs]).tobytes()
+            for i in range(n):
+                raw = buf[i * bs8 : (i + 1) * bs8]
+                h = hash((parent, raw))
+                b = cached.get(h)
+                if b is None or content.get(b) != (parent, raw):  # the key finds, the content decides (see _same)
+                    done = True
+                    break
+                if ref[b] == 0:
+                    lru.pop(b, None)
+                ref[b] += 1
+                blocks.append(b)
+                parent = h
+            if done:
                 break
-            if self._ref[b] == 0:
-                self._lru.pop(b, None)
-            self._ref[b] += 1
-            blocks.append(b)
-            parent = h
         if blocks:
             self.prefix_hits += 1
         return blocks, len(blocks) * bs
@@ -117,15 +154,14 @@ class BlockManager:
         parent = self._hash_of.get(blocks[already - 1]) if already > 0 else 0
         if parent is None:
             parent = 0
-            for i in range(already):
-                parent = self.chain_hash(parent, token_ids[i * bs : (i + 1) * bs])
-        for i in range(already, n_full):
-            h = self.chain_hash(parent, token_ids[i * bs : (i + 1) * bs])
+            for parent, _p, _r in self._chain(token_ids, 0, already, 0):
+                pass
+        for i, (h, par, raw) in enumerate(self._chain(token_ids, already, n_full, parent), already):
             b = blocks[i]
             if h not in self._cached:
                 self._cached[h] = b
                 self._hash_of[b] = h
-            parent = h
+                self._content[b] = (par, raw)
         return n_full
 
     def reset_prefix_cache(self) -> None:
@@ -134,3 +170,4 @@ class BlockManager:
         self._lru.clear()
         self._cached.clear()
         self._hash_of.clear()
+        self._content.clear()

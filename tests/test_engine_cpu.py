@@ -799,3 +799,37 @@ def test_speculative_decoding_with_temperature_uses_rejection_sampling():
         mixed.step()
     plain = LLMEngine(EngineConfig(**common)).generate([prompts[0]], SamplingParams(max_tokens=10, ignore_eos=True))[0]
     assert seqs[0].output_ids == plain and len(seqs[1].output_ids) == 10
+
+
+def test_prefix_cache_serves_a_block_only_for_equal_tokens_behind_an_equal_chain():
+    """The hash key is a lookup, not a proof: a block is re-used only when its stored tokens and parent chain
+    equal the request's (a forged or accidental key collision is a miss), chains registered in pieces continue,
+    and an evicted block's content record goes with it."""
+    from kvmini.engine.kv_cache import BlockManager
+
+    bm = BlockManager(64, 16)
+    a = list(range(100, 132))
+    blk = bm.allocate(2)
+    assert bm.register_full_blocks(a, blk, 32, 0) == 2
+    other = list(range(500, 532))
+    bm._cached[bm.chain_hash(0, other[:16])] = blk[0]  # as if the keys of two different blocks collided
+    got, n = bm.match_prefix(other + [1])
+    assert (got, n) == ([], 0)
+    # same second block behind a different first block: the parent chain differs, no hit beyond what is equal
+    mixed = other[:16] + a[16:]
+    assert bm.match_prefix(mixed + [1]) == ([], 0)
+    got, n = bm.match_prefix(a + [1])
+    assert n == 32 and got == blk
+    bm.free(got)
+    # registered in two pieces, found as one chain
+    bm2 = BlockManager(64, 16)
+    bl, t4 = bm2.allocate(4), list(range(64))
+    n1 = bm2.register_full_blocks(t4, bl, 32, 0)
+    assert bm2.register_full_blocks(t4, bl, 64, n1) == 4
+    got, n = bm2.match_prefix(t4 + [9])
+    assert n == 64 and got == bl
+    bm2.free(got)
+    bm2.free(bl)
+    assert len(bm2._content) == 4
+    taken = bm2.allocate(63)  # evicts every cached block
+    assert taken is not None and not bm2._content and not bm2._cached
