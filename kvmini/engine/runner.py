@@ -567,7 +567,7 @@ class ModelRunner:
             return None
         seen = self._variant_seen.get(key, 0)
         self._variant_seen[key] = seen + 1
-        if seen == 0 or sum(1 for k in self.graphs if len(k) > 2) >= self.variant_graphs_max:
+        if seen == 0 or seen < 0 or sum(1 for k in self.graphs if len(k) > 2) >= self.variant_graphs_max:
             return None
         import gc
 
@@ -578,6 +578,10 @@ class ModelRunner:
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
                 logits = self.forward(t_pad, decode_only=0, quads=quads, dec_split=dec_split, pf_split=pf_split)
+        except Exception as e:  # noqa: BLE001 - a shape that does not capture keeps running eagerly; the serving loop must not die over it
+            self._variant_seen[key] = -(1 << 30)  # never tried again
+            print(f"[runner] no graph for step shape {key}: {type(e).__name__}: {e}", flush=True)
+            return None
         finally:
             if gc_was_enabled:
                 gc.enable()
