@@ -313,8 +313,24 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
   constexpr int XF = KS * MT;
   constexpr int XL = (XF + NW - 1) / NW;  // x fragments of a chunk per wave
   constexpr int PD = NB - 1;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * XF * 1024];
-  frag_ab* xs = reinterpret_cast<frag_ab*>(lds_raw);  // [2][XF][64]
+  // XCO (48 .. 128 token rows): the x chunk is fetched in whole 256-byte row segments — a wave-level load covers four
+  // consecutive rows x 128 columns, two full cache lines per row — instead of one 64-byte piece of 16 different rows
+  // per 16 lanes (the B-fragment order), and the pieces are scattered into fragment order on the way into LDS.
+  // Measured on MI355X (gate/up projection, weights rotated): the time of this kernel follows the bytes that pass
+  // the CUs' vector-memory path, x included (32 / 64 / 128 rows: 38.5 / 45.0 / 69.5 us = 7.2 - 8.2 TB/s of weights +
+  // x whatever the split between them), and x in 64-byte pieces costs far more than its bytes: with wave-linear x
+  // loads 64 rows take 39.7 us and 128 rows 57.0.  At 32 rows x does not show (39.1 either way): the old order stays.
+  // LDS image: 16-byte slot of (k-step ks, row tile j, lane quarter q, row r) = ks * KSS + j * 64 + q * 16 + (r ^ q),
+  // KSS = 64 MT + 4.  Reads (ds_read_b128: four groups of 16 lanes, e.g. q = 0 with r in {0-3, 12-15} and q = 1 with
+  // r in {4-11}; banks by slot modulo 16): r ^ q only permutes rows inside aligned groups of four, so every group
+  // still covers 16 different slots.  Writes (ds_write_b128: groups of 8 contiguous lanes, slot modulo 8): the 8
+  // lanes are the pieces (ks, q) of ONE row for two values of ks — r ^ q gives four different slots inside one
+  // half of the bank row, and the + 4 per k-step puts the second k-step into the other half.
+  constexpr bool XCO = MT >= 3 && MT <= 8 && KS == 4;
+  constexpr int FSZ = 64, KSS = MT * FSZ + 4;                 // slots per fragment / per k-step
+  constexpr int XBUF = XCO ? KS * KSS : XF * 64;              // slots per buffer
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * XBUF * 16];
+  frag_ab* xs = reinterpret_cast<frag_ab*>(lds_raw);  // [2][XF][64] (XCO: [2][KS][KSS])
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int ksteps = K >> 5;
@@ -329,12 +345,22 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
   unsigned int sc[NB][FT][W4 ? AL : 1];
 
   const __bf16* xsrc[XL];
+  int xdst[XL];  // slot of the load's 16 bytes inside a buffer
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
     const int f = wave + NW * i;
-    const int ks = (f < XF ? f : 0) / MT, j = (f < XF ? f : 0) % MT;
-    xsrc[i] = x + (long long)(j * 16 + r) * ldx + ks * 32 + q * 8;
+    if constexpr (XCO) {
+      const int g = (f < XF ? f : 0) * 64 + lane;  // piece g of the chunk: row g / 16, 16-byte piece g % 16 of its 128 columns
+      const int row = g >> 4, piece = g & 15;
+      xsrc[i] = x + (long long)row * ldx + piece * 8;
+      xdst[i] = (piece >> 2) * KSS + (row >> 4) * FSZ + (piece & 3) * 16 + ((row & 15) ^ (piece & 3));
+    } else {
+      const int ks = (f < XF ? f : 0) / MT, j = (f < XF ? f : 0) % MT;
+      xsrc[i] = x + (long long)(j * 16 + r) * ldx + ks * 32 + q * 8;
+      xdst[i] = (f < XF ? f : 0) * 64 + lane;
+    }
   }
+  const int xrd = XCO ? q * 16 + (r ^ q) : lane;  // a lane's slot inside a fragment
 
   frag_cd acc[FT][MT];
 #pragma unroll
@@ -361,11 +387,11 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
   do {                                                                                                          \
     const int buf = (chunk) & 1;                                                                                \
     _Pragma("unroll") for (int i = 0; i < XL; ++i) if (wave + NW * i < XF)                                      \
-        xs[(buf * XF + wave + NW * i) * 64 + lane] = xr[slot][i];                                               \
+        xs[buf * XBUF + xdst[i]] = xr[slot][i];                                                                 \
     __syncthreads();                                                                                            \
     _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                            \
       frag_ab b[MT];                                                                                            \
-      _Pragma("unroll") for (int j = 0; j < MT; ++j) b[j] = xs[(buf * XF + u * MT + j) * 64 + lane];            \
+      _Pragma("unroll") for (int j = 0; j < MT; ++j) b[j] = xs[buf * XBUF + (XCO ? u * KSS + j * FSZ : (u * MT + j) * 64) + xrd]; \
       _Pragma("unroll") for (int f = 0; f < FT; ++f) {                                                          \
         frag_ab af;                                                                                             \
         if constexpr (W4) af = a_frag4(a[slot][f][u >> 2], sc[slot][f][u >> 2], u & 3);                         \
