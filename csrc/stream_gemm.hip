@@ -859,7 +859,7 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
   // weight_bits: 16, 8 (w_scale = fp32 per-row scales), 4 (MXFP4; w_scale = packed E8M0 block scales) or 0 = 8 if w_scale else 16
   const int wb = weight_bits ? weight_bits : (w_scale != nullptr ? 8 : 16);
   if ((wb != 16 && wb != 8 && wb != 4) || ((wb != 16) != (w_scale != nullptr))) return -1;
-  const bool wide = M == 128 || M == 256;  // 8 / 16 row tiles per wave: 2-chunk groups only (registers)
+  const bool wide = M == 96 || M == 128 || M == 256;  // 6 / 8 / 16 row tiles per wave: 2-chunk groups only (registers)
   const int chunk_cols = 32 * chunk_ksteps(M >> 4, wb);
   if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw * ft)) || (nb != 2 && nb != 4 && nb != 8) || (K % (chunk_cols * nb))) return -1;
   if (wide && nb != 2) return -1;
@@ -887,6 +887,7 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
     case 2: return dispatch3_wb<2>(epi, nb, nw, wb, a);
     case 3: return dispatch3_wb<3>(epi, nb, nw, wb, a);
     case 4: return dispatch3_wb<4>(epi, nb, nw, wb, a);
+    case 6: return dispatch3_wide_wb<6>(epi, nw, wb, a);
     case 8: return dispatch3_wide_wb<8>(epi, nw, wb, a);
     case 16: return wb == 4 ? -1 : (wb == 8 ? dispatch3_wide<16, 8>(epi, nw, a) : dispatch3_wide<16, 16>(epi, nw, a));  // (256-row tiles are not built for MXFP4: callers use 128-row passes)
   }

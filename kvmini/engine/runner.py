@@ -36,7 +36,7 @@ from .scheduler import PLACEHOLDER, Batch
 # Token buckets a step is padded to (one captured graph each).  From 128 rows on they grow by a quarter to
 # a half, which keeps the padding of a prompt step small: a 1100-token prompt runs as 1280 rows instead of
 # 2048 (first token 27.9 -> 21.6 ms on Llama-3-8B), a 600-token one as 640 instead of 1024 (15.9 -> 13.2 ms).
-DEFAULT_BUCKETS = (16, 32, 48, 64, 128, 192, 256, 320, 384, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048)
+DEFAULT_BUCKETS = (16, 32, 48, 64, 96, 128, 192, 256, 320, 384, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048)
 
 
 @dataclass

@@ -441,7 +441,7 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
         # 65..128 tokens (a handful of short prompts next to the running decodes): still one pass
         # over the weights, 8 row tiles per wave.  (The 16-tile / 256-row variant remains for
         # K that is not a multiple of 64, which the tiled kernel does not take.)
-        mw = 128 if m <= 128 else 256
+        mw = 96 if m <= 96 else 128 if m <= 128 else 256  # (96: six row tiles per wave, for the 96-token bucket)
         if x.shape[0] != mw:
             xw = torch.zeros((mw, x.shape[1]), dtype=x.dtype, device=x.device)
             xw[:m] = x[:m]

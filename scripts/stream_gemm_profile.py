@@ -13,7 +13,7 @@ import torch
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", type=int, default=64)
+    ap.add_argument("--rows", type=int, default=64, help="16, 32, 48, 64, 96, 128 or 256")
     ap.add_argument("--n", type=int, default=28672)
     ap.add_argument("--k", type=int, default=4096)
     ap.add_argument("--epi", type=int, default=2)

@@ -301,7 +301,7 @@ def test_engine_with_weight_prefetch_generates_the_same_tokens(graphs):
 
 
 # ---- weight-streaming GEMM v2 ---------------------------------------------------------
-@pytest.mark.parametrize("M", [16, 32, 48, 64, 20, 100])
+@pytest.mark.parametrize("M", [16, 32, 48, 64, 20, 100, 70, 96])
 @pytest.mark.parametrize("N,K", [(256, 128), (4096, 4096), (6144, 4096), (4096, 14336), (1000, 512)])
 def test_stream_gemm_bf16_and_slabs(M, N, K):
     from kvmini.ops import hip_ops
@@ -421,7 +421,7 @@ def test_folded_norm_pipeline_matches_reference():
 
 
 # ---- FP8 (OCP e4m3) weight-only path of the streaming GEMM ---------------------------
-@pytest.mark.parametrize("M", [16, 32, 64, 20, 100])
+@pytest.mark.parametrize("M", [16, 32, 64, 20, 100, 96])
 @pytest.mark.parametrize("N,K", [(256, 128), (4096, 4096), (6144, 4096), (4096, 14336), (1000, 512)])
 def test_stream_gemm_fp8_weights(M, N, K):
     """y = x @ dequant(W_fp8)^T: the kernel must match a plain fp32 matmul against the
@@ -1056,10 +1056,10 @@ def test_scale_rows_matches_reference(C):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [128, 256])
+@pytest.mark.parametrize("M", [96, 128, 256])
 @pytest.mark.parametrize("nw", [4, 7, 8])
 def test_stream_gemm3_wide_rows(C, M, nw):
-    """128 / 256 token rows in one pass over the weights (8 / 16 row tiles per wave)."""
+    """96 / 128 / 256 token rows in one pass over the weights (6 / 8 / 16 row tiles per wave)."""
     from kvmini.models.llama import interleave_gate_up
     from kvmini.ops import torch_ops
 
