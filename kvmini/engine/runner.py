@@ -397,7 +397,7 @@ class ModelRunner:
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             kw = {"kv_scale": self.kv_scale[li]} if self.kv_fp8 else {}
-            if decode_only and self._fused_ok(qkv, kc):
+            if decode_only and t_pad <= self.DECODE_FUSED_MAX_ROWS and self._fused_ok(qkv, kc):
                 if side is not None:
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
@@ -529,7 +529,9 @@ class ModelRunner:
         # decode-sized buckets also get the decode-only variant (fused RoPE + attention kernel)
         # (up to the bucket that holds max_num_seqs one-token rows: with 2 sequences that is still the 16-row bucket)
         dec_max = self.bucket_for(min(self.rcfg.max_num_seqs, self.tmax))
-        variants += [(b, 1) for b, _ in variants if b <= dec_max and b <= self.DECODE_FUSED_MAX_ROWS and hasattr(self.ops, "rope_attention_fused")]
+        # (wider decode-only buckets, up to 256 rows, get the variant too: RoPE + KV write and the per-token attention
+        # kernel without the launch of the prompt-tile kernel that the general graph carries — 5.3 us per layer)
+        variants += [(b, 1) for b, _ in variants if b <= dec_max and b <= max(self.DECODE_FUSED_MAX_ROWS, 256) and hasattr(self.ops, "rope_attention_fused")]
         variants += [(b, 2) for b, k in variants if k == 1 and self.step_kind(b, True, self.rcfg.max_model_len) == 2]
         for b, dec in variants:
             key = (b, dec)

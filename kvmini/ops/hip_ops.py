@@ -307,6 +307,7 @@ _WIDE_TILES_FP8A = (((256, 128, 0), 0.92, 7.4), ((128, 256, 0), 0.92, 8.8), ((12
 # block-scaled matrix instruction (twice the bf16 MFMA rate); "0" keeps bf16 activations (the weights
 # are then widened to bf16 in registers).
 FP8_ACTIVATIONS = os.environ.get("KVMINI_FP8_ACT", "1") == "1"
+TILED_GATE_UP_128 = os.environ.get("KVMINI_TILED_GATE_UP_128", "0") == "1"
 _WIDE_ROUND_SLOPE = {(256, 128): 0.025, (128, 256): 0.025}
 _WIDE_STAGE_KSTEPS = {1: 1, 3: 1}  # pipeline variants with 32-wide stages (kv_wide_gemm_stage_ksteps)
 
@@ -405,6 +406,11 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
         return _stream_fp4(w, h, epi, allow_slabs)
     if rows > STREAM_MAX_M and w.k % 64 == 0:
         return _wide(w, h, epi, allow_slabs)
+    if 96 < rows <= STREAM_MAX_M and epi == 2 and w.bits == 16 and w.k % 64 == 0 and w.n_pad % 128 == 0 and TILED_GATE_UP_128:
+        # the gate/up projection at 97-128 rows on the tiled kernel's 128 x 128 tile (both operands by LDS-DMA).  OFF by
+        # default: measured on MI355X it wins alone (28672 x 4096 with rotated weights: 53.9 against 61.6 us for the
+        # streaming kernel's eight row tiles per wave) and loses inside the decode step at batch 128 (5.13 against 4.94 ms)
+        return _wide(w, h, epi, False)
     C = native()
     ss, eps = (h.ss, h.eps) if isinstance(h, Normed) else (None, 0.0)
     x, m = _pad_rows(h.x if isinstance(h, Normed) else h)
