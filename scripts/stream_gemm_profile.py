@@ -22,7 +22,6 @@ def main():
     ap.add_argument("--ft", type=int, default=1)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--time", action="store_true")
-    ap.add_argument("--eps", type=float, default=0.0)
     a = ap.parse_args()
     from kvmini.ops import hip_ops, native
 
@@ -36,7 +35,7 @@ def main():
 
     def run(i):
         w = Ws[i % copies]
-        C.stream_gemm3(w.wp, a.n, a.k, x, y, a.epi, a.nb, 1, gps, None, a.eps, w.wscale, a.nw, 0, ft=a.ft)
+        C.stream_gemm3(w.wp, a.n, a.k, x, y, a.epi, a.nb, 1, gps, None, 0.0, w.wscale, a.nw, 0, ft=a.ft)
 
     for i in range(a.iters):
         run(i)
