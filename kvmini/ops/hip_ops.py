@@ -307,6 +307,14 @@ _WIDE_TILES_FP8A = (((256, 128, 0), 0.92, 7.4), ((128, 256, 0), 0.92, 8.8), ((12
 # block-scaled matrix instruction (twice the bf16 MFMA rate); "0" keeps bf16 activations (the weights
 # are then widened to bf16 in registers).
 FP8_ACTIVATIONS = os.environ.get("KVMINI_FP8_ACT", "1") == "1"
+# Quantised weights (FP8, MXFP4) with FP8 activations: rows from which a step's projections run on the tiled
+# scaled-MFMA kernel instead of the streaming kernel (which widens the weights to bf16 in registers and, from ~64
+# rows on, is bound by the x operand rather than by the weight bytes: the quantised formats gain nothing there).
+# Measured on MI355X, Llama-3-8B decode step at batch 64 / 96 / 128, streaming -> tiled: FP8 3.30 -> 3.90, 4.05 ->
+# 4.28, 4.60 -> 4.57 ms (stays on the streaming kernel up to 128 rows); MXFP4 3.37 -> 3.62, 4.88 (128-row pass) ->
+# 3.98, 4.88 -> 4.29 ms (tiled from 65 rows on).
+QUANT_WIDE_FROM = int(os.environ.get("KVMINI_QUANT_WIDE_FROM", "129"))
+QUANT_WIDE_FROM_FP4 = int(os.environ.get("KVMINI_QUANT_WIDE_FROM_FP4", "65"))
 TILED_GATE_UP_128 = os.environ.get("KVMINI_TILED_GATE_UP_128", "0") == "1"
 _WIDE_ROUND_SLOPE = {(256, 128): 0.025, (128, 256): 0.025}
 _WIDE_STAGE_KSTEPS = {1: 1, 3: 1}  # pipeline variants with 32-wide stages (kv_wide_gemm_stage_ksteps)
@@ -406,6 +414,8 @@ def _stream(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow_sla
         return _stream_fp4(w, h, epi, allow_slabs)
     if rows > STREAM_MAX_M and w.k % 64 == 0:
         return _wide(w, h, epi, allow_slabs)
+    if rows >= QUANT_WIDE_FROM and w.bits == 8 and FP8_ACTIVATIONS and w.k % 128 == 0:
+        return _wide(w, h, epi, allow_slabs)  # FP8 weights: the scaled-MFMA tiled kernel from this many rows on (see QUANT_WIDE_FROM)
     if 96 < rows <= STREAM_MAX_M and epi == 2 and w.bits == 16 and w.k % 64 == 0 and w.n_pad % 128 == 0 and TILED_GATE_UP_128:
         # the gate/up projection at 97-128 rows on the tiled kernel's 128 x 128 tile (both operands by LDS-DMA).  OFF by
         # default: measured on MI355X it wins alone (28672 x 4096 with rotated weights: 53.9 against 61.6 us for the
@@ -521,7 +531,7 @@ def _stream_fp4(w: PackedLinear, h: Union[torch.Tensor, Normed], epi: int, allow
     m = x.shape[0]
     n_out = w.n_pad // 2 if epi == 2 else w.n_pad
     n_true = w.n // 2 if epi == 2 else w.n
-    if m > 128 and FP8_ACTIVATIONS and w.k % 128 == 0 and w.n_pad % 128 == 0:
+    if m >= min(129, QUANT_WIDE_FROM_FP4) and FP8_ACTIVATIONS and w.k % 128 == 0 and w.n_pad % 128 == 0:
         # the tiled kernel reads the MXFP4 weights themselves: FP4 operand + hardware block scales on the scaled
         # MFMA against per-token FP8 activations (no expansion pass, no scratch buffer, any matrix size)
         x8, a_scale = C.quantize_rows_fp8(x, False)

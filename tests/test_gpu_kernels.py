@@ -1895,8 +1895,8 @@ def test_stream_gemm_mxfp4_weights(M, N, K):
     x = torch.randn(M, K, device=_dev()).bfloat16()
     codes, scales = quantize_mxfp4(W)
     Wdq = dequantize_mxfp4(codes, scales, torch.float32)
-    # (more than 128 rows with a width the tiled kernel takes: MXFP4 x FP8 on the scaled MFMA — the activations are e4m3 there)
-    wide = M > 128 and K % 128 == 0 and ((N + 63) // 64 * 64) % 128 == 0
+    # (more than 64 rows with a width the tiled kernel takes: MXFP4 x FP8 on the scaled MFMA — the activations are e4m3 there)
+    wide = M > 64 and K % 128 == 0 and ((N + 63) // 64 * 64) % 128 == 0
     ref = (_fp8_rows(x) if wide else x.float()) @ Wdq.T
     tol = 1e-2 * ref.abs().max().item() + 1e-2
     pw = hip_ops.PackedLinear(W, mxfp4=True)
@@ -2006,7 +2006,7 @@ def test_mxfp4_expansion_is_the_packed_bf16_weight_bit_for_bit(C):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [16, 48, 200])
+@pytest.mark.parametrize("M", [16, 48, 96, 200])
 def test_stream_gemm_mxfp4_swiglu_and_folded_norm(M):
     from kvmini.models.llama import GU_GROUP, dequantize_mxfp4, quantize_mxfp4
     from kvmini.ops import hip_ops, torch_ops
@@ -2017,7 +2017,7 @@ def test_stream_gemm_mxfp4_swiglu_and_folded_norm(M):
     x = torch.randn(M, K, device=_dev()).bfloat16()
     Wdq = dequantize_mxfp4(*quantize_mxfp4(W), torch.float32)
     pw = hip_ops.PackedLinear(W, mxfp4=True)
-    xr = _fp8_rows(x) if M > 128 else x.float()  # wide steps: e4m3 activations on the scaled MFMA
+    xr = _fp8_rows(x) if M > 64 else x.float()  # steps of more than 64 rows: e4m3 activations on the scaled MFMA
     ref = torch_ops.swiglu_interleaved((xr @ Wdq.T))
     y = hip_ops.linear_swiglu(x, pw)
     assert y.shape == (M, I)
