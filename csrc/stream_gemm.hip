@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
   // still covers 16 different slots.  Writes (ds_write_b128: groups of 8 contiguous lanes, slot modulo 8): the 8
   // lanes are the pieces (ks, q) of ONE row for two values of ks — r ^ q gives four different slots inside one
   // half of the bank row, and the + 4 per k-step puts the second k-step into the other half.
-  constexpr bool XCO = MT >= 3 && MT <= 8 && KS == 4;
+  constexpr bool XCO = MT >= (WB == 16 ? 3 : 2) && MT <= 8 && KS == 4;  // (32 rows: only where the weight bytes are few — FP8 2.49 -> 2.42 ms per decode step, MXFP4 2.22 -> 2.19; bf16 3.33 either way)
   constexpr int FSZ = 64, KSS = MT * FSZ + 4;                 // slots per fragment / per k-step
   constexpr int XBUF = XCO ? KS * KSS : XF * 64;              // slots per buffer
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * XBUF * 16];
