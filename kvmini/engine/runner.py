@@ -395,6 +395,8 @@ class ModelRunner:
             if h is None:
                 h, residual = self._add_rmsnorm(x, residual, lw.attn_norm, pending_reduce, **pf(lw.wqkv, "qkv"))
             qkv = ops.linear(h, lw.wqkv, allow_slabs=True)
+            if lw.bqkv is not None:
+                qkv = ops.add_bias(qkv, lw.bqkv)
             kc, vc = self.kv_cache[li, 0], self.kv_cache[li, 1]
             kw = {"kv_scale": self.kv_scale[li]} if self.kv_fp8 else {}
             if decode_only and t_pad <= self.DECODE_FUSED_MAX_ROWS and self._fused_ok(qkv, kc):

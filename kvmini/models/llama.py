@@ -53,6 +53,7 @@ class LlamaConfig:
     # original_max_position); None = plain rotary frequencies
     rope_scaling: Optional["tuple[float, float, float, int]"] = None
     tie_word_embeddings: bool = False
+    qkv_bias: bool = False  # Qwen2 form: the Q / K / V projections carry a bias (no other projection does)
 
     @property
     def softmax_scale(self) -> float:
@@ -78,8 +79,10 @@ PRESETS: Dict[str, LlamaConfig] = {
     # test-sized
     "tiny": LlamaConfig(),
     "tiny-draft": LlamaConfig(name="tiny-draft", num_layers=1),
+    "tiny-qkv-bias": LlamaConfig(name="tiny-qkv-bias", qkv_bias=True),
     # smallest shape that exercises every HIP kernel specialisation (head_dim 128)
     "small-hd128": LlamaConfig("small-hd128", 1024, 256, 512, 2, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
+    "small-hd128-qkv-bias": LlamaConfig("small-hd128-qkv-bias", 1024, 256, 512, 2, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2, qkv_bias=True),
     "small-hd128-draft": LlamaConfig("small-hd128-draft", 1024, 256, 512, 1, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
     # smallest shape the persistent decode-layers kernel serves (head groups of 4, K multiples of 256)
     "mid-hd128": LlamaConfig("mid-hd128", 1024, 1024, 2048, 3, 8, 2, 128, 500000.0, 1e-5, 4096, 1, 2),
@@ -96,6 +99,9 @@ PRESETS: Dict[str, LlamaConfig] = {
     "llama-2-13b": LlamaConfig("llama-2-13b", 32000, 5120, 13824, 40, 40, 40, 128, 10000.0, 1e-5, 4096, 1, 2),
     "codellama-7b": LlamaConfig("codellama-7b", 32016, 4096, 11008, 32, 32, 32, 128, 1000000.0, 1e-5, 16384, 1, 2),
     "mistral-7b": LlamaConfig("mistral-7b", 32000, 4096, 14336, 32, 32, 8, 128, 10000.0, 1e-5, 32768, 1, 2),
+    # Qwen2 / Qwen2.5: the Llama form plus a bias on the Q / K / V projections
+    "qwen2.5-7b": LlamaConfig("qwen2.5-7b", 152064, 3584, 18944, 28, 28, 4, 128, 1000000.0, 1e-6, 32768, 151643, 151645, qkv_bias=True),
+    "qwen2.5-0.5b": LlamaConfig("qwen2.5-0.5b", 151936, 896, 4864, 24, 14, 2, 64, 1000000.0, 1e-6, 32768, 151643, 151645, tie_word_embeddings=True, qkv_bias=True),
     # a 2.7B dense decoder in Llama form (stand-in shape for the phi-2 engine profile)
     "phi-2.7b": LlamaConfig("phi-2.7b", 51200, 2560, 10240, 32, 32, 32, 80, 10000.0, 1e-5, 2048, 1, 2),
 }
@@ -147,6 +153,7 @@ class LayerWeights:
     mlp_norm: torch.Tensor
     wgu: torch.Tensor
     wdown: torch.Tensor
+    bqkv: Optional[torch.Tensor] = None  # [(nh + 2 nkv) * hd] bias of the fused Q / K / V projection (Qwen2 form), else None
     # optional fp8 (e4m3) copies + per-output-row scales for the quantised GEMM path
     fp8: Dict[str, Any] = field(default_factory=dict)
 
@@ -231,6 +238,8 @@ def random_weights(
                 mlp_norm=torch.ones(h, device=dev, dtype=dtype),
                 wgu=interleave_gate_up(wg, wu).contiguous(),
                 wdown=wd,
+                bqkv=(torch.cat((shard_rows(rnd(cfg.q_size, 1), nh_l * hd), shard_rows(rnd(cfg.kv_size, 1), nkv_l * hd), shard_rows(rnd(cfg.kv_size, 1), nkv_l * hd))).view(-1).contiguous()
+                      if cfg.qkv_bias else None),
             )
         )
         del wq, wk, wv, wg, wu
@@ -241,11 +250,11 @@ def random_weights(
 
 def config_from_hf(config: "str | Dict[str, Any]", name: Optional[str] = None) -> LlamaConfig:
     """The architecture of a Hugging Face checkpoint from its ``config.json`` (a path to the file or
-    its directory, or the parsed document): any decoder of the Llama form — ``model_type`` llama or
-    mistral; grouped-query attention, SwiGLU, RMSNorm, rotary positions (plain or "llama3" scaled),
+    its directory, or the parsed document): any decoder of the Llama form — ``model_type`` llama,
+    mistral or qwen2 (Q / K / V bias); grouped-query attention, SwiGLU, RMSNorm, rotary positions (plain or "llama3" scaled),
     tied or separate output embeddings, an explicit ``head_dim``.  What the engine has no kernels for
-    is refused here rather than loaded wrongly: projection biases (Qwen2), other rotary scalings
-    (linear / dynamic / yarn), mixture-of-experts layers.  A sliding attention window (Mistral-7B
+    is refused here rather than loaded wrongly: projection biases other than Qwen2's Q / K / V bias,
+    other rotary scalings (linear / dynamic / yarn), mixture-of-experts layers.  A sliding attention window (Mistral-7B
     v0.1: 4096) is honoured by limiting the context to the window, inside which it changes nothing."""
     import json
     import os
@@ -259,10 +268,12 @@ def config_from_hf(config: "str | Dict[str, Any]", name: Optional[str] = None) -
     else:
         hf = dict(config)
     mt = hf.get("model_type", "llama")
-    if mt not in ("llama", "mistral"):
-        raise ValueError(f"model_type {mt!r} is not a Llama-form decoder this engine serves (llama, mistral)")
+    if mt not in ("llama", "mistral", "qwen2"):
+        raise ValueError(f"model_type {mt!r} is not a Llama-form decoder this engine serves (llama, mistral, qwen2)")
     if hf.get("attention_bias") or hf.get("mlp_bias"):
-        raise ValueError("projection biases (attention_bias / mlp_bias) are not supported")
+        raise ValueError("projection biases beyond Qwen2's Q / K / V bias (attention_bias / mlp_bias) are not supported")
+    if mt == "qwen2" and hf.get("use_sliding_window"):
+        raise ValueError("Qwen2 checkpoints with use_sliding_window are not supported")
     if hf.get("hidden_act", "silu") not in ("silu", "swish"):
         raise ValueError(f"hidden_act {hf.get('hidden_act')!r} is not supported (SwiGLU only)")
     if hf.get("num_local_experts") or hf.get("num_experts"):
@@ -277,7 +288,7 @@ def config_from_hf(config: "str | Dict[str, Any]", name: Optional[str] = None) -
             raise ValueError(f"rope_scaling type {kind!r} is not supported (llama3 only)")
         scaling = (float(rs.get("factor", 1.0)), float(rs.get("low_freq_factor", 1.0)), float(rs.get("high_freq_factor", 4.0)), int(rs.get("original_max_position_embeddings", 8192)))
     max_pos = int(hf.get("max_position_embeddings", 8192))
-    window = hf.get("sliding_window")
+    window = hf.get("sliding_window") if mt != "qwen2" else None  # (Qwen2 carries the field but leaves it off: use_sliding_window false)
     if window and int(window) < max_pos:
         max_pos = int(window)
     rope_theta = hf.get("rope_theta", (rs or {}).get("rope_theta"))
@@ -303,6 +314,7 @@ def config_from_hf(config: "str | Dict[str, Any]", name: Optional[str] = None) -
         eos_token_id=first(hf.get("eos_token_id"), 2),
         rope_scaling=scaling,
         tie_word_embeddings=bool(hf.get("tie_word_embeddings", False)),
+        qkv_bias=mt == "qwen2",
     )
 
 
@@ -370,15 +382,25 @@ def load_hf_safetensors(path: str, cfg: LlamaConfig, device: torch.device | str 
     def whole(name: str) -> torch.Tensor:
         return need(name).get_tensor(name).to(dtype)
 
-    if any(k.endswith("self_attn.q_proj.bias") for k in where):
-        raise ValueError(f"{path}: the checkpoint has projection biases, which this engine does not apply")
+    has_bias = any(k.endswith("self_attn.q_proj.bias") for k in where)
+    if has_bias != cfg.qkv_bias:
+        raise ValueError(f"{path}: the checkpoint {'has' if has_bias else 'lacks'} Q / K / V biases but the architecture {cfg.name!r} says otherwise")
+    if any(k.endswith("self_attn.o_proj.bias") or k.endswith("mlp.down_proj.bias") for k in where):
+        raise ValueError(f"{path}: biases on the output / MLP projections are not supported")
+
+    def vec(name: str, n: int) -> torch.Tensor:  # this rank's n entries of a bias
+        return need(name).get_slice(name)[tp_rank * n : (tp_rank + 1) * n].to(dtype)
     layers = []
     for li in range(cfg.num_layers):
         p = f"model.layers.{li}."
         wqkv = torch.cat((rows(p + "self_attn.q_proj.weight", nh_l * hd), rows(p + "self_attn.k_proj.weight", nkv_l * hd), rows(p + "self_attn.v_proj.weight", nkv_l * hd)), 0)
         wgu = interleave_gate_up(rows(p + "mlp.gate_proj.weight", i_l).contiguous(), rows(p + "mlp.up_proj.weight", i_l).contiguous())
+        bqkv = None
+        if has_bias:
+            bqkv = torch.cat((vec(p + "self_attn.q_proj.bias", nh_l * hd), vec(p + "self_attn.k_proj.bias", nkv_l * hd), vec(p + "self_attn.v_proj.bias", nkv_l * hd))).contiguous().to(dev)
         layers.append(
             LayerWeights(
+                bqkv=bqkv,
                 attn_norm=whole(p + "input_layernorm.weight").to(dev),
                 wqkv=wqkv.contiguous().to(dev),
                 wo=cols(p + "self_attn.o_proj.weight", nh_l * hd).contiguous().to(dev),
@@ -412,6 +434,8 @@ def check_hf_config(config_json: str, cfg: LlamaConfig) -> None:
         hd = hf.get("head_dim") or hf["hidden_size"] // nh
         if hd != (cfg.rope_dim or cfg.head_dim):
             bad.append(f"head_dim: checkpoint {hd}, preset {cfg.rope_dim or cfg.head_dim}")
+    if (hf.get("model_type") == "qwen2") != cfg.qkv_bias:
+        bad.append(f"Q / K / V bias: checkpoint model_type {hf.get('model_type')!r}, preset qkv_bias={cfg.qkv_bias}")
     if "tie_word_embeddings" in hf and bool(hf["tie_word_embeddings"]) != cfg.tie_word_embeddings:
         bad.append(f"tie_word_embeddings: checkpoint {hf['tie_word_embeddings']}, preset {cfg.tie_word_embeddings}")
     rs = _hf_rope(hf)
@@ -476,7 +500,8 @@ def pad_head_dim(weights: "LlamaWeights", to: int = 128) -> "LlamaWeights":
     layers = []
     for lw in weights.layers:
         assert not lw.fp8, "pad before quantising"
-        layers.append(replace(lw, wqkv=widen_rows(lw.wqkv).contiguous(), wo=widen_rows(lw.wo.T.contiguous()).T.contiguous()))
+        bq = None if lw.bqkv is None else widen_rows(lw.bqkv[:, None]).view(-1).contiguous()
+        layers.append(replace(lw, wqkv=widen_rows(lw.wqkv).contiguous(), wo=widen_rows(lw.wo.T.contiguous()).T.contiguous(), bqkv=bq))
     new_cfg = replace(cfg, head_dim=to, attn_scale=cfg.softmax_scale, rope_dim=cfg.rope_dim or hd)
     return replace(weights, cfg=new_cfg, layers=layers)
 
@@ -563,5 +588,11 @@ def replicate_kv_heads(weights: "LlamaWeights", factor: int) -> "LlamaWeights":
         q, k, v = lw.wqkv.split((nh_l * hd, nkv_l * hd, nkv_l * hd), 0)
         k = k.view(nkv_l, 1, hd, -1).expand(nkv_l, factor, hd, k.shape[1]).reshape(nkv_l * factor * hd, -1)
         v = v.view(nkv_l, 1, hd, -1).expand(nkv_l, factor, hd, v.shape[1]).reshape(nkv_l * factor * hd, -1)
-        layers.append(replace(lw, wqkv=torch.cat((q, k, v), 0).contiguous()))
+        bq = lw.bqkv
+        if bq is not None:
+            bq_q, bq_k, bq_v = bq.split((nh_l * hd, nkv_l * hd, nkv_l * hd), 0)
+            bq_k = bq_k.view(nkv_l, 1, hd).expand(nkv_l, factor, hd).reshape(-1)
+            bq_v = bq_v.view(nkv_l, 1, hd).expand(nkv_l, factor, hd).reshape(-1)
+            bq = torch.cat((bq_q, bq_k, bq_v)).contiguous()
+        layers.append(replace(lw, wqkv=torch.cat((q, k, v), 0).contiguous(), bqkv=bq))
     return replace(weights, cfg=replace(cfg, num_kv_heads=cfg.num_kv_heads * factor), layers=layers)

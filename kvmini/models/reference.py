@@ -41,6 +41,8 @@ def dense_logits(w: LlamaWeights, token_ids: List[int]) -> torch.Tensor:
     for lw in w.layers:
         h = norm(x, lw.attn_norm)
         qkv = h @ lw.wqkv.float().T
+        if lw.bqkv is not None:
+            qkv = qkv + lw.bqkv.float()
         q, k, v = qkv.split((nh * hd, nkv * hd, nkv * hd), -1)
         q = rot(q.view(t, nh, hd))
         k = rot(k.view(t, nkv, hd))

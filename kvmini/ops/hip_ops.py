@@ -185,6 +185,22 @@ class Partial:
         return y.to(torch.bfloat16)
 
 
+def add_bias(y: Union[torch.Tensor, Partial], b: torch.Tensor) -> Union[torch.Tensor, Partial]:
+    """A projection's bias ``[N]`` on its output, in place.  Split-K partial sums carry it in their first slab —
+    divided by the row scale their consumer still applies (the folded RMSNorm's 1 / rms), so that
+    ``rs * (sum of slabs) = rs * (x W^T) + b`` and the kernels that sum the slabs need not know about it."""
+    if isinstance(y, Partial):
+        n = b.numel()
+        if y.ss is None:
+            y.slabs[0, :, :n].add_(b.float())
+        else:
+            inv_rs = torch.sqrt(y.ss.sum(-1) / y.h_in + y.eps)  # [T]
+            y.slabs[0, :, :n].addcmul_(inv_rs[:, None], b.float()[None, :])
+        return y
+    y[:, : b.numel()].add_(b.to(y.dtype))
+    return y
+
+
 def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
     """Fold every RMSNorm gain into the projection that consumes it and pack every
     linear weight of a ``LlamaWeights`` into MFMA fragment order, in place.
@@ -1045,6 +1061,8 @@ class DecodeLayers:
             return False
         lw = weights.layers[0]
         ws = (lw.wqkv, lw.wo, lw.wgu, lw.wdown)
+        if getattr(lw, "bqkv", None) is not None:  # (no bias in the persistent kernel's QKV phase)
+            return False
         if not all(isinstance(w, PackedLinear) and w.bits == 16 and w.n == w.n_pad and w.k % 256 == 0 for w in ws):
             return False
         if kv_cache.shape[-1] != 128 or kv_cache.shape[-2] != 16 or n_kv < 1 or n_heads % n_kv or n_heads // n_kv != 4:

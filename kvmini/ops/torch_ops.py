@@ -55,6 +55,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, allow_slabs: bool = False) -> torch
     return F.linear(x, w)
 
 
+def add_bias(y: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``y + b`` for a projection's output ``[T, N]`` and its bias ``[N]``."""
+    return y + b.to(y.dtype)
+
+
 def rope_kv_write(
     qkv: torch.Tensor,
     positions: torch.Tensor,

@@ -833,3 +833,29 @@ def test_prefix_cache_serves_a_block_only_for_equal_tokens_behind_an_equal_chain
     assert len(bm2._content) == 4
     taken = bm2.allocate(63)  # evicts every cached block
     assert taken is not None and not bm2._content and not bm2._cached
+
+
+def test_qkv_bias_models_match_the_dense_oracle():
+    """Qwen2 form (a bias on the fused Q / K / V projection): the engine's tokens equal the dense fp32 forward pass,
+    and the bias survives head padding and K/V head replication."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, pad_head_dim, random_weights, replicate_kv_heads
+    from kvmini.models.reference import dense_greedy
+
+    w = random_weights(get_config("tiny-qkv-bias"), "cpu", torch.float32, seed=4)
+    assert w.layers[0].bqkv is not None and w.layers[0].bqkv.numel() == w.layers[0].wqkv.shape[0]
+    for lw in w.layers:
+        lw.bqkv.mul_(20.0)  # (N(0, 0.02) draws: make the bias matter)
+    prompts = [[1, 7, 9, 30, 2, 44], [1, 100, 101]]
+    want = [dense_greedy(w, p, 8) for p in prompts]
+    eng = LLMEngine(EngineConfig(model="tiny-qkv-bias", device="cpu", dtype="fp32", kernels="torch", max_model_len=64, max_num_seqs=4, max_batched_tokens=32, use_graphs=False), weights=w)
+    assert eng.generate(prompts, SamplingParams(max_tokens=8, ignore_eos=True)) == want
+    zero = random_weights(get_config("tiny-qkv-bias"), "cpu", torch.float32, seed=4)
+    for lw in zero.layers:
+        lw.bqkv.zero_()
+    assert [dense_greedy(zero, p, 8) for p in prompts] != want
+    wide = pad_head_dim(w, 64)
+    assert wide.layers[0].bqkv.numel() == wide.layers[0].wqkv.shape[0] and [dense_greedy(wide, p, 8) for p in prompts] == want
+    rep = replicate_kv_heads(w, 2)
+    assert rep.layers[0].bqkv.numel() == rep.layers[0].wqkv.shape[0] and [dense_greedy(rep, p, 8) for p in prompts] == want

@@ -196,16 +196,21 @@ def test_energy_trapz(C):
 
 
 # ---- engine end to end ---------------------------------------------------------------
-@pytest.mark.parametrize("graphs", [False, True])
-def test_engine_hip_matches_dense_reference(graphs):
+@pytest.mark.parametrize("graphs,model", [(False, "small-hd128"), (True, "small-hd128"), (False, "small-hd128-qkv-bias"), (True, "small-hd128-qkv-bias")])
+def test_engine_hip_matches_dense_reference(graphs, model):
+    """(the -qkv-bias model: Qwen2 form — the bias rides in the first split-K slab, or is added to the bf16 output)"""
     from kvmini.engine.engine import EngineConfig, LLMEngine
     from kvmini.engine.scheduler import SamplingParams
     from kvmini.models.llama import get_config, random_weights
     from kvmini.models.reference import dense_logits
 
-    w = random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)
-    oracle = random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # the engine packs its copy in place
-    eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, use_graphs=graphs, kernels="hip"), weights=w)
+    w = random_weights(get_config(model), "cuda:0", torch.bfloat16, seed=3)
+    oracle = random_weights(get_config(model), "cuda:0", torch.bfloat16, seed=3)  # the engine packs its copy in place
+    for ww in (w, oracle):
+        for lw in ww.layers:
+            if lw.bqkv is not None:
+                lw.bqkv.mul_(20.0)  # (N(0, 0.02) draws: make the bias matter)
+    eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, use_graphs=graphs, kernels="hip"), weights=w)
     if graphs:
         eng.warmup()
         assert eng.runner.graphs
