@@ -90,14 +90,41 @@ class SyntheticTokenizer:
 
 
 class HFTokenizer:
-    """Thin adapter over a ``tokenizer.json`` (Hugging Face ``tokenizers``)."""
+    """Adapter over a ``tokenizer.json`` (Hugging Face ``tokenizers``).  A ``tokenizer_config.json`` beside it
+    supplies the chat template (Jinja, rendered in a sandbox: the file comes with the checkpoint) and the BOS / EOS
+    strings; without one the format is chosen by the control tokens the vocabulary has (ChatML, Llama-3 headers,
+    ``[INST]``), else plain ``role: content`` lines."""
 
     def __init__(self, path: str, bos_id: int, eos_id: int):
+        import json
+        import os
+
         from tokenizers import Tokenizer
 
         self.tk = Tokenizer.from_file(path)
         self.vocab_size = self.tk.get_vocab_size()
         self.bos_id, self.eos_id = bos_id, eos_id
+        self._pieces: Dict[int, str] = {}
+        self._anchor: Optional[int] = None
+        self._anchor_text = ""
+        self.chat_template: Optional[str] = None
+        self.bos_token = self.tk.id_to_token(bos_id) or ""
+        self.eos_token = self.tk.id_to_token(eos_id) or ""
+        cfg_path = os.path.join(os.path.dirname(os.path.abspath(path)), "tokenizer_config.json")
+        if os.path.exists(cfg_path):
+            with open(cfg_path) as f:
+                tc = json.load(f)
+            tpl = tc.get("chat_template")
+            if isinstance(tpl, list):  # several named templates: the default one
+                tpl = next((t.get("template") for t in tpl if t.get("name") == "default"), tpl[0].get("template") if tpl else None)
+            self.chat_template = tpl if isinstance(tpl, str) else None
+
+            def tok_str(v: Any, default: str) -> str:
+                return v.get("content", default) if isinstance(v, dict) else (v if isinstance(v, str) else default)
+
+            self.bos_token, self.eos_token = tok_str(tc.get("bos_token"), self.bos_token), tok_str(tc.get("eos_token"), self.eos_token)
+        vocab = self.tk.get_vocab()
+        self._style = "chatml" if "<|im_start|>" in vocab else "llama3" if "<|start_header_id|>" in vocab else "inst" if "[INST]" in vocab else "plain"
 
     def encode(self, text: str, add_bos: bool = False) -> List[int]:
         ids = self.tk.encode(text, add_special_tokens=False).ids
@@ -108,15 +135,62 @@ class HFTokenizer:
         enc = self.tk.encode(text, add_special_tokens=False)
         return [(i, text[a:b]) for i, (a, b) in zip(enc.ids, enc.offsets)]
 
+    def render_chat(self, messages: List[Dict[str, Any]]) -> str:
+        """The prompt text of a conversation, ending where the assistant's reply begins."""
+        if self.chat_template:
+            try:
+                from jinja2.sandbox import ImmutableSandboxedEnvironment
+
+                def raise_exception(msg: str) -> None:
+                    raise ValueError(msg)
+
+                env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+                env.globals["raise_exception"] = raise_exception
+                return env.from_string(self.chat_template).render(messages=messages, add_generation_prompt=True, bos_token=self.bos_token, eos_token=self.eos_token)
+            except ImportError:
+                pass
+        def text(m: Dict[str, Any]) -> str:
+            c = m.get("content", "")
+            return c if isinstance(c, str) else "".join(p.get("text", "") for p in c if isinstance(p, dict))
+
+        if self._style == "chatml":
+            return "".join(f"<|im_start|>{m.get('role', 'user')}\n{text(m)}<|im_end|>\n" for m in messages) + "<|im_start|>assistant\n"
+        if self._style == "llama3":
+            return ("<|begin_of_text|>" + "".join(f"<|start_header_id|>{m.get('role', 'user')}<|end_header_id|>\n\n{text(m)}<|eot_id|>" for m in messages)
+                    + "<|start_header_id|>assistant<|end_header_id|>\n\n")
+        if self._style == "inst":
+            out, system = self.bos_token, ""
+            for m in messages:
+                role = m.get("role", "user")
+                if role == "system":
+                    system = text(m) + "\n\n"
+                elif role == "user":
+                    out += f"[INST] {system}{text(m)} [/INST]"
+                    system = ""
+                else:
+                    out += f" {text(m)}{self.eos_token}"
+            return out
+        return "".join(f"{m.get('role', 'user')}: {text(m)}\n" for m in messages) + "assistant:"
+
     def apply_chat_template(self, messages: List[Dict[str, Any]]) -> List[int]:
-        parts = ["<|begin_of_text|>"]
-        for m in messages:
-            parts.append(f"<|start_header_id|>{m.get('role', 'user')}<|end_header_id|>\n\n{m.get('content', '')}<|eot_id|>")
-        parts.append("<|start_header_id|>assistant<|end_header_id|>\n\n")
-        return self.tk.encode("".join(parts), add_special_tokens=False).ids
+        return self.tk.encode(self.render_chat(messages), add_special_tokens=False).ids
 
     def decode_token(self, tok: int) -> str:
-        return self.tk.decode([tok], skip_special_tokens=True)
+        """The text one token adds to a reply.  Decoded behind an anchor token: decoders that strip the space in
+        front of a text's first word (SentencePiece-style vocabularies) would otherwise glue streamed words together."""
+        s = self._pieces.get(tok)
+        if s is None:
+            if self._anchor is None:
+                ids = self.tk.encode("a", add_special_tokens=False).ids
+                self._anchor = ids[-1] if ids else -1
+                self._anchor_text = self.tk.decode([self._anchor], skip_special_tokens=True) if ids else ""
+            s = self.tk.decode([tok], skip_special_tokens=True)
+            if self._anchor >= 0 and self._anchor_text:
+                both = self.tk.decode([self._anchor, tok], skip_special_tokens=True)
+                if both.startswith(self._anchor_text):
+                    s = both[len(self._anchor_text):]
+            self._pieces[tok] = s
+        return s
 
     def decode(self, ids: List[int]) -> str:
         return self.tk.decode(ids, skip_special_tokens=True)

@@ -53,6 +53,7 @@ class LlamaConfig:
     # original_max_position); None = plain rotary frequencies
     rope_scaling: Optional["tuple[float, float, float, int]"] = None
     tie_word_embeddings: bool = False
+    extra_eos_token_ids: "tuple[int, ...]" = ()  # further end-of-sequence ids a checkpoint declares (Llama-3 Instruct: <|eot_id|> next to <|end_of_text|>)
     qkv_bias: bool = False  # Qwen2 form: the Q / K / V projections carry a bias (no other projection does)
 
     @property
@@ -259,12 +260,17 @@ def config_from_hf(config: "str | Dict[str, Any]", name: Optional[str] = None) -
     import json
     import os
 
+    gen: Dict[str, Any] = {}
     if isinstance(config, str):
         path = os.path.join(config, "config.json") if os.path.isdir(config) else config
         with open(path) as f:
             hf = json.load(f)
         if name is None:
             name = os.path.basename(os.path.dirname(os.path.abspath(path))) or "hf-model"
+        gpath = os.path.join(os.path.dirname(os.path.abspath(path)), "generation_config.json")
+        if os.path.exists(gpath):  # (chat checkpoints list their end-of-turn token here)
+            with open(gpath) as f:
+                gen = json.load(f)
     else:
         hf = dict(config)
     mt = hf.get("model_type", "llama")
@@ -315,6 +321,8 @@ def config_from_hf(config: "str | Dict[str, Any]", name: Optional[str] = None) -
         rope_scaling=scaling,
         tie_word_embeddings=bool(hf.get("tie_word_embeddings", False)),
         qkv_bias=mt == "qwen2",
+        extra_eos_token_ids=tuple(sorted({int(t) for src in (hf.get("eos_token_id"), gen.get("eos_token_id")) for t in (src if isinstance(src, (list, tuple)) else [src]) if t is not None}
+                                         - {first(hf.get("eos_token_id"), 2)})),
     )
 
 

@@ -70,15 +70,19 @@ class NativeServer:
             n_lp = int(body.get("top_logprobs") or 0) or (1 if body.get("logprobs") else 0)
         else:
             n_lp = int(body.get("logprobs") or 0)
+        ignore_eos = self.ignore_eos if ignore is None else bool(ignore)
+        stops = [int(t) for t in (body.get("stop_token_ids") or [])]
+        if not ignore_eos:  # every end-of-sequence id the checkpoint declares ends a reply, not only the first
+            stops += [t for t in getattr(self.engine.mcfg, "extra_eos_token_ids", ()) if t not in stops]
         return SamplingParams(
             max_tokens=int(max_tokens),
             temperature=float(body.get("temperature") or 0.0),
             top_p=float(body.get("top_p") or 1.0),
             top_k=int(body.get("top_k") or 0),
             seed=self._seed(body.get("seed")),
-            ignore_eos=self.ignore_eos if ignore is None else bool(ignore),
+            ignore_eos=ignore_eos,
             logprobs=max(0, min(n_lp, 20)),
-            stop_token_ids=[int(t) for t in (body.get("stop_token_ids") or [])],
+            stop_token_ids=stops,
         )
 
     @staticmethod

@@ -90,7 +90,13 @@ def test_unsupported_architectures_are_refused(tmp_path):
         with pytest.raises(ValueError, match=msg):
             config_from_hf({**base, **bad})
     cfg = config_from_hf({**base, "model_type": "mistral", "sliding_window": 128, "max_position_embeddings": 4096, "eos_token_id": [7, 9]})
-    assert cfg.max_position == 128 and cfg.eos_token_id == 7 and cfg.num_kv_heads == 2 and cfg.head_dim == 16
+    assert cfg.max_position == 128 and cfg.eos_token_id == 7 and cfg.extra_eos_token_ids == (9,) and cfg.num_kv_heads == 2 and cfg.head_dim == 16
+    # a chat checkpoint's generation_config.json adds its end-of-turn id
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({**base, "eos_token_id": 5}))
+    (d / "generation_config.json").write_text(json.dumps({"eos_token_id": [5, 11, 12]}))
+    assert config_from_hf(str(d)).extra_eos_token_ids == (11, 12)
 
 
 def test_tensor_parallel_ranks_read_only_their_slices(tmp_path):
@@ -154,3 +160,61 @@ def test_hip_kernels_follow_transformers_on_a_checkpoint_directory(tmp_path, kin
         margins = [float(lg[len(p) - 1 + i].max() - lg[len(p) - 1 + i][t]) for i, t in enumerate(got)]
         assert max(margins) <= 0.08 and sum(m == 0.0 for m in margins) >= 10, (got, margins)
         assert margins[0] == 0.0
+
+
+def _word_tokenizer(tmp_path, words, specials, metaspace=False):
+    from tokenizers import AddedToken, Tokenizer, decoders, models, pre_tokenizers
+
+    if metaspace:
+        vocab = {"[UNK]": 0, **{"▁" + w: i + 1 for i, w in enumerate(words)}}
+        tok = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+        tok.pre_tokenizer = pre_tokenizers.Metaspace()
+        tok.decoder = decoders.Metaspace()
+    else:
+        vocab = {"[UNK]": 0, **{w: i + 1 for i, w in enumerate(words)}}
+        tok = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+        tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.add_special_tokens([AddedToken(t, special=True) for t in specials])
+    path = str(tmp_path / "tokenizer.json")
+    tok.save(path)
+    return path
+
+
+def test_chat_template_of_the_checkpoint_is_rendered_and_streamed_pieces_keep_their_spaces(tmp_path):
+    from kvmini.engine.tokenizer import HFTokenizer
+
+    words = ["hello", "there", "you", "are", "a", "bot", "system", "user", "assistant", "hi"]
+    path = _word_tokenizer(tmp_path, words, ["<|im_start|>", "<|im_end|>"], metaspace=True)
+    with open(tmp_path / "tokenizer_config.json", "w") as f:
+        json.dump({"bos_token": "<|im_start|>", "eos_token": {"content": "<|im_end|>"},
+                   "chat_template": "{% for m in messages %}<|im_start|>{{ m['role'] }} {{ m['content'] }}<|im_end|>{% endfor %}{% if add_generation_prompt %}<|im_start|>assistant{% endif %}"}, f)
+    tok = HFTokenizer(path, 11, 12)
+    msgs = [{"role": "system", "content": "you are a bot"}, {"role": "user", "content": "hello there"}]
+    assert tok.render_chat(msgs) == "<|im_start|>system you are a bot<|im_end|><|im_start|>user hello there<|im_end|><|im_start|>assistant"
+    ids = tok.apply_chat_template(msgs)
+    start, end = tok.tk.token_to_id("<|im_start|>"), tok.tk.token_to_id("<|im_end|>")
+    assert ids[0] == start and ids.count(start) == 3 and ids.count(end) == 2 and 0 not in ids
+    assert tok.eos_token == "<|im_end|>"
+    # streamed one token at a time, the words keep the spaces between them
+    reply = tok.encode("hello there you are")
+    assert "".join(tok.decode_token(t) for t in reply).strip() == "hello there you are" == tok.decode(reply).strip()
+    # a template that calls into Python internals is stopped by the sandbox
+    with open(tmp_path / "tokenizer_config.json", "w") as f:
+        json.dump({"chat_template": "{{ ''.__class__.__mro__[1].__subclasses__() }}"}, f)
+    with pytest.raises(Exception):
+        HFTokenizer(path, 11, 12).render_chat(msgs)
+
+
+def test_chat_format_follows_the_vocabulary_without_a_template(tmp_path):
+    from kvmini.engine.tokenizer import HFTokenizer
+
+    words = ["hello", "user", "assistant", "system", "be", "brief"]
+    msgs = [{"role": "system", "content": "be brief"}, {"role": "user", "content": "hello"}]
+    chatml = HFTokenizer(_word_tokenizer(tmp_path, words, ["<|im_start|>", "<|im_end|>"]), 1, 2)
+    assert chatml.render_chat(msgs).endswith("<|im_start|>user\nhello<|im_end|>\n<|im_start|>assistant\n")
+    inst = HFTokenizer(_word_tokenizer(tmp_path, words, ["[INST]", "[/INST]"]), 1, 2)
+    assert "[INST] be brief\n\nhello [/INST]" in inst.render_chat(msgs)
+    l3 = HFTokenizer(_word_tokenizer(tmp_path, words, ["<|begin_of_text|>", "<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>"]), 1, 2)
+    assert l3.render_chat(msgs).startswith("<|begin_of_text|><|start_header_id|>system<|end_header_id|>\n\nbe brief<|eot_id|>")
+    plain = HFTokenizer(_word_tokenizer(tmp_path, words, []), 1, 2)
+    assert plain.render_chat(msgs) == "system: be brief\nuser: hello\nassistant:"
