@@ -83,6 +83,8 @@ PRESETS: Dict[str, LlamaConfig] = {
     "tiny-qkv-bias": LlamaConfig(name="tiny-qkv-bias", qkv_bias=True),
     # smallest shape that exercises every HIP kernel specialisation (head_dim 128)
     "small-hd128": LlamaConfig("small-hd128", 1024, 256, 512, 2, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
+    # four kv heads: the smallest shape that shards over four tensor-parallel ranks
+    "small-hd128-kv4": LlamaConfig("small-hd128-kv4", 1024, 256, 512, 2, 8, 4, 128, 500000.0, 1e-5, 2048, 1, 2),
     "small-hd128-qkv-bias": LlamaConfig("small-hd128-qkv-bias", 1024, 256, 512, 2, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2, qkv_bias=True),
     "small-hd128-draft": LlamaConfig("small-hd128-draft", 1024, 256, 512, 1, 4, 2, 128, 500000.0, 1e-5, 2048, 1, 2),
     # smallest shape the persistent decode-layers kernel serves (head groups of 4, K multiples of 256)

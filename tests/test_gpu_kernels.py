@@ -1371,19 +1371,20 @@ from kvmini.models.llama import get_config, random_weights
 dist.init_process_group("gloo")  # host-side bootstrap: both ranks share GPU 0, which RCCL refuses
 r, ws = dist.get_rank(), dist.get_world_size()
 torch.cuda.set_device(0)
-cfg = get_config("small-hd128")
+MODEL = os.environ.get("KV_TP_MODEL", "small-hd128")
+cfg = get_config(MODEL)
 w = random_weights(cfg, "cuda:0", torch.bfloat16, seed=3, tp_rank=r, tp_size=ws)
-eng = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", tp_size=ws, tp_rank=r,
+eng = LLMEngine(EngineConfig(model=MODEL, device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", tp_size=ws, tp_rank=r,
                              use_graphs=True), weights=w, tp_group=dist.group.WORLD)
 eng.warmup()
 assert eng.runner.xgmi is not None and eng.runner.graphs
 prompts = [[1, 50, 60, 70, 80], list(range(1, 30)), [1, 9, 8, 7]]
 if r == 0:
     outs = eng.generate(prompts, SamplingParams(max_tokens=10, ignore_eos=True))
-    base = LLMEngine(EngineConfig(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", use_graphs=False),
+    base = LLMEngine(EngineConfig(model=MODEL, device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip", use_graphs=False),
                      weights=random_weights(cfg, "cuda:0", torch.bfloat16, seed=3))
     want = base.generate(prompts, SamplingParams(max_tokens=10, ignore_eos=True))
-    # two shards sum in a different order than one GEMM: equal lengths, equal first tokens
+    # the shards sum in a different order than one GEMM: equal lengths, equal first tokens
     ok = [len(o) for o in outs] == [len(o) for o in want] and all(a[:3] == b[:3] for a, b in zip(outs, want)) and eng.pipelined_steps > 0
     print("OUTS", outs, want, eng.pipelined_steps, flush=True)
     # sampled requests (seeded and not): the scheduling rank's picks reach the follower on the device,
@@ -1406,21 +1407,22 @@ sys.exit(0 if ok else 1)
 """
 
 
-def test_tensor_parallel_two_rank_processes_share_one_gpu(tmp_path):
-    """TP = 2 end to end on one GPU: two rank processes, each with its shard of the weights on
-    GPU 0; the all-reduce behind every row-parallel projection runs in the fused peer-memory
-    kernel between the two processes (HIP IPC), inside captured HIP graphs; rank 1 follows the
+@pytest.mark.parametrize("world,model", [(2, "small-hd128"), (4, "small-hd128-kv4")])
+def test_tensor_parallel_two_rank_processes_share_one_gpu(tmp_path, world, model):
+    """TP = 2 and TP = 4 end to end on one GPU: one process per rank, each with its shard of the
+    weights on GPU 0; the all-reduce behind every row-parallel projection runs in the fused peer-memory
+    kernel between the processes (HIP IPC), inside captured HIP graphs; the other ranks follow the
     step images from the host channel; steps are launched ahead."""
     import subprocess
     import sys
 
-    script = tmp_path / "tp2.py"
+    script = tmp_path / "tp.py"
     script.write_text(TP2_ONE_GPU_SCRIPT)
-    env = dict(os.environ, KV_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+    env = dict(os.environ, KV_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", KV_TP_MODEL=model)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(29639 + world), str(script)],
                        capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "RANK0 OK=True" in r.stdout and "RANK1 OK=True" in r.stdout
+    assert all(f"RANK{k} OK=True" in r.stdout for k in range(world))
 
 
 @pytest.mark.gpu
