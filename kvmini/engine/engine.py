@@ -272,6 +272,11 @@ class LLMEngine:
         self._guided_vc = 1
         self._guided_state = torch.zeros((ecfg.max_num_seqs, 4), dtype=torch.int32, device=self.device)
         self._guided_owner: List[Any] = [None] * ecfg.max_num_seqs
+        # sampling penalties: per slot, how often every token was generated (int32 [slots, V]) and which tokens the
+        # prompt holds (bool [slots, V]); allocated when the first penalised request arrives
+        self._pen_counts: Optional[torch.Tensor] = None
+        self._pen_prompt: Optional[torch.Tensor] = None
+        self._pen_owner: List[Any] = [None] * ecfg.max_num_seqs
         # schema-guided sequences: the skeleton script of each slot (entries, rest) and its cursor
         from .guided import SCRIPT_MAX
 
@@ -424,10 +429,17 @@ class LLMEngine:
         draws: List[Optional[float]] = []
         lp_rows: List[int] = []
         lp_k: List[int] = []
+        pen_rows: List[int] = []
+        pen_slots: List[int] = []
+        pen_vals: List[Tuple[float, float, float]] = []
+        pen_greedy: List[int] = []  # positions in pen_rows of greedy, unguided rows: their pick is the argmax of the penalised logits
+        pen_reset: List[Tuple[int, List[int], List[int]]] = []  # (slot, generated so far, prompt) of sequences new to their slot
         r = 0
         for ch in batch.chunks:
             if ch.sample:
                 p = ch.seq.params
+                if p.penalised:
+                    self._stage_penalties(ch.seq, r, pen_rows, pen_slots, pen_vals, pen_greedy, pen_reset)
                 if p.logprobs > 0 and not guided_only:  # (the synchronous path reads them off the logits it gets back)
                     lp_rows.append(r)
                     lp_k.append(int(p.logprobs))
@@ -435,18 +447,41 @@ class LLMEngine:
                     self._stage_guided(ch.seq, r, g_rows, g_slots, g_init, g_cur, g_scripts)
                     if p.temperature <= 0:
                         g_greedy.append(r)
-                if p.temperature > 0 and (p.guided or not guided_only):
+                if p.temperature > 0 and (p.guided or p.penalised or not guided_only):
                     rows.append(r)
                     plist.append(p)
                     draws.append(self._draw_for(ch.seq))
                 r += 1
-        if not rows and not g_rows and not lp_rows:
+        if not rows and not g_rows and not lp_rows and not pen_rows:
             return None
         if lp_rows:
             batch.logprob_rows = self._logprob_holder(lp_rows, lp_k)
 
         def run(logits: torch.Tensor, out_ids: torch.Tensor) -> None:
             ops, dev = self.runner.ops, logits.device
+            if pen_rows:
+                # penalties first: masks and picks below work on the penalised logits
+                cnts, prm = self._pen_counts, self._pen_prompt
+                for slot, gen, prompt in pen_reset:
+                    cnts[slot].zero_()
+                    prm[slot].zero_()
+                    if gen:
+                        cnts[slot].index_add_(0, _host_to_device(gen, torch.int64, dev), torch.ones(len(gen), dtype=cnts.dtype, device=dev))
+                    if prompt:
+                        prm[slot].index_fill_(0, _host_to_device(prompt, torch.int64, dev), True)
+                pr, ps = _host_to_device(pen_rows, torch.int64, dev), _host_to_device(pen_slots, torch.int64, dev)
+                pv = _host_to_device([v for t in pen_vals for v in t], torch.float32, dev).view(-1, 3)
+                cnt = cnts.index_select(0, ps)
+                lg = logits.index_select(0, pr).float()
+                if any(t[2] != 1.0 for t in pen_vals):
+                    seen = (cnt > 0) | prm.index_select(0, ps)
+                    rp = pv[:, 2:3]
+                    lg = torch.where(seen, torch.where(lg > 0, lg / rp, lg * rp), lg)
+                lg = lg - pv[:, 1:2] * cnt.float() - pv[:, 0:1] * (cnt > 0).float()
+                logits.index_copy_(0, pr, lg.to(logits.dtype))
+                if pen_greedy:
+                    pg = _host_to_device(pen_greedy, torch.int64, dev)
+                    out_ids.index_copy_(0, pr.index_select(0, pg), lg.index_select(0, pg).argmax(-1).to(out_ids.dtype))
             if g_rows:
                 gr, gs = _host_to_device(g_rows, torch.int64, dev), _host_to_device(g_slots, torch.int32, dev)
                 for slot, rows2 in g_scripts:  # (stream-ordered: lands before the mask kernel reads it)
@@ -460,6 +495,8 @@ class LLMEngine:
                 self._sample_into(logits, rows, plist, out_ids, draws)
             if g_rows:
                 ops.guided_advance(out_ids, gr, gs, self._guided_state, self._guided_cls, self._guided_script, self._guided_cursor)
+            if pen_rows:  # the picks count from the next step on
+                self._pen_counts.index_put_((ps, out_ids.index_select(0, pr)), torch.ones(len(pen_rows), dtype=self._pen_counts.dtype, device=dev), accumulate=True)
             if lp_rows:
                 # log-probability of the picked token and the top-k of its row, from the logits the pick was
                 # made on (masked ones for guided rows): device ops, then a copy to the host buffer that the
@@ -488,6 +525,28 @@ class LLMEngine:
         if len(rows) > hv.shape[0]:
             raise RuntimeError(f"{len(rows)} rows with logprobs in one step; the host buffers hold {hv.shape[0]}")
         return {r: j for j, r in enumerate(rows)}, [min(k, self.LOGPROBS_MAX) for k in ks], hv, hi
+
+    def _stage_penalties(self, seq: Sequence, row: int, pen_rows: List[int], pen_slots: List[int], pen_vals: List[Tuple[float, float, float]], pen_greedy: List[int],
+                         pen_reset: List[Tuple[int, List[int], List[int]]]) -> None:
+        """One penalised row of the step being launched.  The slot's count / prompt rows are rebuilt by the device
+        ops when this sequence has not used the slot before (first sample, or taken up again after a preemption:
+        recounted over the tokens it already has — a token still in flight was counted by the step that picked it)."""
+        from .scheduler import PLACEHOLDER
+
+        if self._pen_counts is None:
+            v, n = self.mcfg.vocab_size, self.ecfg.max_num_seqs
+            self._pen_counts = torch.zeros((n, v), dtype=torch.int32, device=self.device)
+            self._pen_prompt = torch.zeros((n, v), dtype=torch.bool, device=self.device)
+        p = seq.params
+        key = (seq.req_id, seq.preemptions)
+        if self._pen_owner[seq.slot] != key:
+            self._pen_owner[seq.slot] = key
+            pen_reset.append((seq.slot, [t for t in seq.output_ids if t != PLACEHOLDER], list(seq.prompt_ids) if p.repetition_penalty != 1.0 else []))
+        if p.temperature <= 0 and not p.guided:
+            pen_greedy.append(len(pen_rows))
+        pen_rows.append(row)
+        pen_slots.append(seq.slot)
+        pen_vals.append((float(p.presence_penalty), float(p.frequency_penalty), float(p.repetition_penalty)))
 
     def _stage_guided(self, seq: Sequence, row: int, g_rows: List[int], g_slots: List[int], g_init: List[int], g_cur: List[int],
                       g_scripts: List[Tuple[int, List[List[int]]]]) -> None:
@@ -645,7 +704,7 @@ class LLMEngine:
         batched: Dict[int, int] = {}
         if logits is not None:
             sampled = [ch.seq for ch in batch.chunks if ch.sample]
-            rows_b = [r for r, sq in enumerate(sampled) if sq.params.temperature > 0 and not sq.params.guided]
+            rows_b = [r for r, sq in enumerate(sampled) if sq.params.temperature > 0 and not sq.params.guided and not sq.params.penalised]  # (those were picked by the device ops)
             if rows_b:
                 tmp = torch.zeros(logits.shape[0], dtype=torch.int64, device=logits.device)
                 idx = self._sample_into(logits, rows_b, [sampled[r].params for r in rows_b], tmp, [self._draw_for(sampled[r]) for r in rows_b])
@@ -683,9 +742,12 @@ class LLMEngine:
             events.append((seq.req_id, new, done, seq.finish_reason, seq))
         return events
 
-    def generate(self, prompts: List[List[int]], params: Optional[SamplingParams] = None) -> List[List[int]]:
-        """Offline batch generation (blocking)."""
-        seqs = [self.make_sequence(p, params and SamplingParams(**vars(params))) for p in prompts]
+    def generate(self, prompts: List[List[int]], params: "Optional[SamplingParams | List[SamplingParams]]" = None) -> List[List[int]]:
+        """Offline batch generation (blocking).  ``params``: one set for all prompts, or one per prompt."""
+        plist = params if isinstance(params, (list, tuple)) else [params] * len(prompts)
+        if len(plist) != len(prompts):
+            raise ValueError(f"{len(plist)} sampling parameter sets for {len(prompts)} prompts")
+        seqs = [self.make_sequence(p, q and SamplingParams(**vars(q))) for p, q in zip(prompts, plist)]
         for s in seqs:
             why = self.scheduler.add(s)
             if why is not None:

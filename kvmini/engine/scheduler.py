@@ -42,6 +42,11 @@ class SamplingParams:
     ignore_eos: bool = False
     logprobs: int = 0
     stop_token_ids: List[int] = field(default_factory=list)
+    # OpenAI's penalties over the tokens generated so far (logit -= presence * [count > 0] + frequency * count) and the
+    # multiplicative repetition penalty of vLLM / HF over prompt + generated tokens (positive logits / r, negative * r)
+    presence_penalty: float = 0.0
+    frequency_penalty: float = 0.0
+    repetition_penalty: float = 1.0
     # guided decoding: "json" constrains the output to one JSON object (kvmini/engine/guided.py);
     # guided_start = (state, depth, stack) of the automaton at the first generated token (a server
     # that pre-writes part of the document into the prompt starts it further in)
@@ -50,6 +55,10 @@ class SamplingParams:
     # skeleton script of a schema-guided sequence (kvmini.engine.guided.schema_script): forced
     # literal tokens (>= 0), typed value slots (<= -2), -1 at the end
     guided_script: Optional[Tuple[int, ...]] = None
+
+    @property
+    def penalised(self) -> bool:
+        return self.presence_penalty != 0.0 or self.frequency_penalty != 0.0 or self.repetition_penalty != 1.0
 
 
 @dataclass(eq=False)  # identity semantics: sequences live in lists / sets and are compared per step
@@ -167,6 +176,12 @@ class Scheduler:
             v = getattr(p, name)
             if not isinstance(v, (int, float)) or isinstance(v, bool) or not math.isfinite(v) or v < 0:
                 return f"{name} must be a finite non-negative number, got {v!r}"
+        for name, lo, hi in (("presence_penalty", -2.0, 2.0), ("frequency_penalty", -2.0, 2.0), ("repetition_penalty", 0.01, 100.0)):
+            v = getattr(p, name)
+            if not isinstance(v, (int, float)) or isinstance(v, bool) or not math.isfinite(v) or not lo <= v <= hi:
+                return f"{name} must be a number in [{lo}, {hi}], got {v!r}"
+        if p.penalised and not self.guided_supported:
+            return "sampling penalties are not available on an engine that runs speculative decoding"
         if p.guided not in (None, "json"):
             return f"unknown guided decoding mode {p.guided!r}"
         if p.guided and not self.guided_supported:

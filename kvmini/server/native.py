@@ -83,6 +83,9 @@ class NativeServer:
             ignore_eos=ignore_eos,
             logprobs=max(0, min(n_lp, 20)),
             stop_token_ids=stops,
+            presence_penalty=float(body.get("presence_penalty") or 0.0),
+            frequency_penalty=float(body.get("frequency_penalty") or 0.0),
+            repetition_penalty=float(body.get("repetition_penalty") or 1.0),
         )
 
     @staticmethod

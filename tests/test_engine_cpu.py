@@ -859,3 +859,55 @@ def test_qkv_bias_models_match_the_dense_oracle():
     assert wide.layers[0].bqkv.numel() == wide.layers[0].wqkv.shape[0] and [dense_greedy(wide, p, 8) for p in prompts] == want
     rep = replicate_kv_heads(w, 2)
     assert rep.layers[0].bqkv.numel() == rep.layers[0].wqkv.shape[0] and [dense_greedy(rep, p, 8) for p in prompts] == want
+
+
+def _penalised_greedy(w, prompt, n, presence=0.0, frequency=0.0, repetition=1.0):
+    """Reference: greedy decoding with OpenAI's presence / frequency penalties over the generated tokens and the
+    multiplicative repetition penalty over prompt + generated tokens, on the dense fp32 forward pass."""
+    from kvmini.models.reference import dense_logits
+
+    ids, out = list(prompt), []
+    for _ in range(n):
+        lg = dense_logits(w, ids)[-1].clone()
+        cnt = torch.zeros_like(lg)
+        for t in out:
+            cnt[t] += 1
+        if repetition != 1.0:
+            seen = cnt > 0
+            seen[torch.tensor(prompt)] = True
+            lg = torch.where(seen, torch.where(lg > 0, lg / repetition, lg * repetition), lg)
+        lg = lg - frequency * cnt - presence * (cnt > 0).float()
+        t = int(lg.argmax())
+        out.append(t)
+        ids.append(t)
+    return out
+
+
+@pytest.mark.parametrize("async_scheduling", [True, False])
+def test_sampling_penalties_match_the_reference(async_scheduling):
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.models.reference import dense_greedy
+
+    w = random_weights(get_config("tiny"), "cpu", torch.float32, seed=2)
+    eng = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", kernels="torch", max_model_len=128, max_num_seqs=4, max_batched_tokens=32, use_graphs=False,
+                                 async_scheduling=async_scheduling), weights=w)
+    prompts = [[1, 7, 9, 30, 2, 44], [1, 100, 101, 100, 101, 100]]
+    plain = [dense_greedy(w, p, 24) for p in prompts]
+    cases = [dict(frequency_penalty=1.5), dict(presence_penalty=2.0), dict(repetition_penalty=1.8), dict(presence_penalty=0.5, frequency_penalty=0.7, repetition_penalty=1.2)]
+    for kw in cases:
+        ref_kw = dict(presence=kw.get("presence_penalty", 0.0), frequency=kw.get("frequency_penalty", 0.0), repetition=kw.get("repetition_penalty", 1.0))
+        want = [_penalised_greedy(w, p, 24, **ref_kw) for p in prompts]
+        # one penalised and one plain request in the same steps: the plain one is untouched
+        outs = eng.generate(prompts + [prompts[0]], [SamplingParams(max_tokens=24, ignore_eos=True, **kw)] * 2 + [SamplingParams(max_tokens=24, ignore_eos=True)])
+        assert outs[:2] == want, (kw, outs[:2], want)
+        assert outs[2] == plain[0]
+    assert any(_penalised_greedy(w, prompts[0], 24, frequency=1.5) != plain[0] for _ in range(1))  # (the penalty changes this model's output at all)
+    # sampled, seeded: the same tokens twice, and different from the unpenalised draw
+    sp = SamplingParams(max_tokens=16, ignore_eos=True, temperature=0.9, seed=3, frequency_penalty=1.0, presence_penalty=1.0)
+    a, b = eng.generate([prompts[0]], sp)[0], eng.generate([prompts[0]], sp)[0]
+    assert a == b and len(a) == 16
+    # out-of-range values are refused at intake
+    bad = eng.make_sequence(prompts[0], SamplingParams(max_tokens=4, presence_penalty=9.0))
+    assert "presence_penalty" in (eng.scheduler.validate(bad) or "")

@@ -1459,6 +1459,36 @@ def test_seeded_requests_are_sampled_on_the_device_and_stay_launched_ahead():
     assert outs[True] == outs[False] and alone == outs[True][1] and other != alone
 
 
+@pytest.mark.gpu
+def test_sampling_penalties_run_on_the_device_and_stay_launched_ahead():
+    """Presence / frequency / repetition penalties are device ops in front of the pick: the same tokens with and
+    without launch-ahead, steps launched ahead, a strong frequency penalty keeps a greedy reply from repeating
+    itself, and a request without penalties next to a penalised one is untouched."""
+    from collections import Counter
+
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # noqa: E731
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip")
+    prompts = [[1, 50, 60, 70, 80], list(range(1, 30))]
+    pen = SamplingParams(max_tokens=40, ignore_eos=True, frequency_penalty=2.0, presence_penalty=1.0, repetition_penalty=1.3)
+    plain = SamplingParams(max_tokens=40, ignore_eos=True)
+    outs = {}
+    for mode in (True, False):
+        eng = LLMEngine(EngineConfig(**common, async_scheduling=mode), weights=w())
+        eng.warmup()
+        p0 = eng.pipelined_steps
+        outs[mode] = eng.generate(prompts + [prompts[0]], [pen, pen, plain])
+        if mode:
+            assert eng.pipelined_steps - p0 >= 35
+            alone = eng.generate([prompts[0]], plain)[0]
+    assert outs[True] == outs[False]
+    assert outs[True][2] == alone and outs[True][0] != alone
+    assert max(Counter(outs[True][0]).values()) <= 2 and max(Counter(alone).values()) >= 1
+
+
 # ---------------------------------------------------------------- FP8 (e4m3) KV cache
 def _fp8_cache(nb, nkv, bs, hd, seed):
     g = torch.Generator(device=_dev()); g.manual_seed(seed)
