@@ -50,6 +50,7 @@ int kv_guided_mask(void* logits, long long row_stride, int V, int n_cls, const l
 int kv_guided_advance(const long long* out_ids, const long long* rows, const int* slots, int R, int* state, const unsigned char* cls, int n_cls, const int* script,
                       int* cursor, int L, hipStream_t stream);
 int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, void* y, int T, int H, hipStream_t stream);
+int kv_slab_add_bias(float* slab, long long row_stride, const float* bias, const float* row_ss, int ss_parts, float inv_h, float eps, int T, int N, hipStream_t stream);
 int kv_swiglu_interleaved(const void* gu, void* act, int T, int I, hipStream_t stream);
 int kv_pack_weight(const void* W, void* Wp, int N, int K, hipStream_t stream);
 int kv_stream_gemm_plan(int N, int K, int ks_per_chunk, int max_splits, int* chunks_per_split);
@@ -550,6 +551,23 @@ void scale_rows(at::Tensor x, at::Tensor row_ss, double eps, at::Tensor y) {
   int parts = 0;
   const float* ssp = ss_ptr(row_ss, x.size(0), &parts);
   check(kv_scale_rows(x.data_ptr(), ssp, parts, (float)eps, y.data_ptr(), (int)x.size(0), (int)x.size(1), cur_stream()), "kv_scale_rows");
+}
+
+// slabs[0][t][:N] += bias[n] * sqrt(mean square of row t + eps) (row_ss: [T, parts] partial sums of squares over h_in
+// columns, or None: the bias as it is) — see slab_add_bias_kernel.
+void slab_add_bias(at::Tensor slabs, at::Tensor bias, c10::optional<at::Tensor> row_ss, int64_t h_in, double eps) {
+  CHECK_DEV(slabs); CHECK_DEV(bias); CHECK_CONTIG(bias);
+  TORCH_CHECK(slabs.scalar_type() == at::kFloat && slabs.dim() == 3 && slabs.stride(2) == 1, "slabs must be fp32 [S, T, N] with unit inner stride");
+  TORCH_CHECK(bias.scalar_type() == at::kFloat && bias.numel() <= slabs.size(2), "bias must be fp32 with at most N entries");
+  int parts = 0;
+  const float* ssp = nullptr;
+  if (row_ss.has_value()) {
+    TORCH_CHECK(h_in > 0, "h_in must be positive with a pending row scale");
+    ssp = ss_ptr(row_ss, slabs.size(1), &parts);
+  }
+  check(kv_slab_add_bias((float*)slabs.data_ptr(), slabs.stride(1), (const float*)bias.data_ptr(), ssp, parts, h_in > 0 ? 1.f / (float)h_in : 0.f, (float)eps, (int)slabs.size(1),
+                         (int)bias.numel(), cur_stream()),
+        "kv_slab_add_bias");
 }
 
 void swiglu_interleaved(at::Tensor gu, at::Tensor act) {
@@ -1055,6 +1073,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("split_ws") = py::none(), py::arg("pf_w") = py::none(), py::arg("pf_plan") = py::none(), py::arg("pf_sink") = py::none());
   m.def("argmax", &argmax);
   m.def("embed_fed", &embed_fed);
+  m.def("slab_add_bias", &slab_add_bias, py::arg("slabs"), py::arg("bias"), py::arg("row_ss") = py::none(), py::arg("h_in") = 0, py::arg("eps") = 0.0);
+  m.def("slab_add_bias", &slab_add_bias, py::arg("slabs"), py::arg("bias"), py::arg("row_ss") = py::none(), py::arg("h_in") = 0, py::arg("eps") = 0.0);
   m.def("swiglu_interleaved", &swiglu_interleaved);
   m.def("scale_rows", &scale_rows);
   m.def("sample_rows", &sample_rows);

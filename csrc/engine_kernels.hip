@@ -2360,6 +2360,27 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const unsigned short* _
 }
 
 // silu(gate) * up for the group-of-8 interleaved layout: gu [T, 2I] -> act [T, I]
+// slab[t][n] += bias[n] * sqrt(mean square of row t + eps): a projection's bias carried by its first split-K slab,
+// divided by the row scale (1 / rms of the folded RMSNorm) that the slabs' consumer still applies to their sum.
+// row_ss == nullptr: no row scale is pending, the bias is added as it is.  One workgroup per token row.
+__global__ __launch_bounds__(256) void slab_add_bias_kernel(float* __restrict__ slab, long long row_stride, const float* __restrict__ bias, const float* __restrict__ row_ss,
+                                                            int ss_parts, float inv_h, float eps, int N) {
+  __shared__ float red[4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  float f = 1.f;
+  if (row_ss != nullptr) {
+    float ssum = 0.f;
+    for (int i = tid; i < ss_parts; i += 256) ssum += row_ss[(long long)t * ss_parts + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = ssum;
+    __syncthreads();
+    f = sqrtf((red[0] + red[1] + red[2] + red[3]) * inv_h + eps);
+  }
+  float* row = slab + (long long)t * row_stride;
+  for (int n = tid; n < N; n += 256) row[n] += bias[n] * f;
+}
+
 __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ act, int I) {
   const int t = blockIdx.y;
   const int grp = blockIdx.x * 256 + threadIdx.x;  // one thread = one group: 8 gate values, then their 8 up values
@@ -3185,6 +3206,13 @@ int kv_scale_rows(const void* x, const float* row_ss, int ss_parts, float eps, v
   if (T <= 0) return 0;
   if (H % 8 || ss_parts < 1) return -1;
   hipLaunchKernelGGL(scale_rows_kernel, dim3(T), dim3(256), 0, stream, (const unsigned short*)x, row_ss, ss_parts, 1.f / (float)H, eps, (unsigned short*)y, H);
+  return (int)hipGetLastError();
+}
+
+int kv_slab_add_bias(float* slab, long long row_stride, const float* bias, const float* row_ss, int ss_parts, float inv_h, float eps, int T, int N, hipStream_t stream) {
+  if (T <= 0 || N <= 0) return 0;
+  if (!slab || !bias || (row_ss != nullptr && ss_parts < 1)) return -1;
+  hipLaunchKernelGGL(slab_add_bias_kernel, dim3(T), dim3(256), 0, stream, slab, row_stride, bias, row_ss, ss_parts, inv_h, eps, N);
   return (int)hipGetLastError();
 }
 

@@ -190,12 +190,8 @@ def add_bias(y: Union[torch.Tensor, Partial], b: torch.Tensor) -> Union[torch.Te
     divided by the row scale their consumer still applies (the folded RMSNorm's 1 / rms), so that
     ``rs * (sum of slabs) = rs * (x W^T) + b`` and the kernels that sum the slabs need not know about it."""
     if isinstance(y, Partial):
-        n = b.numel()
-        if y.ss is None:
-            y.slabs[0, :, :n].add_(b.float())
-        else:
-            inv_rs = torch.sqrt(y.ss.sum(-1) / y.h_in + y.eps)  # [T]
-            y.slabs[0, :, :n].addcmul_(inv_rs[:, None], b.float()[None, :])
+        bf = b if b.dtype == torch.float32 else b.float()  # (prepare_weights keeps it in fp32)
+        native().slab_add_bias(y.slabs, bf, y.ss, int(y.h_in) if y.ss is not None else 0, float(y.eps))
         return y
     y[:, : b.numel()].add_(b.to(y.dtype))
     return y
@@ -220,6 +216,8 @@ def prepare_weights(weights: Any, quantization: Optional[str] = None) -> None:
 
     for lw in weights.layers:
         lw.wqkv = fold_pack(lw.wqkv, lw.attn_norm)
+        if getattr(lw, "bqkv", None) is not None:
+            lw.bqkv = lw.bqkv.float().contiguous()  # added to fp32 slabs (add_bias)
         lw.wgu = fold_pack(lw.wgu, lw.mlp_norm)
         lw.wo = fold_pack(lw.wo, None)
         lw.wdown = fold_pack(lw.wdown, None)
