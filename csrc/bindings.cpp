@@ -689,7 +689,7 @@ void stream_gemm3(at::Tensor Wp, int64_t N, int64_t K, at::Tensor x, at::Tensor 
   }
   TORCH_CHECK(weight_bits == 0 || weight_bits == 4 || weight_bits == 8 || weight_bits == 16, "weight_bits must be 0 (by w_scale), 4, 8 or 16");
   TORCH_CHECK(nw == 4 || nw == 6 || nw == 7 || nw == 8, "nw (waves per workgroup) must be 4, 6, 7 or 8");
-  TORCH_CHECK(N % (16 * nw * ft) == 0, "N must be a multiple of 16 * nw * ft");
+  TORCH_CHECK(N % (16 * ft) == 0 && (N % (16 * nw * ft) == 0 || (ft == 1 && epi != 3)), "N must be a multiple of 16 * ft (of 16 * nw * ft with two tiles per wave or the residual epilogue)");
   TORCH_CHECK(x.dim() == 2 && x.size(1) == K && x.stride(1) == 1 && x.stride(0) % 8 == 0, "x must be [M, K] with 16-byte aligned rows");
   const int64_t M = x.size(0);
   int parts = 0;

@@ -337,7 +337,13 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
   const int ngroups = ksteps / (KS * NB);
   const int g0 = blockIdx.y * groups_per_split;
   const int g1 = g0 + groups_per_split < ngroups ? g0 + groups_per_split : ngroups;
-  const long long tile = ((long long)blockIdx.x * NW + wave) * FT;  // the wave's first tile
+  // The last workgroup may be ragged (N / 16 not a multiple of NW: any workgroup size then serves any width, and the
+  // planner picks the one that shares the tiles out most evenly over the CUs): a wave past the last tile streams the
+  // last tile again — it takes part in the x staging and the barriers like the others — and stores nothing.
+  const long long ntiles = N >> 4;
+  const long long tile_raw = ((long long)blockIdx.x * NW + wave) * FT;
+  const bool tile_ok = tile_raw + FT <= ntiles;
+  const long long tile = tile_ok ? tile_raw : ntiles - FT;  // the wave's first tile
   const long long tile_units = (long long)(ksteps * AL / KS) * 64;    // 16-byte units of one tile's weights
   const raw16* wp = reinterpret_cast<const raw16*>(Wp) + tile * tile_units + lane;
   const long long sc_units = (long long)(ksteps / 4) * 16;            // scale words of one tile (W4)
@@ -431,8 +437,10 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm3_kernel(const void* __res
 #undef KV_ISSUE
 #undef KV_CONSUME
 
+  if (tile_ok) {
 #pragma unroll
-  for (int f = 0; f < FT; ++f) gemm_epilogue<MT, EPI, W8>(acc[f], lds_raw, out, tile + f, wave, lane, ldy, slab_stride, row_ss, ss_parts, inv_k, eps, w_scale, scale_rows ? rs_lds : nullptr);
+    for (int f = 0; f < FT; ++f) gemm_epilogue<MT, EPI, W8>(acc[f], lds_raw, out, tile + f, wave, lane, ldy, slab_stride, row_ss, ss_parts, inv_k, eps, w_scale, scale_rows ? rs_lds : nullptr);
+  }
 
   if constexpr (EPI == EPI_RESID) {
     // ---- fix-up by the last split of this feature group (16 * NW features x 16 * MT rows)
@@ -649,7 +657,7 @@ constexpr int chunk_ksteps(int mt, int wb) { return 4; }
 
 template <int MT, int NB, int EPI, int WB, bool NT, int NW, int FT = 1>
 int launch3(const Args& a) {
-  dim3 grid(a.N / (16 * NW * FT), a.splits), block(NW * 64);
+  dim3 grid((a.N + 16 * NW * FT - 1) / (16 * NW * FT), a.splits), block(NW * 64);
   hipLaunchKernelGGL((stream_gemm3_kernel<MT, chunk_ksteps(MT, WB), NB, EPI, WB, NT, NW, FT>), grid, block, 0, a.stream, a.Wp, (const __bf16*)a.x, a.out, a.N, a.K, a.ldx, a.ldy, a.cps,
                      a.slab_stride, a.row_ss, a.ss_parts, 1.f / (float)a.K, a.eps, a.w_scale, a.ra);
   return (int)hipGetLastError();
@@ -861,7 +869,7 @@ int kv_stream_gemm3(const void* Wp, const void* x, void* out, int M, int N, int 
   if ((wb != 16 && wb != 8 && wb != 4) || ((wb != 16) != (w_scale != nullptr))) return -1;
   const bool wide = M == 96 || M == 128 || M == 256;  // 6 / 8 / 16 row tiles per wave: 2-chunk groups only (registers)
   const int chunk_cols = 32 * chunk_ksteps(M >> 4, wb);
-  if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * nw * ft)) || (nb != 2 && nb != 4 && nb != 8) || (K % (chunk_cols * nb))) return -1;
+  if (M <= 0 || (M > 64 && !wide) || (M & 15) || (nw != 4 && nw != 6 && nw != 7 && nw != 8) || (N % (16 * ft)) || ((N % (16 * nw * ft)) && (ft != 1 || epi == EPI_RESID)) || (nb != 2 && nb != 4 && nb != 8) || (K % (chunk_cols * nb))) return -1;
   if (wide && nb != 2) return -1;
   if (epi == EPI_SWIGLU && (N & 15)) return -1;
   if (epi != EPI_SLAB && epi != EPI_RESID && splits != 1) return -1;

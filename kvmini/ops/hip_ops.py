@@ -250,18 +250,19 @@ def _num_cus() -> int:
 
 @functools.lru_cache(maxsize=None)
 def _waves_per_workgroup(n_pad: int) -> int:
-    """Waves (16-feature tiles) per workgroup of an unsplit streaming GEMM: the count whose grid
-    fills the CUs most evenly in its last round (28672 features = 1792 tiles = 7 x 256: seven
-    waves give exactly one workgroup per CU where four give 448 workgroups, i.e. 1.75 rounds
-    that cost two); ties go to the larger workgroup (less x traffic per weight byte)."""
-    best, best_eff = 4, -1.0
-    for nw in (4, 7, 8):
-        if n_pad % (16 * nw):
-            continue
-        wgs = n_pad // (16 * nw)
-        eff = wgs / (-(-wgs // _num_cus()) * _num_cus())
-        if eff >= best_eff - 1e-9:
-            best, best_eff = nw, max(eff, best_eff)
+    """Waves (16-feature tiles) per workgroup of an unsplit streaming GEMM.  The kernel's time follows the CU that
+    streams the most: rounds of workgroups over the CUs x (tiles per workgroup + the x chunk every workgroup fetches,
+    worth about two tiles at 32 rows).  28672 features = 1792 tiles: seven waves are exactly one workgroup per CU
+    (cost 9) where four are 448 workgroups, two rounds (12).  The last workgroup may be ragged, so every count serves
+    every width: 22016 features (Llama-2-7B gate/up, 1376 tiles) take six waves — 230 workgroups, one round (8) —
+    where only four or eight divide the tiles (two rounds of four, or 172 workgroups of eight: 12 / 10)."""
+    tiles = -(-n_pad // 16)
+    best, best_cost = 4, float("inf")
+    for nw in (4, 6, 7, 8):
+        wgs = -(-tiles // nw)
+        cost = -(-wgs // _num_cus()) * (nw + 2.0)
+        if cost < best_cost - 1e-9 or (abs(cost - best_cost) <= 1e-9 and nw > best):
+            best, best_cost = nw, cost
     return best
 
 
@@ -662,7 +663,7 @@ def prefetch_plan(w: Weight, rows: int, site: str) -> Optional[Tuple[torch.Tenso
         split_bytes = gps * group_cols * col_bytes
     if gy <= 1:
         nw, gy, split_bytes = _waves_per_workgroup(w.n_pad), 1, tile_bytes
-    if tile_bytes % 1024 or split_bytes % 1024:
+    if tile_bytes % 1024 or split_bytes % 1024 or w.n_pad % (16 * nw):  # (the plan mirrors whole workgroups: no ragged last one)
         return None
     dev = w.wp.device
     sink = _prefetch_sinks.get(dev)
@@ -1062,6 +1063,8 @@ class DecodeLayers:
         if getattr(lw, "bqkv", None) is not None:  # (no bias in the persistent kernel's QKV phase)
             return False
         if not all(isinstance(w, PackedLinear) and w.bits == 16 and w.n == w.n_pad and w.k % 256 == 0 for w in ws):
+            return False
+        if lw.wgu.n_pad % (16 * _waves_per_workgroup(lw.wgu.n_pad)):  # (the persistent kernel's gate/up phase has no ragged last workgroup)
             return False
         if kv_cache.shape[-1] != 128 or kv_cache.shape[-2] != 16 or n_kv < 1 or n_heads % n_kv or n_heads // n_kv != 4:
             return False

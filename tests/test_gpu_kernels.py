@@ -328,6 +328,31 @@ def test_stream_gemm_bf16_and_slabs(M, N, K):
         assert (s.float() - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("N,K,epi", [(22016, 4096, 2), (2368 * 16, 1024, 2), (1376 * 16, 512, 0), (208, 512, 0)])
+@pytest.mark.parametrize("M", [32, 64])
+def test_stream_gemm_ragged_last_workgroup(C, N, K, epi, M):
+    """Widths whose 16-feature tiles do not divide by the waves of a workgroup (Llama-2-7B's and Qwen2.5-7B's gate/up
+    projections): the last workgroup is ragged — its surplus waves stream the last tile again and store nothing —
+    for every workgroup size, and the planner's pick goes through the op layer."""
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(2)
+    W = (torch.randn(N, K, device=_dev()) * 0.05).bfloat16()
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    full = x.float() @ W.float().T
+    ref = torch_ops.swiglu_interleaved(full) if epi == 2 else full
+    tol = 2e-2 * ref.abs().max().item() + 1e-2
+    pw = hip_ops.PackedLinear(W)
+    for nw in (4, 6, 7, 8):
+        n_out = N // 2 if epi == 2 else N
+        out = torch.full((M, pw.n_pad // 2 if epi == 2 else pw.n_pad), float("nan"), dtype=torch.bfloat16, device=_dev())  # (widths are padded to whole tiles when packed)
+        C.stream_gemm3(pw.wp, pw.n_pad, K, x, out, epi, 2, 1, K // 256, None, 0.0, None, nw)
+        assert torch.isfinite(out.float()).all() and (out[:, :n_out].float() - ref.float()).abs().max().item() <= tol, nw
+    y = hip_ops.linear_swiglu(x, pw) if epi == 2 else hip_ops.linear(x, pw)
+    assert (y.float() - ref.float()).abs().max().item() <= tol
+    assert hip_ops._waves_per_workgroup(22016) == 6 and hip_ops._waves_per_workgroup(28672) == 7
+
+
 @pytest.mark.parametrize("nb", [2, 4])
 @pytest.mark.parametrize("M", [16, 48])
 def test_stream_gemm3_every_group_depth(nb, M):
