@@ -237,6 +237,7 @@ class LLMEngine:
         self.weights, self.mcfg = self.runner.w, self.runner.cfg  # the runner may have re-shaped the model (padded heads)
         self.bm = BlockManager(self.runner.num_blocks, ecfg.block_size, ecfg.enable_prefix_caching)
         self.scheduler = Scheduler(self.bm, ecfg.max_num_seqs, ecfg.max_batched_tokens, ecfg.max_model_len, self.mcfg.eos_token_id, ecfg.ride_along_limit)
+        self.scheduler.vocab_size = self.mcfg.vocab_size
         self.spec = None
         if ecfg.draft_model and ecfg.num_speculative_tokens > 0:
             from .speculative import SpeculativeDecoder
@@ -434,12 +435,13 @@ class LLMEngine:
         pen_vals: List[Tuple[float, float, float]] = []
         pen_greedy: List[int] = []  # positions in pen_rows of greedy, unguided rows: their pick is the argmax of the penalised logits
         pen_reset: List[Tuple[int, List[int], List[int]]] = []  # (slot, generated so far, prompt) of sequences new to their slot
+        pen_bias: List[Tuple[int, int, float]] = []  # (position in pen_rows, token, value added): logit_bias, and -inf on the stop tokens before min_tokens
         r = 0
         for ch in batch.chunks:
             if ch.sample:
                 p = ch.seq.params
                 if p.penalised:
-                    self._stage_penalties(ch.seq, r, pen_rows, pen_slots, pen_vals, pen_greedy, pen_reset)
+                    self._stage_penalties(ch.seq, r, pen_rows, pen_slots, pen_vals, pen_greedy, pen_reset, pen_bias)
                 if p.logprobs > 0 and not guided_only:  # (the synchronous path reads them off the logits it gets back)
                     lp_rows.append(r)
                     lp_k.append(int(p.logprobs))
@@ -478,6 +480,9 @@ class LLMEngine:
                     rp = pv[:, 2:3]
                     lg = torch.where(seen, torch.where(lg > 0, lg / rp, lg * rp), lg)
                 lg = lg - pv[:, 1:2] * cnt.float() - pv[:, 0:1] * (cnt > 0).float()
+                if pen_bias:
+                    lg.index_put_((_host_to_device([e[0] for e in pen_bias], torch.int64, dev), _host_to_device([e[1] for e in pen_bias], torch.int64, dev)),
+                                  _host_to_device([e[2] for e in pen_bias], torch.float32, dev), accumulate=True)
                 logits.index_copy_(0, pr, lg.to(logits.dtype))
                 if pen_greedy:
                     pg = _host_to_device(pen_greedy, torch.int64, dev)
@@ -527,7 +532,7 @@ class LLMEngine:
         return {r: j for j, r in enumerate(rows)}, [min(k, self.LOGPROBS_MAX) for k in ks], hv, hi
 
     def _stage_penalties(self, seq: Sequence, row: int, pen_rows: List[int], pen_slots: List[int], pen_vals: List[Tuple[float, float, float]], pen_greedy: List[int],
-                         pen_reset: List[Tuple[int, List[int], List[int]]]) -> None:
+                         pen_reset: List[Tuple[int, List[int], List[int]]], pen_bias: List[Tuple[int, int, float]]) -> None:
         """One penalised row of the step being launched.  The slot's count / prompt rows are rebuilt by the device
         ops when this sequence has not used the slot before (first sample, or taken up again after a preemption:
         recounted over the tokens it already has — a token still in flight was counted by the step that picked it)."""
@@ -544,6 +549,13 @@ class LLMEngine:
             pen_reset.append((seq.slot, [t for t in seq.output_ids if t != PLACEHOLDER], list(seq.prompt_ids) if p.repetition_penalty != 1.0 else []))
         if p.temperature <= 0 and not p.guided:
             pen_greedy.append(len(pen_rows))
+        if p.logit_bias:
+            pen_bias.extend((len(pen_rows), int(t), float(v)) for t, v in p.logit_bias.items())
+        if len(seq.output_ids) < p.min_tokens:  # (tokens in flight included: this pick is number len + 1)
+            stops = set(p.stop_token_ids)
+            if not p.ignore_eos:
+                stops.add(self.mcfg.eos_token_id)
+            pen_bias.extend((len(pen_rows), int(t), float("-inf")) for t in stops if 0 <= t < self.mcfg.vocab_size)
         pen_rows.append(row)
         pen_slots.append(seq.slot)
         pen_vals.append((float(p.presence_penalty), float(p.frequency_penalty), float(p.repetition_penalty)))

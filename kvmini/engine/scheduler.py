@@ -16,7 +16,7 @@ import time
 from collections import deque
 from dataclasses import dataclass, field
 from enum import Enum
-from typing import Tuple,  Any, Deque, List, Optional
+from typing import Any, Deque, Dict, List, Optional, Tuple
 
 from .kv_cache import BlockManager
 
@@ -24,6 +24,7 @@ from .kv_cache import BlockManager
 # stands in ``Sequence.output_ids`` for a token that a launched step has sampled but the host has
 # not read back yet (pipelined stepping: the next step is launched first)
 PLACEHOLDER = -1
+LOGIT_BIAS_MAX = 300  # entries of one request's logit_bias map (OpenAI's limit)
 
 
 class SeqStatus(Enum):
@@ -47,6 +48,10 @@ class SamplingParams:
     presence_penalty: float = 0.0
     frequency_penalty: float = 0.0
     repetition_penalty: float = 1.0
+    # OpenAI's logit_bias (token id -> value added to its logit, -100 .. 100) and vLLM's min_tokens (EOS and the stop
+    # tokens cannot be picked before this many tokens were generated); applied after the penalties, before masks and picks
+    logit_bias: Optional[Dict[int, float]] = None
+    min_tokens: int = 0
     # guided decoding: "json" constrains the output to one JSON object (kvmini/engine/guided.py);
     # guided_start = (state, depth, stack) of the automaton at the first generated token (a server
     # that pre-writes part of the document into the prompt starts it further in)
@@ -58,7 +63,7 @@ class SamplingParams:
 
     @property
     def penalised(self) -> bool:
-        return self.presence_penalty != 0.0 or self.frequency_penalty != 0.0 or self.repetition_penalty != 1.0
+        return self.presence_penalty != 0.0 or self.frequency_penalty != 0.0 or self.repetition_penalty != 1.0 or bool(self.logit_bias) or self.min_tokens > 0
 
 
 @dataclass(eq=False)  # identity semantics: sequences live in lists / sets and are compared per step
@@ -158,6 +163,8 @@ class Scheduler:
         # False on an engine whose steps do not run the guided sampler (speculative decoding verifies
         # drafts against unmasked logits): such a request is refused at intake instead of running unconstrained
         self.guided_supported = True
+        # token ids a request may name (logit_bias, stop tokens); the engine sets it to the model's vocabulary size
+        self.vocab_size: Optional[int] = None
 
     # ------------------------------------------------------------------
     def validate(self, seq: Sequence) -> Optional[str]:
@@ -180,6 +187,21 @@ class Scheduler:
             v = getattr(p, name)
             if not isinstance(v, (int, float)) or isinstance(v, bool) or not math.isfinite(v) or not lo <= v <= hi:
                 return f"{name} must be a number in [{lo}, {hi}], got {v!r}"
+        if p.logit_bias is not None:
+            lb = p.logit_bias
+            if not isinstance(lb, dict) or len(lb) > LOGIT_BIAS_MAX:
+                return f"logit_bias must be a map of at most {LOGIT_BIAS_MAX} token ids to numbers"
+            for t, v in lb.items():
+                if isinstance(t, bool) or not isinstance(t, int) or t < 0 or (self.vocab_size is not None and t >= self.vocab_size):
+                    return f"logit_bias names token {t!r}; the vocabulary has ids 0 .. {(self.vocab_size or 0) - 1}"
+                if not isinstance(v, (int, float)) or isinstance(v, bool) or not math.isfinite(v) or not -100.0 <= v <= 100.0:
+                    return f"logit_bias values must be numbers in [-100, 100], got {v!r}"
+        if isinstance(p.min_tokens, bool) or not isinstance(p.min_tokens, int) or p.min_tokens < 0:
+            return f"min_tokens must be a non-negative integer, got {p.min_tokens!r}"
+        if isinstance(p.max_tokens, int) and p.min_tokens > p.max_tokens:
+            return f"min_tokens ({p.min_tokens}) is larger than max_tokens ({p.max_tokens})"
+        if p.min_tokens > 0 and self.vocab_size is not None and any(isinstance(t, bool) or not isinstance(t, int) or not 0 <= t < self.vocab_size for t in p.stop_token_ids):
+            return "min_tokens needs every stop token id inside the vocabulary"
         if p.penalised and not self.guided_supported:
             return "sampling penalties are not available on an engine that runs speculative decoding"
         if p.guided not in (None, "json"):

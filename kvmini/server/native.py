@@ -86,7 +86,21 @@ class NativeServer:
             presence_penalty=float(body.get("presence_penalty") or 0.0),
             frequency_penalty=float(body.get("frequency_penalty") or 0.0),
             repetition_penalty=float(body.get("repetition_penalty") or 1.0),
+            logit_bias=self._logit_bias(body.get("logit_bias")),
+            min_tokens=int(body.get("min_tokens") or 0),
         )
+
+    @staticmethod
+    def _logit_bias(v: Any) -> Optional[Dict[int, float]]:
+        """OpenAI's ``logit_bias``: a JSON object whose keys are token ids written as strings."""
+        if not v:
+            return None
+        if not isinstance(v, dict):
+            raise ValueError("logit_bias must be an object of token id -> bias")
+        try:
+            return {int(k): float(b) for k, b in v.items()}
+        except (TypeError, ValueError):
+            raise ValueError("logit_bias must map token ids to numbers") from None
 
     @staticmethod
     def _seed(v: Any) -> Optional[int]:

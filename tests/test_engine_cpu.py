@@ -911,3 +911,52 @@ def test_sampling_penalties_match_the_reference(async_scheduling):
     # out-of-range values are refused at intake
     bad = eng.make_sequence(prompts[0], SamplingParams(max_tokens=4, presence_penalty=9.0))
     assert "presence_penalty" in (eng.scheduler.validate(bad) or "")
+
+
+@pytest.mark.parametrize("async_scheduling", [True, False])
+def test_logit_bias_and_min_tokens(async_scheduling):
+    """``logit_bias`` adds to the named logits before the pick; ``min_tokens`` keeps EOS and the stop tokens from being
+    picked before that many tokens exist — both against the dense fp32 forward pass with the same rule."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+    from kvmini.models.reference import dense_greedy, dense_logits
+
+    cfg = get_config("tiny")
+    w = random_weights(cfg, "cpu", torch.float32, seed=2)
+    eng = LLMEngine(EngineConfig(model="tiny", device="cpu", dtype="fp32", kernels="torch", max_model_len=128, max_num_seqs=4, max_batched_tokens=32, use_graphs=False,
+                                 async_scheduling=async_scheduling), weights=w)
+    prompt = [1, 7, 9, 30, 2, 44]
+    plain = dense_greedy(w, prompt, 12)
+
+    def biased(bias, banned_until=0, banned=()):
+        ids, out = list(prompt), []
+        for i in range(12):
+            lg = dense_logits(w, ids)[-1].clone()
+            for t, v in bias.items():
+                lg[t] += v
+            if i < banned_until:
+                lg[list(banned)] = float("-inf")
+            out.append(int(lg.argmax()))
+            ids.append(out[-1])
+        return out
+
+    # a ban on the tokens the plain run picks, and a push for a token it never does
+    bias = {plain[0]: -100.0, plain[1]: -100.0, 77: 6.0}
+    got = eng.generate([prompt, prompt], [SamplingParams(max_tokens=12, ignore_eos=True, logit_bias=bias), SamplingParams(max_tokens=12, ignore_eos=True)])
+    assert got[0] == biased(bias) and got[1] == plain
+    assert plain[0] not in got[0] and plain[1] not in got[0]
+    # min_tokens: a token of the plain run as a stop token ends the reply there; with min_tokens = 8 it cannot be picked before
+    k = next(i for i in range(1, 8) if plain[i] not in plain[:i])
+    stop = plain[k]
+    short = eng.generate([prompt], SamplingParams(max_tokens=12, ignore_eos=True, stop_token_ids=[stop]))[0]
+    assert short == plain[: k + 1]
+    held = eng.generate([prompt], SamplingParams(max_tokens=12, stop_token_ids=[stop], min_tokens=8))[0]
+    want = biased({}, banned_until=8, banned=(stop, cfg.eos_token_id))
+    cut = next((i for i, t in enumerate(want) if i >= 8 and t in (stop, cfg.eos_token_id)), len(want) - 1)
+    assert held == want[: cut + 1] and len(held) >= 8 and stop not in held[:8]
+    # refused at intake: ids outside the vocabulary (they would index past the logits), values out of range, min > max
+    for bad, word in ((dict(logit_bias={cfg.vocab_size: 1.0}), "logit_bias"), (dict(logit_bias={3: 1e9}), "logit_bias"), (dict(logit_bias={-1: 1.0}), "logit_bias"),
+                      (dict(min_tokens=99), "min_tokens"), (dict(min_tokens=2, stop_token_ids=[cfg.vocab_size + 5]), "min_tokens")):
+        seq = eng.make_sequence(prompt, SamplingParams(max_tokens=12, **bad))
+        assert word in (eng.scheduler.validate(seq) or ""), bad

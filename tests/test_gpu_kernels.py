@@ -1514,6 +1514,38 @@ def test_sampling_penalties_run_on_the_device_and_stay_launched_ahead():
     assert max(Counter(outs[True][0]).values()) <= 2 and max(Counter(alone).values()) >= 1
 
 
+@pytest.mark.gpu
+def test_logit_bias_and_min_tokens_on_the_graph_path():
+    """logit_bias bans and pushes tokens, min_tokens holds the stop token back, in steps launched ahead of the
+    read-back on captured graphs; launch-ahead and synchronous stepping give the same tokens."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=3)  # noqa: E731
+    common = dict(model="small-hd128", device="cuda:0", max_num_seqs=8, max_batched_tokens=64, max_model_len=256, num_blocks=128, kernels="hip")
+    prompt = [1, 50, 60, 70, 80]
+    plain = SamplingParams(max_tokens=24, ignore_eos=True)
+    outs = {}
+    for mode in (True, False):
+        eng = LLMEngine(EngineConfig(**common, async_scheduling=mode), weights=w())
+        eng.warmup()
+        alone = eng.generate([prompt], plain)[0]
+        k = next(i for i in range(1, 12) if alone[i] not in alone[:i])
+        ban = SamplingParams(max_tokens=24, ignore_eos=True, logit_bias={alone[0]: -100.0, alone[1]: -100.0})
+        push = SamplingParams(max_tokens=24, ignore_eos=True, logit_bias={777: 100.0})
+        stop = SamplingParams(max_tokens=24, ignore_eos=True, stop_token_ids=[alone[k]])
+        held = SamplingParams(max_tokens=24, ignore_eos=True, stop_token_ids=[alone[k]], min_tokens=16)
+        outs[mode] = eng.generate([prompt] * 5, [ban, push, stop, held, plain])
+        o = outs[mode]
+        assert alone[0] not in o[0] and alone[1] not in o[0]
+        assert o[1] == [777] * 24
+        assert o[2] == alone[: k + 1]
+        assert len(o[3]) >= 16 and alone[k] not in o[3][:16] and o[3][:k] == alone[:k]
+        assert o[4] == alone
+    assert outs[True] == outs[False]
+
+
 # ---------------------------------------------------------------- FP8 (e4m3) KV cache
 def _fp8_cache(nb, nkv, bs, hd, seed):
     g = torch.Generator(device=_dev()); g.manual_seed(seed)
