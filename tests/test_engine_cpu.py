@@ -580,12 +580,14 @@ def test_native_server_n_choices_stop_strings_and_logprobs():
     ``stop`` strings (text-level: the engine only knows stop tokens), ``logprobs`` /
     ``top_logprobs`` in both dialects, streamed and not."""
     import math
+    import urllib.error
     import urllib.request
 
     from kvmini.server.native import start_native_in_thread
 
     eng, _w = _engine(max_num_seqs=8, max_batched_tokens=32)
-    _ns, url, stop = start_native_in_thread(eng, model_name="tiny")
+    ns, url, stop = start_native_in_thread(eng, model_name="tiny")
+    eng_text = lambda ids: ns.tok.decode(ids)  # noqa: E731
 
     def post(path, body):
         req = urllib.request.Request(url + path, data=json.dumps(body).encode(), headers={"Content-Type": "application/json"})
@@ -623,6 +625,18 @@ def test_native_server_n_choices_stop_strings_and_logprobs():
                 per_choice[c["index"]] += (c.get("delta") or {}).get("content") or ""
         assert per_choice[0] == per_choice[1] != "" and events[-1]["usage"]["completion_tokens"] == 8
         assert sum(1 for ev in events for c in ev["choices"] if c.get("logprobs")) == 8
+        # logit_bias (string keys, as JSON has them): +100 on one token makes it every pick; a bad id is the client's error
+        r = json.loads(post("/v1/completions", {"model": "tiny", "prompt": "abc", "max_tokens": 4, "logit_bias": {"65": 100}, "logprobs": 1}))
+        assert r["choices"][0]["logprobs"]["tokens"] == [r["choices"][0]["logprobs"]["tokens"][0]] * 4
+        assert r["choices"][0]["text"] == eng_text([65] * 4)
+        for bad in ({"logit_bias": {"x": 1}}, {"logit_bias": {"99999999": 1}}, {"min_tokens": 50}):
+            try:
+                post("/v1/completions", {"model": "tiny", "prompt": "abc", "max_tokens": 4, **bad})
+                raise AssertionError(f"accepted {bad}")
+            except urllib.error.HTTPError as e:
+                assert e.code == 400, (bad, e.code)
+        r = json.loads(post("/v1/completions", {"model": "tiny", "prompt": "abc", "max_tokens": 6, "min_tokens": 6, "ignore_eos": False}))
+        assert r["usage"]["completion_tokens"] == 6
         assert eng.metrics()["running"] == 0
     finally:
         stop()
