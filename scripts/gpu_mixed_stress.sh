@@ -2,7 +2,7 @@
 # Mixed traffic against one native server: greedy streaming, unseeded sampling, seeded sampling with
 # logprobs, long prompts, 5000-token prompts that hit the prefix cache (their short tails go to the
 # split-KV / split-tile attention forms, whose graphs are captured while other steps are in flight)
-# and guided JSON — all at once.  Every request must succeed.
+# guided JSON, and penalised requests with a logit bias and a minimum length — all at once.  Every request must succeed.
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
@@ -25,12 +25,14 @@ timeout -k 10 200 $LT --requests 40 --concurrency 2 --max-tokens 16 --target-rps
 echo '{"response_format": {"type": "json_object"}}' > "$OUT/json.json"
 timeout -k 10 200 $LT --requests 40 --concurrency 2 --max-tokens 8 --target-rps 4 --prompt-tokens 5000 --run-dir "$OUT/deep" > "$OUT/deep.log" 2>&1 & P5=$!
 timeout -k 10 200 $LT --requests 60 --concurrency 3 --max-tokens 48 --target-rps 10 --no-stream --extra-openai-json "$OUT/json.json" --run-dir "$OUT/guided" > "$OUT/guided.log" 2>&1 & P6=$!
+echo '{"frequency_penalty": 0.8, "presence_penalty": 0.4, "repetition_penalty": 1.1, "logit_bias": {"1000": -100, "2000": 5}, "min_tokens": 8}' > "$OUT/pen.json"
+timeout -k 10 200 $LT --requests 120 --concurrency 4 --max-tokens 32 --target-rps 1000 --temperature 0.8 --extra-openai-json "$OUT/pen.json" --run-dir "$OUT/penalised" > "$OUT/penalised.log" 2>&1 & P7=$!
 rc=0
-for p in $P1 $P2 $P3 $P4 $P5 $P6; do wait $p || rc=1; done
+for p in $P1 $P2 $P3 $P4 $P5 $P6 $P7; do wait $p || rc=1; done
 python - "$OUT" <<'PY'
 import csv, sys, os
 bad = 0
-for name in ("greedy", "sampled", "seeded", "long", "deep", "guided"):
+for name in ("greedy", "sampled", "seeded", "long", "deep", "guided", "penalised"):
     rows = list(csv.DictReader(open(os.path.join(sys.argv[1], name, "requests.csv"))))
     ok = sum(1 for r in rows if r["status"] == "200")
     lat = sorted(float(r["latency_ms"]) for r in rows if r["status"] == "200")
