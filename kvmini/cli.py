@@ -57,6 +57,7 @@ COMMANDS: Dict[str, Tuple[str, str, str]] = {
     "docs-site": ("kvmini.report.docsite", "main", "render README + docs/ into a static documentation site"),
     # servers
     "serve": ("kvmini.server.native", "main", "native MI355X OpenAI-compatible server"),
+    "generate": ("kvmini.server.offline", "main", "offline batch generation on the native engine (no server)"),
     "router": ("kvmini.server.router", "main", "data-parallel front-end over N engine replicas"),
     "mock": ("kvmini.server.mock", "main", "deterministic mock LLM endpoint"),
 }

@@ -218,3 +218,35 @@ def test_chat_format_follows_the_vocabulary_without_a_template(tmp_path):
     assert l3.render_chat(msgs).startswith("<|begin_of_text|><|start_header_id|>system<|end_header_id|>\n\nbe brief<|eot_id|>")
     plain = HFTokenizer(_word_tokenizer(tmp_path, words, []), 1, 2)
     assert plain.render_chat(msgs) == "system: be brief\nuser: hello\nassistant:"
+
+
+def test_offline_generation_on_a_checkpoint_directory(tmp_path, capsys):
+    """`kvmini generate --model DIR`: prompts from flags and a file (plain lines, JSON lines with a token budget of
+    their own), replies as JSON lines whose tokens are the library's greedy continuation of the same ids."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+
+    from kvmini.server.offline import main
+
+    path, hf = _save(tmp_path, "llama")
+    tok = Tokenizer(models.WordLevel({**{f"w{i}": i for i in range(1, 160)}, "[UNK]": 0}, unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.save(os.path.join(path, "tokenizer.json"))
+    pf = tmp_path / "prompts.txt"
+    pf.write_text('w5 w9 w33\n{"prompt": "w7 w8", "max_tokens": 3}\n\n')
+    out = tmp_path / "gen.jsonl"
+    rc = main(["--model", path, "--device", "cpu", "--dtype", "fp32", "--kernels", "torch", "--no-graphs", "--max-model-len", "64", "--max-num-seqs", "4",
+               "--max-batched-tokens", "32", "--prompt", "w11 w12 w13 w14", "--prompts-file", str(pf), "--max-tokens", "6", "--out", str(out)])
+    assert rc == 0
+    rows = [json.loads(ln) for ln in out.read_text().splitlines()]
+    assert [r["completion_tokens"] for r in rows] == [6, 6, 3]
+    summary = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert summary["requests"] == 3 and summary["completion_tokens"] == 15
+    from kvmini.engine.tokenizer import get_tokenizer
+
+    t = get_tokenizer(hf.config.vocab_size, 1, 2, os.path.join(path, "tokenizer.json"))
+    for text, r in zip(["w11 w12 w13 w14", "w5 w9 w33", "w7 w8"], rows):
+        ids = t.encode(text, add_bos=True)
+        assert r["prompt_tokens"] == len(ids)
+        with torch.no_grad():
+            want = hf.generate(torch.tensor([ids]), max_new_tokens=r["completion_tokens"], do_sample=False, eos_token_id=None, pad_token_id=0)[0, len(ids):].tolist()
+        assert r["token_ids"] == want
