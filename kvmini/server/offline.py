@@ -114,7 +114,7 @@ def main(argv: Optional[List[str]] = None) -> int:
         sink.close()
     st = engine.metrics()
     summary = {"requests": len(items), "prompt_tokens": sum(len(p) for p in ids), "completion_tokens": n_out, "seconds": round(dt, 4),
-               "output_tokens_per_s": round(n_out / dt, 1) if dt > 0 else None, "engine_steps": st["steps"], "prefix_cache_hits": st["prefix_cache_hits"],
+               "output_tokens_per_s": round(n_out / dt, 1) if dt > 0 else None, "engine_steps": st["steps"], "step_ms_ewma": round(st["step_ms_ewma"], 3), "prefix_cache_hits": st["prefix_cache_hits"],
                "load_and_warmup_s": round(t_load, 2), "model": cfg.name, "device": str(engine.device)}
     print(json.dumps(summary), file=sys.stderr if sink is None else sys.stdout)
     engine.stop()
