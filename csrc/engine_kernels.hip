@@ -131,6 +131,16 @@ struct KVStage<true> {
     v0 = *reinterpret_cast<const uint4*>(vp);           // token tg + 4 (0 + odd), dims [16 (dv >> 1), + 16)
     v1 = *reinterpret_cast<const uint4*>(vp + 8 * HD);  // token tg + 4 (2 + odd)
   }
+  // the same loads from wave-uniform block bases (scalar registers) plus per-lane byte offsets that do not change
+  // from block to block: koff = key * 128 + chunk * 32, voff = (dv >> 1) * 16 + (tg + 4 (dv & 1)) * 128
+  __device__ inline void load_at(const char* kbase, const char* vbase, unsigned koff, unsigned voff) {
+    k0 = *reinterpret_cast<const uint4*>(kbase + koff);
+    k1 = *reinterpret_cast<const uint4*>(kbase + koff + 16);
+    v0 = *reinterpret_cast<const uint4*>(vbase + voff);
+    v1 = *reinterpret_cast<const uint4*>(vbase + voff + 8 * 128);
+  }
+  static __device__ inline unsigned k_off(int key, int chunk) { return (unsigned)(key * 128 + chunk * 32); }
+  static __device__ inline unsigned v_off(int tg, int dv) { return (unsigned)((dv >> 1) * 16 + (tg + 4 * (dv & 1)) * 128); }
   __device__ inline void unpack(bf16x8 (&kk)[4], bf16x8 (&vv)[4], int dv) const {
     kk[0] = fp8x8_widen(k0.x, k0.y); kk[1] = fp8x8_widen(k0.z, k0.w);
     kk[2] = fp8x8_widen(k1.x, k1.y); kk[3] = fp8x8_widen(k1.z, k1.w);
@@ -146,6 +156,28 @@ struct KVStage<true> {
       const bf16x8 own = fp8x8_widen(mine0, mine1), other = fp8x8_widen(got0, got1);
       vv[2 * j] = odd ? other : own;
       vv[2 * j + 1] = odd ? own : other;
+    }
+  }
+  // K as above; V as fp32 straight from the bytes (packed conversion, two values per instruction) and in the
+  // lane's OWN order: vf[i] is token tg + 4 (i ^ (dv & 1)) — the lane's loaded token first, its neighbour's second —
+  // so nothing is selected by lane parity after the exchange (the consumer reads P at that token instead).
+  __device__ inline void unpack_f32(bf16x8 (&kk)[4], float (&vf)[4][8], int dv) const {
+    kk[0] = fp8x8_widen(k0.x, k0.y); kk[1] = fp8x8_widen(k0.z, k0.w);
+    kk[2] = fp8x8_widen(k1.x, k1.y); kk[3] = fp8x8_widen(k1.z, k1.w);
+    const bool odd = dv & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint4 r = j ? v1 : v0;
+      const unsigned int w[4] = {odd ? r.z : r.x, odd ? r.w : r.y,  // my dims of my token
+                                 (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(odd ? r.x : r.z), 0xB1, 0xF, 0xF, true),
+                                 (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(odd ? r.y : r.w), 0xB1, 0xF, 0xF, true)};  // my dims of the neighbour's token
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[d], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[d], true);
+        float* o = vf[2 * j + (d >> 1)] + 4 * (d & 1);
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+      }
     }
   }
 };
@@ -170,6 +202,18 @@ struct PAStage {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = kv_loadn<KV8, DP>(v_cache, blk + dv * DP + (tg + 4 * i) * HD);
   }
+  static constexpr int ESZ = KV8 ? 1 : 2;
+  __device__ inline void load_at(const char* kbase, const char* vbase, unsigned koff, unsigned voff) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) k[i] = kv_load8_at<KV8>(kbase, koff + i * 8 * ESZ);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (DP == 8) v[i] = kv_load8_at<KV8>(vbase, voff + 4 * i * HD * ESZ);
+      else v[i] = kv_load4<KV8>(vbase, (long long)((voff + 4 * i * HD * ESZ) / ESZ));
+    }
+  }
+  static __device__ inline unsigned k_off(int key, int chunk) { return (unsigned)((key * HD + chunk * DQ) * ESZ); }
+  static __device__ inline unsigned v_off(int tg, int dv) { return (unsigned)((dv * DP + tg * HD) * ESZ); }
   __device__ inline void unpack(bf16x8 (&kk)[NV], vrow_t (&vv)[4], int dv) const {
     (void)dv;
 #pragma unroll
@@ -582,6 +626,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   constexpr int DQ = HD / 4;   // dims of the QK dot owned by a lane
   constexpr int NV = DQ / 8;   // 16-byte K loads per lane
   constexpr int DP = HD / 16;  // output dims owned by a lane in PV
+  constexpr bool RAWV = KV8 && HD == 128;
   static_assert(HD == 64 || HD == 128, "head_dim 64 or 128");
   __shared__ float p_lds[NWAVE][REP][BS];    // per-wave probabilities of the current block
   __shared__ float m_lds[NWAVE][REP], l_lds[NWAVE][REP];
@@ -605,14 +650,34 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   const int* bt = block_tables + (long long)tok_seq[t] * max_blocks_per_seq;
   const int n_blocks = (ctx + BS - 1) / BS;
 
-  // each wave keeps two K/V blocks in flight beyond the one it computes on: the first loads go
-  // out before anything else
+  // Each wave keeps two K/V blocks in flight beyond the one it computes on, in three register stages whose roles
+  // rotate through a loop unrolled by three (no register copies, and no copy that would wait for the newest loads).
+  // The loads are unconditional — past the sequence's end the last block is read again and never used — so the
+  // number of loads in flight is the same on every path and a stage is waited for by count (two stages stay in
+  // flight), not by draining the queue; the block-table entry of a stage is fetched one block earlier still.
   const int qk_tok = lane >> 2, qk_c = lane & 3;
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
   typedef __attribute__((ext_vector_type(DP))) unsigned short vrow_t;  // 16 B (HD 128) or 8 B (HD 64)
-  PAStage<HD, KV8> st_cur, st_nxt;
-  if (wave < n_blocks) st_cur.load(k_cache, v_cache, ((long long)bt[wave] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
-  if (wave + NWAVE < n_blocks) st_nxt.load(k_cache, v_cache, ((long long)bt[wave + NWAVE] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
+  typedef PAStage<HD, KV8> stage_t;
+  const int last_b = n_blocks - 1;
+  auto entry = [&](int b) __attribute__((always_inline)) {
+    int e = bt[b < last_b ? b : last_b];
+    asm volatile("" : "+s"(e));  // wave-uniform: stays in a scalar register across the loop (a vector copy would share a register with a stage in flight and wait for it)
+    return e;
+  };
+  // block bases in scalar registers (the block id is wave-uniform), per-lane offsets fixed for the whole walk: the
+  // loads need no vector address arithmetic, whose temporaries would otherwise share registers with a stage in flight
+  // and wait for it
+  const unsigned koff = stage_t::k_off(qk_tok, qk_c), voff = stage_t::v_off(pv_tg, pv_dv);
+  constexpr int ESZ = KV8 ? 1 : 2;
+  auto issue = [&](stage_t& st, int blk) __attribute__((always_inline)) {
+    const long long base = ((long long)__builtin_amdgcn_readfirstlane(blk) * nkv + g) * (BS * HD * ESZ);
+    st.load_at(reinterpret_cast<const char*>(k_cache) + base, reinterpret_cast<const char*>(v_cache) + base, koff, voff);
+  };
+  stage_t s0, s1, s2;
+  issue(s0, entry(wave));
+  issue(s1, entry(wave + NWAVE));
+  int blk_far = entry(wave + 2 * NWAVE);
   // this lane's DQ-dim slice of the REP query heads, kept as packed bf16 pairs for
   // v_dot2_f32_bf16 (half the registers and multiplies of an fp32 copy, no unpacking of K)
   bf16x2 qp[REP][DQ / 2];
@@ -636,14 +701,13 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
     for (int j = 0; j < DP; ++j) acc[h][j] = 0.f;
   }
 
-  for (int b = wave; b < n_blocks; b += NWAVE) {
-    // this block's K / V and the next one's are in registers or on their way; start the loads
-    // of the block after those before computing
-    PAStage<HD, KV8> st_far;
-    if (b + 2 * NWAVE < n_blocks) st_far.load(k_cache, v_cache, ((long long)bt[b + 2 * NWAVE] * nkv + g) * BS * HD, qk_tok, qk_c, pv_tg, pv_dv);
+  // one block: scores, online softmax, P V on the stage that holds block b
+  auto block = [&](const stage_t& st, int b) __attribute__((always_inline)) {
     bf16x8 kv[NV];
     vrow_t vv[4];
-    st_cur.unpack(kv, vv, pv_dv);
+    float vf[RAWV ? 4 : 1][8];  // e4m3 cache, head width 128: V as fp32, in the lane's own token order (KVStage<true>::unpack_f32)
+    if constexpr (RAWV) st.unpack_f32(kv, vf, pv_dv);
+    else st.unpack(kv, vv, pv_dv);
     // ---- QK^T
     float s[REP];
 #pragma unroll
@@ -686,18 +750,32 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
     // ---- PV
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int tok = pv_tg + 4 * i;
+      const int tok = RAWV ? pv_tg + 4 * (i ^ (pv_dv & 1)) : pv_tg + 4 * i;
 #pragma unroll
       for (int h = 0; h < REP; ++h) {
         const float p = p_lds[wave][h][tok];
 #pragma unroll
-        for (int j = 0; j < DP; ++j) acc[h][j] += p * bf2f(vv[i][j]);
+        for (int j = 0; j < DP; ++j) {
+          if constexpr (RAWV) acc[h][j] += p * vf[i][j];
+          else acc[h][j] += p * bf2f(vv[i][j]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_sched_barrier(0);  // the rotation waits for the newest loads: keep it behind the PV math
-    st_cur = st_nxt;
-    st_nxt = st_far;
+  };
+
+  for (int b = wave; b < n_blocks; b += 3 * NWAVE) {
+    issue(s2, blk_far);
+    blk_far = entry(b + 3 * NWAVE);
+    block(s0, b);
+    if (b + NWAVE >= n_blocks) break;
+    issue(s0, blk_far);
+    blk_far = entry(b + 4 * NWAVE);
+    block(s1, b + NWAVE);
+    if (b + 2 * NWAVE >= n_blocks) break;
+    issue(s1, blk_far);
+    blk_far = entry(b + 5 * NWAVE);
+    block(s2, b + 2 * NWAVE);
   }
   // ---- sum the 4 token groups inside the wave (lanes l, l^16, l^32, ...)
 #pragma unroll
