@@ -1606,6 +1606,41 @@ def test_fp8_kv_paged_attention_matches_fp32_reference(rep, hd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kv8", [False, True])
+@pytest.mark.parametrize("rep, hd", [(4, 128), (8, 128), (1, 128), (4, 64)])
+def test_paged_attention_long_walks_every_remainder(kv8, rep, hd):
+    """The decode kernel walks a sequence's blocks in rounds of three register stages per wave: contexts whose
+    blocks per wave are 3 n, 3 n + 1 and 3 n + 2 (several rounds, so the loop's back edge runs), odd block counts
+    over the waves, and short ones next to them in one launch."""
+    from kvmini.ops import hip_ops, torch_ops
+
+    torch.manual_seed(9)
+    nkv, bs = 2, 16
+    nh = nkv * rep
+    ctx_list = [193, 208, 209, 250, 385, 400, 577, 640, 777, 1000, 1023, 1024, 3, 0, 49]
+    T = len(ctx_list)
+    max_blocks = 64
+    nb = T * max_blocks
+    if kv8:
+        kc, vc = _fp8_cache(nb, nkv, bs, hd, 1), _fp8_cache(nb, nkv, bs, hd, 2)
+        sc = torch.tensor([[0.7, 1.3], [2.0, 0.5]], device=_dev())
+    else:
+        kc, vc = _rand_cache(nb, nkv, bs, hd), _rand_cache(nb, nkv, bs, hd)
+        sc = None
+    bt = torch.randperm(nb, device=_dev()).view(T, max_blocks).int()
+    tok_seq = torch.arange(T, device=_dev(), dtype=torch.int32)
+    ctx = torch.tensor(ctx_list, device=_dev(), dtype=torch.int32)
+    q = torch.randn(T, nh, hd, device=_dev()).bfloat16()
+    scale = 1 / math.sqrt(hd)
+    kw = dict(kv_scale=sc) if kv8 else {}
+    ref = torch_ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, scale, **kw)
+    out = hip_ops.paged_attention(q, kc, vc, bt, tok_seq, ctx, scale, **kw)
+    err = (out.float() - ref.float()).abs().amax(dim=(1, 2)) if out.dim() == 3 else (out.float() - ref.float()).abs().view(T, -1).amax(dim=1)
+    assert err.max().item() <= 2e-2, err.tolist()
+    assert out[13].abs().max().item() == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rep,nkv", [(1, 2), (4, 2), (8, 2), (4, 8)])
 def test_fp8_kv_prefill_attention_matches_fp32_reference(rep, nkv):
     from kvmini.ops import hip_ops, torch_ops
