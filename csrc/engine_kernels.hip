@@ -604,6 +604,9 @@ __device__ inline float quad_rows_sum(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// lane `lane`'s value of v, in a scalar register (lane: wave-uniform)
+__device__ inline float lane_value(float v, int lane) { return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane)); }
+
 // ---------------------------------------------------------------------------------
 // Ragged paged attention.  One workgroup per (token, kv head); the REP = nh/nkv query
 // heads of the group share every K/V load.  Each of the 4 waves walks KV blocks
@@ -655,7 +658,11 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   // The loads are unconditional — past the sequence's end the last block is read again and never used — so the
   // number of loads in flight is the same on every path and a stage is waited for by count (two stages stay in
   // flight), not by draining the queue; the block-table entry of a stage is fetched one block earlier still.
-  const int qk_tok = lane >> 2, qk_c = lane & 3;
+  // MF (e4m3 cache, head width 128): the scores come from the matrix cores — a K fragment lane is (key = lane & 15,
+  // dims 32 (lane >> 4) ..), the A operand of v_mfma_f32_16x16x32_bf16 as it is loaded, against q as the B operand
+  // (column = head); the vector ALU keeps the softmax and P V
+  constexpr bool MF = RAWV;
+  const int qk_tok = MF ? (lane & 15) : (lane >> 2), qk_c = MF ? (lane >> 4) : (lane & 3);
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
   typedef __attribute__((ext_vector_type(DP))) unsigned short vrow_t;  // 16 B (HD 128) or 8 B (HD 64)
   typedef PAStage<HD, KV8> stage_t;
@@ -680,8 +687,20 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   int blk_far = entry(wave + 2 * NWAVE);
   // this lane's DQ-dim slice of the REP query heads, kept as packed bf16 pairs for
   // v_dot2_f32_bf16 (half the registers and multiplies of an fp32 copy, no unpacking of K)
-  bf16x2 qp[REP][DQ / 2];
-  {
+  bf16x2 qp[MF ? 1 : REP][DQ / 2];
+  typedef __attribute__((ext_vector_type(8))) __bf16 mf_ab;
+  typedef __attribute__((ext_vector_type(4))) float mf_cd;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  mf_ab qb[4];             // MF: q of head (lane & 15), dims 32 qk_c + 8 v .. + 8 (zero for columns past the group's heads)
+  const int col = lane & 15;
+  if constexpr (MF) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      bf16x8 raw = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (col < REP) raw = *reinterpret_cast<const bf16x8*>(q + (long long)t * q_row_stride + (long long)(g * REP + col) * HD + qk_c * 32 + v * 8);
+      qb[v] = __builtin_bit_cast(mf_ab, raw);
+    }
+  } else {
     const unsigned short* qrow = q + (long long)t * q_row_stride + (long long)g * REP * HD + qk_c * DQ;
 #pragma unroll
     for (int h = 0; h < REP; ++h)
@@ -692,6 +711,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
         for (int j = 0; j < 4; ++j) qp[h][v * 4 + j] = a.p[j];
       }
   }
+  float m_own = -1e30f;    // MF: running maximum of this lane's own head (equals m_run[col])
   float acc[REP][DP];
   float m_run[REP], l_run[REP];
 #pragma unroll
@@ -708,6 +728,53 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
     float vf[RAWV ? 4 : 1][8];  // e4m3 cache, head width 128: V as fp32, in the lane's own token order (KVStage<true>::unpack_f32)
     if constexpr (RAWV) st.unpack_f32(kv, vf, pv_dv);
     else st.unpack(kv, vv, pv_dv);
+    if constexpr (MF) {
+      mf_cd sc = (mf_cd){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_ab, kv[v]), qb[v], sc, 0, 0, 0);
+      // lane (head col, quarter qk_c): sc[e] = q_col . k of key 4 qk_c + e of the block
+      float mx = -1e30f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = (col < REP && b * BS + 4 * qk_c + e < ctx) ? sc[e] * scale_log2e : -1e30f;
+        mx = fmaxf(mx, sc[e]);
+      }
+      mx = quad_rows_max(mx);  // over the four quarters: the block's maximum for head col
+      const float m_own_new = fmaxf(m_own, mx);
+      mf_cd pe;
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pe[e] = __builtin_amdgcn_exp2f(sc[e] - m_own_new);
+        ps += pe[e];
+      }
+      m_own = m_own_new;
+      ps = quad_rows_sum(ps);
+      if (col < REP) *reinterpret_cast<mf_cd*>(&p_lds[wave][col][4 * qk_c]) = pe;
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {  // (head h's maximum and sum sit in lane h: scalar reads)
+        const float m_new = fmaxf(m_run[h], lane_value(mx, h));
+        const float corr = __builtin_amdgcn_exp2f(m_run[h] - m_new);
+        l_run[h] = l_run[h] * corr + lane_value(ps, h);
+        m_run[h] = m_new;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) acc[h][j] *= corr;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): p_lds visible to the wave
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tok = pv_tg + 4 * (i ^ (pv_dv & 1));
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+          const float p = p_lds[wave][h][tok];
+#pragma unroll
+          for (int j = 0; j < DP; ++j) acc[h][j] += p * vf[i][j];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
     // ---- QK^T
     float s[REP];
 #pragma unroll
@@ -1878,7 +1945,6 @@ __device__ inline float quarters_sum(float v) {
   const u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
-__device__ inline float lane_value(float v, int lane) { return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane)); }
 
 //
 // ATTN (with SPLIT; decode tokens of a step that also carries prompt chunks): phase A is another
