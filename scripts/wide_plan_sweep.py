@@ -67,7 +67,7 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     us = e0.elapsed_time(e1) / a.iters * 1e3
-                    slab = 2.0 * splits * m * n * 4 / 2.5e6 if splits > 1 else 0.0
+                    slab = 1.0 * splits * m * n * 4 / 2.5e6 if splits > 1 else 0.0  # the consumer's read; the write is inside the measured kernel
                     cands.append({"tile": [bm, bn, variant], "splits": splits, "sps": sps, "wgs": tiles * splits, "us": round(us, 1), "with_slabs_us": round(us + slab, 1)})
             cands.sort(key=lambda c: c["with_slabs_us"])
             mine = next((c for c in cands if tuple(c["tile"]) == tuple(pick[:3]) and c["splits"] == pick[3]), None)
