@@ -553,6 +553,32 @@ class NativeServer:
         return StreamingResponse(gen())
 
     # misc -----------------------------------------------------------------
+    async def tokenize(self, req: Request) -> Response:
+        """vLLM's ``POST /tokenize``: ``{"prompt": ...}`` (``add_special_tokens``, default true, puts BOS in front) or
+        ``{"messages": [...]}`` (the chat template) -> the ids the server would feed the model, and their count."""
+        bad = self._auth(req)
+        if bad:
+            return bad
+        body = req.json() or {}
+        if isinstance(body.get("messages"), list) and body["messages"]:
+            ids = self.tok.apply_chat_template(body["messages"])
+        elif isinstance(body.get("prompt"), str):
+            ids = self.tok.encode(body["prompt"], add_bos=bool(body.get("add_special_tokens", True)))
+        else:
+            return Response.json({"error": {"message": "give 'prompt' (a string) or 'messages' (a non-empty list)", "type": "invalid_request_error"}}, 400)
+        return Response.json({"count": len(ids), "max_model_len": self.engine.ecfg.max_model_len, "tokens": ids})
+
+    async def detokenize(self, req: Request) -> Response:
+        """vLLM's ``POST /detokenize``: ``{"tokens": [ids]}`` -> ``{"prompt": text}``."""
+        bad = self._auth(req)
+        if bad:
+            return bad
+        toks = (req.json() or {}).get("tokens")
+        v = self.engine.mcfg.vocab_size
+        if not isinstance(toks, list) or any(isinstance(t, bool) or not isinstance(t, int) or not 0 <= t < v for t in toks):
+            return Response.json({"error": {"message": f"'tokens' must be a list of token ids in [0, {v})", "type": "invalid_request_error"}}, 400)
+        return Response.json({"prompt": self.tok.decode(toks)})
+
     async def models(self, req: Request) -> Response:
         return Response.json({"object": "list", "data": [{"id": self.model_name, "object": "model", "created": int(self.started_at), "owned_by": "kvmini", "max_model_len": self.engine.ecfg.max_model_len}]})
 
@@ -609,6 +635,8 @@ class NativeServer:
         s.route("GET", "/metrics", self.metrics)
         s.route("POST", "/generate", self.tgi)
         s.route("POST", "/generate_stream", self.tgi)
+        s.route("POST", "/tokenize", self.tokenize)
+        s.route("POST", "/detokenize", self.detokenize)
         return s
 
     async def serve(self, host: str, port: int, announce: bool = True) -> None:

@@ -30,7 +30,7 @@ from typing import Any, AsyncIterator, List, Optional
 from kvmini.loadgen.httpclient import HttpClient
 from kvmini.server.httpd import HttpServer, Request, Response, StreamingResponse
 
-FORWARD_ROUTES = [("POST", "/v1/chat/completions"), ("POST", "/v1/completions"), ("POST", "/generate"), ("POST", "/generate_stream"), ("GET", "/v1/models"), ("GET", "/info")]
+FORWARD_ROUTES = [("POST", "/v1/chat/completions"), ("POST", "/v1/completions"), ("POST", "/generate"), ("POST", "/generate_stream"), ("POST", "/tokenize"), ("POST", "/detokenize"), ("GET", "/v1/models"), ("GET", "/info")]
 
 
 class Replica:

@@ -637,6 +637,19 @@ def test_native_server_n_choices_stop_strings_and_logprobs():
                 assert e.code == 400, (bad, e.code)
         r = json.loads(post("/v1/completions", {"model": "tiny", "prompt": "abc", "max_tokens": 6, "min_tokens": 6, "ignore_eos": False}))
         assert r["usage"]["completion_tokens"] == 6
+        # /tokenize and /detokenize: the ids a completion request would be fed, and back
+        tk = json.loads(post("/tokenize", {"prompt": "Hello, world!"}))
+        r = json.loads(post("/v1/completions", {"model": "tiny", "prompt": "Hello, world!", "max_tokens": 1}))
+        assert tk["count"] == len(tk["tokens"]) == r["usage"]["prompt_tokens"] and tk["max_model_len"] == eng.ecfg.max_model_len
+        assert json.loads(post("/tokenize", {"prompt": "Hello, world!", "add_special_tokens": False}))["tokens"] == tk["tokens"][1:]
+        assert json.loads(post("/tokenize", {"messages": msgs}))["count"] == base["usage"]["prompt_tokens"]
+        assert json.loads(post("/detokenize", {"tokens": tk["tokens"][1:]}))["prompt"] == eng_text(tk["tokens"][1:])
+        for path, bad in (("/tokenize", {}), ("/detokenize", {"tokens": [10 ** 9]}), ("/detokenize", {"tokens": "x"})):
+            try:
+                post(path, bad)
+                raise AssertionError(f"accepted {bad}")
+            except urllib.error.HTTPError as e:
+                assert e.code == 400
         assert eng.metrics()["running"] == 0
     finally:
         stop()
