@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   // MF (e4m3 cache, head width 128): the scores come from the matrix cores — a K fragment lane is (key = lane & 15,
   // dims 32 (lane >> 4) ..), the A operand of v_mfma_f32_16x16x32_bf16 as it is loaded, against q as the B operand
   // (column = head); the vector ALU keeps the softmax and P V
-  constexpr bool MF = RAWV;
+  constexpr bool MF = HD == 128;
   const int qk_tok = MF ? (lane & 15) : (lane >> 2), qk_c = MF ? (lane >> 4) : (lane & 3);
   const int pv_tg = lane >> 4, pv_dv = lane & 15;
   typedef __attribute__((ext_vector_type(DP))) unsigned short vrow_t;  // 16 B (HD 128) or 8 B (HD 64)
@@ -764,12 +764,15 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int tok = pv_tg + 4 * (i ^ (pv_dv & 1));
+        const int tok = RAWV ? pv_tg + 4 * (i ^ (pv_dv & 1)) : pv_tg + 4 * i;
 #pragma unroll
         for (int h = 0; h < REP; ++h) {
           const float p = p_lds[wave][h][tok];
 #pragma unroll
-          for (int j = 0; j < DP; ++j) acc[h][j] += p * vf[i][j];
+          for (int j = 0; j < DP; ++j) {
+            if constexpr (RAWV) acc[h][j] += p * vf[i][j];
+            else acc[h][j] += p * bf2f(vv[i][j]);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
