@@ -561,7 +561,10 @@ class NativeServer:
             return bad
         body = req.json() or {}
         if isinstance(body.get("messages"), list) and body["messages"]:
-            ids = self.tok.apply_chat_template(body["messages"])
+            try:
+                ids = self.tok.apply_chat_template(body["messages"])
+            except Exception as e:  # a message the template cannot render is the client's error
+                return Response.json({"error": {"message": f"messages cannot be rendered: {e}", "type": "invalid_request_error"}}, 400)
         elif isinstance(body.get("prompt"), str):
             ids = self.tok.encode(body["prompt"], add_bos=bool(body.get("add_special_tokens", True)))
         else:
