@@ -1961,6 +1961,34 @@ def test_decode_only_graphs_of_wide_buckets_match_eager():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_hundred_sequences_with_longer_contexts_agree_with_small_batches(kv):
+    """100 sequences of 150-230 prompt tokens decode together (rows beyond the fused kernel's 64: RoPE / cache write and
+    the batch decode-attention kernel — MFMA scores, three rotating K/V stages, several blocks per wave) and the same
+    prompts four at a time (the fused decode kernel): the first tokens agree everywhere, whole replies nearly
+    everywhere (different kernels round differently; a near-tie may flip)."""
+    from kvmini.engine.engine import EngineConfig, LLMEngine
+    from kvmini.engine.scheduler import SamplingParams
+    from kvmini.models.llama import get_config, random_weights
+
+    w = lambda: random_weights(get_config("small-hd128"), "cuda:0", torch.bfloat16, seed=5)  # noqa: E731
+    prompts = [[1] + [(13 * i + 7 * j) % 900 + 10 for j in range(150 + (i * 37) % 80)] for i in range(100)]
+    params = SamplingParams(max_tokens=8, ignore_eos=True)
+    common = dict(model="small-hd128", device="cuda:0", max_batched_tokens=2048, max_model_len=512, kernels="hip", kv_cache_dtype=kv, kv_memory_fraction=0.05)
+    small = LLMEngine(EngineConfig(**common, max_num_seqs=4), weights=w())
+    small.warmup()
+    want = small.generate(prompts, params)
+    del small
+    big = LLMEngine(EngineConfig(**common, max_num_seqs=128), weights=w())
+    big.warmup()
+    got = big.generate(prompts, params)
+    assert all(len(g) == 8 for g in got)
+    assert all(a[0] == b[0] for a, b in zip(want, got))
+    same = sum(a == b for a, b in zip(want, got))
+    assert same >= 90, (same, [(a, b) for a, b in zip(want, got) if a != b][:3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
 def test_new_turns_behind_a_cached_prefix_take_the_split_tile_kernel_inside_a_graph(monkeypatch, kv):
     """Chat continuation: a 3000-token conversation is in the prefix cache and every request adds a new turn of 40
     tokens.  The turn's tiles go to the split form of the tile kernel (key ranges shared out over the chip), from the
