@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   // rotate through a loop unrolled by three (no register copies, and no copy that would wait for the newest loads).
   // The loads are unconditional — past the sequence's end the last block is read again and never used — so the
   // number of loads in flight is the same on every path and a stage is waited for by count (two stages stay in
-  // flight), not by draining the queue; the block-table entry of a stage is fetched one block earlier still.
+  // flight), not by draining the queue.
   // MF (e4m3 cache, head width 128): the scores come from the matrix cores — a K fragment lane is (key = lane & 15,
   // dims 32 (lane >> 4) ..), the A operand of v_mfma_f32_16x16x32_bf16 as it is loaded, against q as the B operand
   // (column = head); the vector ALU keeps the softmax and P V
@@ -668,9 +668,7 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   typedef PAStage<HD, KV8> stage_t;
   const int last_b = n_blocks - 1;
   auto entry = [&](int b) __attribute__((always_inline)) {
-    int e = bt[b < last_b ? b : last_b];
-    asm volatile("" : "+s"(e));  // wave-uniform: stays in a scalar register across the loop (a vector copy would share a register with a stage in flight and wait for it)
-    return e;
+    return bt[b < last_b ? b : last_b];
   };
   // block bases in scalar registers (the block id is wave-uniform), per-lane offsets fixed for the whole walk: the
   // loads need no vector address arithmetic, whose temporaries would otherwise share registers with a stage in flight
@@ -684,7 +682,6 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   stage_t s0, s1, s2;
   issue(s0, entry(wave));
   issue(s1, entry(wave + NWAVE));
-  int blk_far = entry(wave + 2 * NWAVE);
   // this lane's DQ-dim slice of the REP query heads, kept as packed bf16 pairs for
   // v_dot2_f32_bf16 (half the registers and multiplies of an fp32 copy, no unpacking of K)
   bf16x2 qp[MF ? 1 : REP][DQ / 2];
@@ -835,16 +832,16 @@ __global__ __launch_bounds__(64 * NWAVE) void paged_attention_kernel(const unsig
   };
 
   for (int b = wave; b < n_blocks; b += 3 * NWAVE) {
-    issue(s2, blk_far);
-    blk_far = entry(b + 3 * NWAVE);
+    // the round's three block-table entries: scalar loads issued together (nothing about them is carried around the
+    // loop — a carried id ends up in a vector register that doubles as a load destination, and waiting for it drains the queue)
+    const int e2 = entry(b + 2 * NWAVE), e3 = entry(b + 3 * NWAVE), e4 = entry(b + 4 * NWAVE);
+    issue(s2, e2);
     block(s0, b);
     if (b + NWAVE >= n_blocks) break;
-    issue(s0, blk_far);
-    blk_far = entry(b + 4 * NWAVE);
+    issue(s0, e3);
     block(s1, b + NWAVE);
     if (b + 2 * NWAVE >= n_blocks) break;
-    issue(s1, blk_far);
-    blk_far = entry(b + 5 * NWAVE);
+    issue(s1, e4);
     block(s2, b + 2 * NWAVE);
   }
   // ---- sum the 4 token groups inside the wave (lanes l, l^16, l^32, ...)
