@@ -72,6 +72,7 @@ int kvx_residual_allreduce(void* h, const float* slabs, int n_slabs, long long s
                            int H, hipStream_t stream);
 int kvx_destroy(void* h);
 void kv_set_attention_mfma(int on);
+void kv_set_attention_mfma_unsplit(int on);
 int kv_get_attention_mfma();
 int kv_mfma_scale_probe(const int* a, const int* b, const int* sa, const int* sb, float* out, int fmt_a, int fmt_b, hipStream_t stream);
 int kv_quantize_rows_fp8(const void* x, long long ldx, int M, int K, void* x8, float* scale, int permute, hipStream_t stream);
@@ -1105,6 +1106,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("wide_gemm_w4a8", &wide_gemm_w4a8);
   m.def("mfma_scale_probe", &mfma_scale_probe);
   m.def("set_attention_mfma", [](bool on) { kv_set_attention_mfma(on ? 1 : 0); });
+  m.def("set_attention_mfma_unsplit", [](bool on) { kv_set_attention_mfma_unsplit(on ? 1 : 0); });
   m.def("get_attention_mfma", []() { return kv_get_attention_mfma() != 0; });
   m.def("wide_gemm", &wide_gemm, py::arg("Wp"), py::arg("N"), py::arg("K"), py::arg("x"), py::arg("out"), py::arg("epi"), py::arg("bm"), py::arg("bn"), py::arg("variant") = 0,
         py::arg("splits") = 1, py::arg("stages_per_split") = 0, py::arg("row_ss") = py::none(), py::arg("eps") = 0.0, py::arg("w_scale") = py::none(), py::arg("m_fastest") = true);

@@ -3171,6 +3171,11 @@ int kv_prefill_attention_split(const void* q, long long q_row_stride, const void
 // for the bf16 cache (bound by the KV stream already; measured slower in the matrix form: 8.0 against 6.5 ms per step
 // at 128k tokens, the three bf16 stages of the ring cost too many registers).
 static int g_attention_mfma = 1;
+// The unsplit fused decode kernel takes its scores from the matrix cores too on an e4m3 cache (KVMINI_FUSED_MFMA_UNSPLIT=0:
+// the dot-product form).  Measured, Llama-3-8B decode step at batch 20 / 32, dot products -> matrix cores: 98 tokens of context
+// 3.41 -> 3.42 / 3.48 -> 3.50 ms, 1060 tokens 3.85 -> 3.80 / 3.92 -> 3.90, 4150 tokens 5.14 -> 4.87 / 5.27 -> 5.07.
+static int g_attention_mfma_unsplit = [] { const char* e = getenv("KVMINI_FUSED_MFMA_UNSPLIT"); return e ? (e[0] == '1' ? 1 : 0) : 1; }();
+void kv_set_attention_mfma_unsplit(int on) { g_attention_mfma_unsplit = on ? 1 : 0; }
 void kv_set_attention_mfma(int on) { g_attention_mfma = on ? 1 : 0; }
 int kv_get_attention_mfma() { return g_attention_mfma; }
 
@@ -3210,9 +3215,15 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
   } else {                          \
     KV_LAUNCH_S(R, W, K8, false);   \
   }
+#define KV_LAUNCH_MF1(R, W, K8)                                                                                                                           \
+  hipLaunchKernelGGL((decode_attention_fused_kernel<R, W, K8, false, false, true>), grid, block, 0, stream, slabs, n_slabs, slab_stride, positions, cos_t, sin_t, \
+                     k_cache, v_cache, slot_mapping, block_tables, max_blocks_per_seq, tok_seq, ctx_lens, (unsigned short*)out, nh, nkv, row_ss, ss_parts,      \
+                     inv_h, eps, sl, kv_scale, part_o, part_ml, counters, plan)
 #define KV_LAUNCH_KM(R, W, K8)                        \
   if (n_split > 1 && g_attention_mfma) {              \
     KV_LAUNCH_MF(R, W, K8);                           \
+  } else if (g_attention_mfma && g_attention_mfma_unsplit) { \
+    KV_LAUNCH_MF1(R, W, K8);                          \
   } else {                                            \
     KV_LAUNCH_K(R, W, K8);                            \
   }
@@ -3254,6 +3265,7 @@ int kv_decode_attention_fused(const float* slabs, int n_slabs, long long slab_st
 #undef KV_LAUNCH_W
 #undef KV_LAUNCH_K
 #undef KV_LAUNCH_MF
+#undef KV_LAUNCH_MF1
 #undef KV_LAUNCH_KM
 #undef KV_LAUNCH_WM
 #undef KV_LAUNCHM

@@ -2329,6 +2329,9 @@ def _decode_layers_pair(model, n_seqs, kv_dtype, graphs, max_tokens=12, prompt_l
     from kvmini.ops import hip_ops
 
     out = []
+    # (the persistent kernel's attention phase is the dot-product form: the per-phase engine it is compared with bit
+    # for bit keeps the fused decode kernel on that form too)
+    hip_ops.native().set_attention_mfma_unsplit(False)
     for persistent in (True, False):
         hip_ops.DECODE_LAYERS = persistent  # read when the runner is built
         eng = LLMEngine(EngineConfig(model=model, device="cuda:0", max_num_seqs=max(n_seqs, 4), max_batched_tokens=128, max_model_len=1024, kernels="hip", num_blocks=512,
@@ -2343,6 +2346,7 @@ def _decode_layers_pair(model, n_seqs, kv_dtype, graphs, max_tokens=12, prompt_l
         torch.cuda.synchronize()
         out.append((toks, eng.runner.kv_cache.clone(), eng.runner))
     hip_ops.DECODE_LAYERS = False
+    hip_ops.native().set_attention_mfma_unsplit(True)
     return out
 
 
