@@ -333,10 +333,11 @@ class ModelRunner:
     # batch 96: 5.39 / 5.36 ms, 128: 5.50 / 5.45, 192: 6.21 / 6.26, 256: 5.67 / 5.68 (one workgroup per token and
     # kv head: from ~500 workgroups on the one launch takes as long as the three) — and cost start-up time.
     DECODE_FUSED_MAX_ROWS = int(os.environ.get("KVMINI_DECODE_FUSED_MAX_ROWS", "64"))
-    # With an e4m3 cache the limit is 32 rows: from 33 rows on the batch decode-attention kernel (scores on the matrix
-    # cores, three K/V stages in flight) reads the cache faster than the one-launch kernel does once contexts are long —
-    # batch 64, one launch / three launches: 4.06 / 4.09 ms at 290 tokens of context, 4.74 / 4.60 at 1070, 7.51 / 7.16 at
-    # 4190 (bf16 cache: 4.20 / 4.29, 5.25 / 5.33, 9.72 / 9.81 — it stays on the one launch).
+    # With an e4m3 cache the limit is 32 rows: from 33 rows on the batch decode-attention kernel (three K/V stages in
+    # flight per wave) reads the cache at least as fast as the one-launch kernel once contexts are long — one launch /
+    # three launches, batch 48: 3.85 / 3.86 ms at 290 tokens of context, 4.38 / 4.29 at 1070, 6.56 / 6.39 at 4180; batch 64:
+    # 4.11 / 4.10, 4.61 / 4.60, 7.12 / 7.17 (bf16 cache at batch 64: 4.20 / 4.29, 5.25 / 5.33, 9.72 / 9.81 — it stays on the
+    # one launch).
     DECODE_FUSED_MAX_ROWS_KV8 = int(os.environ.get("KVMINI_DECODE_FUSED_MAX_ROWS_KV8", "32"))
     # contexts from this many tokens on take the split-KV variant of a decode-only step (when the
     # step's shape has one: few rows); below it the extra workgroups only cost launch time
