@@ -250,3 +250,24 @@ def test_offline_generation_on_a_checkpoint_directory(tmp_path, capsys):
         with torch.no_grad():
             want = hf.generate(torch.tensor([ids]), max_new_tokens=r["completion_tokens"], do_sample=False, eos_token_id=None, pad_token_id=0)[0, len(ids):].tolist()
         assert r["token_ids"] == want
+
+
+def test_offline_generation_reads_prompts_from_stdin_and_refuses_what_cannot_run(monkeypatch, capsys):
+    """`kvmini generate --prompts-file -` on a preset: plain lines, JSON lines with messages, blank lines skipped; a
+    prompt longer than the model length ends the command with the scheduler's reason before anything is generated."""
+    import io
+
+    from kvmini.server.offline import main
+
+    common = ["--model", "tiny", "--device", "cpu", "--dtype", "fp32", "--kernels", "torch", "--no-graphs", "--max-model-len", "64", "--max-num-seqs", "4", "--max-batched-tokens", "32"]
+    monkeypatch.setattr("sys.stdin", io.StringIO('hello there\n\n{"messages": [{"role": "user", "content": "hi"}]}\n{not json\n'))
+    assert main(common + ["--prompts-file", "-", "--max-tokens", "4", "--temperature", "0.8", "--sampling-seed", "7"]) == 0
+    out = capsys.readouterr()
+    assert out.out.count("--- [") == 3 and "4 generated" in out.out
+    summary = json.loads(out.err.strip().splitlines()[-1])
+    assert summary["requests"] == 3 and summary["completion_tokens"] == 12
+    with pytest.raises(SystemExit) as e:
+        main(common + ["--prompt", " ".join(["word"] * 200)])
+    assert "max_model_len" in str(e.value)
+    with pytest.raises(SystemExit):
+        main(common)  # no prompts at all
